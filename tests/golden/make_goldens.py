@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures (tests/golden/*.npz) from the REAL reference.
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference.  It imports the reference's `src.models`, `train_mnist`, `train_particles`
+and `train_galaxy` (torchvision is stubbed: it is only used inside `main`), runs them on
+the CPU with fixed seeds, and stores inputs, parameters, the injected noise and every
+output / gradient as small float arrays.  No reference source is copied; fixtures are data.
+
+Noise replay: the reference draws, per step, `empty(B,P).exponential_()` (models.py:387),
+`normal(B,z,1)` (train_mnist.py:206) and `normal(B,1,1)` (train_mnist.py:230) in that order;
+we pre-draw the same three tensors under the same seed and store them.
+
+Usage:  python tests/golden/make_goldens.py        (writes next to this file)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import numpy as np
+import torch
+
+torch.set_num_threads(8)
+
+
+def _import_reference():
+    sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    sys.path.insert(0, REF)
+    import src.models as models          # noqa
+    import train_mnist                   # noqa
+    import train_particles               # noqa
+    import train_galaxy                  # noqa
+    sys.path.pop(0)
+    return models, train_mnist, train_particles, train_galaxy
+
+
+models, train_mnist, train_particles, train_galaxy = _import_reference()
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **npd(arrs))
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def coords(n):
+    xg = np.linspace(-1, 1, n)
+    yg = np.linspace(1, -1, n)
+    x0, x1 = np.meshgrid(xg, yg)
+    return torch.from_numpy(np.stack([x0.ravel(), x1.ravel()], 1)).float()
+
+
+def draw_noise(seed, B, P, zd):
+    torch.manual_seed(seed)
+    E = torch.empty(B, P).exponential_()
+    eps_z = torch.normal(torch.zeros(B, zd, 1), torch.ones(B, zd, 1))
+    eps_t = torch.normal(torch.zeros(B, 1, 1), torch.ones(B, 1, 1))
+    return E, eps_z.view(B, zd), eps_t.view(B)
+
+
+# ---------------------------------------------------------------------------------------
+def gen_bank():
+    for k in (5, 28):
+        for R in (4, 8, 16):
+            for Cin in (1, 3):
+                torch.manual_seed(k * 100 + R * 10 + Cin)
+                gc = models.GroupConv(Cin, 3, k, padding=0, input_rot_dim=1, output_rot_dim=R)
+                tw = gc.trans_filter('cpu')
+                gup = torch.randn_like(tw)
+                (tw * gup).sum().backward()
+                save(f'bank_k{k}_R{R}_Cin{Cin}', weight=gc.weight, bank=tw, gbank=gup,
+                     gweight=gc.weight.grad)
+
+
+def gen_groupconv():
+    torch.manual_seed(7)
+    gc = models.GroupConv(1, 8, 28, padding=8, input_rot_dim=1, output_rot_dim=8)
+    y = torch.rand(2, 1, 28, 28)
+    out = gc(y, 'cpu')
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    save('groupconv_fwd_bwd', y=y, weight=gc.weight, bias=gc.bias, out=out, gout=gout,
+         gweight=gc.weight.grad, gbias=gc.bias.grad)
+    # 3 input channels, odd kernel, R=4
+    torch.manual_seed(8)
+    gc = models.GroupConv(3, 4, 9, padding=3, input_rot_dim=1, output_rot_dim=4)
+    y = torch.rand(3, 3, 12, 12)
+    out = gc(y, 'cpu')
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    save('groupconv_cin3_k9_R4', y=y, weight=gc.weight, bias=gc.bias, out=out, gout=gout,
+         gweight=gc.weight.grad, gbias=gc.bias.grad)
+
+
+def _enc(n, cin, zd, C, k, p, R, refine, theta_prior, normal, seed, scale_heads=1.0):
+    torch.manual_seed(seed)
+    enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, cin, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R,
+        rot_refinement=refine, theta_prior=theta_prior, normal_prior_over_r=normal)
+    if scale_heads != 1.0:
+        with torch.no_grad():
+            for nm in ('conv_a', 'conv_r', 'conv_z'):
+                getattr(enc, nm).weight.mul_(scale_heads)
+    return enc
+
+
+def gen_encoder():
+    cases = [
+        ('encoder_P8_28', dict(n=28, cin=1, zd=2, C=128, k=28, p=8, R=8, refine=True,
+                               theta_prior=np.pi, normal=False, seed=0), 2, 'rand'),
+        ('encoder_P16_28_normal', dict(n=28, cin=1, zd=2, C=16, k=28, p=8, R=16, refine=True,
+                                       theta_prior=np.pi / 4, normal=True, seed=1,
+                                       scale_heads=20.0), 3, 'rand'),
+        ('encoder_P4_20_norefine', dict(n=20, cin=1, zd=3, C=16, k=20, p=4, R=4, refine=False,
+                                        theta_prior=np.pi, normal=False, seed=2,
+                                        scale_heads=20.0), 2, 'randn'),
+        ('encoder_P8_64', dict(n=64, cin=1, zd=2, C=16, k=64, p=16, R=8, refine=True,
+                               theta_prior=np.pi, normal=False, seed=3, scale_heads=10.0), 2, 'randn'),
+    ]
+    for name, kw, B, data in cases:
+        enc = _enc(**kw)
+        torch.manual_seed(100)
+        y = torch.rand(B, kw['cin'], kw['n'], kw['n']) if data == 'rand' else \
+            torch.randn(B, kw['cin'], kw['n'], kw['n'])
+        Ho = kw['n'] + 2 * kw['p'] - kw['k'] + 1
+        P = kw['R'] * Ho * Ho
+        E, _, _ = draw_noise(123, B, P, kw['zd'])
+        torch.manual_seed(123)
+        attn, q, p_r, a_s, offs, theta, z = enc(y, 'cpu')
+        # scalar probe for gradients through every differentiable output
+        torch.manual_seed(5)
+        w_q, w_a, w_t, w_z = (torch.randn_like(q), torch.randn_like(a_s), torch.randn_like(theta),
+                              torch.randn_like(z))
+        probe = (q * w_q).sum() + (a_s * w_a).sum() * 50 + (theta * w_t).sum() + (z * w_z).sum() \
+            + (attn * w_q).sum() * 0.5
+        probe.backward()
+        out = dict(y=y, E=E, attn=attn, q_t_r=q, p_r=p_r, a_sampled=a_s, offsets=offs, theta=theta,
+                   z=z, w_q=w_q, w_a=w_a, w_t=w_t, w_z=w_z,
+                   cfg=np.array([kw['n'], kw['cin'], kw['zd'], kw['C'], kw['k'], kw['p'], kw['R'],
+                                 int(kw['refine']), int(kw['normal'])]),
+                   theta_prior=np.float64(kw['theta_prior']))
+        for k_, v in enc.state_dict().items():
+            out['p.' + k_] = v
+        for k_, v in enc.named_parameters():
+            out['g.' + k_] = v.grad
+        save(name, **out)
+
+
+def gen_decoder():
+    cases = [
+        ('decoder_plain', dict(latent_dim=2, hidden_dim=64, n_out=1, num_layers=2), 2, 64),
+        ('decoder_plain512', dict(latent_dim=2, hidden_dim=512, n_out=1, num_layers=2), 2, 49),
+        ('decoder_fourier', dict(latent_dim=2, hidden_dim=64, n_out=1, num_layers=2,
+                                 fourier_expansion=True, sigma=2.0 / 27), 2, 100),
+        ('decoder_resid', dict(latent_dim=3, hidden_dim=64, n_out=1, num_layers=3, resid=True), 2, 64),
+        ('decoder_nout2', dict(latent_dim=2, hidden_dim=64, n_out=2, num_layers=2), 2, 64),
+        ('decoder_nout3_z50_L4', dict(latent_dim=50, hidden_dim=64, n_out=3, num_layers=4,
+                                      fourier_expansion=True, sigma=2.0 / 31), 2, 81),
+        ('decoder_z0_L1', dict(latent_dim=0, hidden_dim=64, n_out=1, num_layers=1), 2, 36),
+    ]
+    for name, kw, B, N in cases:
+        torch.manual_seed(11)
+        gen = models.SpatialGenerator(**kw)
+        torch.manual_seed(12)
+        x = (torch.rand(B, N, 2) * 2 - 1).requires_grad_(True)
+        z = torch.randn(B, max(kw['latent_dim'], 1)).requires_grad_(True) if kw['latent_dim'] > 0 else None
+        yh = gen(x, z)
+        gy = torch.randn_like(yh)
+        (yh * gy).sum().backward()
+        out = dict(x=x, y_hat=yh, gy=gy, gx=x.grad,
+                   cfg=np.array([kw['latent_dim'], kw['hidden_dim'], kw['n_out'], kw['num_layers'],
+                                 int(kw.get('resid', False)), int(kw.get('fourier_expansion', False))]),
+                   sigma=np.float64(kw.get('sigma', 0.0)))
+        if z is not None:
+            out['z'] = z
+            out['gz'] = z.grad
+        for k_, v in gen.state_dict().items():
+            out['p.' + k_] = v
+        for k_, v in gen.named_parameters():
+            out['g.' + k_] = v.grad
+        save(name, **out)
+
+
+def _step_case(name, tm, *, n, cin, zd, C, k, p, R, r_inf, dataset_normal, hidden, layers, n_out,
+               fourier, resid, B, data, scale_heads, particles=False, seed=0):
+    torch.manual_seed(seed)
+    sigma = 2.0 / (n - 1)
+    gen = models.SpatialGenerator(zd, hidden, n_out=n_out, num_layers=layers, resid=resid,
+                                  fourier_expansion=fourier, sigma=sigma)
+    theta_prior = np.pi / 4 if dataset_normal else np.pi
+    enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, cin, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R,
+        rot_refinement=(r_inf == 'attention+offsets'), theta_prior=theta_prior,
+        normal_prior_over_r=dataset_normal)
+    if scale_heads != 1.0:
+        with torch.no_grad():
+            for nm in ('conv_a', 'conv_r', 'conv_z'):
+                getattr(enc, nm).weight.mul_(scale_heads)
+    torch.manual_seed(0)
+    y = torch.rand(B, cin, n, n) if data == 'rand' else torch.randn(B, cin, n, n)
+    x_coord = coords(n)
+    Ho = n + 2 * p - k + 1
+    P = R * Ho * Ho
+    E, eps_z, eps_t = draw_noise(123, B, P, zd)
+    torch.manual_seed(123)
+    if particles:
+        elbo, logp, kl = tm.eval_minibatch(x_coord, y, None, gen, enc, 'attention', r_inf, 0, 'cpu',
+                                           theta_prior, R, p, 0)
+    else:
+        elbo, logp, kl = tm.eval_minibatch(x_coord, y, gen, enc, 'attention', r_inf, 0, 'cpu',
+                                           theta_prior, R, n)
+    (-elbo).backward()
+    out = dict(y=y, E=E, eps_z=eps_z, eps_theta=eps_t, elbo=elbo, log_p=logp, kl=kl,
+               cfg=np.array([n, cin, zd, C, k, p, R, int(r_inf == 'attention+offsets'),
+                             int(dataset_normal), hidden, layers, n_out, int(fourier), int(resid)]),
+               theta_prior=np.float64(theta_prior), sigma=np.float64(sigma))
+    for k_, v in enc.state_dict().items():
+        out['e.' + k_] = v
+    for k_, v in gen.state_dict().items():
+        out['d.' + k_] = v
+    for k_, v in enc.named_parameters():
+        out['ge.' + k_] = v.grad
+    for k_, v in gen.named_parameters():
+        out['gd.' + k_] = v.grad
+    save(name, **out)
+    print('   ', name, 'elbo', float(elbo), 'log_p', float(logp), 'kl', float(kl), elbo.dtype, logp.dtype)
+
+
+def gen_steps():
+    common = dict(hidden=512, layers=2, n_out=1, fourier=False, resid=False)
+    _step_case('step_mnist28_P8_init', train_mnist, n=28, cin=1, zd=2, C=128, k=28, p=8, R=8,
+               r_inf='attention+offsets', dataset_normal=False, B=4, data='rand', scale_heads=1.0, **common)
+    _step_case('step_mnist28_P8_peaked', train_mnist, n=28, cin=1, zd=2, C=32, k=28, p=8, R=8,
+               r_inf='attention+offsets', dataset_normal=False, B=4, data='rand', scale_heads=25.0,
+               hidden=128, layers=2, n_out=1, fourier=False, resid=False)
+    _step_case('step_mnist28_P16_fourier_normal', train_mnist, n=28, cin=1, zd=2, C=16, k=28, p=8, R=16,
+               r_inf='attention+offsets', dataset_normal=True, B=3, data='rand', scale_heads=25.0,
+               hidden=64, layers=2, n_out=1, fourier=True, resid=False)
+    _step_case('step_mnist28_P4_attention_resid', train_mnist, n=28, cin=1, zd=3, C=16, k=28, p=8, R=4,
+               r_inf='attention', dataset_normal=False, B=3, data='rand', scale_heads=25.0,
+               hidden=64, layers=3, n_out=1, fourier=False, resid=True)
+    _step_case('step_particles64_P8', train_particles, n=64, cin=1, zd=2, C=32, k=64, p=16, R=8,
+               r_inf='attention+offsets', dataset_normal=False, B=2, data='randn', scale_heads=10.0,
+               hidden=128, layers=2, n_out=1, fourier=False, resid=False, particles=True)
+    _step_case('step_particles32_fitnoise', train_particles, n=32, cin=1, zd=2, C=16, k=32, p=8, R=8,
+               r_inf='attention+offsets', dataset_normal=False, B=2, data='randn', scale_heads=10.0,
+               hidden=64, layers=2, n_out=2, fourier=False, resid=False, particles=True)
+    _step_case('step_galaxy_small', train_galaxy, n=32, cin=3, zd=50, C=16, k=16, p=8, R=16,
+               r_inf='attention+offsets', dataset_normal=False, B=2, data='rand', scale_heads=10.0,
+               hidden=64, layers=4, n_out=3, fourier=True, resid=False)
+
+
+def gen_epoch():
+    """train_epoch over 2 minibatches (train_mnist.py:300-346): running means + post-Adam params."""
+    torch.manual_seed(0)
+    n, zd, C, R, p, k = 28, 2, 16, 8, 8, 28
+    gen = models.SpatialGenerator(zd, 64, num_layers=2)
+    enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 1, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False)
+    torch.manual_seed(0)
+    data = torch.rand(8, 1, n, n)
+    x_coord = coords(n)
+    params = list(gen.parameters()) + list(enc.parameters())
+    optim = torch.optim.Adam(params, lr=2e-4)
+    Ho = n + 2 * p - k + 1
+    P = R * Ho * Ho
+    init = {('e.' + k_): v.clone() for k_, v in enc.state_dict().items()}
+    init.update({('d.' + k_): v.clone() for k_, v in gen.state_dict().items()})
+    # noise for the two steps, drawn back-to-back from one seeded stream like the reference does
+    torch.manual_seed(321)
+    noises = []
+    for _ in range(2):
+        E = torch.empty(4, P).exponential_()
+        ez = torch.normal(torch.zeros(4, zd, 1), torch.ones(4, zd, 1)).view(4, zd)
+        et = torch.normal(torch.zeros(4, 1, 1), torch.ones(4, 1, 1)).view(4)
+        noises.append((E, ez, et))
+    it = [(data[0:4],), (data[4:8],)]
+    torch.manual_seed(321)
+    elbo, err, kl = train_mnist.train_epoch(it, x_coord, gen, enc, optim, 'attention', 'attention+offsets',
+                                            0, 1, 8, 'cpu', params, np.pi, R, n)
+    out = dict(data=data, elbo=np.float64(elbo), err=np.float64(err), kl=np.float64(kl),
+               cfg=np.array([n, 1, zd, C, k, p, R, 1, 0, 64, 2, 1, 0, 0]),
+               theta_prior=np.float64(np.pi), sigma=np.float64(2.0 / (n - 1)))
+    for i, (E, ez, et) in enumerate(noises):
+        out[f'E{i}'], out[f'eps_z{i}'], out[f'eps_theta{i}'] = E, ez, et
+    out.update(init)
+    for k_, v in enc.state_dict().items():
+        out['e1.' + k_] = v
+    for k_, v in gen.state_dict().items():
+        out['d1.' + k_] = v
+    save('epoch_2steps', **out)
+    print('    epoch', elbo, err, kl)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch']
+    for w in which:
+        {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
+         'steps': gen_steps, 'epoch': gen_epoch}[w]()

@@ -1,0 +1,166 @@
+"""Pin the CPU oracle (oracle/tvae_oracle.py) against fixtures generated from the real reference
+(tests/golden/make_goldens.py).  CPU-only; runs under `-m "not gpu"`."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_grad_close, load_golden, rel_err, tdict
+from oracle import tvae_oracle as O
+
+TOL = 2e-5   # oracle restates the same ATen CPU ops; only summation order differs
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'bank_*.npz'))))
+def test_bank(path):
+    fx = load_golden(os.path.basename(path)[:-4])
+    w = torch.from_numpy(fx['weight']).requires_grad_(True)
+    R = fx['bank'].shape[1]
+    tw = O.rotated_bank(w, R)
+    assert rel_err(tw, fx["bank"]) < 1e-5
+    (tw * torch.from_numpy(fx['gbank'])).sum().backward()
+    assert rel_err(w.grad, fx["gweight"]) < 1e-5
+
+
+def test_bank_known_answers():
+    """r=0 is the identity and r=R/4 is rot90(w,-1) (property ii)."""
+    torch.manual_seed(0)
+    w = torch.randn(2, 1, 1, 12, 12)
+    tw = O.rotated_bank(w, 8)
+    assert rel_err(tw[:, 0], w) < 1e-6
+    assert rel_err(tw[:, 2], torch.rot90(w, -1, dims=(3, 4))) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['groupconv_fwd_bwd', 'groupconv_cin3_k9_R4'])
+def test_groupconv(name):
+    fx = load_golden(name)
+    w = torch.from_numpy(fx['weight']).requires_grad_(True)
+    b = torch.from_numpy(fx['bias']).requires_grad_(True)
+    R = fx['out'].shape[2]
+    n, k, Ho = fx['y'].shape[-1], fx['weight'].shape[-1], fx['out'].shape[-1]
+    pad = (Ho - 1 + k - n) // 2
+    out = O.groupconv_forward(torch.from_numpy(fx['y']), w, b, R, pad)
+    assert rel_err(out, fx['out']) < TOL
+    (out * torch.from_numpy(fx['gout'])).sum().backward()
+    assert rel_err(w.grad, fx['gweight']) < TOL
+    assert rel_err(b.grad, fx['gbias']) < TOL
+
+
+def test_groupconv_rot90_equivariance():
+    """gc(rot90(y)) == rot90(roll(gc(y), -R/4, dim=2)) for even k, symmetric pad (i)."""
+    torch.manual_seed(1)
+    R = 8
+    w = torch.randn(3, 1, 1, 12, 12) * 0.1
+    y = torch.rand(2, 1, 12, 12)
+    a = O.groupconv_forward(torch.rot90(y, 1, dims=(2, 3)), w, None, R, 4)
+    b = torch.rot90(torch.roll(O.groupconv_forward(y, w, None, R, 4), -R // 4, dims=2), 1, dims=(3, 4))
+    assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['encoder_P8_28', 'encoder_P16_28_normal', 'encoder_P4_20_norefine',
+                                  'encoder_P8_64'])
+def test_encoder(name):
+    fx = load_golden(name)
+    n, cin, zd, C, k, p, R, refine, normal = [int(v) for v in fx['cfg']]
+    prm = tdict(fx, 'p.', requires_grad=True)
+    outs = O.encoder_forward(prm, torch.from_numpy(fx['y']), torch.from_numpy(fx['E']), R, p,
+                             bool(refine), float(fx['theta_prior']), bool(normal))
+    attn, q, p_r, a_s, offs, theta, z = outs
+    for got, key in ((attn, 'attn'), (q, 'q_t_r'), (p_r, 'p_r'), (a_s, 'a_sampled'), (offs, 'offsets'),
+                     (theta, 'theta'), (z, 'z')):
+        assert rel_err(got, fx[key]) < TOL, key
+    assert abs(float(torch.exp(q).reshape(q.shape[0], -1).sum(1).max()) - 1) < 1e-5
+    w = {k_: torch.from_numpy(fx[k_]) for k_ in ('w_q', 'w_a', 'w_t', 'w_z')}
+    probe = (q * w['w_q']).sum() + (a_s * w['w_a']).sum() * 50 + (theta * w['w_t']).sum() \
+        + (z * w['w_z']).sum() + (attn * w['w_q']).sum() * 0.5
+    probe.backward()
+    floor = 1e-3 * max(float(np.abs(fx['g.' + k_]).max()) for k_ in prm)
+    for k_, t in prm.items():
+        assert_grad_close(t.grad, fx['g.' + k_], floor=floor, name=k_)
+
+
+@pytest.mark.parametrize('name', ['decoder_plain', 'decoder_plain512', 'decoder_fourier', 'decoder_resid',
+                                  'decoder_nout2', 'decoder_nout3_z50_L4', 'decoder_z0_L1'])
+def test_decoder(name):
+    fx = load_golden(name)
+    zd, hid, n_out, L, resid, fourier = [int(v) for v in fx['cfg']]
+    prm = tdict(fx, 'p.', requires_grad=True)
+    x = torch.from_numpy(fx['x']).requires_grad_(True)
+    z = torch.from_numpy(fx['z']).requires_grad_(True) if zd > 0 else None
+    yh = O.generator_forward(prm, x, z, L, bool(resid), float(fx['sigma']) if fourier else None)
+    assert rel_err(yh, fx['y_hat']) < TOL
+    (yh * torch.from_numpy(fx['gy'])).sum().backward()
+    assert_grad_close(x.grad.reshape(-1, 2), fx['gx'].reshape(-1, 2), name='gx')
+    if zd > 0:
+        assert_grad_close(z.grad, fx['gz'], name='gz')
+    for k_, t in prm.items():
+        if ('g.' + k_) in fx:
+            assert_grad_close(t.grad, fx['g.' + k_], name=k_)
+
+
+STEP_LIK = {'step_mnist28_P8_init': 'bce', 'step_mnist28_P8_peaked': 'bce',
+            'step_mnist28_P16_fourier_normal': 'bce', 'step_mnist28_P4_attention_resid': 'bce',
+            'step_particles64_P8': 'gauss', 'step_particles32_fitnoise': 'gauss_var',
+            'step_galaxy_small': 'bce3'}
+
+
+def step_cfg(fx):
+    n, cin, zd, C, k, p, R, refine, normal, hid, L, n_out, fourier, resid = [int(v) for v in fx['cfg']]
+    return dict(R=R, padding=p, rot_refinement=bool(refine), theta_prior=float(fx['theta_prior']),
+                normal_prior_over_r=bool(normal), num_layers=L, resid=bool(resid),
+                fourier_sigma=float(fx['sigma']) if fourier else None), n
+
+
+@pytest.mark.parametrize('name', sorted(STEP_LIK))
+def test_step(name):
+    fx = load_golden(name)
+    cfg, n = step_cfg(fx)
+    enc = tdict(fx, 'e.', requires_grad=True)
+    gen = tdict(fx, 'd.', requires_grad=True)
+    elbo, logp, kl = O.elbo_step(O.image_coords(n), torch.from_numpy(fx['y']), enc, gen,
+                                 likelihood=STEP_LIK[name], E=torch.from_numpy(fx['E']),
+                                 eps_z=torch.from_numpy(fx['eps_z']),
+                                 eps_theta=torch.from_numpy(fx['eps_theta']), **cfg)
+    assert elbo.dtype == torch.float64 and kl.dtype == torch.float64 and logp.dtype == torch.float32
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < 1e-6
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < 1e-6
+    assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < 1e-5
+    (-elbo).backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.items():
+        assert_grad_close(t.grad, fx['ge.' + k_], floor=floor, name=k_)
+    for k_, t in gen.items():
+        if ('gd.' + k_) in fx:
+            assert_grad_close(t.grad, fx['gd.' + k_], name=k_)
+
+
+def test_epoch_two_steps():
+    """train_epoch (train_mnist.py:300-346): running means and post-Adam parameters."""
+    fx = load_golden('epoch_2steps')
+    cfg, n = step_cfg(fx)
+    enc = tdict(fx, 'e.', requires_grad=True)
+    gen = tdict(fx, 'd.', requires_grad=True)
+    st = O.new_opt_state(enc, gen)
+    data = torch.from_numpy(fx['data'])
+    c = 0
+    acc = [0.0, 0.0, 0.0]
+    for i in range(2):
+        noise = dict(E=torch.from_numpy(fx[f'E{i}']), eps_z=torch.from_numpy(fx[f'eps_z{i}']),
+                     eps_theta=torch.from_numpy(fx[f'eps_theta{i}']))
+        e, lp, kl = O.train_step(O.image_coords(n), data[4 * i:4 * i + 4], enc, gen, st, noise,
+                                 likelihood='bce', **cfg)
+        c += 4
+        for j, v in enumerate((e, -lp, kl)):
+            acc[j] += 4 * (v - acc[j]) / c
+    assert abs(acc[0] - float(fx['elbo'])) / abs(float(fx['elbo'])) < 1e-6
+    assert abs(acc[1] - float(fx['err'])) / abs(float(fx['err'])) < 1e-6
+    assert abs(acc[2] - float(fx['kl'])) / abs(float(fx['kl'])) < 1e-5
+    for k_, t in enc.items():
+        if k_ == 'conv_a.bias':   # analytic grad is 0 (softmax shift invariance): Adam follows rounding noise
+            assert (t - torch.from_numpy(fx['e1.' + k_])).abs().max() <= 2 * 2e-4 * 2 + 1e-7
+            continue
+        assert rel_err(t, fx['e1.' + k_]) < 1e-5, k_
+    for k_, t in gen.items():
+        assert rel_err(t, fx['d1.' + k_]) < 1e-5, k_
