@@ -1,0 +1,124 @@
+/* tvae_hip.h -- C ABI of libtvae_hip.so: the MI355X (gfx950) kernels of the TARGET-VAE training hot path.
+ *
+ * The reference (SMLC-NYSBC/TARGET-VAE) is pure Python on PyTorch and has no FFI of its own; every entry
+ * point below replaces a group of ATen call sites of the reference hot path (file:line cited per function,
+ * paths relative to the reference root).  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32 (or int32 where stated);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing allocates, frees or
+ *     synchronises (graph-capturable); workspaces are provided by the caller;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch;
+ *   - activations are FEATURE-MAJOR: X[feature][column] with column = image*positions + position
+ *     contiguous (ld = leading dimension in floats).  "act" codes: 0 none, 1 LeakyReLU(slope), 2 tanh.
+ */
+#ifndef TVAE_HIP_H
+#define TVAE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tvae_stream_t;
+
+int tvae_abi_version(void);
+
+/* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
+ * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
+ * rotations (idx < 0 = outside, zero padding).  bwd applies the transposed operator through a CSR table
+ * (csr_ptr [k*k+1], entries r / dst / w), writing (or accumulating into) dweight. */
+int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
+                         int ksz, int R, tvae_stream_t stream);
+int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_r, const int* csr_dst,
+                         const float* csr_w, float* dweight, int C, int Cin, int ksz, int R, int accumulate,
+                         tvae_stream_t stream);
+
+/* ---- lifting convolution: GroupConv.forward, src/models.py:202-225 (F.conv2d + bias) fused with the following
+ * activation (models.py:355).  y [B][Cin][n][n]; bank [C*R][Cin*k*k]; bias [C] (may be NULL);
+ * out feature-major [C][B][R][Ho*Ho] (ld = B*R*Ho*Ho), Ho = n + 2*pad - k + 1, stride 1. */
+int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
+                   int pad, int C, int R, int act, float slope, tvae_stream_t stream);
+/* weight gradient of the same convolution (autograd of F.conv2d, models.py:215): dbank [C*R][Cin*k*k] =
+ * sum over (img, position) of dpre[c][img][r][p] * window(y).  dpre is the PRE-activation gradient in the layout
+ * of `out`.  ws: split-K workspace of ws_floats floats (>= 2*C*R*Cin*k*k recommended; fewer disables split-K). */
+int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, int B, int Cin,
+                     int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
+
+/* ---- dense layers (nn.Conv3d(.,.,1) src/models.py:347-351,356-358,390-392; nn.Linear src/models.py:107-121) ----
+ * fwd:   Y[M][N] = act( W[M][K] X[K][N] + bias[m] + gbias[(n/group)][m] + res[m][n] )   (NULL terms skipped)
+ * dgrad: dX[K][N] = ( W^T dpre[M][N] + add[K][N] ) * act'(aux[K][N])   (mask code as act; aux = saved output)
+ * wgrad: dW[M][K] (+)= sum_n dpre[M][n] X[K][n]      (split-K through ws) */
+int tvae_linear_fwd(const float* W, const float* X, const float* bias, const float* gbias, int group,
+                    const float* res, float* Y, int M, int N, int K, long ldx, long ldy, int act, float slope,
+                    tvae_stream_t stream);
+int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const float* aux, float* dX, int M, int N,
+                      int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream);
+int tvae_linear_wgrad(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
+                      long ldd, long ldx, int accumulate, tvae_stream_t stream);
+
+/* ---- reductions / skinny products used by bias grads, coordinate layer, last decoder layer ----
+ * rowdot_seg: out[seg][m][o] = sum_{n in seg} X[m][n] * V[n][o]   (V NULL -> ones, no = 1; no in {1,2,3,4})
+ * seg_sum:    out[i] (+)= scale * sum_s in[s][i]
+ * coldot:     out[n][o] = b[o] + sum_m W[m*wsm + o*wso] X[m][n]
+ * outer_mask: D[m][n] = (sum_o W[m*wsm + o*wso] dy[n][o]) * act'(H[m][n])
+ * act_bwd:    dpre[i] = dY[i] * act'(Y[i]) */
+int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out,
+                    tvae_stream_t stream);
+int tvae_seg_sum(const float* in, int S, long L, float* out, float scale, int accumulate, tvae_stream_t stream);
+int tvae_coldot(const float* X, long ldx, int M, int N, const float* W, int wsm, int wso, const float* bias, int no,
+                float* out, tvae_stream_t stream);
+int tvae_outer_mask(const float* dy, int no, const float* W, int wsm, int wso, const float* H, long ldh, float* D,
+                    long ldd, int M, int N, int act, float slope, tvae_stream_t stream);
+int tvae_act_bwd(const float* dY, const float* Y, float* dpre, long n, int act, float slope, tvae_stream_t stream);
+
+/* ---- attention head: src/models.py:358-401 (prior add, log_softmax, gumbel_softmax, offsets) fused with the
+ * pooling / sampling / KL block of eval_minibatch, train_mnist.py:192-231,242-282.
+ * heads [3+2*zd][ldh] rows: 0 logit, 1 theta_mu, 2 theta_logstd, 3.. z_mu, 3+zd.. z_logstd (column = img*R*P + j).
+ * E [B][R*P] Exp(1) noise, eps_z [B][zd], eps_t [B]; tables p_r [R], off [R], p_tr [R*P], grid [P][2].
+ * Outputs: attn, q (log-softmax), a (Gumbel-softmax sample) [B][R*P]; z [B][zd]; theta [B]; dx [B][2]; kl [B]. */
+int tvae_attn_head_fwd(const float* heads, long ldh, const float* E, const float* eps_z, const float* eps_t,
+                       const float* p_r, const float* off, const float* p_tr, const float* grid, int B, int R, int P,
+                       int zd, float sigma_p, float theta_off_scale, float* attn, float* q, float* a, float* z,
+                       float* theta, float* dx, float* kl, tvae_stream_t stream);
+/* upstream gz [B][zd], gth [B], gdx [B][2], gkl [B]; optional g_attn/g_q/g_a [B][R*P] (NULL = zero) -> dheads */
+int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float* a, const float* eps_z,
+                       const float* eps_t, const float* p_r, const float* off, const float* p_tr, const float* grid,
+                       int B, int R, int P, int zd, float sigma_p, float theta_off_scale, const float* gz,
+                       const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
+                       const float* g_a, float* dheads, tvae_stream_t stream);
+
+/* ---- coordinate transform: train_mnist.py:222,234-239.  xc [Np][2], dx [B][2], theta [B] -> xr [B][Np][2] ---- */
+int tvae_coord_fwd(const float* xc, const float* dx, const float* theta, float* xr, int B, int Np,
+                   tvae_stream_t stream);
+int tvae_coord_bwd(const float* xc, const float* dx, const float* theta, const float* gxr, float* gdx, float* gtheta,
+                   int B, int Np, tvae_stream_t stream);
+
+/* ---- spatial decoder ends: src/models.py:95-123 ----
+ * dec_l0_fwd:  h[f][pix] = act(Wc[f][0] x0 + Wc[f][1] x1 + bc[f] + LB[img][f])      (coord_linear, in_dim = 2)
+ * latent_bias: LB[img][f] = sum_d Wl[f][d] z[img][d]                                 (latent_linear, models.py:111-116)
+ * latent_bwd:  from S[img][f] = sum_pix dpre0[f][pix]: dWl[f][d], dz[img][d]
+ * fourier_fwd: feat[f][pix] = cos((Wf[f]/sigma) . x + bf[f])                         (models.py:53-58)
+ * fourier_bwd: gxr[pix][j] = sum_f -sin(arg) (Wf[f][j]/sigma) dfeat[f][pix] */
+int tvae_dec_l0_fwd(const float* xr, const float* Wc, const float* bc, const float* LB, float* h, long ldh, int F,
+                    long Ntot, int Np, int act, float slope, tvae_stream_t stream);
+int tvae_latent_bias(const float* Wl, const float* z, float* LB, int B, int F, int zd, tvae_stream_t stream);
+int tvae_latent_bwd(const float* S, const float* Wl, const float* z, float* dWl, float* dz, int B, int F, int zd,
+                    tvae_stream_t stream);
+int tvae_fourier_fwd(const float* xr, const float* Wf, const float* bf, float sigma, float* feat, long ld, int F,
+                     long Ntot, tvae_stream_t stream);
+int tvae_fourier_bwd(const float* xr, const float* Wf, const float* bf, float sigma, const float* dfeat, long ld,
+                     int F, long Ntot, float* gxr, tvae_stream_t stream);
+
+/* ---- likelihoods over flat per-image vectors: kind 0 BCE-with-logits (train_mnist.py:288-291,
+ * train_galaxy.py:288-292), 1 Gaussian (train_particles.py:338), 2 Gaussian with learned log-variance
+ * (train_particles.py:293-296,336; mu = yh[i], logvar = yh[L+i]).  lp [B] = per-image log-likelihood. */
+int tvae_loglik_fwd(const float* yh, const float* y, float* lp, int B, int L, int kind, tvae_stream_t stream);
+int tvae_loglik_bwd(const float* yh, const float* y, const float* glp, float* gyh, int B, int L, int kind,
+                    tvae_stream_t stream);
+
+/* ---- fused Adam over the flat parameter buffer: torch.optim.Adam defaults, train_mnist.py:579,323 ----
+ * bc1 = 1 - b1^t, bc2_sqrt = sqrt(1 - b2^t) computed by the host; grad_scale folds the DP average. */
+int tvae_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                   float bc1, float bc2_sqrt, float grad_scale, tvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVAE_HIP_H */

@@ -257,6 +257,27 @@ def elbo_step(x_coord: Tensor, y: Tensor, enc: Dict[str, Tensor], gen: Dict[str,
     x = x_coord.expand(b, x_coord.shape[0], x_coord.shape[1])                           # :31
     attn, q_t_r, p_r, a_s, offsets, theta_vals, z_vals = encoder_forward(
         enc, y, E, R, padding, rot_refinement, theta_prior, normal_prior_over_r)        # :190
+    z, theta, dx, x, kl_per_image = posterior_pool_kl(x, attn, q_t_r, p_r, a_s, offsets, theta_vals, z_vals,
+                                                      float(spacing), eps_z, eps_theta, R, theta_prior)
+    kl_div = kl_per_image.mean()                                                        # :281-282
+
+    y_hat = generator_forward(gen, x.contiguous(), z, num_layers, resid, fourier_sigma)  # :287
+    log_p = likelihood_logp(y_hat, y, likelihood)
+    elbo = log_p - kl_div
+    if return_aux:
+        aux = dict(attn=attn, q_t_r=q_t_r, a_sampled=a_s, theta_vals=theta_vals, z_vals=z_vals,
+                   z=z, theta=theta, dx=dx.view(b, 2), x_rot=x, y_hat=y_hat,
+                   kl_per_image=kl_per_image)
+        return elbo, log_p, kl_div, aux
+    return elbo, log_p, kl_div
+
+
+def posterior_pool_kl(x, attn, q_t_r, p_r, a_s, offsets, theta_vals, z_vals, spacing, eps_z, eps_theta, R,
+                      theta_prior=np.pi):
+    """Pooling, sampling, coordinate transform and KL of eval_minibatch (train_mnist.py:192-282), given the
+    encoder 7-tuple.  x (b,N,2) expanded coordinates.  Returns z (b,zd), theta (b,), dx (b,1,2), rotated
+    coordinates (b,N,2) and the per-image KL (float64, b)."""
+    b = attn.shape[0]
     Ho = attn.shape[3]
     a_over_locs = a_s.sum(dim=1).view(b, -1, 1)                                         # :192
     a_flat = a_s.reshape(b, -1).unsqueeze(2)                                            # :193
@@ -302,17 +323,8 @@ def elbo_step(x_coord: Tensor, y: Tensor, enc: Dict[str, Tensor], gen: Dict[str,
     t1 = ((th_mu4 - off) / sp_t) ** 2
     kl_theta = 0.5 * (var_ratio + t1 - 1.0 - torch.log(var_ratio))                      # :274-276
     val2 = (torch.exp(q_t_r) * (kl_theta + kl_z)).view(b, -1).sum(1)                    # :278-279
-    kl_div = (val1 + val2).mean()                                                       # :281-282
 
-    y_hat = generator_forward(gen, x.contiguous(), z, num_layers, resid, fourier_sigma)  # :287
-    log_p = likelihood_logp(y_hat, y, likelihood)
-    elbo = log_p - kl_div
-    if return_aux:
-        aux = dict(attn=attn, q_t_r=q_t_r, a_sampled=a_s, theta_vals=theta_vals, z_vals=z_vals,
-                   z=z, theta=theta, dx=dx.view(b, 2), x_rot=x, y_hat=y_hat,
-                   kl_per_image=(val1 + val2))
-        return elbo, log_p, kl_div, aux
-    return elbo, log_p, kl_div
+    return z, theta, dx, x, val1 + val2
 
 
 def likelihood_logp(y_hat: Tensor, y: Tensor, kind: str) -> Tensor:

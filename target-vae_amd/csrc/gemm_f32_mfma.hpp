@@ -1,0 +1,396 @@
+// f32-in / f32-accumulate MFMA GEMM core for gfx950 (MI355X), with pluggable operand loaders.
+//
+//   C[m][n] = epilogue( sum_k A(m,k) * B(k,n) )          m<M (feature rows), n<N (positions / pixels)
+//
+// All activations of the TARGET-VAE hot path are kept "feature-major": [feature][batch*position]
+// with the position index contiguous, so every layer is W[M][K] * X[K][N] and the MFMA D tile
+// (lane = column) stores 128-B coalesced row segments.  The same core serves
+//   * conv1 forward  (B operand = implicit im2col window of the zero-padded image)
+//   * conv1 wgrad    (A = dY gathered [cr][(img,p)], B = implicit window, reduction over img*p)
+//   * 1x1x1 conv / linear layers: fwd, dgrad (A col-major), wgrad (both operands k-contiguous).
+//
+// Tile: 128x128x16 per 256-thread workgroup, 2x2 waves, each wave 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 cycles/instr, 157 TF peak).  Operands are
+// staged global -> registers -> LDS (double buffered, one barrier per k-step); LDS tiles are
+// k-major  S[k][x]  with a 132-float row so that
+//   * MFMA fragment reads (32 consecutive x at fixed k) are conflict-free ds_read_b32,
+//   * both staging mappings below write with at most 2-way conflicts (free for ds_write_b32).
+//
+// Operand lane maps (cdna_hip_programming.md section 3): for 32x32x2f32 lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D: col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int BK = 16;
+constexpr int GEMM_THREADS = 256;
+constexpr int LDS_LD = 132;
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2 };
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------
+// Epilogue: bias / per-image bias / residual / activation / activation-derivative mask / store
+// ------------------------------------------------------------------------------------------
+struct Epilogue {
+    float* C = nullptr;
+    long ldc = 0;
+    const float* bias = nullptr;   // bias[m >> bias_shift]
+    int bias_shift = 0;
+    const float* gbias = nullptr;  // gbias[(n / group) * ldg + m]   (per-image latent term)
+    long ldg = 0;
+    int group = 1;
+    const float* res = nullptr;    // res[m*ldres + n] added before act / mask
+    long ldres = 0;
+    const float* aux = nullptr;    // aux[m*ldaux + n]: saved activation whose derivative masks the result
+    long ldaux = 0;
+    int act = ACT_NONE;            // applied to (acc + bias + gbias + res)
+    int mask = ACT_NONE;           // multiply by act'(aux): lrelu -> (aux>0 ? 1 : slope), tanh -> 1-aux^2
+    float slope = 0.01f;
+    int accumulate = 0;            // C += instead of C =
+    // conv1 output remap: column n = img*convP + p, row m = c*convR + r  ->  C[c*ldc + img*convR*convP + r*convP + p]
+    int convR = 0;                 // power of two (reference allows R in {4,8,16})
+    int conv_shift = 0;            // log2(convR)
+    int convP = 0;
+
+    // Column-dependent terms are prepared once per thread (each thread owns one column in the epilogue).
+    struct Col {
+        long coff;             // offset of column n inside a row of C
+        const float* gb;       // gbias row of this column's image (or nullptr)
+    };
+    __device__ __forceinline__ Col prep(int n) const {
+        Col c;
+        if (convP > 0) {
+            const int img = n / convP, p = n - img * convP;
+            c.coff = (long)img * convR * convP + p;
+        } else {
+            c.coff = n;
+        }
+        c.gb = gbias ? gbias + (long)(n / group) * ldg : nullptr;
+        return c;
+    }
+    __device__ __forceinline__ void store(int m, int n, const Col& c, float v) const {
+        float x = v;
+        if (bias) x += bias[m >> bias_shift];
+        if (c.gb) x += c.gb[m];
+        if (res) x += res[(long)m * ldres + n];
+        if (act == ACT_LRELU) x = x > 0.f ? x : x * slope;
+        else if (act == ACT_TANH) x = tanhf(x);
+        if (mask != ACT_NONE) {
+            const float a = aux[(long)m * ldaux + n];
+            x *= (mask == ACT_LRELU) ? (a > 0.f ? 1.f : slope) : (1.f - a * a);
+        }
+        long i;
+        if (convP > 0) i = (long)(m >> conv_shift) * ldc + (long)(m & ((1 << conv_shift) - 1)) * convP + c.coff;
+        else i = (long)m * ldc + c.coff;
+        if (accumulate) C[i] += x; else C[i] = x;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Operand loaders.  Each thread owns 8 elements of a [BK][128] tile.
+//   mapping K ("k fast"):  kk = tid & 15,      x = (tid >> 4) + 16 j      -- for k-contiguous memory
+//   mapping X ("x fast"):  x  = tid & 127,     kk = (tid >> 7) * 8 + j    -- for x-contiguous memory
+// ------------------------------------------------------------------------------------------
+struct LoadKContig {           // element (x, k) at ptr[x*ld + k]
+    const float* ptr; long ld; int X;
+    int x0, kk, xb;
+    __device__ __forceinline__ void init(int x0_, int tid) { x0 = x0_; kk = tid & 15; xb = tid >> 4; }
+    __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
+        const int k = k0 + kk;
+        const bool kok = k < kend;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = x0 + xb + 16 * j;
+            r[j] = (kok && x < X) ? ptr[(long)x * ld + k] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* S, const float (&r)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[kk * LDS_LD + xb + 16 * j] = r[j];
+    }
+};
+
+struct LoadXContig {           // element (x, k) at ptr[k*ld + x]
+    const float* ptr; long ld; int X;
+    int x0, x, kh;
+    __device__ __forceinline__ void init(int x0_, int tid) { x0 = x0_; x = tid & 127; kh = tid >> 7; }
+    __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
+        const bool xok = (x0 + x) < X;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + kh * 8 + j;
+            r[j] = (xok && k < kend) ? ptr[(long)k * ld + x0 + x] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* S, const float (&r)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[(kh * 8 + j) * LDS_LD + x] = r[j];
+    }
+};
+
+// Geometry of the lifting convolution (GroupConv.forward, reference src/models.py:202-225).
+struct ConvGeom {
+    int B, Cin, n, ksz, pad, Ho, R;
+    int P;     // Ho*Ho
+    int K2;    // ksz*ksz
+};
+
+// B operand of conv1 forward: element (k = (ci,u,v), col = (img,p)) = ypad[img][ci][h+u][w+v].  Mapping X.
+struct LoadConvPatchFwd {
+    const float* y; ConvGeom g; int Ntot;
+    int x, kh, img, h, w; bool nok;
+    __device__ __forceinline__ void init(int n0, int tid) {
+        x = tid & 127; kh = tid >> 7;
+        const int nn = n0 + x;
+        nok = nn < Ntot;
+        const int nc = nok ? nn : 0;
+        img = nc / g.P;
+        const int p = nc - img * g.P;
+        h = p / g.Ho;
+        w = p - h * g.Ho;
+    }
+    __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
+        int k = k0 + kh * 8;
+        int ci = k / g.K2;
+        int rem = k - ci * g.K2;
+        int u = rem / g.ksz;
+        int v = rem - u * g.ksz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = h + u - g.pad, ix = w + v - g.pad;
+            const bool ok = nok && (k + j) < kend && iy >= 0 && iy < g.n && ix >= 0 && ix < g.n;
+            r[j] = ok ? y[((long)(img * g.Cin + ci) * g.n + iy) * g.n + ix] : 0.f;
+            if (++v == g.ksz) { v = 0; if (++u == g.ksz) { u = 0; ++ci; } }
+        }
+    }
+    __device__ __forceinline__ void store(float* S, const float (&r)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[(kh * 8 + j) * LDS_LD + x] = r[j];
+    }
+};
+
+// B operand of conv1 wgrad: element (kr = (img,p), col = (ci,u,v)) = ypad[img][ci][h+u][w+v].  Mapping X.
+struct LoadConvPatchWgrad {
+    const float* y; ConvGeom g; int Ntot;   // Ntot = Cin*K2
+    int x, kh, ci, u, v; bool nok;
+    __device__ __forceinline__ void init(int n0, int tid) {
+        x = tid & 127; kh = tid >> 7;
+        const int nn = n0 + x;
+        nok = nn < Ntot;
+        const int nc = nok ? nn : 0;
+        ci = nc / g.K2;
+        const int rem = nc - ci * g.K2;
+        u = rem / g.ksz;
+        v = rem - u * g.ksz;
+    }
+    __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
+        int kr = k0 + kh * 8;
+        int img = kr / g.P;
+        int p = kr - img * g.P;
+        int h = p / g.Ho;
+        int w = p - h * g.Ho;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = h + u - g.pad, ix = w + v - g.pad;
+            const bool ok = nok && (kr + j) < kend && iy >= 0 && iy < g.n && ix >= 0 && ix < g.n;
+            r[j] = ok ? y[((long)(img * g.Cin + ci) * g.n + iy) * g.n + ix] : 0.f;
+            if (++w == g.Ho) { w = 0; if (++h == g.Ho) { h = 0; ++img; } }
+        }
+    }
+    __device__ __forceinline__ void store(float* S, const float (&r)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[(kh * 8 + j) * LDS_LD + x] = r[j];
+    }
+};
+
+// A operand of conv1 wgrad: element (row = cr = c*R + r, kr = (img,p)) of the pre-activation gradient stored
+// feature-major [c][img][r][p] (ld = B*R*P).  Mapping K.
+struct LoadConvDY {
+    const float* dy; long ld; int M; int R; int P;
+    int x0, kk, xb;
+    long rowoff[8];
+    __device__ __forceinline__ void init(int x0_, int tid) {
+        x0 = x0_; kk = tid & 15; xb = tid >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = x0 + xb + 16 * j;
+            const int mc = m < M ? m : 0;
+            const int c = mc / R, rr = mc - c * R;
+            rowoff[j] = (long)c * ld + (long)rr * P;
+        }
+    }
+    __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
+        const int kr = k0 + kk;
+        const bool kok = kr < kend;
+        const int krc = kok ? kr : 0;
+        const int img = krc / P;
+        const int p = krc - img * P;
+        const long col = (long)img * R * P + p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = x0 + xb + 16 * j;
+            r[j] = (kok && m < M) ? dy[rowoff[j] + col] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* S, const float (&r)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[kk * LDS_LD + xb + 16 * j] = r[j];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// The kernel.  grid.x = tilesM*tilesN (n fastest, so concurrently running workgroups share the
+// A/weight panel of one m-tile in their XCD's L2), grid.y = split-K slices.
+// With ws != nullptr the raw partial tile is written to ws[split][M][N]; the epilogue then runs in
+// splitk_finalize_kernel (deterministic reduction order).
+// ------------------------------------------------------------------------------------------
+template <class AL, class BL>
+__global__ __launch_bounds__(GEMM_THREADS, 3)
+void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, int tilesN) {
+    __shared__ float lds[2 * 2 * BK * LDS_LD];   // [buf][A|B][BK][LDS_LD]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_n = blockIdx.x % tilesN;
+    const int tile_m = blockIdx.x / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[8], rb[8];
+    al.init(m0, tid);
+    bl.init(n0, tid);
+    if (nk > 0) {
+        al.load(ra, kbeg, kend);
+        bl.load(rb, kbeg, kend);
+        al.store(lds, ra);
+        bl.store(lds + BK * LDS_LD, rb);
+    }
+    __syncthreads();
+
+    const int arow = wm * 64 + (lane & 31);
+    const int bcol = wn * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1) < nk;
+        if (more) {
+            al.load(ra, kbeg + (t + 1) * BK, kend);
+            bl.load(rb, kbeg + (t + 1) * BK, kend);
+        }
+        const float* as = lds + cur * (2 * BK * LDS_LD);
+        const float* bs = as + BK * LDS_LD;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + khalf;
+            const float a0 = as[kk * LDS_LD + arow];
+            const float a1 = as[kk * LDS_LD + arow + 32];
+            const float b0 = bs[kk * LDS_LD + bcol];
+            const float b1 = bs[kk * LDS_LD + bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            float* an = lds + (cur ^ 1) * (2 * BK * LDS_LD);
+            al.store(an, ra);
+            bl.store(an + BK * LDS_LD, rb);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue through LDS (free after the last barrier of the k-loop): two passes of 64 rows x 128 columns.
+    // Accumulator lane map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Reading back one column
+    // per thread gives 512-B coalesced global rows and keeps the bias/activation/mask code out of the unrolled part.
+    float* ct = lds;                       // [64][128] floats = 32 KiB
+    const int ecol = tid & 127;
+    const int n = n0 + ecol;
+    const bool nok = n < N;
+    const Epilogue::Col ecl = ep.prep(nok ? n : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * 128 + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rl = (tid >> 7) + 2 * it;                       // 0..63
+            const int m = m0 + (rl >> 5) * 64 + i * 32 + (rl & 31);
+            if (nok && m < M) {
+                const float v = ct[rl * 128 + ecol];
+                if (ws) ws[((long)split * M + m) * N + n] = v;
+                else ep.store(m, n, ecl, v);
+            }
+        }
+    }
+}
+
+__global__ void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(long)k * total + i];
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        ep.store(m, n, ep.prep(n), s);
+    }
+}
+
+// Host-side launcher.  `splits_wanted` <= 1 means no split-K.  `ws_floats` is the capacity of ws.
+template <class AL, class BL>
+static hipError_t launch_gemm(AL al, BL bl, const Epilogue& ep, int M, int N, int K, int splits_wanted,
+                              float* ws, long ws_floats, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BN);
+    int splits = splits_wanted < 1 ? 1 : splits_wanted;
+    if (splits > 1) {
+        const long per = (long)M * N;
+        const long cap = ws ? ws_floats / per : 0;
+        if (cap < 2) splits = 1; else if (splits > cap) splits = (int)cap;
+        if (splits > 65535) splits = 65535;
+    }
+    int kchunk = cdiv(cdiv(K > 0 ? K : 1, splits), BK) * BK;
+    splits = cdiv(K > 0 ? K : 1, kchunk);
+    dim3 grid((unsigned)(tilesM * tilesN), (unsigned)splits);
+    float* wsp = splits > 1 ? ws : nullptr;
+    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, kchunk,
+                       wsp, tilesN);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (splits > 1) {
+        const long total = (long)M * N;
+        int blocks = cdiv(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, splits, M, N,
+                           ep);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace tvae

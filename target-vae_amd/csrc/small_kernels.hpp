@@ -1,0 +1,565 @@
+// HBM-bound kernels of the TARGET-VAE hot path for gfx950: rotated filter bank, attention head
+// (prior + log-softmax + Gumbel-softmax + expected-value pooling + KL), coordinate transform,
+// first/last decoder layers, likelihoods, segmented row/column reductions, fused Adam.
+//
+// Layout convention (see gemm_f32_mfma.hpp): activations are feature-major [feature][batch*position]
+// with the position index contiguous; every kernel here keeps lanes along the position index so
+// that global accesses are coalesced 256-B wave segments.  Reductions are wave64 shuffles followed
+// by one LDS exchange per workgroup; no float atomics (bitwise reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_f32_mfma.hpp"
+
+namespace tvae {
+
+constexpr float EPS_STD = 1e-6f;      // reference train_mnist.py:197
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Sum NV values over the workgroup; every thread returns with the totals.  sm: >= NV*16 floats.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float s = wave_sum(v[i]);
+        if (lane == 0) sm[i * 16 + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += sm[i * 16 + w];
+        v[i] = s;
+    }
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    const float s = wave_max(v);
+    if (lane == 0) sm[wave] = s;
+    __syncthreads();
+    float m = sm[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, sm[w]);
+    return m;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act, float slope) {
+    if (act == ACT_LRELU) return x > 0.f ? x : x * slope;
+    if (act == ACT_TANH) return tanhf(x);
+    return x;
+}
+__device__ __forceinline__ float act_deriv_from_out(float y, int act, float slope) {
+    if (act == ACT_LRELU) return y > 0.f ? 1.f : slope;
+    if (act == ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Rotated filter bank (reference GroupConv.trans_filter, src/models.py:174-197).
+// The R fixed rotations are a constant sparse interpolation operator: 4 taps per output pixel.
+// bank[(c*R + r)][ci*k2 + d] = sum_t w[r][d][t] * weight[(c*Cin + ci)*k2 + idx[r][d][t]]
+// ------------------------------------------------------------------------------------------
+__global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const int* __restrict__ tap_idx,
+                                       const float* __restrict__ tap_w, float* __restrict__ bank, int C, int Cin,
+                                       int k2, int R) {
+    const long total = (long)C * R * Cin * k2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % k2);
+        long t = i / k2;
+        const int ci = (int)(t % Cin); t /= Cin;
+        const int r = (int)(t % R);
+        const int c = (int)(t / R);
+        const float* wsrc = weight + ((long)c * Cin + ci) * k2;
+        const int* ti = tap_idx + ((long)r * k2 + d) * 4;
+        const float* tw = tap_w + ((long)r * k2 + d) * 4;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = ti[q];
+            if (id >= 0) s += tw[q] * wsrc[id];
+        }
+        bank[i] = s;
+    }
+}
+
+// Transposed operator in gather (CSR) form: deterministic, no atomics.
+// dweight[(c*Cin+ci)*k2 + s] = sum_{e in [ptr[s],ptr[s+1])} w[e] * dbank[(c*R + r[e])][ci*k2 + dst[e]]
+__global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const int* __restrict__ csr_ptr,
+                                       const int* __restrict__ csr_r, const int* __restrict__ csr_dst,
+                                       const float* __restrict__ csr_w, float* __restrict__ dweight, int C, int Cin,
+                                       int k2, int R, int accumulate) {
+    const long total = (long)C * Cin * k2;
+    const long ldb = (long)Cin * k2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % k2);
+        const long t = i / k2;
+        const int ci = (int)(t % Cin);
+        const int c = (int)(t / Cin);
+        float acc = 0.f;
+        for (int e = csr_ptr[s]; e < csr_ptr[s + 1]; ++e)
+            acc += csr_w[e] * dbank[((long)c * R + csr_r[e]) * ldb + (long)ci * k2 + csr_dst[e]];
+        if (accumulate) dweight[i] += acc; else dweight[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Segmented row reductions:  out[seg][m][o] = sum_{n in segment} X[m][n] * V[n][o]   (V == nullptr -> 1, no = 1)
+// grid (M, nseg), block 256.  Used for bias grads, per-image sums, coordinate-layer weight grads.
+// ------------------------------------------------------------------------------------------
+template <int NO>
+__global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ V, int N,
+                                  int seglen, float* __restrict__ out, int M) {
+    __shared__ float sm[NO * 16];
+    const int m = blockIdx.x, seg = blockIdx.y;
+    const int nbeg = seg * seglen;
+    const int nend = min(N, nbeg + seglen);
+    float acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+    const float* xr = X + (long)m * ldx;
+    for (int n = nbeg + threadIdx.x; n < nend; n += blockDim.x) {
+        const float x = xr[n];
+        if (V) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) acc[o] += x * V[(long)n * NO + o];
+        } else {
+            acc[0] += x;
+        }
+    }
+    block_sum<NO>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) out[((long)seg * M + m) * NO + o] = acc[o];
+    }
+}
+
+// out[i] (+)= scale * sum_s in[s*L + i]
+__global__ void seg_sum_kernel(const float* __restrict__ in, int S, long L, float* __restrict__ out, float scale,
+                               int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += in[(long)k * L + i];
+        s *= scale;
+        if (accumulate) out[i] += s; else out[i] = s;
+    }
+}
+
+// Column "dot" with a skinny matrix: out[n*NO + o] = b[o] + sum_m W[m*wsm + o*wso] * X[m*ldx + n]
+// (last decoder layer n_out <= 4; coordinate gradient dx'[pix][2]).  Lanes run along n.
+template <int NO>
+__global__ void coldot_kernel(const float* __restrict__ X, long ldx, int M, int N, const float* __restrict__ W,
+                              int wsm, int wso, const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ float wsh[];   // [M][NO]
+    for (int i = threadIdx.x; i < M * NO; i += blockDim.x) {
+        const int m = i / NO, o = i - m * NO;
+        wsh[i] = W[(long)m * wsm + (long)o * wso];
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = bias ? bias[o] : 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float x = X[(long)m * ldx + n];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] += wsh[m * NO + o] * x;
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[(long)n * NO + o] = acc[o];
+}
+
+// D[m][n] = (sum_o W[m*wsm + o*wso] * dy[n*NO + o]) * act'(H[m][n])      (backward of the last decoder layer)
+template <int NO>
+__global__ void outer_mask_kernel(const float* __restrict__ dy, const float* __restrict__ W, int wsm, int wso,
+                                  const float* __restrict__ H, long ldh, float* __restrict__ D, long ldd, int M, int N,
+                                  int act, float slope) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float g[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) g[o] = dy[(long)n * NO + o];
+    const int mbeg = blockIdx.y * 16;
+    const int mend = min(M, mbeg + 16);
+    for (int m = mbeg; m < mend; ++m) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) s += W[(long)m * wsm + (long)o * wso] * g[o];
+        const float h = H[(long)m * ldh + n];
+        D[(long)m * ldd + n] = s * act_deriv_from_out(h, act, slope);
+    }
+}
+
+// dpre = dY * act'(Y) elementwise
+__global__ void act_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dpre,
+                               long n, int act, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dpre[i] = dY[i] * act_deriv_from_out(Y[i], act, slope);
+}
+
+// ------------------------------------------------------------------------------------------
+// Coordinate transform (reference train_mnist.py:222,234-239):  x' = (x - dx) * [[c, s], [-s, c]]
+// ------------------------------------------------------------------------------------------
+__global__ void coord_fwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
+                                 const float* __restrict__ theta, float* __restrict__ xr, int B, int Np) {
+    const long total = (long)B * Np;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / Np), p = (int)(i - (long)b * Np);
+        const float c = cosf(theta[b]), s = sinf(theta[b]);
+        const float x0 = xc[2 * p] - dx[2 * b], x1 = xc[2 * p + 1] - dx[2 * b + 1];
+        xr[2 * i] = x0 * c - x1 * s;
+        xr[2 * i + 1] = x0 * s + x1 * c;
+    }
+}
+// one workgroup per image: d_theta[b], d_dx[b][2] from gxr[b][p][2]
+__global__ void coord_bwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
+                                 const float* __restrict__ theta, const float* __restrict__ gxr,
+                                 float* __restrict__ gdx, float* __restrict__ gtheta, int Np) {
+    __shared__ float sm[3 * 16];
+    const int b = blockIdx.x;
+    const float c = cosf(theta[b]), s = sinf(theta[b]);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int p = threadIdx.x; p < Np; p += blockDim.x) {
+        const float x0 = xc[2 * p] - dx[2 * b], x1 = xc[2 * p + 1] - dx[2 * b + 1];
+        const float g0 = gxr[2 * ((long)b * Np + p)], g1 = gxr[2 * ((long)b * Np + p) + 1];
+        acc[0] += -(g0 * c + g1 * s);
+        acc[1] += g0 * s - g1 * c;
+        const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;
+        acc[2] += -g0 * r1 + g1 * r0;
+    }
+    block_sum<3>(acc, sm);
+    if (threadIdx.x == 0) { gdx[2 * b] = acc[0]; gdx[2 * b + 1] = acc[1]; gtheta[b] = acc[2]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decoder first layer without Fourier features (reference src/models.py:107-118, in_dim = 2):
+//   h[f][pix] = act( Wc[f][0]*x0 + Wc[f][1]*x1 + bc[f] + LB[img][f] )
+// ------------------------------------------------------------------------------------------
+__global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wc,
+                                  const float* __restrict__ bc, const float* __restrict__ LB, float* __restrict__ h,
+                                  long ldh, int F, long Ntot, int Np, int act, float slope) {
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Ntot) return;
+    const float x0 = xr[2 * n], x1 = xr[2 * n + 1];
+    const int img = (int)(n / Np);
+    const int fbeg = blockIdx.y * 16, fend = min(F, fbeg + 16);
+    for (int f = fbeg; f < fend; ++f) {
+        float v = Wc[2 * f] * x0 + Wc[2 * f + 1] * x1 + bc[f];
+        if (LB) v += LB[(long)img * F + f];
+        h[(long)f * ldh + n] = act_apply(v, act, slope);
+    }
+}
+// LB[img][f] = sum_d Wl[f][d] * z[img][d]     (latent_linear, no bias; models.py:111-116)
+__global__ void latent_bias_kernel(const float* __restrict__ Wl, const float* __restrict__ z, float* __restrict__ LB,
+                                   int B, int F, int zd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * F) return;
+    const int img = i / F, f = i - img * F;
+    float s = 0.f;
+    for (int d = 0; d < zd; ++d) s += Wl[f * zd + d] * z[img * zd + d];
+    LB[i] = s;
+}
+// From S[img][f] = sum_{pix in img} dpre0[f][pix]:  dWl[f][d] = sum_img S*z,  dz[img][d] = sum_f Wl[f][d]*S
+__global__ void latent_bwd_kernel(const float* __restrict__ S, const float* __restrict__ Wl,
+                                  const float* __restrict__ z, float* __restrict__ dWl, float* __restrict__ dz, int B,
+                                  int F, int zd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F * zd) {
+        const int f = i / zd, d = i - f * zd;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += S[(long)b * F + f] * z[b * zd + d];
+        dWl[i] = s;
+    }
+    if (i < B * zd) {
+        const int b = i / zd, d = i - b * zd;
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s += Wl[f * zd + d] * S[(long)b * F + f];
+        dz[i] = s;
+    }
+}
+
+// Random Fourier features (reference RandomFourierEmbedding2d.forward, models.py:53-58):
+//   feat[f][pix] = cos( (Wf[f][0]/sigma)*x0 + (Wf[f][1]/sigma)*x1 + bf[f] )
+__global__ void fourier_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
+                                   const float* __restrict__ bf, float sigma, float* __restrict__ feat, long ld, int F,
+                                   long Ntot) {
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Ntot) return;
+    const float x0 = xr[2 * n], x1 = xr[2 * n + 1];
+    const int fbeg = blockIdx.y * 16, fend = min(F, fbeg + 16);
+    for (int f = fbeg; f < fend; ++f) {
+        const float w0 = Wf[2 * f] / sigma, w1 = Wf[2 * f + 1] / sigma;
+        feat[(long)f * ld + n] = cosf(x0 * w0 + x1 * w1 + bf[f]);
+    }
+}
+// gxr[pix][j] = sum_f -sin(arg_f) * (Wf[f][j]/sigma) * dfeat[f][pix]
+__global__ void fourier_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
+                                   const float* __restrict__ bf, float sigma, const float* __restrict__ dfeat, long ld,
+                                   int F, long Ntot, float* __restrict__ gxr) {
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Ntot) return;
+    const float x0 = xr[2 * n], x1 = xr[2 * n + 1];
+    float g0 = 0.f, g1 = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float w0 = Wf[2 * f] / sigma, w1 = Wf[2 * f + 1] / sigma;
+        const float t = -sinf(x0 * w0 + x1 * w1 + bf[f]) * dfeat[(long)f * ld + n];
+        g0 += t * w0;
+        g1 += t * w1;
+    }
+    gxr[2 * n] = g0;
+    gxr[2 * n + 1] = g1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Likelihoods.  One workgroup per image over the FLAT per-image vectors (the reference compares
+// y_hat.view(b,-1) with y.view(b,-1): train_mnist.py:288-291, train_galaxy.py:288-292,
+// train_particles.py:284-296,336-338).  kind: 0 BCE-with-logits, 1 Gaussian, 2 Gaussian with learned log-variance
+// (mu = yh[i], logvar = yh[L+i], i < L).
+// ------------------------------------------------------------------------------------------
+__global__ void loglik_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y, float* __restrict__ lp,
+                                  int L, int kind) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x;
+    const long ldy = kind == 2 ? 2L * L : L;
+    const float* a = yh + (long)b * ldy;
+    const float* t = y + (long)b * L;
+    float acc[1] = {0.f};
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const float x = a[i], yy = t[i];
+        if (kind == 0) acc[0] -= fmaxf(x, 0.f) - x * yy + log1pf(expf(-fabsf(x)));
+        else if (kind == 1) acc[0] -= 0.5f * (x - yy) * (x - yy);
+        else { const float lv = a[L + i]; acc[0] -= 0.5f * ((x - yy) * (x - yy) * expf(-lv) + lv); }
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) lp[b] = acc[0];
+}
+__global__ void loglik_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+                                  const float* __restrict__ glp, float* __restrict__ gyh, int B, int L, int kind) {
+    const long total = (long)B * L;
+    const long ldy = kind == 2 ? 2L * L : L;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / L), j = (int)(i - (long)b * L);
+        const float g = glp[b];
+        const float x = yh[(long)b * ldy + j], yy = y[i];
+        if (kind == 0) gyh[(long)b * ldy + j] = -g * (1.f / (1.f + expf(-x)) - yy);
+        else if (kind == 1) gyh[(long)b * ldy + j] = -g * (x - yy);
+        else {
+            const float lv = yh[(long)b * ldy + L + j];
+            const float e = expf(-lv), d = x - yy;
+            gyh[(long)b * ldy + j] = -g * d * e;
+            gyh[(long)b * ldy + L + j] = -0.5f * g * (1.f - d * d * e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention head (reference models.py:358-401 + train_mnist.py:192-282): one workgroup per image.
+// heads[ch][img*RP + j], ch: 0 logit, 1 theta_mu, 2 theta_logstd, 3..3+zd-1 z_mu, 3+zd.. z_logstd.
+// ------------------------------------------------------------------------------------------
+struct HeadParams {
+    const float* heads; long ldh;
+    const float* E;        // [B][RP]  Exp(1) draws of the Gumbel-softmax
+    const float* eps_z;    // [B][zd]
+    const float* eps_t;    // [B]
+    const float* p_r;      // [R]   log prior over rotations
+    const float* off;      // [R]   rotation offsets (zeros without refinement)
+    const float* p_tr;     // [RP]  log-softmax of p_t + p_r (joint prior, float64 on host -> f32)
+    const float* grid;     // [P][2] translation grid
+    int R, P, zd;
+    float sigma_p;         // pi / R  (train_mnist.py:269-272)
+    float theta_off_scale; // 1 if offsets are added to theta_mu (rot_refinement), else 0
+};
+
+__global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, float* __restrict__ q,
+                                     float* __restrict__ a, float* __restrict__ zs, float* __restrict__ th,
+                                     float* __restrict__ dxo, float* __restrict__ kl) {
+    __shared__ float sm[4 * 16];
+    const int b = blockIdx.x;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    const float* logit = hp.heads + base;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+        const float l = logit[j] + hp.p_r[j / hp.P];
+        attn[base + j] = l;
+        m1 = fmaxf(m1, l);
+        m2 = fmaxf(m2, l - logf(hp.E[base + j]));
+    }
+    m1 = block_max(m1, sm);
+    m2 = block_max(m2, sm);
+    float s[2] = {0.f, 0.f};
+    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+        const float l = attn[base + j];
+        s[0] += expf(l - m1);
+        s[1] += expf(l - logf(hp.E[base + j]) - m2);
+    }
+    block_sum<2>(s, sm);
+    const float lse = m1 + logf(s[0]);
+    const float inv2 = 1.f / s[1];
+    // translation pooling + val1
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+        const float l = attn[base + j];
+        const float qq = l - lse;
+        const float aa = expf(l - logf(hp.E[base + j]) - m2) * inv2;
+        q[base + j] = qq;
+        a[base + j] = aa;
+        const int hw = j % hp.P;
+        t[0] += aa * hp.grid[2 * hw];
+        t[1] += aa * hp.grid[2 * hw + 1];
+        t[2] += expf(qq) * (qq - hp.p_tr[j]);
+    }
+    block_sum<3>(t, sm);
+    float klsum = t[2];
+    if (threadIdx.x == 0) { dxo[2 * b] = t[0]; dxo[2 * b + 1] = t[1]; }
+    // theta (c = -1) and the zd latent dims: pooled mean / std and E_q[KL]
+    for (int c = -1; c < hp.zd; ++c) {
+        const float* mu_p = hp.heads + (long)(c < 0 ? 1 : 3 + c) * hp.ldh + base;
+        const float* ls_p = hp.heads + (long)(c < 0 ? 2 : 3 + hp.zd + c) * hp.ldh + base;
+        float u[3] = {0.f, 0.f, 0.f};
+        for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+            const float aa = a[base + j];
+            const float eq = expf(q[base + j]);
+            float mu = mu_p[j];
+            float sd = expf(ls_p[j]) + EPS_STD;
+            float klv;
+            if (c < 0) {
+                const float o = hp.off[j / hp.P];
+                mu += hp.theta_off_scale * o;
+                u[0] += aa * mu;
+                u[1] += aa * sd;
+                if (eq == 0.f) { mu = 0.f; sd = 1.f; }
+                const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
+                const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
+                klv = 0.5f * (vr + t1 - 1.f - logf(vr));
+            } else {
+                u[0] += aa * mu;
+                u[1] += aa * sd;
+                if (eq == 0.f) { mu = 0.f; sd = 1.f; }
+                klv = 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
+            }
+            u[2] += eq * klv;
+        }
+        block_sum<3>(u, sm);
+        klsum += u[2];
+        if (threadIdx.x == 0) {
+            if (c < 0) th[b] = u[1] * hp.eps_t[b] + u[0];
+            else zs[b * hp.zd + c] = u[1] * hp.eps_z[b * hp.zd + c] + u[0];
+        }
+    }
+    if (threadIdx.x == 0) kl[b] = klsum;
+}
+
+// Backward of the head.  Upstream: gz[B][zd], gth[B], gdx[B][2], gkl[B] and (optional, may be null)
+// g_attn, g_q, g_a [B][RP] for the module-level 7-tuple API.  Output dheads[ch][img*RP + j].
+__global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q, const float* __restrict__ a,
+                                     const float* __restrict__ gz, const float* __restrict__ gth,
+                                     const float* __restrict__ gdx, const float* __restrict__ gkl,
+                                     const float* __restrict__ g_attn, const float* __restrict__ g_q,
+                                     const float* __restrict__ g_a, float* __restrict__ dheads) {
+    __shared__ float sm[2 * 16];
+    const int b = blockIdx.x;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    const float w = gkl[b];
+    const float gt = gth[b];
+    const float et = hp.eps_t[b];
+    const float gd0 = gdx[2 * b], gd1 = gdx[2 * b + 1];
+    const float isp2 = 1.f / (hp.sigma_p * hp.sigma_p);
+    float red[2] = {0.f, 0.f};
+    for (int pass = 0; pass < 2; ++pass) {
+        const float sa = red[0], sq = red[1];   // valid in pass 1
+        float acc[2] = {0.f, 0.f};
+        for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+            const float aa = a[base + j];
+            const float qq = q[base + j];
+            const float eq = expf(qq);
+            const bool dead = (eq == 0.f);
+            const int r = j / hp.P, hw = j - r * hp.P;
+            const float o = hp.off[r];
+            // theta
+            const float tmu_raw = hp.heads[1 * hp.ldh + base + j];
+            const float tls = hp.heads[2 * hp.ldh + base + j];
+            const float tmu = tmu_raw + hp.theta_off_scale * o;
+            const float tex = expf(tls);
+            const float tsd = tex + EPS_STD;
+            float da = gt * (tmu + et * tsd) + gd0 * hp.grid[2 * hw] + gd1 * hp.grid[2 * hw + 1];
+            float klsum;
+            {
+                const float mu = dead ? 0.f : tmu, sd = dead ? 1.f : tsd;
+                const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
+                const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
+                klsum = 0.5f * (vr + t1 - 1.f - logf(vr));
+            }
+            if (pass == 1) {
+                float dmu = aa * gt, dsd = aa * gt * et;
+                if (!dead) { dmu += w * eq * (tmu - o) * isp2; dsd += w * eq * (tsd * isp2 - 1.f / tsd); }
+                dheads[1 * hp.ldh + base + j] = dmu;
+                dheads[2 * hp.ldh + base + j] = dsd * tex;
+            }
+            for (int d = 0; d < hp.zd; ++d) {
+                const float zmu = hp.heads[(long)(3 + d) * hp.ldh + base + j];
+                const float zls = hp.heads[(long)(3 + hp.zd + d) * hp.ldh + base + j];
+                const float zex = expf(zls);
+                const float zsd = zex + EPS_STD;
+                const float g = gz[b * hp.zd + d], ez = hp.eps_z[b * hp.zd + d];
+                da += g * (zmu + ez * zsd);
+                const float mu = dead ? 0.f : zmu, sd = dead ? 1.f : zsd;
+                klsum += 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
+                if (pass == 1) {
+                    float dmu = aa * g, dsd = aa * g * ez;
+                    if (!dead) { dmu += w * eq * zmu; dsd += w * eq * (zsd - 1.f / zsd); }
+                    dheads[(long)(3 + d) * hp.ldh + base + j] = dmu;
+                    dheads[(long)(3 + hp.zd + d) * hp.ldh + base + j] = dsd * zex;
+                }
+            }
+            if (g_a) da += g_a[base + j];
+            float dq = w * eq * (qq - hp.p_tr[j] + 1.f + klsum);
+            if (g_q) dq += g_q[base + j];
+            if (pass == 0) {
+                acc[0] += aa * da;
+                acc[1] += dq;
+            } else {
+                float dl = aa * (da - sa) + dq - eq * sq;
+                if (g_attn) dl += g_attn[base + j];
+                dheads[base + j] = dl;
+            }
+        }
+        if (pass == 0) {
+            block_sum<2>(acc, sm);
+            red[0] = acc[0];
+            red[1] = acc[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused Adam over the flat parameter buffer (torch.optim.Adam defaults, reference train_mnist.py:579).
+// grad_scale folds the data-parallel 1/world averaging into the update.
+// ------------------------------------------------------------------------------------------
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                                 float bc2_sqrt, float grad_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * grad_scale;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mm / denom);
+    }
+}
+
+}  // namespace tvae

@@ -1,0 +1,311 @@
+// libtvae_hip.so -- C ABI (include/tvae_hip.h) over the gfx950 kernels of the TARGET-VAE hot path.
+#include <hip/hip_runtime.h>
+
+#include "../../include/tvae_hip.h"
+#include "gemm_f32_mfma.hpp"
+#include "small_kernels.hpp"
+
+using namespace tvae;
+
+#define TVAE_CHECK_LAUNCH()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+static inline hipStream_t S(tvae_stream_t s) { return (hipStream_t)s; }
+static inline int grid1d(long total, int block, int cap = 8192) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+// number of split-K slices that brings a GEMM with `tiles` output tiles to ~4 workgroups per CU
+static inline int pick_splits(int tiles, long K) {
+    long want = (1024 + tiles - 1) / tiles;
+    long maxs = K / (4 * BK);
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" {
+
+int tvae_abi_version(void) { return 1; }
+
+int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
+                         int ksz, int R, tvae_stream_t stream) {
+    const int k2 = ksz * ksz;
+    const long total = (long)C * R * Cin * k2;
+    hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight, tap_idx,
+                       tap_w, bank, C, Cin, k2, R);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_r, const int* csr_dst,
+                         const float* csr_w, float* dweight, int C, int Cin, int ksz, int R, int accumulate,
+                         tvae_stream_t stream) {
+    const int k2 = ksz * ksz;
+    const long total = (long)C * Cin * k2;
+    hipLaunchKernelGGL(rotate_bank_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), dbank, csr_ptr,
+                       csr_r, csr_dst, csr_w, dweight, C, Cin, k2, R, accumulate);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
+    ConvGeom g;
+    g.B = B; g.Cin = Cin; g.n = n; g.ksz = ksz; g.pad = pad; g.R = R;
+    g.Ho = n + 2 * pad - ksz + 1;
+    g.P = g.Ho * g.Ho;
+    g.K2 = ksz * ksz;
+    return g;
+}
+
+int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
+                   int pad, int C, int R, int act, float slope, tvae_stream_t stream) {
+    const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
+    if (g.Ho <= 0) return (int)hipErrorInvalidValue;
+    const int M = C * R, N = B * g.P, K = Cin * g.K2;
+    LoadKContig al{bank, (long)K, M};
+    LoadConvPatchFwd bl{y, g, N};
+    Epilogue ep;
+    ep.C = out; ep.ldc = (long)B * R * g.P;
+    int sh = 0; while ((1 << sh) < R) ++sh;
+    if ((1 << sh) != R) return (int)hipErrorInvalidValue;   // reference allows R in {4, 8, 16}
+    ep.bias = bias; ep.bias_shift = sh;
+    ep.act = act; ep.slope = slope;
+    ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
+    return (int)launch_gemm(al, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
+}
+
+int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, int B, int Cin,
+                     int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+    const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
+    if (g.Ho <= 0) return (int)hipErrorInvalidValue;
+    const int M = C * R, N = Cin * g.K2;
+    const long Kl = (long)B * g.P;
+    if (Kl > 2147483647L) return (int)hipErrorInvalidValue;
+    const int K = (int)Kl;
+    LoadConvDY al{dpre, (long)B * R * g.P, M, R, g.P};
+    LoadConvPatchWgrad bl{y, g, N};
+    Epilogue ep;
+    ep.C = dbank; ep.ldc = N;
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    return (int)launch_gemm(al, bl, ep, M, N, K, pick_splits(tiles, K), ws, ws_floats, S(stream));
+}
+
+int tvae_linear_fwd(const float* W, const float* X, const float* bias, const float* gbias, int group,
+                    const float* res, float* Y, int M, int N, int K, long ldx, long ldy, int act, float slope,
+                    tvae_stream_t stream) {
+    LoadKContig al{W, (long)K, M};
+    LoadXContig bl{X, ldx, N};
+    Epilogue ep;
+    ep.C = Y; ep.ldc = ldy;
+    ep.bias = bias;
+    ep.gbias = gbias; ep.ldg = M; ep.group = group > 0 ? group : 1;
+    ep.res = res; ep.ldres = ldy;
+    ep.act = act; ep.slope = slope;
+    return (int)launch_gemm(al, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
+}
+
+int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const float* aux, float* dX, int M, int N,
+                      int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream) {
+    // dX[k][n] = sum_m W[m][k] dpre[m][n]: output rows = K, reduction = M
+    LoadXContig al{W, (long)K, K};
+    LoadXContig bl{dpre, ldd, N};
+    Epilogue ep;
+    ep.C = dX; ep.ldc = ldx;
+    ep.res = add; ep.ldres = ldx;
+    ep.aux = aux; ep.ldaux = ldx;
+    ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
+    return (int)launch_gemm(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
+}
+
+int tvae_linear_wgrad(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
+                      long ldd, long ldx, int accumulate, tvae_stream_t stream) {
+    // dW[m][k] = sum_n dpre[m][n] X[k][n]: output M x K, reduction = N
+    LoadKContig al{dpre, ldd, M};
+    LoadKContig bl{X, ldx, K};
+    Epilogue ep;
+    ep.C = dW; ep.ldc = K;
+    ep.accumulate = accumulate;
+    const int tiles = cdiv(M, BM) * cdiv(K, BN);
+    return (int)launch_gemm(al, bl, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
+}
+
+int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out,
+                    tvae_stream_t stream) {
+    if (seglen <= 0 || M <= 0) return (int)hipErrorInvalidValue;
+    const int nseg = (N + seglen - 1) / seglen;
+    dim3 grid(M, nseg), block(256);
+    if (!V) no = 1;
+    switch (no) {
+        case 1: hipLaunchKernelGGL(rowdot_seg_kernel<1>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
+        case 2: hipLaunchKernelGGL(rowdot_seg_kernel<2>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
+        case 3: hipLaunchKernelGGL(rowdot_seg_kernel<3>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
+        case 4: hipLaunchKernelGGL(rowdot_seg_kernel<4>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_seg_sum(const float* in, int S_, long L, float* out, float scale, int accumulate, tvae_stream_t stream) {
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(grid1d(L, 256)), dim3(256), 0, S(stream), in, S_, L, out, scale,
+                       accumulate);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_coldot(const float* X, long ldx, int M, int N, const float* W, int wsm, int wso, const float* bias, int no,
+                float* out, tvae_stream_t stream) {
+    dim3 grid((N + 255) / 256), block(256);
+    const size_t sh = (size_t)M * no * sizeof(float);
+    switch (no) {
+        case 1: hipLaunchKernelGGL(coldot_kernel<1>, grid, block, sh, S(stream), X, ldx, M, N, W, wsm, wso, bias, out); break;
+        case 2: hipLaunchKernelGGL(coldot_kernel<2>, grid, block, sh, S(stream), X, ldx, M, N, W, wsm, wso, bias, out); break;
+        case 3: hipLaunchKernelGGL(coldot_kernel<3>, grid, block, sh, S(stream), X, ldx, M, N, W, wsm, wso, bias, out); break;
+        case 4: hipLaunchKernelGGL(coldot_kernel<4>, grid, block, sh, S(stream), X, ldx, M, N, W, wsm, wso, bias, out); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_outer_mask(const float* dy, int no, const float* W, int wsm, int wso, const float* H, long ldh, float* D,
+                    long ldd, int M, int N, int act, float slope, tvae_stream_t stream) {
+    dim3 grid((N + 255) / 256, (M + 15) / 16), block(256);
+    switch (no) {
+        case 1: hipLaunchKernelGGL(outer_mask_kernel<1>, grid, block, 0, S(stream), dy, W, wsm, wso, H, ldh, D, ldd, M, N, act, slope); break;
+        case 2: hipLaunchKernelGGL(outer_mask_kernel<2>, grid, block, 0, S(stream), dy, W, wsm, wso, H, ldh, D, ldd, M, N, act, slope); break;
+        case 3: hipLaunchKernelGGL(outer_mask_kernel<3>, grid, block, 0, S(stream), dy, W, wsm, wso, H, ldh, D, ldd, M, N, act, slope); break;
+        case 4: hipLaunchKernelGGL(outer_mask_kernel<4>, grid, block, 0, S(stream), dy, W, wsm, wso, H, ldh, D, ldd, M, N, act, slope); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_act_bwd(const float* dY, const float* Y, float* dpre, long n, int act, float slope, tvae_stream_t stream) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n, 256)), dim3(256), 0, S(stream), dY, Y, dpre, n, act, slope);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+static HeadParams make_head(const float* heads, long ldh, const float* E, const float* eps_z, const float* eps_t,
+                            const float* p_r, const float* off, const float* p_tr, const float* grid, int R, int P,
+                            int zd, float sigma_p, float theta_off_scale) {
+    HeadParams hp;
+    hp.heads = heads; hp.ldh = ldh; hp.E = E; hp.eps_z = eps_z; hp.eps_t = eps_t;
+    hp.p_r = p_r; hp.off = off; hp.p_tr = p_tr; hp.grid = grid;
+    hp.R = R; hp.P = P; hp.zd = zd; hp.sigma_p = sigma_p; hp.theta_off_scale = theta_off_scale;
+    return hp;
+}
+
+int tvae_attn_head_fwd(const float* heads, long ldh, const float* E, const float* eps_z, const float* eps_t,
+                       const float* p_r, const float* off, const float* p_tr, const float* grid, int B, int R, int P,
+                       int zd, float sigma_p, float theta_off_scale, float* attn, float* q, float* a, float* z,
+                       float* theta, float* dx, float* kl, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    HeadParams hp = make_head(heads, ldh, E, eps_z, eps_t, p_r, off, p_tr, grid, R, P, zd, sigma_p, theta_off_scale);
+    hipLaunchKernelGGL(attn_head_fwd_kernel, dim3(B), dim3(1024), 0, S(stream), hp, attn, q, a, z, theta, dx, kl);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float* a, const float* eps_z,
+                       const float* eps_t, const float* p_r, const float* off, const float* p_tr, const float* grid,
+                       int B, int R, int P, int zd, float sigma_p, float theta_off_scale, const float* gz,
+                       const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
+                       const float* g_a, float* dheads, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    HeadParams hp = make_head(heads, ldh, nullptr, eps_z, eps_t, p_r, off, p_tr, grid, R, P, zd, sigma_p,
+                              theta_off_scale);
+    hipLaunchKernelGGL(attn_head_bwd_kernel, dim3(B), dim3(1024), 0, S(stream), hp, q, a, gz, gth, gdx, gkl, g_attn,
+                       g_q, g_a, dheads);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_coord_fwd(const float* xc, const float* dx, const float* theta, float* xr, int B, int Np,
+                   tvae_stream_t stream) {
+    hipLaunchKernelGGL(coord_fwd_kernel, dim3(grid1d((long)B * Np, 256)), dim3(256), 0, S(stream), xc, dx, theta, xr,
+                       B, Np);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_coord_bwd(const float* xc, const float* dx, const float* theta, const float* gxr, float* gdx, float* gtheta,
+                   int B, int Np, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(coord_bwd_kernel, dim3(B), dim3(256), 0, S(stream), xc, dx, theta, gxr, gdx, gtheta, Np);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_dec_l0_fwd(const float* xr, const float* Wc, const float* bc, const float* LB, float* h, long ldh, int F,
+                    long Ntot, int Np, int act, float slope, tvae_stream_t stream) {
+    dim3 grid((unsigned)((Ntot + 255) / 256), (F + 15) / 16), block(256);
+    hipLaunchKernelGGL(dec_l0_fwd_kernel, grid, block, 0, S(stream), xr, Wc, bc, LB, h, ldh, F, Ntot, Np, act, slope);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_latent_bias(const float* Wl, const float* z, float* LB, int B, int F, int zd, tvae_stream_t stream) {
+    hipLaunchKernelGGL(latent_bias_kernel, dim3((B * F + 255) / 256), dim3(256), 0, S(stream), Wl, z, LB, B, F, zd);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_latent_bwd(const float* S_, const float* Wl, const float* z, float* dWl, float* dz, int B, int F, int zd,
+                    tvae_stream_t stream) {
+    const int tot = (F * zd > B * zd) ? F * zd : B * zd;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, S(stream), S_, Wl, z, dWl, dz, B, F,
+                       zd);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_fourier_fwd(const float* xr, const float* Wf, const float* bf, float sigma, float* feat, long ld, int F,
+                     long Ntot, tvae_stream_t stream) {
+    dim3 grid((unsigned)((Ntot + 255) / 256), (F + 15) / 16), block(256);
+    hipLaunchKernelGGL(fourier_fwd_kernel, grid, block, 0, S(stream), xr, Wf, bf, sigma, feat, ld, F, Ntot);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_fourier_bwd(const float* xr, const float* Wf, const float* bf, float sigma, const float* dfeat, long ld,
+                     int F, long Ntot, float* gxr, tvae_stream_t stream) {
+    hipLaunchKernelGGL(fourier_bwd_kernel, dim3((unsigned)((Ntot + 255) / 256)), dim3(256), 0, S(stream), xr, Wf, bf,
+                       sigma, dfeat, ld, F, Ntot, gxr);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_loglik_fwd(const float* yh, const float* y, float* lp, int B, int L, int kind, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(loglik_fwd_kernel, dim3(B), dim3(256), 0, S(stream), yh, y, lp, L, kind);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_loglik_bwd(const float* yh, const float* y, const float* glp, float* gyh, int B, int L, int kind,
+                    tvae_stream_t stream) {
+    hipLaunchKernelGGL(loglik_bwd_kernel, dim3(grid1d((long)B * L, 256)), dim3(256), 0, S(stream), yh, y, glp, gyh, B,
+                       L, kind);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                   float bc1, float bc2_sqrt, float grad_scale, tvae_stream_t stream) {
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid1d(n, 256, 2048)), dim3(256), 0, S(stream), p, g, m, v, n, lr, b1,
+                       b2, eps, bc1, bc2_sqrt, grad_scale);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""ctypes binding of libtvae_hip.so (C ABI declared in include/tvae_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a tensor is not a contiguous
+fp32/int32 CUDA(HIP) tensor, the call raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libtvae_hip.so')
+
+# signature codes: p = device pointer (tensor or None), i = int, l = long, f = float; the trailing
+# stream argument is appended automatically (torch.cuda.current_stream()).
+SIGNATURES = {
+    'tvae_rotate_bank_fwd': 'ppppiiii',
+    'tvae_rotate_bank_bwd': 'ppppppiiiii',
+    'tvae_conv1_fwd': 'ppppiiiiiiiif',
+    'tvae_conv1_wgrad': 'ppppl iiiiiii'.replace(' ', ''),
+    'tvae_linear_fwd': 'ppppippiiillif',
+    'tvae_linear_dgrad': 'pppppiiillif',
+    'tvae_linear_wgrad': 'ppppliiilli',
+    'tvae_rowdot_seg': 'plpiiiip',
+    'tvae_seg_sum': 'pilpfi',
+    'tvae_coldot': 'pliipiipip',
+    'tvae_outer_mask': 'pipiiplpliiif',
+    'tvae_act_bwd': 'ppplif',
+    'tvae_attn_head_fwd': 'plpppppppiiiiffppppppp',
+    'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppp',
+    'tvae_coord_fwd': 'ppppii',
+    'tvae_coord_bwd': 'ppppppii',
+    'tvae_dec_l0_fwd': 'pppppliliif',   # xr, Wc, bc, LB, h, ldh(l), F(i), Ntot(l), Np(i), act(i), slope(f)
+    'tvae_latent_bias': 'pppiii',
+    'tvae_latent_bwd': 'pppppiii',
+    'tvae_fourier_fwd': 'pppfplil',
+    'tvae_fourier_bwd': 'pppfplilp',
+    'tvae_loglik_fwd': 'pppiii',
+    'tvae_loglik_bwd': 'ppppiii',
+    'tvae_adam_flat': 'pppplfffffff',
+}
+
+_CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
+_lib = None
+
+
+class TvaeHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TvaeHipError(
+                f'{LIB_PATH} not found: build it with `make -C target-vae_amd/csrc` '
+                '(or __graft_entry__.build()).  There is no CPU fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, sig in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [_CT[c] for c in sig] + [ctypes.c_void_p]
+        L.tvae_abi_version.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ['tvae_abi_version'] + sorted(SIGNATURES)
+
+
+def _ptr(t, name, pos):
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise TvaeHipError(f'{name} arg {pos}: expected a tensor or None, got {type(t)}')
+    if not t.is_cuda:
+        raise TvaeHipError(f'{name} arg {pos}: tensor must live on the GPU (no CPU fallback)')
+    if t.dtype not in (torch.float32, torch.int32):
+        raise TvaeHipError(f'{name} arg {pos}: dtype {t.dtype} not supported (fp32 / int32 only)')
+    if not t.is_contiguous():
+        raise TvaeHipError(f'{name} arg {pos}: tensor must be contiguous')
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point on the current torch stream."""
+    L = lib()
+    sig = SIGNATURES[name]
+    if len(args) != len(sig):
+        raise TvaeHipError(f'{name}: expected {len(sig)} arguments, got {len(args)}')
+    conv = []
+    for pos, (c, a) in enumerate(zip(sig, args)):
+        if c == 'p':
+            conv.append(_ptr(a, name, pos))
+        elif c == 'f':
+            conv.append(float(a))
+        else:
+            conv.append(int(a))
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = getattr(L, name)(*conv, stream)
+    if rc != 0:
+        raise TvaeHipError(f'{name} failed with hipError_t {rc}')

@@ -1,0 +1,108 @@
+"""Data parallelism for the TARGET-VAE step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device; every image is independent through encoder, sampling,
+decoder and per-image ELBO and the loss is a batch mean (train_mnist.py:282,291), so the step shards
+over images with ONE exchange: a sum all-reduce of the flat gradient buffer (1.5-12 MB).
+On CPU-only boxes the same code runs over the `gloo` backend (tests/test_dp_gloo.py).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank).  A single process needs no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # "nccl" IS RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """Sum all-reduce of the flat gradient buffer; returns the scale Adam applies (1/world for equal shards).
+
+    `weight` handles a ragged last minibatch: rank r holds b_r images and its loss is a mean over b_r, so the
+    global-batch gradient is sum_r (b_r / b_global) g_r; ranks pre-scale by b_r * world / b_global."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.weight = 1.0
+
+    def set_local_fraction(self, local_b: int, global_b: int):
+        self.weight = float(local_b) * self.world / float(global_b)
+
+    def __call__(self, flat_g: torch.Tensor) -> float:
+        if self.world == 1:
+            return 1.0
+        if self.weight != 1.0:
+            flat_g.mul_(self.weight)
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+
+def shard_slices(n_items: int, global_batch: int, rank: int, world: int):
+    """Contiguous per-rank slice of every global minibatch: yields (lo, hi, b_global) index ranges into the
+    epoch permutation.  Each global batch of size g is split as evenly as possible (first g % world ranks get
+    one extra), so the union over ranks is exactly the reference's minibatch."""
+    for start in range(0, n_items, global_batch):
+        g = min(global_batch, n_items - start)
+        base, extra = divmod(g, world)
+        lo = start + rank * base + min(rank, extra)
+        hi = lo + base + (1 if rank < extra else 0)
+        yield lo, hi, g
+
+
+def epoch_permutation(n_items: int, seed: int, epoch: int, shuffle: bool = True) -> torch.Tensor:
+    """Same permutation on every rank (shared seed), like DataLoader(shuffle=True) with one generator."""
+    if not shuffle:
+        return torch.arange(n_items)
+    gen = torch.Generator()
+    gen.manual_seed(int(seed) * 1000003 + int(epoch))
+    return torch.randperm(n_items, generator=gen)
+
+
+class ShardedBatches:
+    """Iterator of (y,) minibatch shards over a device-resident dataset tensor (the reference keeps the whole
+    dataset on the device, train_mnist.py:495).  Empty shards (ragged tail smaller than world) are skipped by
+    the reducer weight being 0 -- they still take part in the collective."""
+
+    def __init__(self, data: torch.Tensor, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
+                 seed: int = 0, reducer: GradReducer = None):
+        self.data, self.gb, self.rank, self.world = data, global_batch, rank, world
+        self.shuffle, self.seed, self.reducer = shuffle, seed, reducer
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self):
+        return (self.data.shape[0] + self.gb - 1) // self.gb
+
+    def __iter__(self):
+        n = self.data.shape[0]
+        perm = epoch_permutation(n, self.seed, self.epoch, self.shuffle).to(self.data.device)
+        for lo, hi, g in shard_slices(n, self.gb, self.rank, self.world):
+            if self.reducer is not None:
+                self.reducer.set_local_fraction(hi - lo, g)
+            yield (self.data.index_select(0, perm[lo:hi]),)
+
+
+def allreduce_stats(values, device, group=None):
+    """Sum a short list of python floats over ranks (logging scalars: sum b*elbo, sum b*err, sum b*kl, sum b)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()

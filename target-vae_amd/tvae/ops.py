@@ -1,0 +1,456 @@
+"""torch.autograd.Function wrappers over the libtvae_hip.so C ABI (include/tvae_hip.h).
+
+Internal activation layout is feature-major: [feature][image*positions + position].  Each Function
+mirrors one stage of the reference hot path and cites the reference lines it replaces.  All compute
+happens in the HIP library on the current torch stream; torch only provides device memory.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import tables
+from ._lib import call
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+LRELU_SLOPE = 0.01
+
+
+def act_code(activation) -> int:
+    """Map an nn activation class/instance (reference ctor argument `activation`) to the kernel code."""
+    import torch.nn as nn
+    a = activation() if isinstance(activation, type) else activation
+    if isinstance(a, nn.LeakyReLU):
+        if abs(a.negative_slope - LRELU_SLOPE) > 0:
+            raise NotImplementedError('only the default LeakyReLU slope 0.01 is built')
+        return ACT_LRELU
+    if isinstance(a, nn.Tanh):
+        return ACT_TANH
+    raise NotImplementedError(f'activation {type(a).__name__} has no HIP kernel (reference CLI: tanh | leakyrelu)')
+
+
+# ---------------------------------------------------------------------------------------------
+# workspaces and device tables (cached per device)
+# ---------------------------------------------------------------------------------------------
+_WS = {}
+_TABLES = {}
+
+
+def workspace(device, floats: int) -> torch.Tensor:
+    """Split-K scratch (grown on demand, reused across calls on the same stream)."""
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < floats:
+        t = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+def _dev_table(key, device, builder):
+    k = (key, device.type, device.index)
+    t = _TABLES.get(k)
+    if t is None:
+        t = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in builder())
+        _TABLES[k] = t
+    return t
+
+
+def tap_tables(k: int, R: int, device):
+    return _dev_table(('taps', k, R), device, lambda: tables.rotation_taps(k, R))
+
+
+def tap_tables_csr(k: int, R: int, device):
+    return _dev_table(('csr', k, R), device, lambda: tables.rotation_taps_csr(k, R))
+
+
+def _seglen(N: int) -> int:
+    return max(2048, (N + 255) // 256)
+
+
+def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = sum_n X[m][n] (deterministic two-level reduction)."""
+    sl = _seglen(N)
+    nseg = (N + sl - 1) // sl
+    tmp = torch.empty(nseg, M, dtype=torch.float32, device=X.device)
+    call('tvae_rowdot_seg', X, N, None, 1, M, N, sl, tmp)
+    if out is None:
+        out = torch.empty(M, dtype=torch.float32, device=X.device)
+    call('tvae_seg_sum', tmp, nseg, M, out, 1.0, 0)
+    return out
+
+
+def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
+    dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
+    need = 64 * max(M, 128) * max(K, 128)
+    ws = workspace(dpre.device, max(need, 1 << 24))
+    call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
+    return dW
+
+
+# ---------------------------------------------------------------------------------------------
+# rotated bank + lifting convolution
+# ---------------------------------------------------------------------------------------------
+def rotate_bank(weight: torch.Tensor, R: int) -> torch.Tensor:
+    """GroupConv.trans_filter (src/models.py:174-197): (C,Cin,1,k,k) -> bank [C*R][Cin*k*k]."""
+    C, Cin, D, k, _ = weight.shape
+    if D != 1:
+        raise NotImplementedError('input_rot_dim != 1 is never used by the reference (models.py:290,346)')
+    idx, w = tap_tables(k, R, weight.device)
+    bank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=weight.device)
+    call('tvae_rotate_bank_fwd', weight.contiguous(), idx, w, bank, C, Cin, k, R)
+    return bank
+
+
+def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> torch.Tensor:
+    ptr, er, ed, ew = tap_tables_csr(k, R, dbank.device)
+    dW = torch.empty(C, Cin, 1, k, k, dtype=torch.float32, device=dbank.device)
+    call('tvae_rotate_bank_bwd', dbank, ptr, er, ed, ew, dW, C, Cin, k, R, 0)
+    return dW
+
+
+def conv1_forward(y, bank, bias, C, R, k, pad, act):
+    B, Cin, n, _ = y.shape
+    Ho = n + 2 * pad - k + 1
+    out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
+    call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
+    return out
+
+
+def conv1_wgrad(y, dpre, C, R, k, pad):
+    B, Cin, n, _ = y.shape
+    dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
+    ws = workspace(y.device, max(1 << 24, 8 * dbank.numel()))
+    call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    return dbank
+
+
+class BankFn(torch.autograd.Function):
+    """GroupConv.trans_filter as a differentiable op: (C,Cin,1,k,k) -> [C*R][Cin*k*k]."""
+
+    @staticmethod
+    def forward(ctx, weight, R):
+        ctx.cfg = (weight.shape[0], weight.shape[1], weight.shape[3], R)
+        return rotate_bank(weight, R)
+
+    @staticmethod
+    def backward(ctx, g):
+        C, Cin, k, R = ctx.cfg
+        return rotate_bank_bwd(g.contiguous().view(C * R, Cin * k * k), C, Cin, k, R), None
+
+
+class GroupConvFn(torch.autograd.Function):
+    """GroupConv.forward (src/models.py:202-225) as one op: rotated bank + implicit-GEMM conv + bias.
+    Returns the reference layout (B, C, R, Ho, Ho).  No input gradient (the input is data)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, R, pad):
+        C, Cin, _, k, _ = weight.shape
+        y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
+        B, n = y.shape[0], y.shape[-1]
+        Ho = n + 2 * pad - k + 1
+        bank = rotate_bank(weight, R)
+        out = conv1_forward(y, bank, bias, C, R, k, pad, ACT_NONE)
+        ctx.save_for_backward(y)
+        ctx.cfg = (C, Cin, k, R, pad, B, Ho, bias is not None)
+        return out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        C, Cin, k, R, pad, B, Ho, has_bias = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError('GroupConv input gradient is not part of the hot path (input is data)')
+        dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, B * R * Ho * Ho)
+        dbank = conv1_wgrad(y, dpre, C, R, k, pad)
+        dW = rotate_bank_bwd(dbank, C, Cin, k, R)
+        db = _rowsum(dpre, C, dpre.shape[1]) if has_bias else None
+        return None, dW, db, None, None
+
+
+class EncoderFn(torch.autograd.Function):
+    """conv1 -> act -> conv2 (1x1x1) -> act -> {conv_a, conv_r, conv_z} (src/models.py:354-358,390-392).
+
+    Output: heads [3+2*zd][B*R*Ho*Ho] feature-major, rows = (logit, theta_mu, theta_logstd, z_mu.., z_logstd..).
+    Backward fuses every activation derivative into the producing dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, W2, b2, Wh, bh, R, pad, act):
+        C, Cin, _, k, _ = w1.shape
+        y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
+        B, n = y.shape[0], y.shape[-1]
+        Ho = n + 2 * pad - k + 1
+        N = B * R * Ho * Ho
+        C2, nh = W2.shape[0], Wh.shape[0]
+        bank = rotate_bank(w1, R)
+        A1 = conv1_forward(y, bank, b1, C, R, k, pad, act)
+        H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
+        heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
+        call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
+        ctx.save_for_backward(y, W2, Wh, A1, H)
+        ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
+        return heads
+
+    @staticmethod
+    def backward(ctx, dheads):
+        y, W2, Wh, A1, H = ctx.saved_tensors
+        C, Cin, k, R, pad, B, Ho, act = ctx.cfg
+        N = B * R * Ho * Ho
+        C2, nh = W2.shape[0], Wh.shape[0]
+        dheads = dheads.contiguous()
+        dWh = _wgrad(dheads, H, nh, N, C2)
+        dbh = _rowsum(dheads, nh, N)
+        dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
+        dW2 = _wgrad(dH, A1, C2, N, C)
+        db2 = _rowsum(dH, C2, N)
+        dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
+        call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
+        del dH
+        db1 = _rowsum(dA1, C, N)
+        dbank = conv1_wgrad(y, dA1, C, R, k, pad)
+        dw1 = rotate_bank_bwd(dbank, C, Cin, k, R)
+        return None, dw1, db1, dW2, db2, dWh, dbh, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# attention head
+# ---------------------------------------------------------------------------------------------
+class HeadTables:
+    """Device-resident constants of the attention head for one (R, Ho, spacing, prior) configuration."""
+
+    def __init__(self, R, Ho, spacing, rot_refinement, theta_prior, normal_prior_over_r, device):
+        self.R, self.Ho, self.P = R, Ho, Ho * Ho
+        p_r = tables.rotation_log_prior(R, rot_refinement, theta_prior, normal_prior_over_r)
+        off = tables.rotation_offsets(R, rot_refinement)
+        grid = tables.translation_grid(Ho, spacing)
+        p_tr = tables.joint_log_prior(Ho, spacing, p_r)
+        self.p_r = torch.from_numpy(p_r).to(device)
+        self.off = torch.from_numpy(off).to(device)
+        self.grid = torch.from_numpy(grid.astype(np.float32)).contiguous().to(device)
+        self.p_tr = torch.from_numpy(p_tr).to(device)
+        self.sigma_p = math.pi / R                       # train_mnist.py:269-272
+        self.theta_off_scale = 1.0 if rot_refinement else 0.0
+
+
+class HeadFn(torch.autograd.Function):
+    """Prior add + log-softmax + Gumbel-softmax (src/models.py:382-388) fused with expected-value pooling,
+    reparameterised sampling, translation expectation and the KL block (train_mnist.py:192-231,242-282).
+
+    Returns (attn, q_t_r, a_sampled) [B][R*P], z [B][zd], theta [B], dx [B][2], kl [B]."""
+
+    @staticmethod
+    def forward(ctx, heads, E, eps_z, eps_t, tb: HeadTables, B, zd):
+        RP = tb.R * tb.P
+        dev = heads.device
+        attn = torch.empty(B, RP, dtype=torch.float32, device=dev)
+        q = torch.empty_like(attn)
+        a = torch.empty_like(attn)
+        z = torch.empty(B, zd, dtype=torch.float32, device=dev)
+        th = torch.empty(B, dtype=torch.float32, device=dev)
+        dx = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        kl = torch.empty(B, dtype=torch.float32, device=dev)
+        heads = heads.contiguous()
+        E, eps_z, eps_t = E.contiguous(), eps_z.contiguous(), eps_t.contiguous()
+        call('tvae_attn_head_fwd', heads, heads.shape[1], E, eps_z, eps_t, tb.p_r, tb.off, tb.p_tr, tb.grid, B, tb.R,
+             tb.P, zd, tb.sigma_p, tb.theta_off_scale, attn, q, a, z, th, dx, kl)
+        ctx.save_for_backward(heads, q, a, eps_z, eps_t)
+        ctx.tb, ctx.B, ctx.zd = tb, B, zd
+        return attn, q, a, z, th, dx, kl
+
+    @staticmethod
+    def backward(ctx, g_attn, g_q, g_a, g_z, g_th, g_dx, g_kl):
+        heads, q, a, eps_z, eps_t = ctx.saved_tensors
+        tb, B, zd = ctx.tb, ctx.B, ctx.zd
+        dev = heads.device
+
+        def dense(g, shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
+
+        g_z, g_th, g_dx, g_kl = dense(g_z, (B, zd)), dense(g_th, (B,)), dense(g_dx, (B, 2)), dense(g_kl, (B,))
+        opt = [None if g is None else g.contiguous() for g in (g_attn, g_q, g_a)]
+        dheads = torch.empty_like(heads)
+        call('tvae_attn_head_bwd', heads, heads.shape[1], q, a, eps_z, eps_t, tb.p_r, tb.off, tb.p_tr, tb.grid, B,
+             tb.R, tb.P, zd, tb.sigma_p, tb.theta_off_scale, g_z, g_th, g_dx, g_kl, opt[0], opt[1], opt[2], dheads)
+        return dheads, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# coordinate transform, decoder, likelihood
+# ---------------------------------------------------------------------------------------------
+class CoordFn(torch.autograd.Function):
+    """x' = (x - dx) R(theta) (train_mnist.py:222,234-239).  xc [Np][2] -> [B][Np][2]."""
+
+    @staticmethod
+    def forward(ctx, xc, dx, theta):
+        B, Np = theta.shape[0], xc.shape[0]
+        xc, dx, theta = xc.contiguous(), dx.contiguous(), theta.contiguous()
+        xr = torch.empty(B, Np, 2, dtype=torch.float32, device=xc.device)
+        call('tvae_coord_fwd', xc, dx, theta, xr, B, Np)
+        ctx.save_for_backward(xc, dx, theta)
+        return xr
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, dx, theta = ctx.saved_tensors
+        B, Np = theta.shape[0], xc.shape[0]
+        gdx = torch.empty(B, 2, dtype=torch.float32, device=xc.device)
+        gth = torch.empty(B, dtype=torch.float32, device=xc.device)
+        call('tvae_coord_bwd', xc, dx, theta, g.contiguous(), gdx, gth, B, Np)
+        return None, gdx, gth
+
+
+class DecoderFn(torch.autograd.Function):
+    """SpatialGenerator.forward (src/models.py:95-123): [Fourier] -> coord_linear + latent_linear -> act ->
+    (Linear | ResidLinear, act) x (L-1) -> Linear(hid, n_out).  x [B][Np][2], z [B][zd] -> (B, Np, n_out).
+
+    params order: Wc, bc, Wl (or None), [W_i, b_i]*(L-1), Wo, bo, then Fourier buffers Wf, bf (or None)."""
+
+    @staticmethod
+    def forward(ctx, xr, z, act, resid, sigma, n_hidden, *params):
+        Wc, bc, Wl = params[0], params[1], params[2]
+        hidden = [(params[3 + 2 * i], params[4 + 2 * i]) for i in range(n_hidden)]
+        Wo, bo = params[3 + 2 * n_hidden], params[4 + 2 * n_hidden]
+        Wf, bf = params[5 + 2 * n_hidden], params[6 + 2 * n_hidden]
+        xr = xr.contiguous()
+        B, Np = xr.shape[0], xr.shape[1]
+        Nt = B * Np
+        F_, n_out = Wc.shape[0], Wo.shape[0]
+        dev = xr.device
+        LB = None
+        if Wl is not None:
+            zd = Wl.shape[1]
+            z = z.contiguous()
+            LB = torch.empty(B, F_, dtype=torch.float32, device=dev)
+            call('tvae_latent_bias', Wl.contiguous(), z, LB, B, F_, zd)
+        feat = None
+        h = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        if Wf is not None:
+            Ff = Wf.shape[0]
+            feat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
+            call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, Nt, Ff, Nt)
+            call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
+        else:
+            call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
+        hs = [h]
+        for (W, b) in hidden:
+            hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+            call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_, Nt,
+                 Nt, act, LRELU_SLOPE)
+            hs.append(hn)
+        yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
+        call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
+        ctx.save_for_backward(xr, z if Wl is not None else None, feat, *hs, *[p for p in params if p is not None])
+        ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
+        return yh
+
+    @staticmethod
+    def backward(ctx, gy):
+        act, resid, sigma, n_hidden, has_l, has_f, B, Np = ctx.meta
+        sv = list(ctx.saved_tensors)
+        xr, z, feat = sv[0], sv[1], sv[2]
+        hs = sv[3:3 + n_hidden + 1]
+        ps = sv[3 + n_hidden + 1:]
+        it = iter(ps)
+        Wc, bc = next(it), next(it)
+        Wl = next(it) if has_l else None
+        hidden = [(next(it), next(it)) for _ in range(n_hidden)]
+        Wo, bo = next(it), next(it)
+        Wf, bf = (next(it), next(it)) if has_f else (None, None)
+        Nt = B * Np
+        F_, n_out = Wc.shape[0], Wo.shape[0]
+        dev = xr.device
+        gy = gy.contiguous().view(Nt, n_out)
+        sl = _seglen(Nt)
+        nseg = (Nt + sl - 1) // sl
+        # last layer
+        tmp = torch.empty(nseg, F_, n_out, dtype=torch.float32, device=dev)
+        call('tvae_rowdot_seg', hs[-1], Nt, gy, n_out, F_, Nt, sl, tmp)
+        dWoT = torch.empty(F_, n_out, dtype=torch.float32, device=dev)
+        call('tvae_seg_sum', tmp, nseg, F_ * n_out, dWoT, 1.0, 0)
+        dWo = dWoT.t().contiguous()
+        gyT = gy.t().contiguous()
+        dbo = _rowsum(gyT, n_out, Nt)
+        d = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        call('tvae_outer_mask', gy, n_out, Wo.contiguous(), 1, F_, hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE)
+        grads_hidden = []
+        for li in range(n_hidden - 1, -1, -1):
+            W, b = hidden[li]
+            hprev = hs[li]
+            dW = _wgrad(d, hprev, F_, Nt, F_)
+            db = _rowsum(d, F_, Nt)
+            dprev = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+            call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
+                 LRELU_SLOPE)
+            d = dprev
+            grads_hidden.append((dW, db))
+        grads_hidden.reverse()
+        # first layer: d is the pre-activation gradient [F][Nt]
+        Simg = torch.empty(B, F_, dtype=torch.float32, device=dev)
+        call('tvae_rowdot_seg', d, Nt, None, 1, F_, Nt, Np, Simg)
+        dbc = torch.empty(F_, dtype=torch.float32, device=dev)
+        call('tvae_seg_sum', Simg, B, F_, dbc, 1.0, 0)
+        dWl = dz = None
+        if has_l:
+            zd = Wl.shape[1]
+            dWl = torch.empty(F_, zd, dtype=torch.float32, device=dev)
+            dz = torch.empty(B, zd, dtype=torch.float32, device=dev)
+            call('tvae_latent_bwd', Simg, Wl.contiguous(), z, dWl, dz, B, F_, zd)
+        gxr = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
+        if has_f:
+            Ff = Wf.shape[0]
+            dWc = _wgrad(d, feat, F_, Nt, Ff)
+            dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
+            call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
+            call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
+        else:
+            tmp2 = torch.empty(nseg, F_, 2, dtype=torch.float32, device=dev)
+            call('tvae_rowdot_seg', d, Nt, xr.view(Nt, 2), 2, F_, Nt, sl, tmp2)
+            dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
+            call('tvae_seg_sum', tmp2, nseg, F_ * 2, dWc, 1.0, 0)
+            call('tvae_coldot', d, Nt, F_, Nt, Wc.contiguous(), 2, 1, None, 2, gxr)
+        out = [gxr, dz, None, None, None, None, dWc, dbc, dWl]
+        for (dW, db) in grads_hidden:
+            out += [dW, db]
+        out += [dWo, dbo, None, None]
+        return tuple(out)
+
+
+LIK_KIND = {'bce': 0, 'bce3': 0, 'gauss': 1, 'gauss_var': 2}
+
+
+class LogLikFn(torch.autograd.Function):
+    """Per-image log-likelihood over flat vectors (train_mnist.py:288-291; train_galaxy.py:288-292;
+    train_particles.py:284-296,336-338).  yh (B, ...), y (B, ...) -> lp [B]."""
+
+    @staticmethod
+    def forward(ctx, yh, y, kind):
+        B = y.shape[0]
+        y = y.contiguous().view(B, -1)
+        yh = yh.contiguous().view(B, -1)
+        L = y.shape[1]
+        assert yh.shape[1] == (2 * L if kind == 2 else L), (yh.shape, y.shape, kind)
+        lp = torch.empty(B, dtype=torch.float32, device=yh.device)
+        call('tvae_loglik_fwd', yh, y, lp, B, L, kind)
+        ctx.save_for_backward(yh, y)
+        ctx.kind = kind
+        ctx.shape = None
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        yh, y = ctx.saved_tensors
+        B, L = y.shape
+        gyh = torch.empty_like(yh)
+        call('tvae_loglik_bwd', yh, y, g.contiguous(), gyh, B, L, ctx.kind)
+        return gyh, None, None
+
+
+def adam_flat(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+    """Fused Adam on flat buffers (torch.optim.Adam defaults; reference train_mnist.py:579,323)."""
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    call('tvae_adam_flat', p, g, m, v, p.numel(), lr, b1, b2, eps, bc1, math.sqrt(bc2), grad_scale)

@@ -1,0 +1,63 @@
+"""Flat-buffer Adam for the MI355X hot path.
+
+All parameters of generator + encoder (<= 2.9 M floats) live in ONE contiguous fp32 buffer,
+their gradients in another; `p.data` / `p.grad` are views.  One fused HIP kernel (tvae_adam_flat)
+replaces torch.optim.Adam's per-tensor loop (reference train_mnist.py:579,323-324) and one RCCL
+all-reduce of the flat gradient buffer implements data parallelism (tvae/dp.py).
+It subclasses torch.optim.Optimizer so that ReduceLROnPlateau (train_mnist.py:581) drives `lr` unchanged.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, update_fn=None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._ps = [p for g in self.param_groups for p in g['params']]
+        if len(self.param_groups) != 1:
+            raise ValueError('FlatAdam keeps one parameter group (the reference uses one)')
+        dev = self._ps[0].device
+        total = sum(p.numel() for p in self._ps)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._gviews = []
+        off = 0
+        with torch.no_grad():
+            for p in self._ps:
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + n].view_as(p)
+                gv = self.flat_g[off:off + n].view_as(p)
+                p.grad = gv
+                self._gviews.append(gv)
+                off += n
+        self.steps = 0
+        self.reducer = reducer            # callable(flat_g) -> grad_scale  (data-parallel all-reduce)
+        self._update = update_fn or ops.adam_flat
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+        for p, gv in zip(self._ps, self._gviews):
+            p.grad = gv
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for p, gv in zip(self._ps, self._gviews):
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
+        scale = 1.0
+        if self.reducer is not None:
+            scale = self.reducer(self.flat_g)
+        g = self.param_groups[0]
+        self.steps += 1
+        self._update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.steps, g['lr'], g['betas'][0],
+                     g['betas'][1], g['eps'], scale)

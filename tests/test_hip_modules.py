@@ -1,0 +1,238 @@
+"""GPU parity of the drop-in `src.models` classes and the ELBO step against the golden fixtures generated from
+the reference (tests/golden/make_goldens.py) and against the CPU oracle on fresh seeded inputs.
+Tolerance: 1e-4 relative fp32 on outputs (BASELINE.json north_star), gradients within 1e-3 of max-norm with
+LeakyReLU-kink outliers allowed (conftest.assert_grad_close)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_grad_close, load_golden, rel_err, tdict
+from oracle import tvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+OUT_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def build_encoder(fx, prefix):
+    import src.models as M
+    cfg = [int(v) for v in fx['cfg']]
+    n, cin, zd, C, k, p, R, refine, normal = cfg[:9]
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, cin, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R, rot_refinement=bool(refine),
+        theta_prior=float(fx['theta_prior']), normal_prior_over_r=bool(normal))
+    enc.load_state_dict({k_: v for k_, v in tdict(fx, prefix).items()})
+    return enc.to(dev())
+
+
+def build_generator(fx, prefix, zd, hid, n_out, L, resid, fourier, sigma):
+    import src.models as M
+    gen = M.SpatialGenerator(zd, hid, n_out=n_out, num_layers=L, resid=bool(resid), fourier_expansion=bool(fourier),
+                             sigma=sigma)
+    gen.load_state_dict({k_: v for k_, v in tdict(fx, prefix).items()})
+    return gen.to(dev())
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'bank_*.npz'))))
+def test_trans_filter_golden(path):
+    import src.models as M
+    fx = load_golden(os.path.basename(path)[:-4])
+    C, Cin, _, k, _ = fx['weight'].shape
+    R = fx['bank'].shape[1]
+    gc = M.GroupConv(Cin, C, k, output_rot_dim=R)
+    gc.weight.data.copy_(torch.from_numpy(fx['weight']))
+    gc = gc.to(dev())
+    tw = gc.trans_filter(dev())
+    assert tw.shape == fx['bank'].shape
+    assert rel_err(tw, fx['bank']) < 1e-5
+    (tw * torch.from_numpy(fx['gbank']).to(dev())).sum().backward()
+    assert rel_err(gc.weight.grad, fx['gweight']) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['groupconv_fwd_bwd', 'groupconv_cin3_k9_R4'])
+def test_groupconv_golden(name):
+    import src.models as M
+    fx = load_golden(name)
+    C, Cin, _, k, _ = fx['weight'].shape
+    R = fx['out'].shape[2]
+    n, Ho = fx['y'].shape[-1], fx['out'].shape[-1]
+    pad = (Ho - 1 + k - n) // 2
+    gc = M.GroupConv(Cin, C, k, padding=pad, output_rot_dim=R)
+    gc.weight.data.copy_(torch.from_numpy(fx['weight']))
+    gc.bias.data.copy_(torch.from_numpy(fx['bias']))
+    gc = gc.to(dev())
+    out = gc(torch.from_numpy(fx['y']).to(dev()), dev())
+    assert out.shape == fx['out'].shape
+    assert rel_err(out, fx['out']) < OUT_TOL
+    (out * torch.from_numpy(fx['gout']).to(dev())).sum().backward()
+    assert rel_err(gc.weight.grad, fx['gweight']) < OUT_TOL
+    assert rel_err(gc.bias.grad, fx['gbias']) < OUT_TOL
+
+
+def test_groupconv_rot90_equivariance_gpu():
+    """Known-answer property that needs no reference: 90-degree equivariance of the lifting conv."""
+    import src.models as M
+    torch.manual_seed(1)
+    R = 8
+    gc = M.GroupConv(1, 5, 12, padding=4, bias=False, output_rot_dim=R).to(dev())
+    y = torch.rand(2, 1, 12, 12, device=dev())
+    a = gc(torch.rot90(y, 1, dims=(2, 3)), dev())
+    b = torch.rot90(torch.roll(gc(y, dev()), -R // 4, dims=2), 1, dims=(3, 4))
+    assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['encoder_P8_28', 'encoder_P16_28_normal', 'encoder_P4_20_norefine',
+                                  'encoder_P8_64'])
+def test_encoder_golden(name):
+    fx = load_golden(name)
+    enc = build_encoder(fx, 'p.')
+    outs = enc(torch.from_numpy(fx['y']).to(dev()), dev(), E=torch.from_numpy(fx['E']).to(dev()))
+    attn, q, p_r, a_s, offs, theta, z = outs
+    for got, key in ((attn, 'attn'), (q, 'q_t_r'), (p_r, 'p_r'), (a_s, 'a_sampled'), (offs, 'offsets'),
+                     (theta, 'theta'), (z, 'z')):
+        assert tuple(got.shape) == tuple(fx[key].shape), key
+        assert rel_err(got, fx[key]) < OUT_TOL, key
+    assert abs(float(torch.exp(q).reshape(q.shape[0], -1).sum(1).max()) - 1) < 1e-4
+    w = {k_: torch.from_numpy(fx[k_]).to(dev()) for k_ in ('w_q', 'w_a', 'w_t', 'w_z')}
+    probe = (q * w['w_q']).sum() + (a_s * w['w_a']).sum() * 50 + (theta * w['w_t']).sum() \
+        + (z * w['w_z']).sum() + (attn * w['w_q']).sum() * 0.5
+    probe.backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('g.'))
+    for k_, t in enc.named_parameters():
+        assert_grad_close(t.grad, fx['g.' + k_], tol=GRAD_TOL, floor=floor, name=k_)
+
+
+@pytest.mark.parametrize('name', ['decoder_plain', 'decoder_plain512', 'decoder_fourier', 'decoder_resid',
+                                  'decoder_nout2', 'decoder_nout3_z50_L4', 'decoder_z0_L1'])
+def test_decoder_golden(name):
+    fx = load_golden(name)
+    zd, hid, n_out, L, resid, fourier = [int(v) for v in fx['cfg']]
+    gen = build_generator(fx, 'p.', zd, hid, n_out, L, resid, fourier, float(fx['sigma']) if fourier else 0.01)
+    x = torch.from_numpy(fx['x']).to(dev()).requires_grad_(True)
+    z = torch.from_numpy(fx['z']).to(dev()).requires_grad_(True) if zd > 0 else None
+    yh = gen(x, z)
+    assert tuple(yh.shape) == tuple(fx['y_hat'].shape)
+    assert rel_err(yh, fx['y_hat']) < OUT_TOL
+    (yh * torch.from_numpy(fx['gy']).to(dev())).sum().backward()
+    assert_grad_close(x.grad.reshape(-1, 2), fx['gx'].reshape(-1, 2), tol=GRAD_TOL, name='gx')
+    if zd > 0:
+        assert_grad_close(z.grad, fx['gz'], tol=GRAD_TOL, name='gz')
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, fx['g.' + k_], tol=GRAD_TOL, name=k_)
+
+
+STEP_LIK = {'step_mnist28_P8_init': 'bce', 'step_mnist28_P8_peaked': 'bce',
+            'step_mnist28_P16_fourier_normal': 'bce', 'step_mnist28_P4_attention_resid': 'bce',
+            'step_particles64_P8': 'gauss', 'step_particles32_fitnoise': 'gauss_var', 'step_galaxy_small': 'bce'}
+
+
+def build_step_models(fx):
+    n, cin, zd, C, k, p, R, refine, normal, hid, L, n_out, fourier, resid = [int(v) for v in fx['cfg']]
+    enc = build_encoder(fx, 'e.')
+    gen = build_generator(fx, 'd.', zd, hid, n_out, L, resid, fourier, float(fx['sigma']))
+    return enc, gen, n
+
+
+@pytest.mark.parametrize('name', sorted(STEP_LIK))
+def test_step_golden(name):
+    """eval_minibatch (reference train_*.py) -> (elbo, log_p, kl) and every parameter gradient."""
+    from tvae import step
+    fx = load_golden(name)
+    enc, gen, n = build_step_models(fx)
+    x = O.image_coords(n).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    elbo, logp, kl = step.elbo_terms(x, torch.from_numpy(fx['y']).to(dev()), gen, enc, STEP_LIK[name], noise)
+    assert elbo.dtype == torch.float64 and kl.dtype == torch.float64 and logp.dtype == torch.float32
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
+    assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    (-elbo).backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.named_parameters():
+        assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
+
+
+def test_step_intermediates_vs_oracle():
+    """Latent sample z, theta, dx, reconstruction y_hat against the oracle on the peaked fixture (SURVEY 8d gate)."""
+    from tvae import step
+    fx = load_golden('step_mnist28_P8_peaked')
+    enc, gen, n = build_step_models(fx)
+    cfgv = [int(v) for v in fx['cfg']]
+    noise_c = dict(E=torch.from_numpy(fx['E']), eps_z=torch.from_numpy(fx['eps_z']),
+                   eps_theta=torch.from_numpy(fx['eps_theta']))
+    _, _, _, aux = O.elbo_step(O.image_coords(n), torch.from_numpy(fx['y']), tdict(fx, 'e.'), tdict(fx, 'd.'),
+                               R=cfgv[6], padding=cfgv[5], rot_refinement=bool(cfgv[7]),
+                               theta_prior=float(fx['theta_prior']), normal_prior_over_r=bool(cfgv[8]),
+                               num_layers=cfgv[10], resid=bool(cfgv[13]), fourier_sigma=None, likelihood='bce',
+                               return_aux=True, **noise_c)
+    x = O.image_coords(n).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    with torch.no_grad():
+        _, _, _, got = step.elbo_terms(x, torch.from_numpy(fx['y']).to(dev()), gen, enc, 'bce', noise,
+                                       return_aux=True)
+    assert float(aux['a_sampled'].max()) > 0.2          # attention really is peaked in this fixture
+    for k_ in ('z', 'theta', 'dx', 'x_rot', 'y_hat', 'kl_per_image', 'a_sampled', 'q_t_r'):
+        assert rel_err(got[k_].reshape(-1), aux[k_].reshape(-1)) < OUT_TOL, k_
+
+
+def test_epoch_two_steps_golden():
+    """train_epoch with the fused flat Adam reproduces the reference running means and post-step parameters."""
+    from tvae import optim, step
+    fx = load_golden('epoch_2steps')
+    enc, gen, n = build_step_models({**fx, **{k_: v for k_, v in fx.items()}})
+    params = list(gen.parameters()) + list(enc.parameters())
+    opt = optim.FlatAdam(params, lr=2e-4)
+    data = torch.from_numpy(fx['data']).to(dev())
+    noises = iter([tuple(torch.from_numpy(fx[f'{k_}{i}']).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+                   for i in range(2)])
+    it = [(data[0:4],), (data[4:8],)]
+    x = O.image_coords(n).to(dev())
+    e, err, kl = step.train_epoch(it, x, gen, enc, opt, 'attention', 'attention+offsets', 0, 1, 8, dev(), params,
+                                  np.pi, 8, n, progress=False, noise_iter=noises)
+    assert abs(e - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(err - float(fx['err'])) / abs(float(fx['err'])) < OUT_TOL
+    assert abs(kl - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    for k_, t in enc.state_dict().items():
+        if k_ == 'conv_a.bias':      # analytic gradient is 0 (softmax shift invariance): Adam follows rounding noise
+            assert (t.cpu() - torch.from_numpy(fx['e1.' + k_])).abs().max() <= 2 * 2e-4 * 2 + 1e-7
+            continue
+        assert rel_err(t, fx['e1.' + k_]) < 2e-5, k_
+    for k_, t in gen.state_dict().items():
+        assert rel_err(t, fx['d1.' + k_]) < 2e-5, k_
+
+
+def test_full_size_properties():
+    """BASELINE size (64x64, P8, z=2, B=256 reduced to B=32 here for memory/time): size-independent properties --
+    exp(q) sums to 1, a sums to 1, KL >= 0 finite, determinism (bitwise equal on a second run), and the encoder's
+    batch independence (image b's outputs do not depend on its neighbours)."""
+    import src.models as M
+    from tvae import step
+    torch.manual_seed(0)
+    n, R, B = 64, 8, 32
+    gen = M.SpatialGenerator(2, 512, num_layers=2).to(dev())
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 1, 2, kernels_num=128, kernels_size=64, padding=16, groupconv=R, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False).to(dev())
+    y = torch.randn(B, 1, n, n, device=dev())
+    x = O.image_coords(n).to(dev())
+    noise = step.draw_noise(B, R * 33 * 33, 2, dev())
+    with torch.no_grad():
+        e1, lp1, kl1, aux = step.elbo_terms(x, y, gen, enc, 'gauss', noise, return_aux=True)
+        e2, lp2, kl2 = step.elbo_terms(x, y, gen, enc, 'gauss', noise)
+        assert float(e1) == float(e2) and float(lp1) == float(lp2) and float(kl1) == float(kl2)
+        assert (torch.exp(aux['q_t_r']).sum(1) - 1).abs().max() < 1e-4
+        assert (aux['a_sampled'].sum(1) - 1).abs().max() < 1e-4
+        assert torch.isfinite(aux['kl_per_image']).all() and (aux['kl_per_image'] > -1e-4).all()
+        sub = slice(5, 9)
+        _, _, _, aux_s = step.elbo_terms(x, y[sub], gen, enc, 'gauss', tuple(t[sub] for t in noise), return_aux=True)
+        assert rel_err(aux_s['y_hat'], aux['y_hat'][sub]) < 1e-5
+        assert rel_err(aux_s['kl_per_image'], aux['kl_per_image'][sub]) < 1e-5

@@ -1,0 +1,318 @@
+"""GPU parity of every C-ABI entry point of libtvae_hip.so against plain torch fp64/fp32 math.
+These call through the C ABI (tvae._lib.call -> ctypes) on cuda:0."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import tvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+SLOPE = 0.01
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def call(*a):
+    from tvae._lib import call as c
+    return c(*a)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def act_ref(x, act):
+    return x if act == 0 else (F.leaky_relu(x, SLOPE) if act == 1 else torch.tanh(x))
+
+
+def dact_ref(y, act):
+    if act == 0:
+        return torch.ones_like(y)
+    return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, SLOPE)) if act == 1 else 1 - y * y
+
+
+@pytest.mark.parametrize('M,N,K,act,use_g,use_res', [
+    (128, 8712, 128, 1, False, False), (7, 300, 128, 0, False, False), (512, 1000, 1024, 1, True, False),
+    (64, 517, 64, 1, False, True), (130, 129, 17, 2, True, True), (103, 2000, 128, 0, False, False)])
+def test_linear_fwd(M, N, K, act, use_g, use_res):
+    W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
+    group = 100
+    ng = (N + group - 1) // group
+    gb = rnd(ng, M, seed=4) if use_g else None
+    res = rnd(M, N, seed=5) if use_res else None
+    ref = W.double() @ X.double() + b.double()[:, None]
+    if use_g:
+        ref = ref + gb.double()[torch.arange(N) // group].t()
+    if use_res:
+        ref = ref + res.double()
+    ref = act_ref(ref, act)
+    Y = torch.empty(M, N, device=dev())
+    call('tvae_linear_fwd', W.to(dev()), X.to(dev()), b.to(dev()), gb.to(dev()) if use_g else None, group,
+         res.to(dev()) if use_res else None, Y, M, N, K, N, N, act, SLOPE)
+    assert rel_err(Y, ref) < TOL
+
+
+@pytest.mark.parametrize('M,N,K,mask,use_add', [(7, 3000, 128, 1, False), (128, 1111, 128, 1, False),
+                                                (64, 300, 64, 1, True), (512, 700, 1024, 0, False),
+                                                (33, 257, 65, 2, True)])
+def test_linear_dgrad(M, N, K, mask, use_add):
+    W, d = rnd(M, K, seed=1, scale=M ** -0.5), rnd(M, N, seed=2)
+    aux = rnd(K, N, seed=3).clamp(-0.9, 0.9)
+    add = rnd(K, N, seed=4) if use_add else None
+    ref = W.double().t() @ d.double()
+    if use_add:
+        ref = ref + add.double()
+    ref = ref * dact_ref(aux.double(), mask)
+    dX = torch.empty(K, N, device=dev())
+    call('tvae_linear_dgrad', W.to(dev()), d.to(dev()), add.to(dev()) if use_add else None,
+         aux.to(dev()) if mask else None, dX, M, N, K, N, N, mask, SLOPE)
+    assert rel_err(dX, ref) < TOL
+
+
+@pytest.mark.parametrize('M,N,K,acc', [(7, 50000, 128, 0), (128, 8712 * 3, 128, 0), (64, 1000, 2, 1),
+                                       (512, 20000, 512, 0), (130, 777, 1024, 0)])
+def test_linear_wgrad(M, N, K, acc):
+    d, X = rnd(M, N, seed=1), rnd(K, N, seed=2)
+    init = rnd(M, K, seed=3)
+    ref = d.double() @ X.double().t() + (init.double() if acc else 0)
+    dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
+    ws = torch.empty(1 << 24, device=dev())
+    call('tvae_linear_wgrad', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc)
+    assert rel_err(dW, ref) < TOL
+
+
+def test_linear_wgrad_no_workspace():
+    M, N, K = 20, 5000, 30
+    d, X = rnd(M, N, seed=1), rnd(K, N, seed=2)
+    dW = torch.empty(M, K, device=dev())
+    call('tvae_linear_wgrad', d.to(dev()), X.to(dev()), dW, None, 0, M, N, K, N, N, 0)
+    assert rel_err(dW, d.double() @ X.double().t()) < TOL
+
+
+@pytest.mark.parametrize('k,R,Cin,C', [(5, 4, 1, 3), (28, 8, 1, 4), (9, 16, 3, 2)])
+def test_rotate_bank(k, R, Cin, C):
+    from tvae import ops
+    w = rnd(C, Cin, 1, k, k, seed=k)
+    wr = w.clone().requires_grad_(True)
+    ref = O.rotated_bank(wr, R)                      # (C,R,Cin,1,k,k)
+    wg = w.to(dev()).requires_grad_(True)
+    bank = ops.BankFn.apply(wg, R)
+    assert rel_err(bank.view(C, R, Cin, 1, k, k), ref) < 1e-6
+    g = rnd(*ref.shape, seed=9)
+    (ref * g).sum().backward()
+    (bank.view(C, R, Cin, 1, k, k) * g.to(dev())).sum().backward()
+    assert rel_err(wg.grad, wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,Cin,n,k,pad,C,R,act', [(2, 1, 28, 28, 8, 8, 8, 1), (3, 3, 12, 9, 3, 4, 4, 0),
+                                                   (2, 1, 64, 64, 16, 4, 8, 1), (5, 2, 20, 7, 0, 3, 16, 0)])
+def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act):
+    y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
+    bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(C, seed=3, scale=0.1)
+    Ho = n + 2 * pad - k + 1
+    ref = F.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho) \
+        + bias.double().view(1, C, 1, 1, 1)
+    ref = act_ref(ref, act)
+    out = torch.empty(C, B * R * Ho * Ho, device=dev())
+    call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE)
+    got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+    assert rel_err(got, ref) < TOL
+    # weight gradient
+    g = rnd(B, C, R, Ho, Ho, seed=4)
+    ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
+    dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
+    dbank = torch.empty(C * R, Cin * k * k, device=dev())
+    ws = torch.empty(1 << 22, device=dev())
+    call('tvae_conv1_wgrad', y.to(dev()), dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < TOL
+
+
+def test_reductions():
+    M, N = 37, 10007
+    X = rnd(M, N, seed=1)
+    V = rnd(N, 3, seed=2)
+    sl = 1000
+    nseg = (N + sl - 1) // sl
+    out = torch.empty(nseg, M, 3, device=dev())
+    call('tvae_rowdot_seg', X.to(dev()), N, V.to(dev()), 3, M, N, sl, out)
+    ref = torch.stack([X[:, s * sl:(s + 1) * sl].double() @ V[s * sl:(s + 1) * sl].double() for s in range(nseg)])
+    assert rel_err(out, ref) < TOL
+    out1 = torch.empty(nseg, M, device=dev())
+    call('tvae_rowdot_seg', X.to(dev()), N, None, 1, M, N, sl, out1)
+    ref1 = torch.stack([X[:, s * sl:(s + 1) * sl].double().sum(1) for s in range(nseg)])
+    assert rel_err(out1, ref1) < TOL
+    tot = torch.full((M,), 2.0, device=dev())
+    call('tvae_seg_sum', out1, nseg, M, tot, 0.5, 1)
+    assert rel_err(tot, 2.0 + 0.5 * X.double().sum(1)) < TOL
+
+
+@pytest.mark.parametrize('no', [1, 2, 3])
+def test_coldot_outer_mask(no):
+    M, N = 64, 1500
+    X, W, b = rnd(M, N, seed=1), rnd(no, M, seed=2), rnd(no, seed=3)
+    out = torch.empty(N, no, device=dev())
+    call('tvae_coldot', X.to(dev()), N, M, N, W.to(dev()), 1, M, b.to(dev()), no, out)
+    assert rel_err(out, (W.double() @ X.double()).t() + b.double()) < TOL
+    dy = rnd(N, no, seed=4)
+    D = torch.empty(M, N, device=dev())
+    call('tvae_outer_mask', dy.to(dev()), no, W.to(dev()), 1, M, X.to(dev()), N, D, N, M, N, 1, SLOPE)
+    ref = (W.double().t() @ dy.double().t()) * dact_ref(X.double(), 1)
+    assert rel_err(D, ref) < TOL
+    pre = torch.empty(M, N, device=dev())
+    call('tvae_act_bwd', D, X.to(dev()), pre, M * N, 1, SLOPE)
+    assert rel_err(pre, ref * dact_ref(X.double(), 1)) < TOL
+
+
+def test_coord():
+    B, n = 3, 9
+    xc = O.image_coords(n)
+    dx = rnd(B, 2, seed=1, scale=0.2).requires_grad_(True)
+    th = rnd(B, seed=2).requires_grad_(True)
+    x = xc.expand(B, -1, -1) - dx.unsqueeze(1)
+    rot = torch.stack([torch.stack([torch.cos(th), torch.sin(th)], 1),
+                       torch.stack([-torch.sin(th), torch.cos(th)], 1)], 1)
+    ref = torch.bmm(x, rot)
+    g = rnd(B, n * n, 2, seed=3)
+    (ref * g).sum().backward()
+    from tvae import ops
+    dxg = dx.detach().to(dev()).requires_grad_(True)
+    thg = th.detach().to(dev()).requires_grad_(True)
+    xr = ops.CoordFn.apply(xc.to(dev()), dxg, thg)
+    assert rel_err(xr, ref) < 1e-6
+    (xr * g.to(dev())).sum().backward()
+    assert rel_err(dxg.grad, dx.grad) < TOL and rel_err(thg.grad, th.grad) < TOL
+
+
+@pytest.mark.parametrize('kind,name', [(0, 'bce'), (1, 'gauss'), (2, 'gauss_var')])
+def test_loglik(kind, name):
+    B, L = 3, 500
+    y = torch.rand(B, L, generator=torch.Generator().manual_seed(1))
+    yh = rnd(B, 2 * L if kind == 2 else L, seed=2, scale=2.0).requires_grad_(True)
+    w = rnd(B, seed=3)
+    if kind == 0:
+        per = -(F.binary_cross_entropy_with_logits(yh, y, reduction='none')).sum(1)
+    elif kind == 1:
+        per = -0.5 * ((yh - y) ** 2).sum(1)
+    else:
+        per = -0.5 * ((yh[:, :L] - y) ** 2 / torch.exp(yh[:, L:]) + yh[:, L:]).sum(1)
+    (per * w).sum().backward()
+    assert abs(float(per.mean()) - float(O.likelihood_logp(yh.detach(), y, name))) < 1e-3 * abs(float(per.mean()))
+    from tvae import ops
+    yg = yh.detach().to(dev()).requires_grad_(True)
+    lp = ops.LogLikFn.apply(yg, y.to(dev()), kind)
+    assert rel_err(lp, per) < TOL
+    (lp * w.to(dev())).sum().backward()
+    assert rel_err(yg.grad, yh.grad) < TOL
+
+
+def test_adam_flat():
+    n = 10001
+    p0, steps = rnd(n, seed=1), 3
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=2e-4)
+    p = p0.clone().to(dev())
+    m = torch.zeros(n, device=dev())
+    v = torch.zeros(n, device=dev())
+    from tvae import ops
+    for s in range(steps):
+        g = rnd(n, seed=10 + s)
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_flat(p, g.to(dev()), m, v, s + 1, 2e-4)
+    assert rel_err(p, p_ref.detach()) < 1e-6
+
+
+def _head_reference(hd, E, eps_z, eps_t, R, Ho, zd, refine, theta_prior, normal, spacing):
+    """Torch restatement of the head through the oracle (encoder tail + posterior_pool_kl)."""
+    B = E.shape[0]
+    hv = hd.view(3 + 2 * zd, B, R, Ho, Ho)
+    p_r = torch.from_numpy(O.rotation_log_prior(R, refine, theta_prior, normal)).view(R, 1, 1)
+    attn = hv[0] + p_r
+    q = F.log_softmax(attn.reshape(B, -1), 1).view(B, R, Ho, Ho)
+    a = F.softmax(attn.reshape(B, -1) - torch.log(E), 1).view(B, R, Ho, Ho)
+    theta = hv[1:3].permute(1, 0, 2, 3, 4)
+    offs = torch.from_numpy(O.rotation_offsets(R)) if refine else torch.zeros(R)
+    if refine:
+        theta = torch.stack((theta[:, 0] + offs.view(1, R, 1, 1), theta[:, 1]), 1)
+    zv = hv[3:].permute(1, 0, 2, 3, 4)
+    x = torch.zeros(B, 4, 2)
+    z, th, dx, _, kl = O.posterior_pool_kl(x, attn, q, p_r, a, offs, theta, zv, spacing, eps_z, eps_t, R, theta_prior)
+    return attn, q, a, z, th, dx.view(B, 2), kl
+
+
+@pytest.mark.parametrize('R,Ho,zd,refine,normal,scale', [(8, 17, 2, True, False, 1.0), (4, 9, 3, False, False, 4.0),
+                                                         (16, 5, 2, True, True, 8.0), (8, 33, 2, True, False, 30.0)])
+def test_attn_head(R, Ho, zd, refine, normal, scale):
+    from tvae import ops
+    B = 3
+    RP = R * Ho * Ho
+    theta_prior = math.pi / 4 if normal else math.pi
+    spacing = 2.0 / 27
+    hd = rnd(3 + 2 * zd, B * RP, seed=1, scale=0.5)
+    hd[0] *= scale                                       # peaked attention for large scale (forces exp(q)==0)
+    g = torch.Generator().manual_seed(2)
+    E = torch.empty(B, RP).exponential_(generator=g)
+    eps_z, eps_t = rnd(B, zd, seed=3), rnd(B, seed=4)
+    hr = hd.clone().requires_grad_(True)
+    ref = _head_reference(hr, E, eps_z, eps_t, R, Ho, zd, refine, theta_prior, normal, spacing)
+    tb = ops.HeadTables(R, Ho, spacing, refine, theta_prior, normal, dev())
+    hg = hd.clone().to(dev()).requires_grad_(True)
+    got = ops.HeadFn.apply(hg, E.to(dev()), eps_z.to(dev()), eps_t.to(dev()), tb, B, zd)
+    names = ['attn', 'q', 'a', 'z', 'theta', 'dx', 'kl']
+    for nm, r_, g_ in zip(names, ref, got):
+        assert rel_err(g_.reshape(-1), r_.reshape(-1)) < 5e-5, nm
+    ws = [rnd(*r_.shape, seed=20 + i) for i, r_ in enumerate(ref)]
+    coef = [0.3, 0.2, 5.0, 1.0, 1.0, 1.0, 1.0]
+    sum(c * (r_ * w.to(r_.dtype)).sum() for c, r_, w in zip(coef, ref, ws)).backward()
+    sum(c * (g_ * w.to(dev()).view_as(g_)).sum() for c, g_, w in zip(coef, got, ws)).backward()
+    assert rel_err(hg.grad, hr.grad) < 2e-4
+
+
+@pytest.mark.parametrize('fourier,zd,F_', [(False, 2, 64), (True, 3, 32)])
+def test_decoder_ends(fourier, zd, F_):
+    """dec_l0 / latent / fourier kernels against torch."""
+    B, Np = 2, 50
+    Nt = B * Np
+    xr = (torch.rand(B, Np, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1)
+    z = rnd(B, zd, seed=2)
+    Wl = rnd(F_, zd, seed=3)
+    LB = torch.empty(B, F_, device=dev())
+    call('tvae_latent_bias', Wl.to(dev()), z.to(dev()), LB, B, F_, zd)
+    assert rel_err(LB, z.double() @ Wl.double().t()) < TOL
+    if not fourier:
+        Wc, bc = rnd(F_, 2, seed=4), rnd(F_, seed=5)
+        h = torch.empty(F_, Nt, device=dev())
+        call('tvae_dec_l0_fwd', xr.to(dev()), Wc.to(dev()), bc.to(dev()), LB, h, Nt, F_, Nt, Np, 1, SLOPE)
+        ref = F.leaky_relu(xr.view(Nt, 2).double() @ Wc.double().t() + bc.double() +
+                           (z.double() @ Wl.double().t()).repeat_interleave(Np, 0), SLOPE).t()
+        assert rel_err(h, ref) < TOL
+    else:
+        Ff, sigma = 48, 2.0 / 27
+        Wf = rnd(Ff, 2, seed=6)
+        bf = torch.rand(Ff, generator=torch.Generator().manual_seed(7)) * 2 * math.pi
+        feat = torch.empty(Ff, Nt, device=dev())
+        call('tvae_fourier_fwd', xr.to(dev()), Wf.to(dev()), bf.to(dev()), sigma, feat, Nt, Ff, Nt)
+        x64 = xr.view(Nt, 2).double().requires_grad_(True)
+        w32 = (Wf / torch.tensor(sigma, dtype=torch.float32)).double()
+        ref = torch.cos(x64 @ w32.t() + bf.double())
+        assert rel_err(feat, ref.t()) < 5e-5
+        g = rnd(Ff, Nt, seed=8)
+        (ref.t() * g.double()).sum().backward()
+        gx = torch.empty(Nt, 2, device=dev())
+        call('tvae_fourier_bwd', xr.to(dev()), Wf.to(dev()), bf.to(dev()), sigma, g.to(dev()), Nt, Ff, Nt, gx)
+        assert rel_err(gx, x64.grad) < 5e-5
+    S = rnd(B, F_, seed=9)
+    dWl = torch.empty(F_, zd, device=dev())
+    dz = torch.empty(B, zd, device=dev())
+    call('tvae_latent_bwd', S.to(dev()), Wl.to(dev()), z.to(dev()), dWl, dz, B, F_, zd)
+    assert rel_err(dWl, S.double().t() @ z.double()) < TOL
+    assert rel_err(dz, S.double() @ Wl.double()) < TOL
