@@ -429,6 +429,7 @@ class LogLikFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, yh, y, kind):
         B = y.shape[0]
+        ctx.shape = tuple(yh.shape)
         y = y.contiguous().view(B, -1)
         yh = yh.contiguous().view(B, -1)
         L = y.shape[1]
@@ -437,7 +438,6 @@ class LogLikFn(torch.autograd.Function):
         call('tvae_loglik_fwd', yh, y, lp, B, L, kind)
         ctx.save_for_backward(yh, y)
         ctx.kind = kind
-        ctx.shape = None
         return lp
 
     @staticmethod
@@ -446,7 +446,7 @@ class LogLikFn(torch.autograd.Function):
         B, L = y.shape
         gyh = torch.empty_like(yh)
         call('tvae_loglik_bwd', yh, y, g.contiguous(), gyh, B, L, ctx.kind)
-        return gyh, None, None
+        return gyh.view(ctx.shape), None, None
 
 
 def adam_flat(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
