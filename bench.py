@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: TARGET-VAE training images/sec (fwd + bwd + Adam [+ RCCL all-reduce]) on synthetic
+64x64 particle stacks, P8 (R=8), z=2, batch 256 per GPU  (BASELINE.json metric / configs[3], SURVEY 8d "S64").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.  A "step" is one full
+training minibatch: encoder fwd, attention head, decoder fwd, likelihood, full backward, gradient all-reduce
+(N>1) and the fused Adam update; inputs are resident in HBM before the timed region (like the reference, which
+keeps the dataset on the device, train_mnist.py:495).  Noise (Exp(1), N(0,1)) is drawn on the device inside the
+step, as the reference does.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'target-vae_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+CFG = dict(n=64, cin=1, zd=2, C=128, k=64, pad=16, R=8, hidden=512, layers=2, n_out=1)
+
+
+def conv1_flops_per_image(c=CFG):
+    """ALGORITHMIC FLOPs of the lifting convolution per image: 2*C*R*Cin*k^2*Ho^2."""
+    ho = c['n'] + 2 * c['pad'] - c['k'] + 1
+    return 2.0 * c['C'] * c['R'] * c['cin'] * c['k'] ** 2 * ho ** 2
+
+
+def build_models(device):
+    import src.models as M
+    torch.manual_seed(0)            # reference default init; generator constructed first (train_mnist.py:522,551)
+    c = CFG
+    gen = M.SpatialGenerator(c['zd'], c['hidden'], n_out=c['n_out'], num_layers=c['layers'])
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        c['n'], c['cin'], c['zd'], kernels_num=c['C'], kernels_size=c['k'], padding=c['pad'], groupconv=c['R'],
+        rot_refinement=True, theta_prior=np.pi, normal_prior_over_r=False)
+    return gen.to(device), enc.to(device)
+
+
+def cpu_baseline(batch=16, steps=2):
+    """The CPU oracle (a port of the reference step onto the same ATen CPU operators) timed on this host's
+    cores on a bounded sample of the same workload: `batch` images per step, 1 warm-up + `steps` timed steps."""
+    from oracle import tvae_oracle as O
+    import src.models as M
+    torch.manual_seed(0)
+    c = CFG
+    gen = M.SpatialGenerator(c['zd'], c['hidden'], n_out=c['n_out'], num_layers=c['layers'])
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        c['n'], c['cin'], c['zd'], kernels_num=c['C'], kernels_size=c['k'], padding=c['pad'], groupconv=c['R'],
+        rot_refinement=True, theta_prior=np.pi, normal_prior_over_r=False)
+    encp = {k_: v.detach().clone().requires_grad_(True) for k_, v in enc.state_dict().items()}
+    genp = {k_: v.detach().clone().requires_grad_(True) for k_, v in gen.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = O.new_opt_state(encp, genp)
+    x = O.image_coords(c['n'])
+    ho = c['n'] + 2 * c['pad'] - c['k'] + 1
+    ts = []
+    for i in range(steps + 1):
+        torch.manual_seed(100 + i)
+        y = torch.randn(batch, c['cin'], c['n'], c['n'])
+        noise = dict(E=torch.empty(batch, c['R'] * ho * ho).exponential_(), eps_z=torch.randn(batch, c['zd']),
+                     eps_theta=torch.randn(batch))
+        t0 = time.perf_counter()
+        O.train_step(x, y, encp, genp, st, noise, R=c['R'], padding=c['pad'], rot_refinement=True,
+                     theta_prior=np.pi, normal_prior_over_r=False, num_layers=c['layers'], likelihood='gauss')
+        ts.append(time.perf_counter() - t0)
+    best = min(ts[1:])
+    return dict(value=batch / best, unit='images/sec', cores=cores, kind='port',
+                sample=f'oracle train step (fwd+bwd+Adam), {batch} images/step, 1 warm-up + {steps} timed steps, '
+                       f'min; torch {torch.__version__} CPU, {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step (BASELINE: 256)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from tvae import dp, ops, optim, step
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    gen, enc = build_models(dev)
+    params = list(gen.parameters()) + list(enc.parameters())
+    reducer = dp.GradReducer() if world > 1 else None
+    opt = optim.FlatAdam(params, lr=2e-4, reducer=reducer)
+    if world > 1:                                   # identical replicas: broadcast rank 0's flat parameters
+        dist.broadcast(opt.flat_p, src=0)
+
+    B, c = args.batch, CFG
+    total_steps = args.steps + args.warmup
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    # synthetic dataset resident in HBM: torch.randn matches --normalize'd particles (SURVEY 8d "S64")
+    n_img = B * min(total_steps, 8)
+    data = torch.randn(n_img, c['cin'], c['n'], c['n'], device=dev, generator=g)
+    x = torch.from_numpy(__import__('tvae.tables', fromlist=['x']).image_coords(c['n'])).to(dev)
+    step.pixel_spacing(x)                           # cached once (the reference syncs for it every step)
+
+    def one_step(i):
+        lo = (i % (n_img // B)) * B
+        y = data[lo:lo + B]
+        elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, 'gauss')
+        (-elbo).backward()
+        opt.step()
+        opt.zero_grad()
+        return elbo.detach()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    ops.KERNEL_EVENTS = {}
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = one_step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    kev = ops.kernel_event_ms()
+    ops.KERNEL_EVENTS = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    elbo_last = float(last)
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        flops = conv1_flops_per_image() * B
+        dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
+        ach = flops / (kev[dom]['mean_ms'] * 1e-3) / 1e12
+        other = 'tvae_conv1_wgrad' if dom == 'tvae_conv1_fwd' else 'tvae_conv1_fwd'
+        out = {
+            'metric': 'training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU',
+            'value': imgs / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'elbo': elbo_last,
+            'config': {'workload': 'S64: synthetic 64x64 particle stack (torch.randn), P8 group-conv encoder '
+                                   'k=64 p=16 C=128, z=2, t-inf attention, r-inf attention+offsets, decoder '
+                                   '2->512->512->1, Gaussian likelihood, Adam lr 2e-4',
+                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}'},
+            'roofline': {'kernel': dom + ' (gemm_f32_kernel, v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
+                         'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
+                         'launches_timed': kev[dom]['launches'],
+                         'other': {'kernel': other, 'mean_launch_ms': kev.get(other, {}).get('mean_ms'),
+                                   'achieved': (flops / (kev[other]['mean_ms'] * 1e-3) / 1e12) if other in kev
+                                   else None}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

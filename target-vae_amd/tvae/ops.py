@@ -33,6 +33,39 @@ def act_code(activation) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# optional in-run kernel timing (bench.py): events are recorded on the stream the kernels are launched on
+# ---------------------------------------------------------------------------------------------
+KERNEL_EVENTS = None     # set to {} to record (start, end) torch.cuda.Event pairs per entry point
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.e.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def kernel_event_ms():
+    """Mean milliseconds per launch for every recorded entry point (call after torch.cuda.synchronize())."""
+    out = {}
+    for k, v in (KERNEL_EVENTS or {}).items():
+        ts = [s.elapsed_time(e) for s, e in v]
+        out[k] = dict(launches=len(ts), mean_ms=sum(ts) / max(len(ts), 1), total_ms=sum(ts))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # workspaces and device tables (cached per device)
 # ---------------------------------------------------------------------------------------------
 _WS = {}
@@ -115,7 +148,8 @@ def conv1_forward(y, bank, bias, C, R, k, pad, act):
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
-    call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
+    with _timed('tvae_conv1_fwd'):
+        call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
     return out
 
 
@@ -123,7 +157,8 @@ def conv1_wgrad(y, dpre, C, R, k, pad):
     B, Cin, n, _ = y.shape
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
     ws = workspace(y.device, max(1 << 24, 8 * dbank.numel()))
-    call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    with _timed('tvae_conv1_wgrad'):
+        call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
     return dbank
 
 

@@ -1,0 +1,114 @@
+"""Data-parallel path on CPU: 2 processes over gloo run the product's sharding / gradient all-reduce / flat-Adam
+logic (tvae.dp, tvae.optim) and must reproduce a single-process run on the same global minibatches.
+Per-rank gradients come from the CPU oracle (the HIP kernels need a GPU); on the GPU box the same wrapper runs
+over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, rel_err
+
+CFG = dict(R=4, padding=2, rot_refinement=True, theta_prior=np.pi, normal_prior_over_r=False, num_layers=2)
+N_IMG, GB, NPIX, ZD, HO = 11, 6, 12, 2, 5
+
+
+def _make_params():
+    import src.models as M
+    torch.manual_seed(3)
+    gen = M.SpatialGenerator(ZD, 8, num_layers=2)
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        NPIX, 1, ZD, kernels_num=4, kernels_size=12, padding=2, groupconv=4, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False)
+    with torch.no_grad():
+        for m in (enc.conv_a, enc.conv_r, enc.conv_z):
+            m.weight.mul_(10.0)
+    return gen, enc
+
+
+def _data_and_noise():
+    g = torch.Generator().manual_seed(11)
+    data = torch.rand(N_IMG, 1, NPIX, NPIX, generator=g)
+    E = torch.empty(N_IMG, 4 * HO * HO).exponential_(generator=g)
+    return data, E, torch.randn(N_IMG, ZD, generator=g), torch.randn(N_IMG, generator=g)
+
+
+def _torch_adam(p, g, m, v, step, lr, b1, b2, eps, scale):
+    from oracle import tvae_oracle as O
+    O.adam_update([p], [g * scale], [m], [v], step, lr, b1, b2, eps)
+
+
+def _train(rank, world, epochs=2):
+    from oracle import tvae_oracle as O
+    from tvae import dp, optim
+    gen, enc = _make_params()
+    params = list(gen.parameters()) + list(enc.parameters())
+    reducer = dp.GradReducer() if world > 1 else None
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    data, E, ez, et = _data_and_noise()
+    x = O.image_coords(NPIX)
+    batches = dp.ShardedBatches(data, GB, rank, world, shuffle=True, seed=5, reducer=reducer)
+    stats = [0.0, 0.0]
+    for ep in range(epochs):
+        batches.set_epoch(ep)
+        perm = dp.epoch_permutation(N_IMG, 5, ep)
+        for (y,), (lo, hi, g) in zip(batches, dp.shard_slices(N_IMG, GB, rank, world)):
+            idx = perm[lo:hi]
+            assert torch.equal(y, data[idx])
+            encp = dict(enc.named_parameters())
+            genp = dict(gen.named_parameters())
+            elbo, _, _ = O.elbo_step(x, y, encp, genp, likelihood='bce', E=E[idx], eps_z=ez[idx],
+                                     eps_theta=et[idx], **CFG)
+            (-elbo).backward()
+            opt.step()
+            opt.zero_grad()
+            stats[0] += float(elbo) * (hi - lo)
+            stats[1] += hi - lo
+    stats = dp.allreduce_stats(stats, torch.device('cpu'))
+    named = {'d.' + k_: v.detach().clone() for k_, v in gen.named_parameters()}
+    named.update({'e.' + k_: v.detach().clone() for k_, v in enc.named_parameters()})
+    return named, stats
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tvae import dp
+    r, w, _ = dp.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    flat, stats = _train(rank, world)
+    torch.save(dict(flat=flat, stats=stats), os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    torch.set_num_threads(4)
+    flat1, stats1 = _train(0, 1)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    for k_ in flat1:
+        assert torch.equal(r0['flat'][k_], r1['flat'][k_]), k_        # replicas stay bit-identical
+        if k_ == 'e.conv_a.bias':
+            continue      # analytic gradient 0 (softmax shift invariance): Adam follows rounding noise
+        assert rel_err(r0['flat'][k_], flat1[k_]) < 2e-4, k_          # == the single-process global-batch run
+    assert r0['stats'][1] == stats1[1] == 2 * N_IMG
+    assert abs(r0['stats'][0] - stats1[0]) / abs(stats1[0]) < 1e-5

@@ -1,0 +1,205 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol of include/tvae_hip.h,
+host tables equal the oracle's, the drop-in classes reproduce the reference's parameter names / shapes /
+default initialisation, checkpoints pickle as `src.models.*`, and the product path refuses CPU tensors."""
+import io
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, rel_err, tdict
+from oracle import tvae_oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    from tvae import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'tvae_hip.h')).read()
+    declared = sorted(set(re.findall(r'\bint\s+(tvae_\w+)\s*\(', hdr)))
+    assert declared == sorted(_lib.exported_symbols())
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.tvae_abi_version() == 1
+
+
+def test_signature_arity_matches_header():
+    from tvae import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'tvae_hip.h')).read()
+    for name, sig in _lib.SIGNATURES.items():
+        m = re.search(r'\bint\s+' + name + r'\s*\(([^;]*?)\)\s*;', hdr, re.S)
+        assert m, name
+        args = [a.strip() for a in m.group(1).split(',')]
+        assert args[-1].startswith('tvae_stream_t'), name
+        assert len(args) - 1 == len(sig), (name, len(args) - 1, len(sig))
+        for a, c in zip(args[:-1], sig):
+            if c == 'p':
+                assert '*' in a, (name, a)
+            elif c == 'f':
+                assert a.startswith('float ') and '*' not in a, (name, a)
+            elif c == 'l':
+                assert a.startswith('long '), (name, a)
+            else:
+                assert a.startswith('int ') and '*' not in a, (name, a)
+
+
+def test_product_path_refuses_cpu_tensors():
+    import src.models as M
+    from tvae import _lib
+    gc = M.GroupConv(1, 2, 5, output_rot_dim=4)
+    with pytest.raises(RuntimeError):
+        gc(torch.rand(1, 1, 8, 8), 'cpu')
+    with pytest.raises(_lib.TvaeHipError):
+        _lib.call('tvae_act_bwd', torch.zeros(4), torch.zeros(4), torch.zeros(4), 4, 1, 0.01)
+    gen = M.SpatialGenerator(2, 8)
+    with pytest.raises(RuntimeError):
+        gen(torch.zeros(1, 4, 2), torch.zeros(1, 2))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'target-vae_amd')
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(d, f)).read()
+                assert 'oracle' not in src.replace('no CPU fallback; use oracle', ''), os.path.join(d, f)
+
+
+@pytest.mark.parametrize('k,R', [(5, 4), (28, 8), (9, 16), (64, 8)])
+def test_tap_tables_match_oracle(k, R):
+    from tvae import tables
+    i1, w1 = tables.rotation_taps(k, R)
+    i2, w2 = O.rotation_taps(k, R)
+    assert np.array_equal(i1, i2.astype(np.int32)) and np.array_equal(w1, w2)
+    if k > 28:
+        return                                   # dense check below is O(R k^4) memory
+    ptr, er, ed, ew = tables.rotation_taps_csr(k, R)
+    dense = np.zeros((R, k * k, k * k), dtype=np.float64)          # [r][dst][src]
+    for t in range(4):
+        ok = i1[:, :, t] >= 0
+        rr, dd = np.nonzero(ok)
+        np.add.at(dense, (rr, dd, i1[rr, dd, t]), w1[rr, dd, t])
+    dense2 = np.zeros_like(dense)
+    for s in range(k * k):
+        for e in range(ptr[s], ptr[s + 1]):
+            dense2[er[e], ed[e], s] += ew[e]
+    assert np.allclose(dense, dense2, atol=1e-7)
+
+
+@pytest.mark.parametrize('R,refine,normal,tp', [(8, True, False, np.pi), (16, True, True, np.pi / 4),
+                                                (4, False, False, np.pi)])
+def test_prior_tables_match_oracle(R, refine, normal, tp):
+    from tvae import tables
+    assert np.allclose(tables.rotation_log_prior(R, refine, tp, normal), O.rotation_log_prior(R, refine, tp, normal),
+                       rtol=1e-6, atol=1e-6)
+    off = O.rotation_offsets(R) if refine else np.zeros(R, np.float32)
+    assert np.array_equal(tables.rotation_offsets(R, refine), off)
+    for Ho in (17, 33, 8):
+        s = 2.0 / 27
+        assert np.array_equal(tables.translation_grid(Ho, s), O.translation_grid(Ho, s))
+        G = torch.from_numpy(O.translation_grid(Ho, s))
+        p_t = torch.distributions.Normal(torch.tensor([0.0]), torch.tensor([0.1])).log_prob(G).sum(1)
+        p_r = torch.from_numpy(O.rotation_log_prior(R, refine, tp, normal))
+        ref = torch.log_softmax((p_t.view(1, -1) + p_r.view(R, 1)).reshape(-1), 0)
+        got = tables.joint_log_prior(Ho, s, tables.rotation_log_prior(R, refine, tp, normal))
+        assert np.allclose(got, ref.numpy(), rtol=1e-5, atol=1e-4)
+    assert np.array_equal(tables.image_coords(28), O.image_coords(28).numpy())
+
+
+def test_default_init_and_names_match_reference():
+    """Same seed + same construction order (generator first, train_mnist.py:522,551) => identical parameters to
+    the reference-generated fixture; state_dict names / shapes are the reference's."""
+    import src.models as M
+    fx = load_golden('step_mnist28_P8_init')
+    torch.manual_seed(0)
+    gen = M.SpatialGenerator(2, 512, n_out=1, num_layers=2, resid=False, fourier_expansion=False, sigma=2.0 / 27)
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        28, 1, 2, kernels_num=128, kernels_size=28, padding=8, groupconv=8, rot_refinement=True, theta_prior=np.pi,
+        normal_prior_over_r=False)
+    e_ref, d_ref = tdict(fx, 'e.'), tdict(fx, 'd.')
+    assert sorted(enc.state_dict()) == sorted(e_ref) and sorted(gen.state_dict()) == sorted(d_ref)
+    for k_, v in enc.state_dict().items():
+        assert tuple(v.shape) == tuple(e_ref[k_].shape) and torch.equal(v, e_ref[k_]), k_
+    for k_, v in gen.state_dict().items():
+        assert tuple(v.shape) == tuple(d_ref[k_].shape) and torch.equal(v, d_ref[k_]), k_
+
+
+def test_fourier_generator_names():
+    import src.models as M
+    fx = load_golden('step_mnist28_P16_fourier_normal')
+    gen = M.SpatialGenerator(2, 64, num_layers=2, fourier_expansion=True, sigma=2.0 / 27)
+    assert sorted(gen.state_dict()) == sorted(tdict(fx, 'd.'))
+    fx = load_golden('decoder_resid')
+    gen = M.SpatialGenerator(3, 64, num_layers=3, resid=True)
+    assert sorted(gen.state_dict()) == sorted(tdict(fx, 'p.'))
+
+
+def test_whole_module_pickle_roundtrip(tmp_path):
+    """Checkpoints are whole-module pickles (reference train_mnist.py:672-681, src/utils.py:37-48) with classes at
+    src.models.*; device tables must not leak into them."""
+    import src.models as M
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(28, 1, 2, kernels_num=8, kernels_size=28,
+                                                                    padding=8, groupconv=8, rot_refinement=True)
+    enc.__dict__['_tb_cache'] = {'x': object()}
+    p = tmp_path / 'inference.sav'
+    torch.save(enc, p)
+    raw = open(p, 'rb').read()
+    assert b'src.models' in raw and b'InferenceNetwork_AttentionTranslation_AttentionRotation' in raw
+    enc2 = torch.load(p, weights_only=False)
+    assert '_tb_cache' not in enc2.__dict__
+    for (k1, v1), (k2, v2) in zip(enc.state_dict().items(), enc2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    gen = M.SpatialGenerator(2, 16, num_layers=2, fourier_expansion=True, sigma=0.1)
+    buf = io.BytesIO()
+    torch.save(gen, buf)
+    buf.seek(0)
+    gen2 = torch.load(buf, weights_only=False)
+    assert float(gen2.embed_latent.sigma) == pytest.approx(0.1)
+
+
+def test_flat_adam_views_and_update_cpu():
+    """FlatAdam bookkeeping (flat views, zero_grad, step counting) with a torch update function on CPU; the default
+    update function is the HIP kernel (checked on the GPU in test_hip_primitives.py::test_adam_flat)."""
+    from tvae import optim
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    calls = []
+
+    def upd(p, g, m, v, step, lr, b1, b2, eps, scale):
+        calls.append(step)
+        O.adam_update([p], [g * scale], [m], [v], step, lr, b1, b2, eps)
+
+    opt = optim.FlatAdam(ps, lr=1e-2, update_fn=upd)
+    ropt = torch.optim.Adam(ref, lr=1e-2)
+    assert ps[0].data_ptr() == opt.flat_p.data_ptr() and ps[1].grad.data_ptr() == opt.flat_g[12:].data_ptr()
+    for it in range(3):
+        loss = sum(((p * (i + 1 + it)) ** 2).sum() for i, p in enumerate(ps))
+        loss.backward()
+        rl = sum(((p * (i + 1 + it)) ** 2).sum() for i, p in enumerate(ref))
+        rl.backward()
+        opt.step(); opt.zero_grad()
+        ropt.step(); ropt.zero_grad()
+        assert float(opt.flat_g.abs().sum()) == 0.0
+    assert calls == [1, 2, 3]
+    for p, r in zip(ps, ref):
+        assert rel_err(p.detach(), r.detach()) < 1e-6
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='max', factor=0.5, patience=0)
+    sched.step(1.0); sched.step(0.0)
+    assert opt.param_groups[0]['lr'] == pytest.approx(5e-3)
+
+
+def test_shard_slices_cover_every_minibatch():
+    from tvae import dp
+    for n, gb, world in ((10, 4, 2), (37, 8, 4), (5, 8, 2), (256, 256, 8)):
+        per_rank = [list(dp.shard_slices(n, gb, r, world)) for r in range(world)]
+        nb = (n + gb - 1) // gb
+        assert all(len(p) == nb for p in per_rank)
+        for b in range(nb):
+            g = per_rank[0][b][2]
+            idx = sorted(i for r in range(world) for i in range(per_rank[r][b][0], per_rank[r][b][1]))
+            assert idx == list(range(b * gb, b * gb + g))
+    assert torch.equal(dp.epoch_permutation(50, 3, 7), dp.epoch_permutation(50, 3, 7))
+    assert not torch.equal(dp.epoch_permutation(50, 3, 7), dp.epoch_permutation(50, 3, 8))
