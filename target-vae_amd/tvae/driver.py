@@ -1,0 +1,296 @@
+"""Experiment driver shared by train_{mnist,particles,galaxy,dsprites}.py.
+
+Keeps the reference command lines (flags and defaults of train_mnist.py:401-432, train_particles.py:481-523,
+train_galaxy.py:401-431, train_dsprites.py:396-428), the stdout TSV log `Epoch Split ELBO Error KL`, the
+`training_logs/<timestamp>_<dataset>_zDim_..._translation_..._rotation_...[_groupconvR]/` artefacts
+(train_log.txt, generator.sav / inference.sav, *_epochNNN.sav; train_mnist.py:593-606,672-681) and the
+optimiser policy (Adam 2e-4, ReduceLROnPlateau on test ELBO, EarlyStopping(20, 1e-4); :579-582,614).
+New optional flags: --seed, --synthetic (synthetic data of the dataset's shape, no files needed), and
+data parallelism through torchrun's RANK / WORLD_SIZE / LOCAL_RANK environment (one process per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from . import dp, optim, step, tables
+
+DEFAULTS = {
+    #            kernel pad  in_ch image_dim gen_layers patience min_lr
+    'mnist':    (28,    8,   1,    50,       2,         9,       0.0),
+    'particles': (64,   16,  1,    None,     2,         9,       1e-6),
+    'galaxy':   (64,    32,  3,    64,       4,         10,      0.0),
+    'dsprites': (64,    32,  1,    64,       2,         9,       0.0),
+}
+
+
+def build_parser(kind: str) -> argparse.ArgumentParser:
+    ksz, pad, in_ch, img, glayers, _, _ = DEFAULTS[kind]
+    titles = {'mnist': 'Train TARGET_VAE on MNIST/MNIST-N/MNIST-U datasets', 'particles': 'Training on particle datasets',
+              'galaxy': 'Train TARGET-VAE on galaxy dataset', 'dsprites': 'Train TARGET-VAE on dSprites dataset'}
+    p = argparse.ArgumentParser(titles[kind])
+    if kind == 'mnist':
+        p.add_argument('--dataset', choices=['mnist', 'mnist-U', 'mnist-N'], default='mnist-U')
+    elif kind == 'galaxy':
+        p.add_argument('--train-path', default='data/galaxy_zoo/galaxy_zoo_train.npy')
+        p.add_argument('--test-path', default='data/galaxy_zoo/galaxy_zoo_test.npy')
+    else:
+        p.add_argument('--train-path', help='path to training data; or path to the whole data')
+        p.add_argument('--test-path', help='path to testing data')
+    if kind == 'particles':
+        p.add_argument('--in-channels', type=int, default=1)
+        p.add_argument('--ctf-train')
+        p.add_argument('--ctf-test')
+        p.add_argument('--scale', default=1, type=float)
+    p.add_argument('-z', '--z-dim', type=int, default=2)
+    p.add_argument('--t-inf', default='attention', choices=['unimodal', 'attention'])
+    p.add_argument('--r-inf', default='attention+offsets', choices=['unimodal', 'attention', 'attention+offsets'])
+    p.add_argument('--groupconv', type=int, default=8, choices=[0, 4, 8, 16])
+    p.add_argument('--encoder-num-layers', type=int, default=2)
+    p.add_argument('--encoder-kernel-number', type=int, default=128)
+    p.add_argument('--encoder-kernel-size', type=int, default=ksz)
+    p.add_argument('--encoder-padding', type=int, default=pad)
+    if kind != 'particles':
+        p.add_argument('--in-channels', type=int, default=in_ch)
+        p.add_argument('--image-dim', type=int, default=img)
+    p.add_argument('--fourier-expansion', action='store_true')
+    p.add_argument('--generator-hidden-dim', type=int, default=512)
+    p.add_argument('--generator-num-layers', type=int, default=glayers)
+    p.add_argument('--generator-resid-layers', action='store_true')
+    p.add_argument('--activation', choices=['tanh', 'leakyrelu'], default='leakyrelu')
+    p.add_argument('-l', '--learning-rate', type=float, default=2e-4)
+    p.add_argument('--minibatch-size', type=int, default=100)
+    if kind == 'particles':
+        p.add_argument('--train-portion', default=0.9, type=float)
+    p.add_argument('--log-root', default='./training_logs')
+    p.add_argument('--save-interval', default=20, type=int)
+    p.add_argument('--num-epochs', type=int, default=500)
+    p.add_argument('-d', '--device', type=int, default=0)
+    if kind == 'particles':
+        p.add_argument('--fit-noise', action='store_true')
+        p.add_argument('--normalize', action='store_true')
+        p.add_argument('--mask-radius', default=0, type=int)
+        p.add_argument('--crop', default=0, type=int)
+    # additions (do not change any reference flag)
+    p.add_argument('--seed', type=int, default=None, help='seed for init / shuffling / noise (reference: unseeded)')
+    p.add_argument('--synthetic', type=int, default=0, metavar='N',
+                   help='train on N synthetic images of the dataset shape instead of loading files')
+    return p
+
+
+def _load_arrays(kind, args):
+    """Returns (train, test) float tensors shaped (N, Cin, n, n) and the dataset name used in the log dir."""
+    if args.synthetic > 0:
+        n = getattr(args, 'image_dim', None) or 64
+        cin = args.in_channels
+        g = torch.Generator().manual_seed(0)
+        mk = (lambda m: torch.randn(m, cin, n, n, generator=g)) if kind == 'particles' else \
+            (lambda m: torch.rand(m, cin, n, n, generator=g))
+        return mk(args.synthetic), mk(max(args.synthetic // 10, 1)), getattr(args, 'dataset', kind)
+    if kind == 'mnist':
+        if args.dataset == 'mnist':
+            try:
+                import torchvision  # noqa: F401
+            except ImportError as e:
+                raise SystemExit('--dataset mnist needs torchvision (not installed here); use mnist-U / mnist-N '
+                                 '(.npy) or --synthetic') from e
+            import torchvision
+            tr = torchvision.datasets.MNIST('data/', train=True, download=True)
+            te = torchvision.datasets.MNIST('data/', train=False, download=True)
+            to_np = lambda ds: np.stack([np.asarray(ds[i][0]) for i in range(len(ds))]).astype(np.uint8)
+            a, b = to_np(tr), to_np(te)
+        else:
+            sub = {'mnist-U': 'mnist_U', 'mnist-N': 'mnist_N'}[args.dataset]
+            a, b = np.load(f'data/{sub}/images_train.npy'), np.load(f'data/{sub}/images_test.npy')
+        tr, te = torch.from_numpy(a).float() / 255, torch.from_numpy(b).float() / 255
+        n = args.image_dim
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), args.dataset
+    if kind == 'galaxy':
+        tr = torch.from_numpy(np.load(args.train_path)).float() / 255
+        te = torch.from_numpy(np.load(args.test_path)).float() / 255
+        n = args.image_dim                              # raw reinterpretation like the reference (train_galaxy.py:454)
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'galaxy'
+    if kind == 'dsprites':
+        tr = torch.from_numpy(np.load(args.train_path)[:1000]).float()      # reference truncation, train_dsprites.py:436
+        te = torch.from_numpy(np.load(args.test_path)[:100]).float()
+        n = args.image_dim
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'dsprites'
+    # particles: .npy stacks; MRC/MRCS reading is a SURVEY 8f "next" row
+    def load(path):
+        if not path.endswith('.npy'):
+            raise NotImplementedError('MRC/MRCS stacks (src/mrc.py) are not built yet; convert to .npy')
+        return np.load(path)
+    if not args.train_path:
+        raise SystemExit('please provide the train_path and/or test_path')
+    if args.test_path:
+        a, b = load(args.train_path), load(args.test_path)
+    else:
+        allim = load(args.train_path)
+        k = int(allim.shape[0] * args.train_portion)
+        a, b = allim[:k], allim[k:]
+    if args.ctf_train or args.ctf_test:
+        raise NotImplementedError('per-image CTF filtering (train_particles.py:298-307) is a SURVEY 8f next row')
+    if args.crop > 0:
+        def crop(s, m):
+            n0 = s.shape[-1]
+            lo = (n0 - m) // 2
+            return s[:, lo:lo + m, lo:lo + m]
+        a, b = crop(a, args.crop), crop(b, args.crop)
+    if args.normalize:                                   # per-image mean/std (train_particles.py:592-600)
+        def norm(s):
+            f = s.reshape(s.shape[0], -1)
+            return (s - f.mean(1)[:, None, None]) / f.std(1)[:, None, None]
+        a, b = norm(a), norm(b)
+    n = a.shape[-1]
+    tr, te = torch.from_numpy(a).float(), torch.from_numpy(b).float()
+    return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'particles'
+
+
+def run(kind: str, argv=None):
+    args = build_parser(kind).parse_args(argv)
+    from src import models                     # drop-in classes (checkpoints pickle as src.models.*)
+    from src.utils import EarlyStopping
+    rank, world, local = dp.init_from_env()
+    is_main = rank == 0
+    num_epochs = args.num_epochs
+    digits = int(np.log10(num_epochs)) + 1
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    y_train, y_test, dataset_name = _load_arrays(kind, args)
+    image_dim = y_train.shape[-1]
+    in_channels = y_train.shape[1]
+    if not torch.cuda.is_available() or args.device == -1:
+        raise SystemExit('the MI355X build has no CPU compute path (reference CPU mode -d -1 is not available)')
+    dev_index = local if world > 1 else args.device
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    if is_main:
+        print('# using device:', device, f'(rank {rank}/{world})', file=sys.stderr)
+    y_train, y_test = y_train.to(device), y_test.to(device)        # whole dataset resident (train_mnist.py:495)
+    x_coord = torch.from_numpy(tables.image_coords(image_dim)).to(device)
+
+    z_dim = args.z_dim
+    activation = nn.Tanh if args.activation == 'tanh' else nn.LeakyReLU
+    fourier_sigma = 2.0 / (image_dim - 1)                           # pixel size (train_mnist.py:511)
+    n_out = {'mnist': 1, 'dsprites': 1, 'galaxy': 3}.get(kind, 2 if getattr(args, 'fit_noise', False) else 1)
+    gen_kw = dict(n_out=n_out, num_layers=args.generator_num_layers, activation=activation,
+                  resid=args.generator_resid_layers, fourier_expansion=args.fourier_expansion)
+    if kind != 'dsprites':
+        gen_kw['sigma'] = fourier_sigma                             # dsprites keeps the 0.01 default (quirk 8)
+    generator_model = models.SpatialGenerator(z_dim, args.generator_hidden_dim, **gen_kw)
+
+    t_inf, r_inf, group_conv = args.t_inf, args.r_inf, args.groupconv
+    if kind == 'mnist' and args.dataset == 'mnist-N':
+        theta_prior, normal_prior_over_r = np.pi / 4, True          # train_mnist.py:538-543
+    else:
+        theta_prior, normal_prior_over_r = np.pi, False
+    if not (t_inf == 'attention' and r_inf in ('attention', 'attention+offsets')):
+        raise SystemExit(f'--t-inf {t_inf} --r-inf {r_inf}: only the TARGET-VAE attention/attention(+offsets) '
+                         'configuration is built on the MI355X hot path')
+    if group_conv == 0:
+        raise SystemExit('--groupconv 0 is not valid with attention over rotations (needs 4, 8 or 16)')
+    encoder_model = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        image_dim, in_channels, z_dim, kernels_num=args.encoder_kernel_number, kernels_size=args.encoder_kernel_size,
+        padding=args.encoder_padding, activation=activation, groupconv=group_conv,
+        rot_refinement=(r_inf == 'attention+offsets'), theta_prior=theta_prior,
+        normal_prior_over_r=normal_prior_over_r)
+    generator_model.to(device)
+    encoder_model.to(device)
+    if is_main:
+        print(encoder_model)
+        print(generator_model)
+
+    N = len(y_train)
+    params = list(generator_model.parameters()) + list(encoder_model.parameters())
+    reducer = dp.GradReducer() if world > 1 else None
+    optimizer = optim.FlatAdam(params, lr=args.learning_rate, reducer=reducer)
+    if world > 1:
+        torch.distributed.broadcast(optimizer.flat_p, src=0)       # identical replicas
+    patience, min_lr = DEFAULTS[kind][5], DEFAULTS[kind][6]
+    scheduler = ReduceLROnPlateau(optimizer, mode='max', factor=0.5, patience=patience, threshold=1e-4,
+                                  threshold_mode='abs', cooldown=0, min_lr=min_lr, eps=1e-08)
+    seed = args.seed if args.seed is not None else 0
+    train_it = dp.ShardedBatches(y_train, args.minibatch_size, rank, world, shuffle=True, seed=seed, reducer=reducer)
+    test_it = dp.ShardedBatches(y_test, args.minibatch_size, rank, world, shuffle=False, seed=seed)
+    likelihood = {'mnist': 'bce', 'dsprites': 'bce', 'galaxy': 'bce3'}.get(kind, 'gauss_var' if n_out == 2 else 'gauss')
+    if kind == 'particles' and args.mask_radius > 0:
+        raise NotImplementedError('--mask-radius (train_particles.py:309-333) is a SURVEY 8f next row')
+
+    output = sys.stdout
+    log_file = None
+    path_prefix = None
+    if is_main:
+        print('\t'.join(['Epoch', 'Split', 'ELBO', 'Error', 'KL']), file=output)
+        os.makedirs(args.log_root, exist_ok=True)
+        desc = '_'.join([datetime.datetime.now().strftime('%Y-%m-%d-%H-%M'), dataset_name, 'zDim', str(z_dim),
+                         'translation', t_inf, 'rotation', r_inf])
+        if group_conv > 0:
+            desc += '_groupconv' + str(group_conv)
+        path_prefix = os.path.join(args.log_root, desc, '')
+        os.makedirs(path_prefix, exist_ok=True)
+        print('# learning-rate is {}'.format(args.learning_rate))
+        log_file = open(path_prefix + 'train_log.txt', 'w', 1)
+        print(desc + '\n', file=log_file)
+        print('\n\nargs:', file=log_file)
+        print(str(args), file=log_file)
+        print('\nEncoder model: \n {}'.format(encoder_model), file=log_file)
+        print('\nGenerator model: \n {}'.format(generator_model), file=log_file)
+        print('\n\n', file=log_file)
+        print('\t'.join(['Epoch', 'Split', 'ELBO', 'Error', 'KL']) + '\n', file=log_file)
+    early_stopping = EarlyStopping(patience=20, delta=1e-4, save_path=path_prefix or './', digits=digits)
+
+    def emit(line, blank=False):
+        if is_main:
+            print(line, file=output)
+            print(line, file=log_file)
+            if blank:
+                print('\n', file=output)
+                print('\n', file=log_file)
+
+    def global_means(e, err, kl, count):
+        """Batch-size weighted means over all ranks (each rank's running means are weighted by its image count)."""
+        s = dp.allreduce_stats([e * count, err * count, kl * count, float(count)], device)
+        return s[0] / s[3], s[1] / s[3], s[2] / s[3]
+
+    for epoch in range(num_epochs):
+        train_it.set_epoch(epoch)
+        n_local = sum(hi - lo for lo, hi, _ in dp.shard_slices(N, args.minibatch_size, rank, world))
+        e, err, kl = step.train_epoch(train_it, x_coord, generator_model, encoder_model, optimizer, t_inf, r_inf, epoch,
+                                      num_epochs, max(n_local, 1), device, params, theta_prior, group_conv, image_dim,
+                                      likelihood=likelihood, progress=is_main)
+        e, err, kl = global_means(e, err, kl, n_local)
+        emit('\t'.join([str(epoch + 1), 'train', str(e), str(err), str(kl)]))
+        n_test = sum(hi - lo for lo, hi, _ in dp.shard_slices(len(y_test), args.minibatch_size, rank, world))
+        e, err, kl = step.eval_model(test_it, x_coord, generator_model, encoder_model, t_inf, r_inf, epoch, device,
+                                     theta_prior, group_conv, image_dim, likelihood=likelihood)
+        e, err, kl = global_means(e, err, kl, n_test)
+        emit('\t'.join([str(epoch + 1), 'test', str(e), str(err), str(kl)]))
+        if is_main:
+            msg = early_stopping(e, encoder_model, generator_model, epoch + 1)
+            emit(msg, blank=True)
+        stop = early_stopping.early_stop
+        if world > 1:                                  # rank 0 decides; one int broadcast
+            flag = torch.tensor([int(stop)], device=device)
+            torch.distributed.broadcast(flag, src=0)
+            stop = bool(flag.item())
+        if stop:
+            if is_main:
+                print('*** Early stopping ***')
+            break
+        scheduler.step(e)                              # same test ELBO on every rank -> same lr everywhere
+        if is_main and (epoch + 1) % args.save_interval == 0:
+            from src.utils import save_module_cpu
+            tag = str(epoch + 1).zfill(digits)
+            save_module_cpu(generator_model, path_prefix + 'generator_epoch{}.sav'.format(tag))
+            save_module_cpu(encoder_model, path_prefix + 'inference_epoch{}.sav'.format(tag))
+    if log_file is not None:
+        log_file.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()

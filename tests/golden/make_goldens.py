@@ -301,8 +301,46 @@ def gen_epoch():
     print('    epoch', elbo, err, kl)
 
 
+def gen_cli():
+    """argparse surface of the four reference scripts (flags, defaults, choices) -> cli_flags.json."""
+    import argparse
+    import importlib
+    import json
+
+    class _Captured(Exception):
+        pass
+
+    out = {}
+    sys.path.insert(0, REF)
+    for name in ('train_mnist', 'train_particles', 'train_galaxy', 'train_dsprites'):
+        mod = importlib.import_module(name)
+        orig = argparse.ArgumentParser.parse_args
+
+        def grab(self, *a, **k):
+            raise _Captured(self)
+        argparse.ArgumentParser.parse_args = grab
+        try:
+            mod.main()
+        except _Captured as e:
+            parser = e.args[0]
+        finally:
+            argparse.ArgumentParser.parse_args = orig
+        flags = {}
+        for act in parser._actions:
+            if act.dest == 'help':
+                continue
+            flags[act.dest] = dict(flags=list(act.option_strings), default=act.default,
+                                   choices=list(act.choices) if act.choices else None,
+                                   type=getattr(act.type, '__name__', None), nargs0=(act.nargs == 0))
+        out[name] = flags
+    sys.path.pop(0)
+    path = os.path.join(HERE, 'cli_flags.json')
+    json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
+    print('wrote', path, {k: len(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli}[w]()

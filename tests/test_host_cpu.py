@@ -203,3 +203,23 @@ def test_shard_slices_cover_every_minibatch():
             assert idx == list(range(b * gb, b * gb + g))
     assert torch.equal(dp.epoch_permutation(50, 3, 7), dp.epoch_permutation(50, 3, 7))
     assert not torch.equal(dp.epoch_permutation(50, 3, 7), dp.epoch_permutation(50, 3, 8))
+
+
+def test_cli_flags_match_reference():
+    """Every flag of the four reference scripts exists with the same option strings, default, choices and type
+    (tests/golden/cli_flags.json is generated from the reference's own argparse objects)."""
+    import json
+    from tvae import driver
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'cli_flags.json')))
+    for script, flags in ref.items():
+        parser = driver.build_parser(script.replace('train_', ''))
+        mine = {a.dest: a for a in parser._actions if a.dest != 'help'}
+        for dest, spec in flags.items():
+            assert dest in mine, (script, dest)
+            a = mine[dest]
+            assert list(a.option_strings) == spec['flags'], (script, dest)
+            assert a.default == spec['default'], (script, dest, a.default, spec['default'])
+            assert (list(a.choices) if a.choices else None) == spec['choices'], (script, dest)
+            assert getattr(a.type, '__name__', None) == spec['type'], (script, dest)
+            assert (a.nargs == 0) == spec['nargs0'], (script, dest)
+        assert set(mine) - set(flags) == {'seed', 'synthetic'}, script
