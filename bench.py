@@ -61,7 +61,8 @@ def cpu_baseline(batch=16, steps=2):
         rot_refinement=True, theta_prior=np.pi, normal_prior_over_r=False)
     encp = {k_: v.detach().clone().requires_grad_(True) for k_, v in enc.state_dict().items()}
     genp = {k_: v.detach().clone().requires_grad_(True) for k_, v in gen.state_dict().items()}
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = int(os.environ.get('TVAE_CPU_THREADS', min(avail, 32)))   # >32 threads oversubscribe this small job
     torch.set_num_threads(cores)
     st = O.new_opt_state(encp, genp)
     x = O.image_coords(c['n'])

@@ -1,0 +1,56 @@
+"""Micro-benchmark of the GEMM-shaped entry points at the cfg4 (64x64, P8, B=256) shapes: prints TFLOP/s
+(algorithmic FLOPs / event time).  Used for the optimisation loop and under rocprofv3 --pmc."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'target-vae_amd')]
+import torch
+from tvae._lib import call
+dev = torch.device('cuda:0')
+reps = int(os.environ.get('REPS', '5'))
+B = int(os.environ.get('B', '256'))
+only = os.environ.get('ONLY', '')
+
+
+def timeit(name, flops, fn):
+    if only and only not in name:
+        return
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    print(f'{name:28s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s', flush=True)
+
+
+C, R, Cin, n, k, pad = 128, 8, 1, 64, 64, 16
+Ho = n + 2 * pad - k + 1
+P = Ho * Ho
+N = B * R * P
+y = torch.randn(B, Cin, n, n, device=dev)
+bank = torch.randn(C * R, Cin * k * k, device=dev) * 0.02
+bias = torch.randn(C, device=dev)
+A1 = torch.empty(C, N, device=dev)
+ws = torch.empty(1 << 26, device=dev)
+fl_conv = 2.0 * C * R * Cin * k * k * P * B
+timeit('conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01))
+dA1 = torch.randn(C, N, device=dev)
+dbank = torch.empty_like(bank)
+timeit('conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R))
+W2 = torch.randn(C, C, device=dev) * 0.1
+b2 = torch.randn(C, device=dev)
+H = torch.empty(C, N, device=dev)
+timeit('conv2_fwd 128x128', 2.0 * C * C * N, lambda: call('tvae_linear_fwd', W2, A1, b2, None, 1, None, H, C, N, C, N, N, 1, 0.01))
+timeit('conv2_dgrad', 2.0 * C * C * N, lambda: call('tvae_linear_dgrad', W2, dA1, None, A1, H, C, N, C, N, N, 1, 0.01))
+dW2 = torch.empty(C, C, device=dev)
+timeit('conv2_wgrad', 2.0 * C * C * N, lambda: call('tvae_linear_wgrad', dA1, A1, dW2, ws, ws.numel(), C, N, C, N, N, 0))
+F_, Nt = 512, B * n * n
+h1 = torch.randn(F_, Nt, device=dev)
+h2 = torch.empty(F_, Nt, device=dev)
+W = torch.randn(F_, F_, device=dev) * 0.05
+bb = torch.randn(F_, device=dev)
+timeit('dec_fwd 512x512', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd', W, h1, bb, None, 1, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
+timeit('dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad', W, h1, None, h1, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
+dW = torch.empty(F_, F_, device=dev)
+timeit('dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad', h1, h1, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))

@@ -1,0 +1,285 @@
+// Image-resident lifting-convolution kernels for gfx950 (forward and weight gradient).
+//
+// The im2col operand of the GroupConv GEMMs is a Toeplitz view of the zero-padded image:
+//     patch(k = (ci,u,v), p = (h,w)) = ypad[ci][h+u][w+v]  =  img_lds[ (ci*Hp + u)*Wp + v   +   h*Wp + w ]
+// i.e. a tap offset that only depends on k PLUS a position offset that only depends on the output position.
+// So the padded image (Hp x Wp fp32, Wp = Hp+1 to break row-wrap bank conflicts; 36 KiB at 64x64/pad 16) is
+// loaded into LDS once and the MFMA B fragments are read STRAIGHT from it:
+//   forward : lane = position  -> per-lane constant position offset + wave-uniform tap offset (ktab)
+//   wgrad   : lane = tap (u,v) -> per-lane constant tap offset + wave-uniform position offset (ptab)
+// Consecutive lanes read consecutive LDS words (conflict-free ds_read_b32); no im2col staging, no per-element
+// guards, the zero padding lives in the LDS image.  Only the A operand (filter bank / dY) is staged through LDS.
+// Same 128x128x16 tile / 2x2 waves / v_mfma_f32_32x32x2_f32 / LDS epilogue as gemm_f32_mfma.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_f32_mfma.hpp"
+
+namespace tvae {
+
+constexpr int CONV_A_FLOATS = 2 * BK * LDS_LD;     // double-buffered A tile
+constexpr int CONV_TAB_INTS = 2 * BK;              // double-buffered uniform-offset table
+
+static inline size_t conv_img_lds_bytes(int Cin, int n, int pad) {
+    const int Hp = n + 2 * pad, Wp = Hp + 1;
+    long img = (long)Cin * Hp * Wp;
+    if (img < 64 * 128) img = 64 * 128;            // the epilogue staging tile aliases the image region
+    return (size_t)(CONV_A_FLOATS + CONV_TAB_INTS + img) * sizeof(float);
+}
+
+__device__ __forceinline__ void load_padded_image(float* img, const float* __restrict__ y, int b, const ConvGeom& g,
+                                                  int Hp, int Wp) {
+    const int total = g.Cin * Hp * Wp;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int ci = i / (Hp * Wp);
+        const int r = i - ci * (Hp * Wp);
+        const int yy = r / Wp, xx = r - yy * Wp;
+        const int iy = yy - g.pad, ix = xx - g.pad;
+        float v = 0.f;
+        if (iy >= 0 && iy < g.n && ix >= 0 && ix < g.n) v = y[((long)(b * g.Cin + ci) * g.n + iy) * g.n + ix];
+        img[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward:  out[cr][img, p] = act( sum_k bank[cr][k] * patch(k, p) + bias[c] )
+// grid.x = tilesM * B * tilesPerImg (position tiles fastest -> concurrently running workgroups share one bank panel
+// in L2).  VEC: K % 16 == 0 and M % 128 == 0 -> unguarded float4 loads of the bank with incremented pointers.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
+                          int K, int tilesPerImg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    int* ktab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
+    float* img = smem + CONV_A_FLOATS + CONV_TAB_INTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
+    const int per_m = g.B * tilesPerImg;
+    const int tile_m = blockIdx.x / per_m;
+    const int rest = blockIdx.x - tile_m * per_m;
+    const int b = rest / tilesPerImg;
+    const int p0 = (rest - b * tilesPerImg) * BN;
+    const int m0 = tile_m * BM;
+    const int nk = (K + BK - 1) / BK;
+
+    load_padded_image(img, y, b, g, Hp, Wp);
+
+    int boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int p = p0 + wn * 64 + j * 32 + (lane & 31);
+        if (p >= g.P) p = g.P - 1;                  // padded columns read a valid address; never stored
+        const int h = p / g.Ho, w = p - h * g.Ho;
+        boff[j] = h * Wp + w;
+    }
+
+    // tap-offset table for one k-step: ktab[buf][kk] = (ci*Hp + u)*Wp + v  (0 beyond K: the A tile is zero there)
+    auto fill_ktab = [&](int* tab, int k0) {
+        if (tid < BK) {
+            const int k = k0 + tid;
+            int off = 0;
+            if (k < K) {
+                const int ci = k / g.K2, rem = k - ci * g.K2;
+                const int u = rem / g.ksz, v = rem - u * g.ksz;
+                off = (ci * Hp + u) * Wp + v;
+            }
+            tab[tid] = off;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A staging
+    LoadKContig al{bank, (long)K, M};
+    float ra[8];
+    float4 va[2];
+    const float* pa[2];
+    const int am = tid >> 2, akq = (tid & 3) * 4;
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pa[i] = bank + (long)(m0 + am + 64 * i) * K + akq;
+        va[0] = *reinterpret_cast<const float4*>(pa[0]);
+        va[1] = *reinterpret_cast<const float4*>(pa[1]);
+    } else {
+        al.init(m0, tid);
+        al.load(ra, 0, K);
+    }
+    auto store_a = [&](float* S) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = am + 64 * i;
+                S[(akq + 0) * LDS_LD + m] = va[i].x;
+                S[(akq + 1) * LDS_LD + m] = va[i].y;
+                S[(akq + 2) * LDS_LD + m] = va[i].z;
+                S[(akq + 3) * LDS_LD + m] = va[i].w;
+            }
+        } else {
+            al.store(S, ra);
+        }
+    };
+    store_a(As);
+    fill_ktab(ktab, 0);
+    __syncthreads();
+
+    const int arow = wm * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1) < nk;
+        if (more) {
+            if (VEC) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    pa[i] += BK;
+                    va[i] = *reinterpret_cast<const float4*>(pa[i]);
+                }
+            } else {
+                al.load(ra, (t + 1) * BK, K);
+            }
+        }
+        const float* as = As + cur * (BK * LDS_LD);
+        const int* kt = ktab + cur * BK;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + khalf;
+            const int ko = kt[kk];
+            const float a0 = as[kk * LDS_LD + arow];
+            const float a1 = as[kk * LDS_LD + arow + 32];
+            const float b0 = img[boff[0] + ko];
+            const float b1 = img[boff[1] + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            store_a(As + (cur ^ 1) * (BK * LDS_LD));
+            fill_ktab(ktab + (cur ^ 1) * BK, (t + 1) * BK);
+        }
+        __syncthreads();
+    }
+    const int p = p0 + (tid & 127);
+    tile_epilogue(acc, img, ep, m0, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)
+// grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
+                            Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    int* ptab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
+    float* img = smem + CONV_A_FLOATS + CONV_TAB_INTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
+    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int ib = split * imgs_per_split;
+    const int ie = min(g.B, ib + imgs_per_split);
+    const int nk = (g.P + BK - 1) / BK;
+
+    int noff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int nn = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (nn >= N) nn = N - 1;
+        const int ci = nn / g.K2, rem = nn - ci * g.K2;
+        const int u = rem / g.ksz, v = rem - u * g.ksz;
+        noff[j] = (ci * Hp + u) * Wp + v;
+    }
+    // A rows (mapping K: kk = tid&15, rows xb + 16 j)
+    const int kkA = tid & 15, xb = tid >> 4;
+    long rowoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int m = m0 + xb + 16 * j;
+        if (m >= M) m = M - 1;                      // clamped rows are never stored
+        const int c = m / g.R, rr = m - c * g.R;
+        rowoff[j] = (long)c * lddy + (long)rr * g.P;
+    }
+    auto fill_ptab = [&](int* tab, int pbeg) {
+        if (tid < BK) {
+            const int p = pbeg + tid;
+            int off = 0;
+            if (p < g.P) { const int h = p / g.Ho; off = h * Wp + (p - h * g.Ho); }
+            tab[tid] = off;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+    float ra[8];
+    for (int b = ib; b < ie; ++b) {
+        __syncthreads();                             // previous image fully consumed
+        load_padded_image(img, y, b, g, Hp, Wp);
+        const float* dyb = dy + (long)b * g.R * g.P + kkA;
+        {
+            const bool kok = kkA < g.P;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) As[kkA * LDS_LD + xb + 16 * j] = ra[j];
+        }
+        fill_ptab(ptab, 0);
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            const bool more = (t + 1) < nk;
+            if (more) {
+                const int pk = (t + 1) * BK;
+                const bool kok = (pk + kkA) < g.P;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
+            }
+            const float* as = As + cur * (BK * LDS_LD);
+            const int* pt = ptab + cur * BK;
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                const int kk = 2 * s + khalf;
+                const int po = pt[kk];
+                const float a0 = as[kk * LDS_LD + arow];
+                const float a1 = as[kk * LDS_LD + arow + 32];
+                const float b0 = img[noff[0] + po];
+                const float b1 = img[noff[1] + po];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (more) {
+                float* an = As + (cur ^ 1) * (BK * LDS_LD);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) an[kkA * LDS_LD + xb + 16 * j] = ra[j];
+                fill_ptab(ptab + (cur ^ 1) * BK, (t + 1) * BK);
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int n = n0 + (tid & 127);
+    tile_epilogue(acc, img, ep, m0, M, n, n < N, ws, split, N);
+}
+
+}  // namespace tvae

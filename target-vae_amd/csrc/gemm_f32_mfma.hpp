@@ -246,6 +246,44 @@ struct LoadConvDY {
 };
 
 // ------------------------------------------------------------------------------------------
+// Shared tile epilogue through LDS (the k-loop's LDS is free after its last barrier): two passes of 64 rows x 128
+// columns.  Accumulator lane map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Reading back one
+// column per thread gives 512-B coalesced global rows and keeps bias/activation/mask out of the unrolled part.
+// `ct` needs 64*128 floats.  `n` is this thread's global column (tid&127 within the tile), `nok` its validity.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[2][2], float* ct, const Epilogue& ep, int m0, int M, int n,
+                                              bool nok, float* ws, int split, int N) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ecol = tid & 127;
+    const Epilogue::Col ecl = ep.prep(nok ? n : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * 128 + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rl = (tid >> 7) + 2 * it;                       // 0..63
+            const int m = m0 + (rl >> 5) * 64 + i * 32 + (rl & 31);
+            if (nok && m < M) {
+                const float v = ct[rl * 128 + ecol];
+                if (ws) ws[((long)split * M + m) * N + n] = v;
+                else ep.store(m, n, ecl, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The kernel.  grid.x = tilesM*tilesN (n fastest, so concurrently running workgroups share the
 // A/weight panel of one m-tile in their XCD's L2), grid.y = split-K slices.
 // With ws != nullptr the raw partial tile is written to ws[split][M][N]; the epilogue then runs in
@@ -319,36 +357,7 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
         __syncthreads();
     }
 
-    // Epilogue through LDS (free after the last barrier of the k-loop): two passes of 64 rows x 128 columns.
-    // Accumulator lane map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Reading back one column
-    // per thread gives 512-B coalesced global rows and keeps the bias/activation/mask code out of the unrolled part.
-    float* ct = lds;                       // [64][128] floats = 32 KiB
-    const int ecol = tid & 127;
-    const int n = n0 + ecol;
-    const bool nok = n < N;
-    const Epilogue::Col ecl = ep.prep(nok ? n : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                ct[rl * 128 + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
-        __syncthreads();
-#pragma unroll 4
-        for (int it = 0; it < 32; ++it) {
-            const int rl = (tid >> 7) + 2 * it;                       // 0..63
-            const int m = m0 + (rl >> 5) * 64 + i * 32 + (rl & 31);
-            if (nok && m < M) {
-                const float v = ct[rl * 128 + ecol];
-                if (ws) ws[((long)split * M + m) * N + n] = v;
-                else ep.store(m, n, ecl, v);
-            }
-        }
-    }
+    tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, ws, split, N);
 }
 
 __global__ void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {

@@ -4,6 +4,7 @@
 #include "../../include/tvae_hip.h"
 #include "gemm_f32_mfma.hpp"
 #include "small_kernels.hpp"
+#include "conv_img_kernels.hpp"
 
 using namespace tvae;
 
@@ -28,6 +29,16 @@ static inline int pick_splits(int tiles, long K) {
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     return (int)want;
+}
+
+// LDS budget for the image-resident conv kernels (160 KiB per CU on gfx950; keep room for 1 workgroup).
+static const size_t CONV_IMG_LDS_MAX = 150 * 1024;
+
+template <class KernelT>
+static hipError_t allow_big_lds(KernelT kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
 }
 
 extern "C" {
@@ -69,8 +80,6 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
     const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const int M = C * R, N = B * g.P, K = Cin * g.K2;
-    LoadKContig al{bank, (long)K, M};
-    LoadConvPatchFwd bl{y, g, N};
     Epilogue ep;
     ep.C = out; ep.ldc = (long)B * R * g.P;
     int sh = 0; while ((1 << sh) < R) ++sh;
@@ -78,6 +87,31 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
     ep.bias = bias; ep.bias_shift = sh;
     ep.act = act; ep.slope = slope;
     ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
+    const size_t lds = conv_img_lds_bytes(Cin, n, pad);
+    if (lds <= CONV_IMG_LDS_MAX) {
+        // image-resident path: padded image in LDS, B fragments read straight from it
+        const int tilesPerImg = cdiv(g.P, BN);
+        const long nblk = (long)cdiv(M, BM) * B * tilesPerImg;
+        if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
+        const bool vec = (K % BK == 0) && (M % BM == 0);
+        hipError_t e;
+        if (vec) {
+            e = allow_big_lds(conv1_fwd_img_kernel<true>, lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(conv1_fwd_img_kernel<true>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
+                               bank, y, g, ep, M, K, tilesPerImg);
+        } else {
+            e = allow_big_lds(conv1_fwd_img_kernel<false>, lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(conv1_fwd_img_kernel<false>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
+                               bank, y, g, ep, M, K, tilesPerImg);
+        }
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
+    // generic path (padded image does not fit in LDS): implicit im2col staged through LDS
+    LoadKContig al{bank, (long)K, M};
+    LoadConvPatchFwd bl{y, g, N};
     return (int)launch_gemm(al, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
 }
 
@@ -89,11 +123,36 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
     const long Kl = (long)B * g.P;
     if (Kl > 2147483647L) return (int)hipErrorInvalidValue;
     const int K = (int)Kl;
-    LoadConvDY al{dpre, (long)B * R * g.P, M, R, g.P};
-    LoadConvPatchWgrad bl{y, g, N};
     Epilogue ep;
     ep.C = dbank; ep.ldc = N;
-    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BN);
+    const int tiles = tilesM * tilesN;
+    const size_t lds = conv_img_lds_bytes(Cin, n, pad);
+    if (lds <= CONV_IMG_LDS_MAX) {
+        int splits = (1024 + tiles - 1) / tiles;
+        if (splits > B) splits = B;
+        const long per = (long)M * N;
+        const long cap = ws ? ws_floats / per : 0;
+        if (cap < 2) splits = 1; else if (splits > cap) splits = (int)cap;
+        if (splits < 1) splits = 1;
+        const int ips = cdiv(B, splits);
+        splits = cdiv(B, ips);
+        hipError_t e = allow_big_lds(conv1_wgrad_img_kernel, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(conv1_wgrad_img_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(GEMM_THREADS), lds,
+                           S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips, splits > 1 ? ws : nullptr, tilesN);
+        TVAE_CHECK_LAUNCH();
+        if (splits > 1) {
+            int blocks = cdiv(per, 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits,
+                               M, N, ep);
+            TVAE_CHECK_LAUNCH();
+        }
+        return 0;
+    }
+    LoadConvDY al{dpre, (long)B * R * g.P, M, R, g.P};
+    LoadConvPatchWgrad bl{y, g, N};
     return (int)launch_gemm(al, bl, ep, M, N, K, pick_splits(tiles, K), ws, ws_floats, S(stream));
 }
 
