@@ -20,6 +20,12 @@ typedef void* tvae_stream_t;
 
 int tvae_abi_version(void);
 
+/* GEMM arithmetic of every MFMA entry point below (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ * 1 = split-bf16 x3 (x = hi + lo in bf16, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; ~1e-5 relative
+ * tensor error, inside the 1e-4 parity gate).  Returns 0 or hipErrorInvalidValue. */
+int tvae_set_gemm_mode(int mode);
+int tvae_get_gemm_mode(void);
+
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
  * rotations (idx < 0 = outside, zero padding).  bwd applies the transposed operator through a CSR table

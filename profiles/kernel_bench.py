@@ -4,7 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'target-vae_amd')]
 import torch
-from tvae._lib import call
+from tvae._lib import call, set_gemm_mode
+set_gemm_mode(os.environ.get('MODE', 'f32'))
+print('mode', os.environ.get('MODE', 'f32'))
 dev = torch.device('cuda:0')
 reps = int(os.environ.get('REPS', '5'))
 B = int(os.environ.get('B', '256'))

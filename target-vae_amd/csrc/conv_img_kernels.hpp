@@ -19,21 +19,37 @@ namespace tvae {
 constexpr int CONV_A_FLOATS = 2 * BK * LDS_LD;     // double-buffered A tile
 constexpr int CONV_TAB_INTS = 2 * BK;              // double-buffered uniform-offset table
 
-static inline size_t conv_img_lds_bytes(int Cin, int n, int pad) {
-    const int Hp = n + 2 * pad, Wp = Hp + 1;
-    long img = (long)Cin * Hp * Wp;
-    if (img < 64 * 128) img = 64 * 128;            // the epilogue staging tile aliases the image region
-    return (size_t)(CONV_A_FLOATS + CONV_TAB_INTS + img) * sizeof(float);
+// Rows of the padded image a forward tile needs: BN consecutive positions span at most (BN-1)/Ho + 2 output rows,
+// each of which reads ksz input rows.
+static inline int conv_fwd_img_rows(int n, int ksz, int pad) {
+    const int Hp = n + 2 * pad, Ho = Hp - ksz + 1;
+    const int rows = (BN - 1) / Ho + 2 + ksz - 1;
+    return rows < Hp ? rows : Hp;
+}
+// Rows a weight-gradient tile needs (single input channel): BN consecutive taps span at most (BN-1)/ksz + 2 tap rows,
+// each combined with Ho output rows.  With several input channels the whole padded image is kept.
+static inline int conv_wgrad_img_rows(int Cin, int n, int ksz, int pad) {
+    const int Hp = n + 2 * pad, Ho = Hp - ksz + 1;
+    if (Cin != 1) return Hp;
+    const int rows = (BN - 1) / ksz + 2 + Ho - 1;
+    return rows < Hp ? rows : Hp;
+}
+static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad) {
+    const int Wp = n + 2 * pad + 1;
+    long tot = CONV_A_FLOATS + CONV_TAB_INTS + (long)Cin * rows * Wp;
+    if (tot < 64 * 128) tot = 64 * 128;            // the epilogue staging tile aliases the whole region
+    return (size_t)tot * sizeof(float);
 }
 
+// rows [row0, row0 + rows) of the zero-padded image of every input channel -> img[ci][rows][Wp]
 __device__ __forceinline__ void load_padded_image(float* img, const float* __restrict__ y, int b, const ConvGeom& g,
-                                                  int Hp, int Wp) {
-    const int total = g.Cin * Hp * Wp;
+                                                  int row0, int rows, int Wp) {
+    const int total = g.Cin * rows * Wp;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int ci = i / (Hp * Wp);
-        const int r = i - ci * (Hp * Wp);
+        const int ci = i / (rows * Wp);
+        const int r = i - ci * (rows * Wp);
         const int yy = r / Wp, xx = r - yy * Wp;
-        const int iy = yy - g.pad, ix = xx - g.pad;
+        const int iy = row0 + yy - g.pad, ix = xx - g.pad;
         float v = 0.f;
         if (iy >= 0 && iy < g.n && ix >= 0 && ix < g.n) v = y[((long)(b * g.Cin + ci) * g.n + iy) * g.n + ix];
         img[i] = v;
@@ -46,9 +62,9 @@ __device__ __forceinline__ void load_padded_image(float* img, const float* __res
 // in L2).  VEC: K % 16 == 0 and M % 128 == 0 -> unguarded float4 loads of the bank with incremented pointers.
 // ------------------------------------------------------------------------------------------
 template <bool VEC>
-__global__ __launch_bounds__(GEMM_THREADS, 2)
+__global__ __launch_bounds__(GEMM_THREADS, 3)
 void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
-                          int K, int tilesPerImg) {
+                          int K, int tilesPerImg, int rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     int* ktab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
@@ -64,7 +80,8 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
     const int m0 = tile_m * BM;
     const int nk = (K + BK - 1) / BK;
 
-    load_padded_image(img, y, b, g, Hp, Wp);
+    const int hmin = p0 / g.Ho;                     // first output row of the tile = first padded-image row kept
+    load_padded_image(img, y, b, g, hmin, rows, Wp);
 
     int boff[2];
 #pragma unroll
@@ -72,7 +89,7 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         int p = p0 + wn * 64 + j * 32 + (lane & 31);
         if (p >= g.P) p = g.P - 1;                  // padded columns read a valid address; never stored
         const int h = p / g.Ho, w = p - h * g.Ho;
-        boff[j] = h * Wp + w;
+        boff[j] = (h - hmin) * Wp + w;
     }
 
     // tap-offset table for one k-step: ktab[buf][kk] = (ci*Hp + u)*Wp + v  (0 beyond K: the A tile is zero there)
@@ -83,9 +100,9 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
             if (k < K) {
                 const int ci = k / g.K2, rem = k - ci * g.K2;
                 const int u = rem / g.ksz, v = rem - u * g.ksz;
-                off = (ci * Hp + u) * Wp + v;
+                off = (ci * rows + u) * Wp + v;
             }
-            tab[tid] = off;
+            tab[(tid & 1) * 8 + (tid >> 1)] = off;     // [half][sub-step]: one lane half reads 8 consecutive ints
         }
     };
 
@@ -147,19 +164,28 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
             }
         }
         const float* as = As + cur * (BK * LDS_LD);
-        const int* kt = ktab + cur * BK;
+        // this lane half's 8 tap offsets of the k-step: two broadcast ds_read_b128, so that the 32 fragment reads
+        // below carry no LDS->LDS dependency and can be pipelined under the MFMAs
+        const int4* kt4 = reinterpret_cast<const int4*>(ktab + cur * BK + khalf * 8);
+        const int4 t0 = kt4[0], t1 = kt4[1];
+        const int kos[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        // all 32 fragment reads of the k-step are issued up front (independent addresses); the MFMAs then drain them
+        // behind counted lgkmcnt waits, so LDS latency is paid once per k-step and hidden by the partner wave
+        float af[BK / 2][2], bf[BK / 2][2];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + khalf;
-            const int ko = kt[kk];
-            const float a0 = as[kk * LDS_LD + arow];
-            const float a1 = as[kk * LDS_LD + arow + 32];
-            const float b0 = img[boff[0] + ko];
-            const float b1 = img[boff[1] + ko];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            af[s][0] = as[kk * LDS_LD + arow];
+            af[s][1] = as[kk * LDS_LD + arow + 32];
+            bf[s][0] = img[boff[0] + kos[s]];
+            bf[s][1] = img[boff[1] + kos[s]];
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][1], acc[1][1], 0, 0, 0);
         }
         if (more) {
             store_a(As + (cur ^ 1) * (BK * LDS_LD));
@@ -168,16 +194,16 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         __syncthreads();
     }
     const int p = p0 + (tid & 127);
-    tile_epilogue(acc, img, ep, m0, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
+    tile_epilogue(acc, smem, ep, m0, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
 }
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)
 // grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 2)
+__global__ __launch_bounds__(GEMM_THREADS, 3)
 void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
-                            Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN) {
+                            Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     int* ptab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
@@ -192,6 +218,8 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     const int ie = min(g.B, ib + imgs_per_split);
     const int nk = (g.P + BK - 1) / BK;
 
+    // rows == Hp: whole padded image(s) resident; otherwise (single channel) only rows [ulo, ulo + rows)
+    const int ulo = (rows == Hp) ? 0 : (n0 / g.ksz);
     int noff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -199,7 +227,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         if (nn >= N) nn = N - 1;
         const int ci = nn / g.K2, rem = nn - ci * g.K2;
         const int u = rem / g.ksz, v = rem - u * g.ksz;
-        noff[j] = (ci * Hp + u) * Wp + v;
+        noff[j] = (ci * rows + (u - ulo)) * Wp + v;
     }
     // A rows (mapping K: kk = tid&15, rows xb + 16 j)
     const int kkA = tid & 15, xb = tid >> 4;
@@ -216,7 +244,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
             const int p = pbeg + tid;
             int off = 0;
             if (p < g.P) { const int h = p / g.Ho; off = h * Wp + (p - h * g.Ho); }
-            tab[tid] = off;
+            tab[(tid & 1) * 8 + (tid >> 1)] = off;
         }
     };
 
@@ -233,7 +261,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     float ra[8];
     for (int b = ib; b < ie; ++b) {
         __syncthreads();                             // previous image fully consumed
-        load_padded_image(img, y, b, g, Hp, Wp);
+        load_padded_image(img, y, b, g, ulo, rows, Wp);
         const float* dyb = dy + (long)b * g.R * g.P + kkA;
         {
             const bool kok = kkA < g.P;
@@ -254,19 +282,24 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
                 for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
             }
             const float* as = As + cur * (BK * LDS_LD);
-            const int* pt = ptab + cur * BK;
+            const int4* pt4 = reinterpret_cast<const int4*>(ptab + cur * BK + khalf * 8);
+            const int4 t0 = pt4[0], t1 = pt4[1];
+            const int pos[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            float af[BK / 2][2], bf[BK / 2][2];
 #pragma unroll
             for (int s = 0; s < BK / 2; ++s) {
                 const int kk = 2 * s + khalf;
-                const int po = pt[kk];
-                const float a0 = as[kk * LDS_LD + arow];
-                const float a1 = as[kk * LDS_LD + arow + 32];
-                const float b0 = img[noff[0] + po];
-                const float b1 = img[noff[1] + po];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                af[s][0] = as[kk * LDS_LD + arow];
+                af[s][1] = as[kk * LDS_LD + arow + 32];
+                bf[s][0] = img[noff[0] + pos[s]];
+                bf[s][1] = img[noff[1] + pos[s]];
+            }
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][1], acc[1][1], 0, 0, 0);
             }
             if (more) {
                 float* an = As + (cur ^ 1) * (BK * LDS_LD);
@@ -279,7 +312,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     }
     __syncthreads();
     const int n = n0 + (tid & 127);
-    tile_epilogue(acc, img, ep, m0, M, n, n < N, ws, split, N);
+    tile_epilogue(acc, smem, ep, m0, M, n, n < N, ws, split, N);
 }
 
 }  // namespace tvae

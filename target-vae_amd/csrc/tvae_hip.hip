@@ -5,6 +5,7 @@
 #include "gemm_f32_mfma.hpp"
 #include "small_kernels.hpp"
 #include "conv_img_kernels.hpp"
+#include "gemm_bf16x3.hpp"
 
 using namespace tvae;
 
@@ -41,9 +42,18 @@ static hipError_t allow_big_lds(KernelT kernel, size_t bytes) {
                                (int)bytes);
 }
 
+// GEMM arithmetic mode: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 x3 (fp32-level accuracy).
+static int g_gemm_mode = 0;
+
 extern "C" {
 
 int tvae_abi_version(void) { return 1; }
+int tvae_set_gemm_mode(int mode) {
+    if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+    g_gemm_mode = mode;
+    return 0;
+}
+int tvae_get_gemm_mode(void) { return g_gemm_mode; }
 
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
                          int ksz, int R, tvae_stream_t stream) {
@@ -87,9 +97,15 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
     ep.bias = bias; ep.bias_shift = sh;
     ep.act = act; ep.slope = slope;
     ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
-    const size_t lds = conv_img_lds_bytes(Cin, n, pad);
+    if (g_gemm_mode == 1) {
+        LoadKContig8 al8{bank, (long)K, M};
+        LoadConvPatchFwd bl8{y, g, N};
+        return (int)launch_gemm_bf16x3(al8, bl8, ep, M, N, K, 1, nullptr, 0, S(stream));
+    }
+    const int rows = conv_fwd_img_rows(n, ksz, pad);
+    const size_t lds = conv_img_lds_bytes(Cin, rows, n, pad);
     if (lds <= CONV_IMG_LDS_MAX) {
-        // image-resident path: padded image in LDS, B fragments read straight from it
+        // image-resident path: the padded-image rows of the tile in LDS, B fragments read straight from them
         const int tilesPerImg = cdiv(g.P, BN);
         const long nblk = (long)cdiv(M, BM) * B * tilesPerImg;
         if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
@@ -99,12 +115,12 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
             e = allow_big_lds(conv1_fwd_img_kernel<true>, lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(conv1_fwd_img_kernel<true>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
-                               bank, y, g, ep, M, K, tilesPerImg);
+                               bank, y, g, ep, M, K, tilesPerImg, rows);
         } else {
             e = allow_big_lds(conv1_fwd_img_kernel<false>, lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(conv1_fwd_img_kernel<false>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
-                               bank, y, g, ep, M, K, tilesPerImg);
+                               bank, y, g, ep, M, K, tilesPerImg, rows);
         }
         TVAE_CHECK_LAUNCH();
         return 0;
@@ -127,7 +143,13 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
     ep.C = dbank; ep.ldc = N;
     const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BN);
     const int tiles = tilesM * tilesN;
-    const size_t lds = conv_img_lds_bytes(Cin, n, pad);
+    if (g_gemm_mode == 1) {
+        LoadConvDY8 al8{dpre, (long)B * R * g.P, M, R, g.P};
+        LoadConvPatchWgrad bl8{y, g, N};
+        return (int)launch_gemm_bf16x3(al8, bl8, ep, M, N, K, pick_splits(tiles, K), ws, ws_floats, S(stream));
+    }
+    const int rows = conv_wgrad_img_rows(Cin, n, ksz, pad);
+    const size_t lds = conv_img_lds_bytes(Cin, rows, n, pad);
     if (lds <= CONV_IMG_LDS_MAX) {
         int splits = (1024 + tiles - 1) / tiles;
         if (splits > B) splits = B;
@@ -140,7 +162,8 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         hipError_t e = allow_big_lds(conv1_wgrad_img_kernel, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv1_wgrad_img_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(GEMM_THREADS), lds,
-                           S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips, splits > 1 ? ws : nullptr, tilesN);
+                           S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips, splits > 1 ? ws : nullptr, tilesN,
+                           rows);
         TVAE_CHECK_LAUNCH();
         if (splits > 1) {
             int blocks = cdiv(per, 256);
@@ -167,6 +190,10 @@ int tvae_linear_fwd(const float* W, const float* X, const float* bias, const flo
     ep.gbias = gbias; ep.ldg = M; ep.group = group > 0 ? group : 1;
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
+    if (g_gemm_mode == 1) {
+        LoadKContig8 al8{W, (long)K, M};
+        return (int)launch_gemm_bf16x3(al8, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
+    }
     return (int)launch_gemm(al, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
 }
 
@@ -180,6 +207,7 @@ int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const
     ep.res = add; ep.ldres = ldx;
     ep.aux = aux; ep.ldaux = ldx;
     ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
+    if (g_gemm_mode == 1) return (int)launch_gemm_bf16x3(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
     return (int)launch_gemm(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
 }
 
@@ -192,6 +220,11 @@ int tvae_linear_wgrad(const float* dpre, const float* X, float* dW, float* ws, l
     ep.C = dW; ep.ldc = K;
     ep.accumulate = accumulate;
     const int tiles = cdiv(M, BM) * cdiv(K, BN);
+    if (g_gemm_mode == 1) {
+        LoadKContig8 al8{dpre, ldd, M};
+        LoadKContig8 bl8{X, ldx, K};
+        return (int)launch_gemm_bf16x3(al8, bl8, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
+    }
     return (int)launch_gemm(al, bl, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
 }
 

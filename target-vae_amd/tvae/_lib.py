@@ -64,12 +64,35 @@ def lib():
             fn.restype = ctypes.c_int
             fn.argtypes = [_CT[c] for c in sig] + [ctypes.c_void_p]
         L.tvae_abi_version.restype = ctypes.c_int
+        L.tvae_set_gemm_mode.restype = ctypes.c_int
+        L.tvae_set_gemm_mode.argtypes = [ctypes.c_int]
+        L.tvae_get_gemm_mode.restype = ctypes.c_int
         _lib = L
+        mode = os.environ.get('TVAE_GEMM', DEFAULT_GEMM_MODE)
+        set_gemm_mode(mode)
     return _lib
 
 
+GEMM_MODES = {'f32': 0, 'bf16x3': 1}
+DEFAULT_GEMM_MODE = 'f32'      # exact fp32 MFMA; 'bf16x3' is opt-in (TVAE_GEMM=bf16x3)
+
+
+def set_gemm_mode(mode: str) -> None:
+    """'f32' = exact fp32 MFMA; 'bf16x3' = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)."""
+    if mode not in GEMM_MODES:
+        raise TvaeHipError(f'unknown GEMM mode {mode!r}; choose from {sorted(GEMM_MODES)}')
+    rc = lib().tvae_set_gemm_mode(GEMM_MODES[mode])
+    if rc != 0:
+        raise TvaeHipError(f'tvae_set_gemm_mode failed with {rc}')
+
+
+def get_gemm_mode() -> str:
+    v = lib().tvae_get_gemm_mode()
+    return {v_: k_ for k_, v_ in GEMM_MODES.items()}[v]
+
+
 def exported_symbols():
-    return ['tvae_abi_version'] + sorted(SIGNATURES)
+    return ['tvae_abi_version', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES)
 
 
 def _ptr(t, name, pos):

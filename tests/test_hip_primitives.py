@@ -13,6 +13,18 @@ from oracle import tvae_oracle as O
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
 SLOPE = 0.01
+# per-tensor relative tolerance of the MFMA entry points by arithmetic mode: exact fp32 MFMA vs split-bf16 x3
+# (fp32 accumulate); the hot-path parity gate is 1e-4 (BASELINE.json north_star)
+GEMM_TOL = {'f32': 2e-5, 'bf16x3': 6e-5}
+
+
+@pytest.fixture(params=['f32', 'bf16x3'])
+def gemm_mode(request):
+    from tvae import _lib
+    old = _lib.get_gemm_mode()
+    _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(old)
 
 
 def dev():
@@ -42,7 +54,7 @@ def dact_ref(y, act):
 @pytest.mark.parametrize('M,N,K,act,use_g,use_res', [
     (128, 8712, 128, 1, False, False), (7, 300, 128, 0, False, False), (512, 1000, 1024, 1, True, False),
     (64, 517, 64, 1, False, True), (130, 129, 17, 2, True, True), (103, 2000, 128, 0, False, False)])
-def test_linear_fwd(M, N, K, act, use_g, use_res):
+def test_linear_fwd(M, N, K, act, use_g, use_res, gemm_mode):
     W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
     group = 100
     ng = (N + group - 1) // group
@@ -57,13 +69,13 @@ def test_linear_fwd(M, N, K, act, use_g, use_res):
     Y = torch.empty(M, N, device=dev())
     call('tvae_linear_fwd', W.to(dev()), X.to(dev()), b.to(dev()), gb.to(dev()) if use_g else None, group,
          res.to(dev()) if use_res else None, Y, M, N, K, N, N, act, SLOPE)
-    assert rel_err(Y, ref) < TOL
+    assert rel_err(Y, ref) < GEMM_TOL[gemm_mode]
 
 
 @pytest.mark.parametrize('M,N,K,mask,use_add', [(7, 3000, 128, 1, False), (128, 1111, 128, 1, False),
                                                 (64, 300, 64, 1, True), (512, 700, 1024, 0, False),
                                                 (33, 257, 65, 2, True)])
-def test_linear_dgrad(M, N, K, mask, use_add):
+def test_linear_dgrad(M, N, K, mask, use_add, gemm_mode):
     W, d = rnd(M, K, seed=1, scale=M ** -0.5), rnd(M, N, seed=2)
     aux = rnd(K, N, seed=3).clamp(-0.9, 0.9)
     add = rnd(K, N, seed=4) if use_add else None
@@ -74,19 +86,19 @@ def test_linear_dgrad(M, N, K, mask, use_add):
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad', W.to(dev()), d.to(dev()), add.to(dev()) if use_add else None,
          aux.to(dev()) if mask else None, dX, M, N, K, N, N, mask, SLOPE)
-    assert rel_err(dX, ref) < TOL
+    assert rel_err(dX, ref) < GEMM_TOL[gemm_mode]
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(7, 50000, 128, 0), (128, 8712 * 3, 128, 0), (64, 1000, 2, 1),
                                        (512, 20000, 512, 0), (130, 777, 1024, 0)])
-def test_linear_wgrad(M, N, K, acc):
+def test_linear_wgrad(M, N, K, acc, gemm_mode):
     d, X = rnd(M, N, seed=1), rnd(K, N, seed=2)
     init = rnd(M, K, seed=3)
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
     call('tvae_linear_wgrad', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc)
-    assert rel_err(dW, ref) < TOL
+    assert rel_err(dW, ref) < GEMM_TOL[gemm_mode]
 
 
 def test_linear_wgrad_no_workspace():
@@ -114,7 +126,7 @@ def test_rotate_bank(k, R, Cin, C):
 
 @pytest.mark.parametrize('B,Cin,n,k,pad,C,R,act', [(2, 1, 28, 28, 8, 8, 8, 1), (3, 3, 12, 9, 3, 4, 4, 0),
                                                    (2, 1, 64, 64, 16, 4, 8, 1), (5, 2, 20, 7, 0, 3, 16, 0)])
-def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act):
+def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act, gemm_mode):
     y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
     bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
     bias = rnd(C, seed=3, scale=0.1)
@@ -125,7 +137,7 @@ def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act):
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
     call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE)
     got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
-    assert rel_err(got, ref) < TOL
+    assert rel_err(got, ref) < GEMM_TOL[gemm_mode]
     # weight gradient
     g = rnd(B, C, R, Ho, Ho, seed=4)
     ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
@@ -133,7 +145,7 @@ def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act):
     dbank = torch.empty(C * R, Cin * k * k, device=dev())
     ws = torch.empty(1 << 22, device=dev())
     call('tvae_conv1_wgrad', y.to(dev()), dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
-    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < TOL
+    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL[gemm_mode]
 
 
 def test_reductions():
