@@ -78,9 +78,22 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
     const int b = rest / tilesPerImg;
     const int p0 = (rest - b * tilesPerImg) * BN;
     const int m0 = tile_m * BM;
-    const int nk = (K + BK - 1) / BK;
-
     const int hmin = p0 / g.Ho;                     // first output row of the tile = first padded-image row kept
+    // Zero skipping: tap row u only meets image rows h+u-pad in [0,n) for h in the tile's output rows [hmin,hmax];
+    // every other tap row multiplies pure zero padding.  (Single channel: the kept taps are one contiguous k range,
+    // rounded outwards to the k-step so the float4 bank loads stay aligned.)
+    int kbeg = 0, kstop = K;
+    if (g.Cin == 1) {
+        const int plast = min(g.P - 1, p0 + BN - 1);
+        const int hmax = plast / g.Ho;
+        const int ulo = max(0, g.pad - hmax);
+        const int uhi = min(g.ksz - 1, g.pad + g.n - 1 - hmin);
+        kbeg = (ulo * g.ksz) / BK * BK;
+        kstop = min(K, ((uhi + 1) * g.ksz + BK - 1) / BK * BK);
+        if (kstop < kbeg) kstop = kbeg;
+    }
+    const int nk = (kstop - kbeg + BK - 1) / BK;
+
     load_padded_image(img, y, b, g, hmin, rows, Wp);
 
     int boff[2];
@@ -122,12 +135,14 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
     const int am = tid >> 2, akq = (tid & 3) * 4;
     if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pa[i] = bank + (long)(m0 + am + 64 * i) * K + akq;
-        va[0] = *reinterpret_cast<const float4*>(pa[0]);
-        va[1] = *reinterpret_cast<const float4*>(pa[1]);
+        for (int i = 0; i < 2; ++i) pa[i] = bank + (long)(m0 + am + 64 * i) * K + kbeg + akq;
+        if (nk > 0) {
+            va[0] = *reinterpret_cast<const float4*>(pa[0]);
+            va[1] = *reinterpret_cast<const float4*>(pa[1]);
+        }
     } else {
         al.init(m0, tid);
-        al.load(ra, 0, K);
+        al.load(ra, kbeg, K);
     }
     auto store_a = [&](float* S) {
         if (VEC) {
@@ -143,8 +158,8 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
             al.store(S, ra);
         }
     };
-    store_a(As);
-    fill_ktab(ktab, 0);
+    if (nk > 0) store_a(As);
+    fill_ktab(ktab, kbeg);
     __syncthreads();
 
     const int arow = wm * 64 + (lane & 31);
@@ -160,7 +175,7 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
                     va[i] = *reinterpret_cast<const float4*>(pa[i]);
                 }
             } else {
-                al.load(ra, (t + 1) * BK, K);
+                al.load(ra, kbeg + (t + 1) * BK, K);
             }
         }
         const float* as = As + cur * (BK * LDS_LD);
@@ -189,7 +204,7 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         }
         if (more) {
             store_a(As + (cur ^ 1) * (BK * LDS_LD));
-            fill_ktab(ktab + (cur ^ 1) * BK, (t + 1) * BK);
+            fill_ktab(ktab + (cur ^ 1) * BK, kbeg + (t + 1) * BK);
         }
         __syncthreads();
     }
@@ -216,10 +231,18 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     const int split = blockIdx.y;
     const int ib = split * imgs_per_split;
     const int ie = min(g.B, ib + imgs_per_split);
-    const int nk = (g.P + BK - 1) / BK;
-
     // rows == Hp: whole padded image(s) resident; otherwise (single channel) only rows [ulo, ulo + rows)
     const int ulo = (rows == Hp) ? 0 : (n0 / g.ksz);
+    // Zero skipping (single channel): the tile's taps have rows u in [ua, ub]; output row h only meets the image if
+    // pad <= h+u <= pad+n-1 for some such u, i.e. h in [pad-ub, pad+n-1-ua] -- a contiguous position range.
+    int pbeg = 0, pend = g.P;
+    if (g.Cin == 1) {
+        const int ua = n0 / g.ksz, ub = min(N - 1, n0 + BN - 1) / g.ksz;
+        const int hlo = max(0, g.pad - ub), hhi = min(g.Ho - 1, g.pad + g.n - 1 - ua);
+        pbeg = hlo * g.Ho;
+        pend = max(pbeg, (hhi + 1) * g.Ho);
+    }
+    const int nk = (pend - pbeg + BK - 1) / BK;
     int noff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -239,11 +262,11 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         const int c = m / g.R, rr = m - c * g.R;
         rowoff[j] = (long)c * lddy + (long)rr * g.P;
     }
-    auto fill_ptab = [&](int* tab, int pbeg) {
+    auto fill_ptab = [&](int* tab, int pfrom) {
         if (tid < BK) {
-            const int p = pbeg + tid;
+            const int p = pfrom + tid;
             int off = 0;
-            if (p < g.P) { const int h = p / g.Ho; off = h * Wp + (p - h * g.Ho); }
+            if (p < pend) { const int h = p / g.Ho; off = h * Wp + (p - h * g.Ho); }
             tab[(tid & 1) * 8 + (tid >> 1)] = off;
         }
     };
@@ -262,22 +285,22 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     for (int b = ib; b < ie; ++b) {
         __syncthreads();                             // previous image fully consumed
         load_padded_image(img, y, b, g, ulo, rows, Wp);
-        const float* dyb = dy + (long)b * g.R * g.P + kkA;
+        const float* dyb = dy + (long)b * g.R * g.P + pbeg + kkA;
         {
-            const bool kok = kkA < g.P;
+            const bool kok = (pbeg + kkA) < pend;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j]] : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) As[kkA * LDS_LD + xb + 16 * j] = ra[j];
         }
-        fill_ptab(ptab, 0);
+        fill_ptab(ptab, pbeg);
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const bool more = (t + 1) < nk;
             if (more) {
                 const int pk = (t + 1) * BK;
-                const bool kok = (pk + kkA) < g.P;
+                const bool kok = (pbeg + pk + kkA) < pend;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
             }
@@ -305,7 +328,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
                 float* an = As + (cur ^ 1) * (BK * LDS_LD);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) an[kkA * LDS_LD + xb + 16 * j] = ra[j];
-                fill_ptab(ptab + (cur ^ 1) * BK, (t + 1) * BK);
+                fill_ptab(ptab + (cur ^ 1) * BK, pbeg + (t + 1) * BK);
             }
             __syncthreads();
         }

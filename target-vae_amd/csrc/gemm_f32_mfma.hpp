@@ -101,6 +101,10 @@ struct Epilogue {
 struct LoadKContig {           // element (x, k) at ptr[x*ld + k]
     const float* ptr; long ld; int X;
     int x0, kk, xb;
+    float r_[8]; int k_, kend_;
+    __device__ __forceinline__ void begin(int x0_, int tid, int kbeg, int kend) { init(x0_, tid); k_ = kbeg; kend_ = kend; }
+    __device__ __forceinline__ void fetch() { load(r_, k_, kend_); k_ += BK; }
+    __device__ __forceinline__ void commit(float* S) const { store(S, r_); }
     __device__ __forceinline__ void init(int x0_, int tid) { x0 = x0_; kk = tid & 15; xb = tid >> 4; }
     __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
         const int k = k0 + kk;
@@ -120,6 +124,10 @@ struct LoadKContig {           // element (x, k) at ptr[x*ld + k]
 struct LoadXContig {           // element (x, k) at ptr[k*ld + x]
     const float* ptr; long ld; int X;
     int x0, x, kh;
+    float r_[8]; int k_, kend_;
+    __device__ __forceinline__ void begin(int x0_, int tid, int kbeg, int kend) { init(x0_, tid); k_ = kbeg; kend_ = kend; }
+    __device__ __forceinline__ void fetch() { load(r_, k_, kend_); k_ += BK; }
+    __device__ __forceinline__ void commit(float* S) const { store(S, r_); }
     __device__ __forceinline__ void init(int x0_, int tid) { x0 = x0_; x = tid & 127; kh = tid >> 7; }
     __device__ __forceinline__ void load(float (&r)[8], int k0, int kend) const {
         const bool xok = (x0 + x) < X;
@@ -135,6 +143,54 @@ struct LoadXContig {           // element (x, k) at ptr[k*ld + x]
     }
 };
 
+
+// ------------------------------------------------------------------------------------------
+// Fast-path loaders (no guards, float4 global loads, incremented pointers): require the tile dimension to be a
+// multiple of 128, the reduction range a multiple of 16, ld % 4 == 0 and a 16-B aligned base.
+// ------------------------------------------------------------------------------------------
+struct LoadKContigV4 {         // element (x, k) at ptr[x*ld + k]; thread: rows (tid>>2) + 64 i, k quad (tid&3)*4
+    const float* ptr; long ld; int X;
+    const float* p_[2]; float4 v_[2]; int am, akq;
+    __device__ __forceinline__ void begin(int x0, int tid, int kbeg, int) {
+        am = tid >> 2; akq = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p_[i] = ptr + (long)(x0 + am + 64 * i) * ld + kbeg + akq;
+    }
+    __device__ __forceinline__ void fetch() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { v_[i] = *reinterpret_cast<const float4*>(p_[i]); p_[i] += BK; }
+    }
+    __device__ __forceinline__ void commit(float* S) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = am + 64 * i;
+            S[(akq + 0) * LDS_LD + m] = v_[i].x;
+            S[(akq + 1) * LDS_LD + m] = v_[i].y;
+            S[(akq + 2) * LDS_LD + m] = v_[i].z;
+            S[(akq + 3) * LDS_LD + m] = v_[i].w;
+        }
+    }
+};
+
+struct LoadXContigV4 {         // element (x, k) at ptr[k*ld + x]; thread: x quad (tid&31)*4, k rows (tid>>5) + 8 i
+    const float* ptr; long ld; int X;
+    const float* p_[2]; float4 v_[2]; int x4, kr;
+    __device__ __forceinline__ void begin(int x0, int tid, int kbeg, int) {
+        x4 = (tid & 31) * 4; kr = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p_[i] = ptr + (long)(kbeg + kr + 8 * i) * ld + x0 + x4;
+    }
+    __device__ __forceinline__ void fetch() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { v_[i] = *reinterpret_cast<const float4*>(p_[i]); p_[i] += (long)BK * ld; }
+    }
+    __device__ __forceinline__ void commit(float* S) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<float4*>(S + (kr + 8 * i) * LDS_LD + x4) = v_[i];
+    }
+};
+
 // Geometry of the lifting convolution (GroupConv.forward, reference src/models.py:202-225).
 struct ConvGeom {
     int B, Cin, n, ksz, pad, Ho, R;
@@ -146,6 +202,10 @@ struct ConvGeom {
 struct LoadConvPatchFwd {
     const float* y; ConvGeom g; int Ntot;
     int x, kh, img, h, w; bool nok;
+    float r_[8]; int k_, kend_;
+    __device__ __forceinline__ void begin(int x0_, int tid, int kbeg, int kend) { init(x0_, tid); k_ = kbeg; kend_ = kend; }
+    __device__ __forceinline__ void fetch() { load(r_, k_, kend_); k_ += BK; }
+    __device__ __forceinline__ void commit(float* S) const { store(S, r_); }
     __device__ __forceinline__ void init(int n0, int tid) {
         x = tid & 127; kh = tid >> 7;
         const int nn = n0 + x;
@@ -180,6 +240,10 @@ struct LoadConvPatchFwd {
 struct LoadConvPatchWgrad {
     const float* y; ConvGeom g; int Ntot;   // Ntot = Cin*K2
     int x, kh, ci, u, v; bool nok;
+    float r_[8]; int k_, kend_;
+    __device__ __forceinline__ void begin(int x0_, int tid, int kbeg, int kend) { init(x0_, tid); k_ = kbeg; kend_ = kend; }
+    __device__ __forceinline__ void fetch() { load(r_, k_, kend_); k_ += BK; }
+    __device__ __forceinline__ void commit(float* S) const { store(S, r_); }
     __device__ __forceinline__ void init(int n0, int tid) {
         x = tid & 127; kh = tid >> 7;
         const int nn = n0 + x;
@@ -216,6 +280,10 @@ struct LoadConvDY {
     const float* dy; long ld; int M; int R; int P;
     int x0, kk, xb;
     long rowoff[8];
+    float r_[8]; int k_, kend_;
+    __device__ __forceinline__ void begin(int x0_, int tid, int kbeg, int kend) { init(x0_, tid); k_ = kbeg; kend_ = kend; }
+    __device__ __forceinline__ void fetch() { load(r_, k_, kend_); k_ += BK; }
+    __device__ __forceinline__ void commit(float* S) const { store(S, r_); }
     __device__ __forceinline__ void init(int x0_, int tid) {
         x0 = x0_; kk = tid & 15; xb = tid >> 4;
 #pragma unroll
@@ -292,7 +360,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[2][2], float* ct, co
 template <class AL, class BL>
 __global__ __launch_bounds__(GEMM_THREADS, 3)
 void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, int tilesN) {
-    __shared__ float lds[2 * 2 * BK * LDS_LD];   // [buf][A|B][BK][LDS_LD]
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDS_LD];   // [buf][A|B][BK][LDS_LD]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -313,14 +381,13 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[8], rb[8];
-    al.init(m0, tid);
-    bl.init(n0, tid);
+    al.begin(m0, tid, kbeg, kend);
+    bl.begin(n0, tid, kbeg, kend);
     if (nk > 0) {
-        al.load(ra, kbeg, kend);
-        bl.load(rb, kbeg, kend);
-        al.store(lds, ra);
-        bl.store(lds + BK * LDS_LD, rb);
+        al.fetch();
+        bl.fetch();
+        al.commit(lds);
+        bl.commit(lds + BK * LDS_LD);
     }
     __syncthreads();
 
@@ -332,8 +399,8 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
         const int cur = t & 1;
         const bool more = (t + 1) < nk;
         if (more) {
-            al.load(ra, kbeg + (t + 1) * BK, kend);
-            bl.load(rb, kbeg + (t + 1) * BK, kend);
+            al.fetch();
+            bl.fetch();
         }
         const float* as = lds + cur * (2 * BK * LDS_LD);
         const float* bs = as + BK * LDS_LD;
@@ -351,8 +418,8 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
         }
         if (more) {
             float* an = lds + (cur ^ 1) * (2 * BK * LDS_LD);
-            al.store(an, ra);
-            bl.store(an + BK * LDS_LD, rb);
+            al.commit(an);
+            bl.commit(an + BK * LDS_LD);
         }
         __syncthreads();
     }

@@ -16,6 +16,7 @@ using namespace tvae;
     } while (0)
 
 static inline hipStream_t S(tvae_stream_t s) { return (hipStream_t)s; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 static inline int grid1d(long total, int block, int cap = 8192) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -194,6 +195,11 @@ int tvae_linear_fwd(const float* W, const float* X, const float* bias, const flo
         LoadKContig8 al8{W, (long)K, M};
         return (int)launch_gemm_bf16x3(al8, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
     }
+    if (M % BM == 0 && N % BN == 0 && K % BK == 0 && ldx % 4 == 0 && aligned16(W) && aligned16(X)) {
+        LoadKContigV4 af{W, (long)K, M};
+        LoadXContigV4 bf{X, ldx, N};
+        return (int)launch_gemm(af, bf, ep, M, N, K, 1, nullptr, 0, S(stream));
+    }
     return (int)launch_gemm(al, bl, ep, M, N, K, 1, nullptr, 0, S(stream));
 }
 
@@ -208,6 +214,11 @@ int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const
     ep.aux = aux; ep.ldaux = ldx;
     ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
     if (g_gemm_mode == 1) return (int)launch_gemm_bf16x3(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
+    if (K % BM == 0 && N % BN == 0 && M % BK == 0 && ldd % 4 == 0 && K % 4 == 0 && aligned16(W) && aligned16(dpre)) {
+        LoadXContigV4 af{W, (long)K, K};
+        LoadXContigV4 bf{dpre, ldd, N};
+        return (int)launch_gemm(af, bf, ep, K, N, M, 1, nullptr, 0, S(stream));
+    }
     return (int)launch_gemm(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
 }
 
@@ -224,6 +235,13 @@ int tvae_linear_wgrad(const float* dpre, const float* X, float* dW, float* ws, l
         LoadKContig8 al8{dpre, ldd, M};
         LoadKContig8 bl8{X, ldx, K};
         return (int)launch_gemm_bf16x3(al8, bl8, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
+    }
+    if (M % BM == 0 && K % BN == 0 && N % (BK * 1) == 0 && ldd % 4 == 0 && ldx % 4 == 0 && aligned16(dpre) &&
+        aligned16(X)) {
+        // split-K chunks are multiples of BK, and N % BK == 0, so every k-step of every slice is full
+        LoadKContigV4 af{dpre, ldd, M};
+        LoadKContigV4 bf{X, ldx, K};
+        return (int)launch_gemm(af, bf, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
     }
     return (int)launch_gemm(al, bl, ep, M, K, N, pick_splits(tiles, N), ws, ws_floats, S(stream));
 }
