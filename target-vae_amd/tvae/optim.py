@@ -13,6 +13,9 @@ import torch
 from . import ops
 
 
+ALIGN = 64      # floats
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, update_fn=None):
         params = list(params)
@@ -21,22 +24,26 @@ class FlatAdam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError('FlatAdam keeps one parameter group (the reference uses one)')
         dev = self._ps[0].device
-        total = sum(p.numel() for p in self._ps)
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        # every parameter starts on a 256-B boundary of the flat buffer so that the float4 / aligned fast paths of
+        # the GEMM loaders apply to parameter views too (padding stays zero: zero grad -> zero Adam update)
+        self._offsets = []
+        total = 0
+        for p in self._ps:
+            self._offsets.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._gviews = []
-        off = 0
         with torch.no_grad():
-            for p in self._ps:
+            for p, off in zip(self._ps, self._offsets):
                 n = p.numel()
                 self.flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + n].view_as(p)
                 gv = self.flat_g[off:off + n].view_as(p)
                 p.grad = gv
                 self._gviews.append(gv)
-                off += n
         self.steps = 0
         self.reducer = reducer            # callable(flat_g) -> grad_scale  (data-parallel all-reduce)
         self._update = update_fn or ops.adam_flat

@@ -174,7 +174,8 @@ def test_flat_adam_views_and_update_cpu():
 
     opt = optim.FlatAdam(ps, lr=1e-2, update_fn=upd)
     ropt = torch.optim.Adam(ref, lr=1e-2)
-    assert ps[0].data_ptr() == opt.flat_p.data_ptr() and ps[1].grad.data_ptr() == opt.flat_g[12:].data_ptr()
+    assert ps[0].data_ptr() == opt.flat_p.data_ptr() and ps[1].grad.data_ptr() == opt.flat_g[64:].data_ptr()
+    assert all(p.data_ptr() % 256 == opt.flat_p.data_ptr() % 256 for p in ps)
     for it in range(3):
         loss = sum(((p * (i + 1 + it)) ** 2).sum() for i, p in enumerate(ps))
         loss.backward()
