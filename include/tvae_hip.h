@@ -119,6 +119,18 @@ int tvae_loglik_fwd(const float* yh, const float* y, float* lp, int B, int L, in
 int tvae_loglik_bwd(const float* yh, const float* y, const float* glp, float* gyh, int B, int L, int kind,
                     tvae_stream_t stream);
 
+/* ---- particle likelihood tail: train_particles.py:298-338 ----
+ * ctf_corr: per-image depthwise cross-correlation out[b] = in[b] (*) ctf[b] with an odd kc x kc filter and zero padding
+ * kc/2 (F.conv2d(y_mu.view(1,B,n,n), ctf, padding=pad, groups=B), :298-302); flip = 1 uses the 180-degree rotated
+ * filter, i.e. the gradient w.r.t. `in`.  in/out [B][n*n], ctf [B][kc*kc].
+ * loglik_masked: Gaussian log-likelihood restricted to a circle of `radius` pixels centred at the inferred
+ * translation dx [B][2] / spacing (:309-333,338); masked pixels get no gradient. */
+int tvae_ctf_corr(const float* in, const float* ctf, float* out, int B, int n, int kc, int flip, tvae_stream_t stream);
+int tvae_loglik_masked_fwd(const float* yh, const float* y, const float* dx, float inv_spacing, float radius, int B,
+                           int n, float* lp, tvae_stream_t stream);
+int tvae_loglik_masked_bwd(const float* yh, const float* y, const float* dx, float inv_spacing, float radius, int B,
+                           int n, const float* glp, float* gyh, tvae_stream_t stream);
+
 /* ---- fused Adam over the flat parameter buffer: torch.optim.Adam defaults, train_mnist.py:579,323 ----
  * bc1 = 1 - b1^t, bc2_sqrt = sqrt(1 - b2^t) computed by the host; grad_scale folds the DP average. */
 int tvae_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

@@ -245,7 +245,8 @@ def elbo_step(x_coord: Tensor, y: Tensor, enc: Dict[str, Tensor], gen: Dict[str,
               R: int, padding: int, rot_refinement: bool, theta_prior: float,
               normal_prior_over_r: bool, num_layers: int, resid: bool = False,
               fourier_sigma: Optional[float] = None, likelihood: str = 'bce',
-              E: Tensor, eps_z: Tensor, eps_theta: Tensor, return_aux: bool = False):
+              E: Tensor, eps_z: Tensor, eps_theta: Tensor, return_aux: bool = False,
+              ctf: Optional[Tensor] = None, mask_radius: int = 0):
     """eval_minibatch, attention-translation / attention-rotation branch.
 
     likelihood: 'bce' (train_mnist.py:286-291), 'bce3' (train_galaxy.py:287-292),
@@ -262,7 +263,10 @@ def elbo_step(x_coord: Tensor, y: Tensor, enc: Dict[str, Tensor], gen: Dict[str,
     kl_div = kl_per_image.mean()                                                        # :281-282
 
     y_hat = generator_forward(gen, x.contiguous(), z, num_layers, resid, fourier_sigma)  # :287
-    log_p = likelihood_logp(y_hat, y, likelihood)
+    if ctf is not None or mask_radius > 0:
+        log_p = particles_logp(y_hat, y, ctf, mask_radius, dx, float(spacing))
+    else:
+        log_p = likelihood_logp(y_hat, y, likelihood)
     elbo = log_p - kl_div
     if return_aux:
         aux = dict(attn=attn, q_t_r=q_t_r, a_sampled=a_s, theta_vals=theta_vals, z_vals=z_vals,
@@ -348,6 +352,55 @@ def likelihood_logp(y_hat: Tensor, y: Tensor, kind: str) -> Tensor:
         mu, logvar = yh[:, :n], yh[:, n:]
         return -0.5 * torch.sum((mu - yy) ** 2 / torch.exp(logvar) + logvar, 1).mean()
     raise ValueError(kind)
+
+
+def particles_logp(y_hat: Tensor, y: Tensor, ctf: Optional[Tensor], mask_radius: int, dx: Tensor,
+                   spacing: float) -> Tensor:
+    """Particle likelihood tail, train_particles.py:284-338 (n_out = 1): optional per-image CTF filter
+    (depthwise conv2d, :298-302), optional circular mask centred at the inferred translation (:309-333),
+    Gaussian log-likelihood (:338).  ctf (B,1,kc,kc); dx (B,1,2)."""
+    b = y.shape[0]
+    n = int(y.shape[-1])
+    y_mu = y_hat.reshape(b, -1)
+    yy = y.reshape(b, -1)
+    if ctf is not None:
+        pad = ctf.size(2) // 2
+        y_mu = F.conv2d(y_mu.view(1, -1, n, n), ctf, padding=pad, groups=ctf.size(0)).view(-1, n * n)
+    if mask_radius > 0:
+        x_img = np.arange(-n // 2, n // 2, 1)
+        y_img = np.arange(n // 2, -n // 2, -1)
+        xg, yg = np.meshgrid(x_img, y_img)
+        grid = np.stack([xg.ravel(), yg.ravel()], 1)
+        gb = np.broadcast_to(grid, (b, grid.shape[0], 2))
+        center = dx.detach().numpy() / np.float32(spacing)
+        dist = np.sqrt((center[:, :, 0] - gb[:, :, 0]) ** 2 + (center[:, :, 1] - gb[:, :, 1]) ** 2)
+        mask = (torch.from_numpy(dist) < mask_radius).view(b, -1)
+        yy = torch.where(mask, yy, torch.zeros_like(yy))
+        y_mu = torch.where(mask, y_mu, torch.zeros_like(y_mu))
+    return -0.5 * torch.sum((y_mu - yy) ** 2, 1).mean()
+
+
+def ctf_filters(defocus, cs, voltage, apix, bfactor, ampcont, dfang, n, m, scale=1.0) -> np.ndarray:
+    """Real-space CTF kernels, src/ctf.py:6-23,32-55 (one (n,m) float32 kernel per parameter row)."""
+    theta, gamma = np.meshgrid(np.fft.fftfreq(n), np.fft.fftfreq(m), indexing='ij')
+    freqs = np.stack([theta.ravel(), gamma.ravel()], 1)
+    out = np.zeros((len(defocus), n, m), dtype=np.float32)
+    for i in range(len(defocus)):
+        f = freqs / (apix[i] * scale)
+        volt = voltage[i] * 1000
+        csv = cs[i] * 10 ** 7
+        lam = 12.2639 / np.sqrt(volt + 0.97845e-6 * volt ** 2)
+        x, yv = f[:, 0], f[:, 1]
+        ang = np.arctan2(yv, x)
+        s2 = x ** 2 + yv ** 2
+        dfu = dfv = defocus[i] * 10000
+        df = 0.5 * (dfu + dfv + (dfu - dfv) * np.cos(2 * (ang - 2 * np.pi * dfang[i] / 360)))
+        gam = 2 * np.pi * (-0.5 * df * lam * s2 + 0.25 * csv * lam ** 3 * s2 ** 2)
+        w = ampcont[i] / 100
+        c = np.sqrt(1 - w ** 2) * np.sin(gam) - w * np.cos(gam)
+        c = c * np.exp(-bfactor[i] / 4 * s2)
+        out[i] = -np.fft.fftshift(np.fft.ifft2(c.reshape(n, m))).real
+    return out
 
 
 # --------------------------------------------------------------------------------------

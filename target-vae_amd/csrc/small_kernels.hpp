@@ -363,6 +363,78 @@ __global__ void loglik_bwd_kernel(const float* __restrict__ yh, const float* __r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Particle likelihood tail (reference train_particles.py:298-338).
+// (1) per-image CTF filter: depthwise cross-correlation with an odd kc x kc kernel, zero padding kc/2
+//     (F.conv2d(y_mu.view(1,B,n,n), ctf, padding=pad, groups=B), :298-302).  flip = 1 applies the 180-degree rotated
+//     kernel = the gradient w.r.t. the input.  One thread per output pixel; the filter row is wave-uniform.
+// (2) circular mask centred at the inferred translation (:309-333): pixel (i,j) is kept iff
+//     (dx0/s - gx_j)^2 + (dx1/s - gy_i)^2 < radius^2 with gx_j = -ceil(n/2) + j, gy_i = floor(n/2) - i; masked pixels
+//     contribute nothing to the Gaussian log-likelihood and get no gradient (the mask itself carries no gradient).
+// ------------------------------------------------------------------------------------------
+__global__ void ctf_corr_kernel(const float* __restrict__ in, const float* __restrict__ ctf, float* __restrict__ out,
+                                int n, int kc, int flip) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= n * n) return;
+    const int i = pix / n, j = pix - i * n;
+    const int p = kc / 2;
+    const float* src = in + (long)b * n * n;
+    const float* w = ctf + (long)b * kc * kc;
+    float acc = 0.f;
+    for (int a = 0; a < kc; ++a) {
+        const int ii = i + a - p;
+        if (ii < 0 || ii >= n) continue;
+        const float* wr = flip ? (w + (long)(kc - 1 - a) * kc) : (w + (long)a * kc);
+        const float* sr = src + (long)ii * n;
+        for (int c = 0; c < kc; ++c) {
+            const int jj = j + c - p;
+            if (jj >= 0 && jj < n) acc += sr[jj] * (flip ? wr[kc - 1 - c] : wr[c]);
+        }
+    }
+    out[(long)b * n * n + pix] = acc;
+}
+
+__device__ __forceinline__ bool mask_keep(int i, int j, int n, float cx, float cy, float r2) {
+    const float gx = (float)(j - (n + 1) / 2);
+    const float gy = (float)(n / 2 - i);
+    const float ddx = cx - gx, ddy = cy - gy;
+    return ddx * ddx + ddy * ddy < r2;
+}
+// Gaussian log-likelihood with optional circular mask: lp[b] = -0.5 * sum_{kept pixels} (yh - y)^2
+__global__ void loglik_masked_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+                                         const float* __restrict__ dx, float inv_spacing, float radius, int n,
+                                         float* __restrict__ lp) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x;
+    const int L = n * n;
+    const float cx = dx[2 * b] * inv_spacing, cy = dx[2 * b + 1] * inv_spacing, r2 = radius * radius;
+    float acc[1] = {0.f};
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+        const int i = t / n, j = t - i * n;
+        if (mask_keep(i, j, n, cx, cy, r2)) {
+            const float d = yh[(long)b * L + t] - y[(long)b * L + t];
+            acc[0] -= 0.5f * d * d;
+        }
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) lp[b] = acc[0];
+}
+__global__ void loglik_masked_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+                                         const float* __restrict__ dx, float inv_spacing, float radius, int n,
+                                         const float* __restrict__ glp, float* __restrict__ gyh, int B) {
+    const long L = (long)n * n, total = (long)B * L;
+    const float r2 = radius * radius;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / L);
+        const int r = (int)(t - (long)b * L);
+        const int i = r / n, j = r - i * n;
+        const bool keep = mask_keep(i, j, n, dx[2 * b] * inv_spacing, dx[2 * b + 1] * inv_spacing, r2);
+        gyh[t] = keep ? -glp[b] * (yh[t] - y[t]) : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Attention head (reference models.py:358-401 + train_mnist.py:192-282): one workgroup per image.
 // heads[ch][img*RP + j], ch: 0 logit, 1 theta_mu, 2 theta_logstd, 3..3+zd-1 z_mu, 3+zd.. z_logstd.

@@ -410,6 +410,32 @@ int tvae_loglik_bwd(const float* yh, const float* y, const float* glp, float* gy
     return 0;
 }
 
+int tvae_ctf_corr(const float* in, const float* ctf, float* out, int B, int n, int kc, int flip, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    if ((kc & 1) == 0) return (int)hipErrorInvalidValue;
+    dim3 grid((n * n + 255) / 256, B), block(256);
+    hipLaunchKernelGGL(ctf_corr_kernel, grid, block, 0, S(stream), in, ctf, out, n, kc, flip);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_loglik_masked_fwd(const float* yh, const float* y, const float* dx, float inv_spacing, float radius, int B,
+                           int n, float* lp, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(loglik_masked_fwd_kernel, dim3(B), dim3(256), 0, S(stream), yh, y, dx, inv_spacing, radius, n,
+                       lp);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_loglik_masked_bwd(const float* yh, const float* y, const float* dx, float inv_spacing, float radius, int B,
+                           int n, const float* glp, float* gyh, tvae_stream_t stream) {
+    hipLaunchKernelGGL(loglik_masked_bwd_kernel, dim3(grid1d((long)B * n * n, 256)), dim3(256), 0, S(stream), yh, y, dx,
+                       inv_spacing, radius, n, glp, gyh, B);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 int tvae_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                    float bc1, float bc2_sqrt, float grad_scale, tvae_stream_t stream) {
     hipLaunchKernelGGL(adam_flat_kernel, dim3(grid1d(n, 256, 2048)), dim3(256), 0, S(stream), p, g, m, v, n, lr, b1,

@@ -39,6 +39,9 @@ SIGNATURES = {
     'tvae_fourier_bwd': 'pppfplilp',
     'tvae_loglik_fwd': 'pppiii',
     'tvae_loglik_bwd': 'ppppiii',
+    'tvae_ctf_corr': 'pppiiii',
+    'tvae_loglik_masked_fwd': 'pppffiip',
+    'tvae_loglik_masked_bwd': 'pppffiipp',
     'tvae_adam_flat': 'pppplfffffff',
 }
 

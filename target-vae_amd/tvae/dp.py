@@ -78,8 +78,11 @@ class ShardedBatches:
     dataset on the device, train_mnist.py:495).  Empty shards (ragged tail smaller than world) are skipped by
     the reducer weight being 0 -- they still take part in the collective."""
 
-    def __init__(self, data: torch.Tensor, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
+    def __init__(self, data, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
                  seed: int = 0, reducer: GradReducer = None):
+        # `data` is one tensor or a tuple of tensors indexed alike (e.g. images and their CTF filters)
+        self.extra = tuple(data[1:]) if isinstance(data, (tuple, list)) else ()
+        data = data[0] if isinstance(data, (tuple, list)) else data
         self.data, self.gb, self.rank, self.world = data, global_batch, rank, world
         self.shuffle, self.seed, self.reducer = shuffle, seed, reducer
         self.epoch = 0
@@ -96,7 +99,8 @@ class ShardedBatches:
         for lo, hi, g in shard_slices(n, self.gb, self.rank, self.world):
             if self.reducer is not None:
                 self.reducer.set_local_fraction(hi - lo, g)
-            yield (self.data.index_select(0, perm[lo:hi]),)
+            idx = perm[lo:hi]
+            yield (self.data.index_select(0, idx),) + tuple(t.index_select(0, idx) for t in self.extra)
 
 
 def allreduce_stats(values, device, group=None):

@@ -135,8 +135,6 @@ def _load_arrays(kind, args):
         allim = load(args.train_path)
         k = int(allim.shape[0] * args.train_portion)
         a, b = allim[:k], allim[k:]
-    if args.ctf_train or args.ctf_test:
-        raise NotImplementedError('per-image CTF filtering (train_particles.py:298-307) is a SURVEY 8f next row')
     if args.crop > 0:
         def crop(s, m):
             n0 = s.shape[-1]
@@ -151,6 +149,22 @@ def _load_arrays(kind, args):
     n = a.shape[-1]
     tr, te = torch.from_numpy(a).float(), torch.from_numpy(b).float()
     return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'particles'
+
+
+def _load_ctf(args, n_train, n_test, n):
+    """Real-space CTF kernels per image (train_particles.py:540-577): odd size n-1 for even images."""
+    if not getattr(args, 'ctf_train', None):
+        return None, None
+    from src import ctf as C
+    kn = n - 1 if n % 2 == 0 else n
+    if args.ctf_test:
+        ftr = C.ctf_filter(C.parse_ctf(args.ctf_train), kn, kn, scale=args.scale)
+        fte = C.ctf_filter(C.parse_ctf(args.ctf_test), kn, kn, scale=args.scale)
+    else:
+        allf = C.ctf_filter(C.parse_ctf(args.ctf_train), kn, kn, scale=args.scale)
+        ftr, fte = allf[:n_train], allf[n_train:]
+    assert len(ftr) == n_train and len(fte) == n_test, 'one CTF parameter row per image is required'
+    return torch.from_numpy(ftr).float().unsqueeze(1), torch.from_numpy(fte).float().unsqueeze(1)
 
 
 def run(kind: str, argv=None):
@@ -173,7 +187,12 @@ def run(kind: str, argv=None):
     device = torch.device('cuda', dev_index)
     if is_main:
         print('# using device:', device, f'(rank {rank}/{world})', file=sys.stderr)
+    ctf_train = ctf_test = None
+    if kind == 'particles' and not args.synthetic:
+        ctf_train, ctf_test = _load_ctf(args, len(y_train), len(y_test), image_dim)
     y_train, y_test = y_train.to(device), y_test.to(device)        # whole dataset resident (train_mnist.py:495)
+    if ctf_train is not None:
+        ctf_train, ctf_test = ctf_train.to(device), ctf_test.to(device)
     x_coord = torch.from_numpy(tables.image_coords(image_dim)).to(device)
 
     z_dim = args.z_dim
@@ -217,11 +236,16 @@ def run(kind: str, argv=None):
     scheduler = ReduceLROnPlateau(optimizer, mode='max', factor=0.5, patience=patience, threshold=1e-4,
                                   threshold_mode='abs', cooldown=0, min_lr=min_lr, eps=1e-08)
     seed = args.seed if args.seed is not None else 0
-    train_it = dp.ShardedBatches(y_train, args.minibatch_size, rank, world, shuffle=True, seed=seed, reducer=reducer)
-    test_it = dp.ShardedBatches(y_test, args.minibatch_size, rank, world, shuffle=False, seed=seed)
+    train_src = (y_train, ctf_train) if ctf_train is not None else y_train
+    test_src = (y_test, ctf_test) if ctf_test is not None else y_test
+    train_it = dp.ShardedBatches(train_src, args.minibatch_size, rank, world, shuffle=True, seed=seed, reducer=reducer)
+    test_it = dp.ShardedBatches(test_src, args.minibatch_size, rank, world, shuffle=False, seed=seed)
     likelihood = {'mnist': 'bce', 'dsprites': 'bce', 'galaxy': 'bce3'}.get(kind, 'gauss_var' if n_out == 2 else 'gauss')
-    if kind == 'particles' and args.mask_radius > 0:
-        raise NotImplementedError('--mask-radius (train_particles.py:309-333) is a SURVEY 8f next row')
+    mask_radius = args.mask_radius if kind == 'particles' else None
+    if kind == 'particles' and n_out == 2 and (ctf_train is not None or args.mask_radius > 0):
+        raise SystemExit('--fit-noise together with CTF filters or --mask-radius does not broadcast in the reference '
+                         '(train_particles.py:303-307,330-333) and is not built')
+    step_dim = args.encoder_padding if kind == 'particles' else image_dim   # reference positional argument
 
     output = sys.stdout
     log_file = None
@@ -263,13 +287,13 @@ def run(kind: str, argv=None):
         train_it.set_epoch(epoch)
         n_local = sum(hi - lo for lo, hi, _ in dp.shard_slices(N, args.minibatch_size, rank, world))
         e, err, kl = step.train_epoch(train_it, x_coord, generator_model, encoder_model, optimizer, t_inf, r_inf, epoch,
-                                      num_epochs, max(n_local, 1), device, params, theta_prior, group_conv, image_dim,
-                                      likelihood=likelihood, progress=is_main)
+                                      num_epochs, max(n_local, 1), device, params, theta_prior, group_conv, step_dim,
+                                      likelihood=likelihood, progress=is_main, mask_radius=mask_radius)
         e, err, kl = global_means(e, err, kl, n_local)
         emit('\t'.join([str(epoch + 1), 'train', str(e), str(err), str(kl)]))
         n_test = sum(hi - lo for lo, hi, _ in dp.shard_slices(len(y_test), args.minibatch_size, rank, world))
         e, err, kl = step.eval_model(test_it, x_coord, generator_model, encoder_model, t_inf, r_inf, epoch, device,
-                                     theta_prior, group_conv, image_dim, likelihood=likelihood)
+                                     theta_prior, group_conv, step_dim, likelihood=likelihood, mask_radius=mask_radius)
         e, err, kl = global_means(e, err, kl, n_test)
         emit('\t'.join([str(epoch + 1), 'test', str(e), str(err), str(kl)]))
         if is_main:

@@ -484,6 +484,57 @@ class LogLikFn(torch.autograd.Function):
         return gyh.view(ctx.shape), None, None
 
 
+class CtfFn(torch.autograd.Function):
+    """Per-image CTF filter of the reconstruction (train_particles.py:298-302): depthwise cross-correlation with an
+    odd kernel, zero padding kc//2.  y_mu (B, n*n), ctf (B, 1, kc, kc) -> (B, n*n).  The filters are constants."""
+
+    @staticmethod
+    def forward(ctx, y_mu, ctf, n):
+        B, kc = ctf.shape[0], ctf.shape[-1]
+        y_mu = y_mu.contiguous()
+        ctf = ctf.contiguous()
+        out = torch.empty_like(y_mu)
+        call('tvae_ctf_corr', y_mu, ctf, out, B, n, kc, 0)
+        ctx.save_for_backward(ctf)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ctf,) = ctx.saved_tensors
+        B, kc = ctf.shape[0], ctf.shape[-1]
+        gi = torch.empty_like(g)
+        call('tvae_ctf_corr', g.contiguous(), ctf, gi, B, ctx.n, kc, 1)
+        return gi, None, None
+
+
+class MaskedLogLikFn(torch.autograd.Function):
+    """Gaussian log-likelihood inside a circle of `radius` pixels centred at the inferred translation
+    (train_particles.py:309-333,338).  The mask is built on the device from dx (the reference builds it on the host
+    with numpy every step); it carries no gradient, like the reference's dx.detach()."""
+
+    @staticmethod
+    def forward(ctx, yh, y, dx, spacing, radius, n):
+        B = y.shape[0]
+        ctx.shape = tuple(yh.shape)
+        yh = yh.contiguous().view(B, -1)
+        y = y.contiguous().view(B, -1)
+        dx = dx.detach().contiguous()
+        lp = torch.empty(B, dtype=torch.float32, device=yh.device)
+        call('tvae_loglik_masked_fwd', yh, y, dx, 1.0 / spacing, float(radius), B, n, lp)
+        ctx.save_for_backward(yh, y, dx)
+        ctx.cfg = (spacing, radius, n)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        yh, y, dx = ctx.saved_tensors
+        spacing, radius, n = ctx.cfg
+        gyh = torch.empty_like(yh)
+        call('tvae_loglik_masked_bwd', yh, y, dx, 1.0 / spacing, float(radius), y.shape[0], n, g.contiguous(), gyh)
+        return gyh.view(ctx.shape), None, None, None, None, None
+
+
 def adam_flat(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
     """Fused Adam on flat buffers (torch.optim.Adam defaults; reference train_mnist.py:579,323)."""
     bc1 = 1.0 - b1 ** step

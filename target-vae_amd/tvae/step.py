@@ -37,7 +37,8 @@ def draw_noise(B: int, RP: int, zd: int, device, generator: Optional[torch.Gener
     return E, eps_z, eps_t
 
 
-def elbo_terms(x, y, generator_model, encoder_model, likelihood='bce', noise=None, return_aux=False):
+def elbo_terms(x, y, generator_model, encoder_model, likelihood='bce', noise=None, return_aux=False, ctf=None,
+               mask_radius=0):
     """(elbo f64, log_p f32, kl f64) of one minibatch, attention/attention branch
     (train_mnist.py:187-294).  `noise` = (E, eps_z, eps_theta) injects the random draws."""
     b = y.shape[0]
@@ -53,7 +54,21 @@ def elbo_terms(x, y, generator_model, encoder_model, likelihood='bce', noise=Non
                                                       eps_t.reshape(b), tb, b, zd)
     xr = ops.CoordFn.apply(x, dx, theta)
     y_hat = generator_model(xr, z)
-    lp = ops.LogLikFn.apply(y_hat, y, ops.LIK_KIND[likelihood])
+    if ctf is not None or mask_radius > 0:
+        # particle tail (train_particles.py:298-338): CTF filter, then circular mask, then Gaussian likelihood
+        if likelihood != 'gauss':
+            raise NotImplementedError('CTF / mask with --fit-noise is inconsistent in the reference '
+                                      '(train_particles.py:303-307,330-333 do not broadcast); only n_out = 1 is built')
+        n = int(y.shape[-1])
+        y_mu = y_hat.reshape(b, -1)
+        if ctf is not None:
+            y_mu = ops.CtfFn.apply(y_mu, ctf, n)
+        if mask_radius > 0:
+            lp = ops.MaskedLogLikFn.apply(y_mu, y, dx, pixel_spacing(x), mask_radius, n)
+        else:
+            lp = ops.LogLikFn.apply(y_mu, y, ops.LIK_KIND['gauss'])
+    else:
+        lp = ops.LogLikFn.apply(y_hat, y, ops.LIK_KIND[likelihood])
     log_p = lp.mean()                       # mean over the batch (train_mnist.py:291: BCE mean * size)
     kl_div = kl_b.double().mean()           # float64 like the reference (its prior grid is float64)
     elbo = log_p - kl_div
@@ -79,28 +94,35 @@ def eval_minibatch(x, y, generator_model, encoder_model, t_inf, r_inf, epoch, de
 
 def eval_minibatch_particles(x, y, ctf, generator_model, encoder_model, t_inf, r_inf, epoch, device, theta_prior,
                              groupconv, padding, mask_radius, noise=None):
-    """Reference signature train_particles.py:28-29.  CTF filtering and the circular mask are SURVEY 8f
-    'next' rows and raise until they are built."""
+    """Reference signature train_particles.py:28-29 (ctf: (B,1,kc,kc) filters of this minibatch or None)."""
     _check_branch(t_inf, r_inf)
-    if ctf is not None or mask_radius > 0:
-        raise NotImplementedError('CTF filter / circular mask (train_particles.py:298-333) are not built yet')
     n_out = list(generator_model.layers)[-1].out_features
     return elbo_terms(x.to(device), y.to(device), generator_model, encoder_model,
-                      'gauss_var' if n_out == 2 else 'gauss', noise)
+                      'gauss_var' if n_out == 2 else 'gauss', noise, ctf=None if ctf is None else ctf.to(device),
+                      mask_radius=mask_radius)
 
 
 def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf, r_inf, epoch, num_epochs, N, device,
-                params, theta_prior, groupconv, image_dim, likelihood='bce', progress=True, noise_iter=None):
-    """Reference train_mnist.py:300-346: loss = -elbo; backward; step; batch-weighted running means."""
+                params, theta_prior, groupconv, image_dim, likelihood='bce', progress=True, noise_iter=None,
+                mask_radius=None):
+    """Reference train_mnist.py:300-346: loss = -elbo; backward; step; batch-weighted running means.
+    With `mask_radius` not None it is the particles variant (train_particles.py:350-410): minibatches are (y,) or
+    (y, ctf) and `image_dim` carries the encoder padding like the reference's positional argument."""
     generator_model.train()
     encoder_model.train()
     c = 0
     gen_loss_accum = kl_loss_accum = elbo_accum = 0.0
-    for (y,) in iterator:
+    for mb in iterator:
+        y = mb[0]
         b = y.size(0)
         noise = next(noise_iter) if noise_iter is not None else None
-        elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch, device,
-                                         theta_prior, groupconv, image_dim, likelihood, noise)
+        if mask_radius is not None:
+            elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None, generator_model,
+                                                       encoder_model, t_inf, r_inf, epoch, device, theta_prior,
+                                                       groupconv, image_dim, mask_radius, noise)
+        else:
+            elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch, device,
+                                             theta_prior, groupconv, image_dim, likelihood, noise)
         (-elbo).backward()
         optim.step()
         optim.zero_grad()
@@ -120,17 +142,24 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
 
 
 def eval_model(iterator, x_coord, generator_model, encoder_model, t_inf, r_inf, epoch, device, theta_prior,
-               groupconv, image_dim, likelihood='bce'):
-    """Reference train_mnist.py:352-387 (noise is still drawn in eval)."""
+               groupconv, image_dim, likelihood='bce', mask_radius=None):
+    """Reference train_mnist.py:352-387 (noise is still drawn in eval); particles variant
+    (train_particles.py:413-470) when `mask_radius` is not None."""
     generator_model.eval()
     encoder_model.eval()
     c = 0
     gen_loss_accum = kl_loss_accum = elbo_accum = 0.0
     with torch.no_grad():
-        for (y,) in iterator:
+        for mb in iterator:
+            y = mb[0]
             b = y.size(0)
-            elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch,
-                                             device, theta_prior, groupconv, image_dim, likelihood)
+            if mask_radius is not None:
+                elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None,
+                                                           generator_model, encoder_model, t_inf, r_inf, epoch, device,
+                                                           theta_prior, groupconv, image_dim, mask_radius)
+            else:
+                elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch,
+                                                 device, theta_prior, groupconv, image_dim, likelihood)
             stats = torch.stack([elbo.double(), log_p.double(), kl.double()]).tolist()
             c += b
             gen_loss_accum += b * (-stats[1] - gen_loss_accum) / c

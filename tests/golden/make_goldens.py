@@ -258,6 +258,58 @@ def gen_steps():
                hidden=64, layers=4, n_out=3, fourier=True, resid=False)
 
 
+def gen_particles_tail():
+    """CTF filter generation (src/ctf.py) and the CTF / mask likelihood tail (train_particles.py:298-338)."""
+    import pandas as pd
+    sys.path.insert(0, REF)
+    import src.ctf as C
+    sys.path.pop(0)
+    rng = np.random.RandomState(0)
+    nrow = 3
+    params = pd.DataFrame(dict(defocus=rng.uniform(1.0, 3.0, nrow), cs=np.full(nrow, 2.7),
+                               voltage=np.full(nrow, 300.0), apix=np.full(nrow, 1.2),
+                               bfactor=rng.uniform(50, 150, nrow), ampcont=np.full(nrow, 7.0),
+                               dfdiff=np.zeros(nrow), dfang=rng.uniform(0, 180, nrow)))
+    n = 32
+    filt = C.ctf_filter(params, n - 1, n - 1, scale=1)
+    save('ctf_filters', filters=filt, **{k_: params[k_].values for k_ in params.columns}, n=np.int64(n - 1))
+    for name, use_ctf, radius in (('step_particles32_ctf', True, 0), ('step_particles32_mask', False, 9),
+                                  ('step_particles32_ctf_mask', True, 11)):
+        torch.manual_seed(4)
+        zd, C_, k, p, R, B = 2, 16, 32, 8, 8, 3
+        gen = models.SpatialGenerator(zd, 64, n_out=1, num_layers=2)
+        enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+            n, 1, zd, kernels_num=C_, kernels_size=k, padding=p, groupconv=R, rot_refinement=True,
+            theta_prior=np.pi, normal_prior_over_r=False)
+        with torch.no_grad():
+            for nm in ('conv_a', 'conv_r', 'conv_z'):
+                getattr(enc, nm).weight.mul_(10.0)
+        torch.manual_seed(0)
+        y = torch.randn(B, 1, n, n)
+        ctf = torch.from_numpy(filt[:B]).float().unsqueeze(1) if use_ctf else None
+        Ho = n + 2 * p - k + 1
+        E, eps_z, eps_t = draw_noise(123, B, R * Ho * Ho, zd)
+        torch.manual_seed(123)
+        elbo, logp, kl = train_particles.eval_minibatch(coords(n), y, ctf, gen, enc, 'attention',
+                                                        'attention+offsets', 0, 'cpu', np.pi, R, p, radius)
+        (-elbo).backward()
+        out = dict(y=y, E=E, eps_z=eps_z, eps_theta=eps_t, elbo=elbo, log_p=logp, kl=kl,
+                   cfg=np.array([n, 1, zd, C_, k, p, R, 1, 0, 64, 2, 1, 0, 0]), theta_prior=np.float64(np.pi),
+                   sigma=np.float64(2.0 / (n - 1)), mask_radius=np.int64(radius))
+        if use_ctf:
+            out['ctf'] = ctf
+        for k_, v in enc.state_dict().items():
+            out['e.' + k_] = v
+        for k_, v in gen.state_dict().items():
+            out['d.' + k_] = v
+        for k_, v in enc.named_parameters():
+            out['ge.' + k_] = v.grad
+        for k_, v in gen.named_parameters():
+            out['gd.' + k_] = v.grad
+        save(name, **out)
+        print('   ', name, float(elbo), float(logp), float(kl))
+
+
 def gen_epoch():
     """train_epoch over 2 minibatches (train_mnist.py:300-346): running means + post-Adam params."""
     torch.manual_seed(0)
@@ -340,7 +392,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail}[w]()

@@ -254,3 +254,55 @@ def test_full_size_properties():
         _, _, _, aux_s = step.elbo_terms(x, y[sub], gen, enc, 'gauss', tuple(t[sub] for t in noise), return_aux=True)
         assert rel_err(aux_s['y_hat'], aux['y_hat'][sub]) < 1e-5
         assert rel_err(aux_s['kl_per_image'], aux['kl_per_image'][sub]) < 1e-5
+
+
+def test_galaxy_full_size_runs(gemm_mode):
+    """BASELINE configs[4] at full size (128x128x3, k=64 p=32, P16, z=50, Fourier, 4 decoder layers, n_out=3), B=2:
+    the padded image does not fit LDS, so conv1 takes the generic implicit-GEMM path.  Size-independent properties:
+    finite ELBO, exp(q) and the Gumbel sample sum to 1, determinism, finite gradients for every parameter."""
+    if gemm_mode != 'f32':
+        pytest.skip('one arithmetic mode is enough at this size')
+    import src.models as M
+    from tvae import step
+    torch.manual_seed(0)
+    n, R, B, zd = 128, 16, 2, 50
+    gen = M.SpatialGenerator(zd, 512, n_out=3, num_layers=4, fourier_expansion=True, sigma=2.0 / (n - 1)).to(dev())
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 3, zd, kernels_num=128, kernels_size=64, padding=32, groupconv=R, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False).to(dev())
+    Ho = n + 2 * 32 - 64 + 1
+    y = torch.rand(B, 3, n, n, device=dev())
+    x = O.image_coords(n).to(dev())
+    noise = step.draw_noise(B, R * Ho * Ho, zd, dev())
+    e1, lp1, kl1, aux = step.elbo_terms(x, y, gen, enc, 'bce3', noise, return_aux=True)
+    assert torch.isfinite(e1) and torch.isfinite(lp1) and torch.isfinite(kl1)
+    assert (torch.exp(aux['q_t_r']).sum(1) - 1).abs().max() < 2e-4
+    assert (aux['a_sampled'].sum(1) - 1).abs().max() < 2e-4
+    (-e1).backward()
+    for nm, p in list(enc.named_parameters()) + list(gen.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), nm
+    with torch.no_grad():
+        e2, _, _ = step.elbo_terms(x, y, gen, enc, 'bce3', noise)
+    assert float(e1) == float(e2)
+
+
+@pytest.mark.parametrize('name', ['step_particles32_ctf', 'step_particles32_mask', 'step_particles32_ctf_mask'])
+def test_particles_tail_golden(name):
+    """CTF filter + circular mask likelihood tail (train_particles.py:298-338) through eval_minibatch_particles."""
+    from tvae import step
+    fx = load_golden(name)
+    enc, gen, n = build_step_models(fx)
+    x = O.image_coords(n).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    ctf = torch.from_numpy(fx['ctf']).to(dev()) if 'ctf' in fx else None
+    elbo, logp, kl = step.eval_minibatch_particles(x, torch.from_numpy(fx['y']).to(dev()), ctf, gen, enc, 'attention',
+                                                   'attention+offsets', 0, dev(), np.pi, 8, 8,
+                                                   int(fx['mask_radius']), noise=noise)
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
+    (-elbo).backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.named_parameters():
+        assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)

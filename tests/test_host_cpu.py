@@ -224,3 +224,14 @@ def test_cli_flags_match_reference():
             assert getattr(a.type, '__name__', None) == spec['type'], (script, dest)
             assert (a.nargs == 0) == spec['nargs0'], (script, dest)
         assert set(mine) - set(flags) == {'seed', 'synthetic'}, script
+
+
+def test_ctf_filter_matches_reference_golden():
+    """src/ctf.py (product, host preprocessing) against filters generated by the reference's src/ctf.py."""
+    import pandas as pd
+    import src.ctf as C
+    fx = load_golden('ctf_filters')
+    cols = ['defocus', 'cs', 'voltage', 'apix', 'bfactor', 'ampcont', 'dfdiff', 'dfang']
+    params = pd.DataFrame({c: fx[c] for c in cols})
+    n = int(fx['n'])
+    assert rel_err(C.ctf_filter(params, n, n), fx['filters']) < 1e-6

@@ -164,3 +164,38 @@ def test_epoch_two_steps():
         assert rel_err(t, fx['e1.' + k_]) < 1e-5, k_
     for k_, t in gen.items():
         assert rel_err(t, fx['d1.' + k_]) < 1e-5, k_
+
+
+PART_TAIL = ['step_particles32_ctf', 'step_particles32_mask', 'step_particles32_ctf_mask']
+
+
+@pytest.mark.parametrize('name', PART_TAIL)
+def test_particles_tail(name):
+    """CTF filter + circular mask likelihood tail (train_particles.py:298-338)."""
+    fx = load_golden(name)
+    cfg, n = step_cfg(fx)
+    enc = tdict(fx, 'e.', requires_grad=True)
+    gen = tdict(fx, 'd.', requires_grad=True)
+    ctf = torch.from_numpy(fx['ctf']) if 'ctf' in fx else None
+    elbo, logp, kl = O.elbo_step(O.image_coords(n), torch.from_numpy(fx['y']), enc, gen, likelihood='gauss',
+                                 E=torch.from_numpy(fx['E']), eps_z=torch.from_numpy(fx['eps_z']),
+                                 eps_theta=torch.from_numpy(fx['eps_theta']), ctf=ctf,
+                                 mask_radius=int(fx['mask_radius']), **cfg)
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < 1e-6
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < 1e-6
+    (-elbo).backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.items():
+        assert_grad_close(t.grad, fx['ge.' + k_], floor=floor, name=k_)
+    for k_, t in gen.items():
+        if ('gd.' + k_) in fx:
+            assert_grad_close(t.grad, fx['gd.' + k_], name=k_)
+
+
+def test_ctf_filters():
+    """Real-space CTF kernels (src/ctf.py:32-55)."""
+    fx = load_golden('ctf_filters')
+    n = int(fx['n'])
+    got = O.ctf_filters(fx['defocus'], fx['cs'], fx['voltage'], fx['apix'], fx['bfactor'], fx['ampcont'],
+                        fx['dfang'], n, n)
+    assert rel_err(got, fx['filters']) < 1e-6
