@@ -90,6 +90,11 @@ int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float
                        const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
                        const float* g_a, float* dheads, tvae_stream_t stream);
 
+/* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
+ * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
+int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,
+                    int P, int zd, float theta_off_scale, float* zc, float* theta_mu, float* dx, tvae_stream_t stream);
+
 /* ---- coordinate transform: train_mnist.py:222,234-239.  xc [Np][2], dx [B][2], theta [B] -> xr [B][Np][2] ---- */
 int tvae_coord_fwd(const float* xc, const float* dx, const float* theta, float* xr, int B, int Np,
                    tvae_stream_t stream);

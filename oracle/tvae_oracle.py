@@ -354,6 +354,31 @@ def likelihood_logp(y_hat: Tensor, y: Tensor, kind: str) -> Tensor:
     raise ValueError(kind)
 
 
+def get_latent(x_coord: Tensor, y: Tensor, enc: Dict[str, Tensor], R: int, padding: int, rot_refinement: bool,
+               theta_prior: float = np.pi, normal_prior_over_r: bool = True):
+    """clustering_mnist.py:121-161 (attention/attention branch): most probable (r,h,w) under attn, content
+    (z_mu, exp(z_logstd)) and theta_mu there, dx = softmax-expected grid position summed over rotations."""
+    b = y.shape[0]
+    spacing = float((x_coord[1, 0] - x_coord[0, 0]).numpy())
+    E = torch.ones(b, 1)       # the Gumbel sample is not used by get_latent
+    Ho = y.shape[-1] + 2 * padding - enc['conv1.weight'].shape[-1] + 1
+    attn, _, _, _, _, theta_vals, z_vals = encoder_forward(enc, y, E.expand(b, R * Ho * Ho), R, padding,
+                                                            rot_refinement, theta_prior, normal_prior_over_r)
+    _, ind1 = attn.reshape(b, -1).max(1)                                                # :127
+    ind0 = torch.arange(b)
+    z_vals = z_vals.reshape(b, z_vals.shape[1], -1)
+    theta_vals = theta_vals.reshape(b, theta_vals.shape[1], -1)
+    zd = z_vals.shape[1] // 2
+    z_mu = z_vals[:, :zd][ind0, :, ind1]
+    z_std = torch.exp(z_vals[:, zd:])[ind0, :, ind1]                                    # :137 (no epsilon)
+    z_content = torch.cat((z_mu, z_std), dim=1)                                         # :142
+    a_soft = F.softmax(attn.reshape(b, -1), dim=1).view(attn.shape).sum(1).view(b, -1).unsqueeze(2)   # :144
+    G = torch.from_numpy(translation_grid(Ho, spacing))
+    dx = torch.bmm(G.expand(b, G.shape[0], 2).transpose(1, 2).type(torch.float), a_soft).squeeze(2)   # :158
+    theta_mu = theta_vals[ind0, 0:1, ind1]                                              # :161
+    return z_content, theta_mu, dx
+
+
 def particles_logp(y_hat: Tensor, y: Tensor, ctf: Optional[Tensor], mask_radius: int, dx: Tensor,
                    spacing: float) -> Tensor:
     """Particle likelihood tail, train_particles.py:284-338 (n_out = 1): optional per-image CTF filter

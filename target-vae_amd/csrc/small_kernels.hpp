@@ -616,6 +616,59 @@ __global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Inference epilogue get_latent (reference clustering_mnist.py:123-161): per image, the most probable (r,h,w) under
+// attn = logit + log p(r); content vector (z_mu, exp(z_logstd)) and theta_mu gathered there; translation = expected
+// grid position under softmax(attn) summed over rotations.  One workgroup per image; first index wins ties.
+// ------------------------------------------------------------------------------------------
+__global__ void get_latent_kernel(HeadParams hp, float* __restrict__ zc, float* __restrict__ th,
+                                  float* __restrict__ dxo) {
+    __shared__ float smv[16];
+    __shared__ int smi[16];
+    __shared__ float sm[3 * 16];
+    const int b = blockIdx.x;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    const float* logit = hp.heads + base;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+        const float l = logit[j] + hp.p_r[j / hp.P];
+        if (l > best || (l == best && j < bidx)) { best = l; bidx = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { smv[wave] = best; smi[wave] = bidx; }
+    __syncthreads();
+    best = smv[0]; bidx = smi[0];
+    for (int w = 1; w < nw; ++w)
+        if (smv[w] > best || (smv[w] == best && smi[w] < bidx)) { best = smv[w]; bidx = smi[w]; }
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+        const float e = expf(logit[j] + hp.p_r[j / hp.P] - best);
+        const int hw = j % hp.P;
+        t[0] += e;
+        t[1] += e * hp.grid[2 * hw];
+        t[2] += e * hp.grid[2 * hw + 1];
+    }
+    block_sum<3>(t, sm);
+    if (threadIdx.x == 0) {
+        dxo[2 * b] = t[1] / t[0];
+        dxo[2 * b + 1] = t[2] / t[0];
+        th[b] = hp.heads[1 * hp.ldh + base + bidx] + hp.theta_off_scale * hp.off[bidx / hp.P];
+    }
+    for (int d = threadIdx.x; d < hp.zd; d += blockDim.x) {
+        zc[b * 2 * hp.zd + d] = hp.heads[(long)(3 + d) * hp.ldh + base + bidx];
+        zc[b * 2 * hp.zd + hp.zd + d] = expf(hp.heads[(long)(3 + hp.zd + d) * hp.ldh + base + bidx]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused Adam over the flat parameter buffer (torch.optim.Adam defaults, reference train_mnist.py:579).
 // grad_scale folds the data-parallel 1/world averaging into the update.

@@ -340,6 +340,16 @@ int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float
     return 0;
 }
 
+int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,
+                    int P, int zd, float theta_off_scale, float* zc, float* theta_mu, float* dx, tvae_stream_t stream) {
+    if (B <= 0) return 0;
+    HeadParams hp = make_head(heads, ldh, nullptr, nullptr, nullptr, p_r, off, nullptr, grid, R, P, zd, 1.f,
+                              theta_off_scale);
+    hipLaunchKernelGGL(get_latent_kernel, dim3(B), dim3(1024), 0, S(stream), hp, zc, theta_mu, dx);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 int tvae_coord_fwd(const float* xc, const float* dx, const float* theta, float* xr, int B, int Np,
                    tvae_stream_t stream) {
     hipLaunchKernelGGL(coord_fwd_kernel, dim3(grid1d((long)B * Np, 256)), dim3(256), 0, S(stream), xc, dx, theta, xr,

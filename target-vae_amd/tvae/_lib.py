@@ -30,6 +30,7 @@ SIGNATURES = {
     'tvae_act_bwd': 'ppplif',
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppp',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppp',
+    'tvae_get_latent': 'plpppiiiifppp',
     'tvae_coord_fwd': 'ppppii',
     'tvae_coord_bwd': 'ppppppii',
     'tvae_dec_l0_fwd': 'pppppliliif',   # xr, Wc, bc, LB, h, ldh(l), F(i), Ntot(l), Np(i), act(i), slope(f)

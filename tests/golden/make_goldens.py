@@ -310,6 +310,44 @@ def gen_particles_tail():
         print('   ', name, float(elbo), float(logp), float(kl))
 
 
+def gen_get_latent():
+    """clustering_mnist.get_latent (the REAL function; plotting / astropy imports are stubbed)."""
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            m = _Stub(self.__name__ + '.' + k)
+            setattr(self, k, m)
+            return m
+
+        def __call__(self, *a, **k):
+            return None
+    for nm in ('seaborn', 'astropy', 'astropy.stats', 'astropy.units', 'matplotlib', 'matplotlib.pyplot',
+               'matplotlib.cm', 'matplotlib.colors', 'mpl_toolkits', 'mpl_toolkits.mplot3d'):
+        try:
+            __import__(nm)
+        except Exception:
+            sys.modules[nm] = _Stub(nm)
+    sys.path.insert(0, REF)
+    import clustering_mnist as cm
+    sys.path.pop(0)
+    for name, kw, B, scale in (('get_latent_P8_28', dict(n=28, cin=1, zd=2, C=16, k=28, p=8, R=8, refine=True,
+                                                          theta_prior=np.pi, normal=False, seed=5), 4, 20.0),
+                               ('get_latent_P4_20_norefine', dict(n=20, cin=1, zd=3, C=16, k=20, p=4, R=4, refine=False,
+                                                                   theta_prior=np.pi, normal=False, seed=6), 3, 20.0)):
+        enc = _enc(scale_heads=scale, **kw)
+        torch.manual_seed(9)
+        y = torch.rand(B, kw['cin'], kw['n'], kw['n'])
+        r_inf = 'attention+offsets' if kw['refine'] else 'attention'
+        zc, th, dx = cm.get_latent(coords(kw['n']), y, enc, 'attention', r_inf, 'cpu', kw['n'])
+        out = dict(y=y, z_content=zc, theta_mu=th, dx=dx,
+                   cfg=np.array([kw['n'], kw['cin'], kw['zd'], kw['C'], kw['k'], kw['p'], kw['R'], int(kw['refine']),
+                                 int(kw['normal'])]), theta_prior=np.float64(kw['theta_prior']))
+        for k_, v in enc.state_dict().items():
+            out['p.' + k_] = v
+        save(name, **out)
+
+
 def gen_epoch():
     """train_epoch over 2 minibatches (train_mnist.py:300-346): running means + post-Adam params."""
     torch.manual_seed(0)
@@ -392,7 +430,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent}[w]()

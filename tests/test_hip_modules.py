@@ -306,3 +306,19 @@ def test_particles_tail_golden(name):
         assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
     for k_, t in gen.named_parameters():
         assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
+
+
+@pytest.mark.parametrize('name', ['get_latent_P8_28', 'get_latent_P4_20_norefine'])
+def test_get_latent_golden(name):
+    """tvae.latent.get_latent against the reference's clustering_mnist.get_latent (golden from the real function)."""
+    from tvae import latent
+    fx = load_golden(name)
+    enc = build_encoder(fx, 'p.')
+    n = int(fx['cfg'][0])
+    r_inf = 'attention+offsets' if int(fx['cfg'][7]) else 'attention'
+    zc, th, dx = latent.get_latent(O.image_coords(n).to(dev()), torch.from_numpy(fx['y']).to(dev()), enc, 'attention',
+                                   r_inf, dev(), n)
+    assert tuple(zc.shape) == tuple(fx['z_content'].shape) and tuple(th.shape) == tuple(fx['theta_mu'].shape)
+    assert rel_err(zc, fx['z_content']) < OUT_TOL
+    assert rel_err(th, fx['theta_mu']) < OUT_TOL
+    assert rel_err(dx, fx['dx']) < OUT_TOL

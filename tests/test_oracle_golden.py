@@ -199,3 +199,12 @@ def test_ctf_filters():
     got = O.ctf_filters(fx['defocus'], fx['cs'], fx['voltage'], fx['apix'], fx['bfactor'], fx['ampcont'],
                         fx['dfang'], n, n)
     assert rel_err(got, fx['filters']) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['get_latent_P8_28', 'get_latent_P4_20_norefine'])
+def test_get_latent(name):
+    fx = load_golden(name)
+    n, cin, zd, C, k, p, R, refine, normal = [int(v) for v in fx['cfg']]
+    zc, th, dx = O.get_latent(O.image_coords(n), torch.from_numpy(fx['y']), tdict(fx, 'p.'), R, p, bool(refine),
+                              float(fx['theta_prior']), bool(normal))
+    assert rel_err(zc, fx['z_content']) < TOL and rel_err(th, fx['theta_mu']) < TOL and rel_err(dx, fx['dx']) < TOL
