@@ -122,11 +122,13 @@ def _load_arrays(kind, args):
         te = torch.from_numpy(np.load(args.test_path)[:100]).float()
         n = args.image_dim
         return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'dsprites'
-    # particles: .npy stacks; MRC/MRCS reading is a SURVEY 8f "next" row
+    # particles: .npy stacks or MRC/MRCS stacks (train_particles.py:454-461)
     def load(path):
-        if not path.endswith('.npy'):
-            raise NotImplementedError('MRC/MRCS stacks (src/mrc.py) are not built yet; convert to .npy')
-        return np.load(path)
+        if path.endswith('.npy'):
+            return np.load(path)
+        from src import mrc
+        mm, _ = mrc.open_stack(path)
+        return np.asarray(mm, dtype=np.float32)
     if not args.train_path:
         raise SystemExit('please provide the train_path and/or test_path')
     if args.test_path:

@@ -348,6 +348,22 @@ def gen_get_latent():
         save(name, **out)
 
 
+def gen_mrc():
+    """A small stack written by the reference's src/mrc.write (fixture = data file), plus one with an extended header."""
+    sys.path.insert(0, REF)
+    import src.mrc as mrc
+    sys.path.pop(0)
+    rng = np.random.RandomState(3)
+    arr = rng.randn(5, 6, 7).astype(np.float32)
+    with open(os.path.join(HERE, 'stack_ref.mrcs'), 'wb') as f:
+        mrc.write(f, arr, ax=1.5, ay=2.5, az=3.5)
+    with open(os.path.join(HERE, 'stack_ref_ext.mrc'), 'wb') as f:
+        hdr = mrc.make_header((1, 6, 7), (1, 1, 1), (90, 90, 90), dtype=np.int16, exthd_size=16)
+        mrc.write(f, (arr[0] * 100).astype(np.int16), header=hdr, extended_header=b'0123456789abcdef')
+    save('mrc_arrays', stack=arr, single=(arr[0] * 100).astype(np.int16))
+    print('wrote mrc fixtures')
+
+
 def gen_epoch():
     """train_epoch over 2 minibatches (train_mnist.py:300-346): running means + post-Adam params."""
     torch.manual_seed(0)
@@ -430,7 +446,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc}[w]()
