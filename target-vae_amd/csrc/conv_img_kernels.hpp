@@ -34,9 +34,15 @@ static inline int conv_wgrad_img_rows(int Cin, int n, int ksz, int pad) {
     const int rows = (BN - 1) / ksz + 2 + Ho - 1;
     return rows < Hp ? rows : Hp;
 }
-static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad) {
+static inline size_t conv_nb_lds_bytes(int Cin, int rows, int n, int pad) {
     const int Wp = n + 2 * pad + 1;
-    long tot = CONV_A_FLOATS + CONV_TAB_INTS + (long)Cin * rows * Wp;
+    long tot = (long)Cin * rows * Wp;
+    if (tot < 64 * 128) tot = 64 * 128;
+    return (size_t)tot * sizeof(float);
+}
+static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad, int mh = 1) {
+    const int Wp = n + 2 * pad + 1;
+    long tot = 2 * BK * (mh * 128 + 4) + CONV_TAB_INTS + (long)Cin * rows * Wp;
     if (tot < 64 * 128) tot = 64 * 128;            // the epilogue staging tile aliases the whole region
     return (size_t)tot * sizeof(float);
 }
@@ -61,14 +67,18 @@ __device__ __forceinline__ void load_padded_image(float* img, const float* __res
 // grid.x = tilesM * B * tilesPerImg (position tiles fastest -> concurrently running workgroups share one bank panel
 // in L2).  VEC: K % 16 == 0 and M % 128 == 0 -> unguarded float4 loads of the bank with incremented pointers.
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(GEMM_THREADS, 3)
+template <bool VEC, int MH>
+__global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
 void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
                           int K, int tilesPerImg, int rows) {
+    // MH = number of 128-row halves per workgroup tile: 1 -> 128 x 128 (wave 64 x 64), 2 -> 256 x 128 (wave 128 x 64:
+    // 8 MFMAs per operand wait, half the B reads per MFMA, image / tap table shared by twice the rows)
+    constexpr int ALD = MH * 128 + 4;               // A tile row stride (floats)
+    constexpr int AFL = 2 * BK * ALD;               // double-buffered A tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    int* ktab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
-    float* img = smem + CONV_A_FLOATS + CONV_TAB_INTS;
+    int* ktab = reinterpret_cast<int*>(smem + AFL);
+    float* img = smem + AFL + CONV_TAB_INTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
@@ -77,7 +87,7 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
     const int rest = blockIdx.x - tile_m * per_m;
     const int b = rest / tilesPerImg;
     const int p0 = (rest - b * tilesPerImg) * BN;
-    const int m0 = tile_m * BM;
+    const int m0 = tile_m * (BM * MH);
     const int hmin = p0 / g.Ho;                     // first output row of the tile = first padded-image row kept
     // Zero skipping: tap row u only meets image rows h+u-pad in [0,n) for h in the tile's output rows [hmin,hmax];
     // every other tap row multiplies pure zero padding.  (Single channel: the kept taps are one contiguous k range,
@@ -119,43 +129,58 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MH][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int hh = 0; hh < MH; ++hh)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[hh][i][j][r] = 0.f;
 
-    // A staging
-    LoadKContig al{bank, (long)K, M};
-    float ra[8];
-    float4 va[2];
-    const float* pa[2];
+    // A staging: rows (tid >> 2) + 64 i, k quad (tid & 3) * 4
+    constexpr int NA = 2 * MH;
+    float ra[MH][8];
+    float4 va[NA];
+    const float* pa[NA];
     const int am = tid >> 2, akq = (tid & 3) * 4;
+    const int kkA = tid & 15, xbA = tid >> 4;       // generic (guarded) mapping
+    auto load_generic = [&](int k0) {
+        const int k = k0 + kkA;
+#pragma unroll
+        for (int hh = 0; hh < MH; ++hh)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = m0 + hh * 128 + xbA + 16 * j;
+                ra[hh][j] = (k < K && m < M) ? bank[(long)m * K + k] : 0.f;
+            }
+    };
     if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pa[i] = bank + (long)(m0 + am + 64 * i) * K + kbeg + akq;
+        for (int i = 0; i < NA; ++i) pa[i] = bank + (long)(m0 + am + 64 * i) * K + kbeg + akq;
         if (nk > 0) {
-            va[0] = *reinterpret_cast<const float4*>(pa[0]);
-            va[1] = *reinterpret_cast<const float4*>(pa[1]);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) va[i] = *reinterpret_cast<const float4*>(pa[i]);
         }
     } else {
-        al.init(m0, tid);
-        al.load(ra, kbeg, K);
+        load_generic(kbeg);
     }
     auto store_a = [&](float* S) {
         if (VEC) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int m = am + 64 * i;
-                S[(akq + 0) * LDS_LD + m] = va[i].x;
-                S[(akq + 1) * LDS_LD + m] = va[i].y;
-                S[(akq + 2) * LDS_LD + m] = va[i].z;
-                S[(akq + 3) * LDS_LD + m] = va[i].w;
+                S[(akq + 0) * ALD + m] = va[i].x;
+                S[(akq + 1) * ALD + m] = va[i].y;
+                S[(akq + 2) * ALD + m] = va[i].z;
+                S[(akq + 3) * ALD + m] = va[i].w;
             }
         } else {
-            al.store(S, ra);
+#pragma unroll
+            for (int hh = 0; hh < MH; ++hh)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) S[kkA * ALD + hh * 128 + xbA + 16 * j] = ra[hh][j];
         }
     };
     if (nk > 0) store_a(As);
@@ -170,44 +195,155 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         if (more) {
             if (VEC) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NA; ++i) {
                     pa[i] += BK;
                     va[i] = *reinterpret_cast<const float4*>(pa[i]);
                 }
             } else {
-                al.load(ra, kbeg + (t + 1) * BK, K);
+                load_generic(kbeg + (t + 1) * BK);
             }
         }
-        const float* as = As + cur * (BK * LDS_LD);
-        // this lane half's 8 tap offsets of the k-step: two broadcast ds_read_b128, so that the 32 fragment reads
+        const float* as = As + cur * (BK * ALD);
+        // this lane half's 8 tap offsets of the k-step: two broadcast ds_read_b128, so that the fragment reads
         // below carry no LDS->LDS dependency and can be pipelined under the MFMAs
         const int4* kt4 = reinterpret_cast<const int4*>(ktab + cur * BK + khalf * 8);
         const int4 t0 = kt4[0], t1 = kt4[1];
         const int kos[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        // all 32 fragment reads of the k-step are issued up front (independent addresses); the MFMAs then drain them
-        // behind counted lgkmcnt waits, so LDS latency is paid once per k-step and hidden by the partner wave
-        float af[BK / 2][2], bf[BK / 2][2];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + khalf;
-            af[s][0] = as[kk * LDS_LD + arow];
-            af[s][1] = as[kk * LDS_LD + arow + 32];
-            bf[s][0] = img[boff[0] + kos[s]];
-            bf[s][1] = img[boff[1] + kos[s]];
-        }
+            const float b0 = img[boff[0] + kos[s]];
+            const float b1 = img[boff[1] + kos[s]];
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][1], acc[1][1], 0, 0, 0);
+            for (int hh = 0; hh < MH; ++hh) {
+                const float a0 = as[kk * ALD + hh * 128 + arow];
+                const float a1 = as[kk * ALD + hh * 128 + arow + 32];
+                acc[hh][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[hh][0][0], 0, 0, 0);
+                acc[hh][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[hh][0][1], 0, 0, 0);
+                acc[hh][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[hh][1][0], 0, 0, 0);
+                acc[hh][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[hh][1][1], 0, 0, 0);
+            }
         }
         if (more) {
-            store_a(As + (cur ^ 1) * (BK * LDS_LD));
+            store_a(As + (cur ^ 1) * (BK * ALD));
             fill_ktab(ktab + (cur ^ 1) * BK, kbeg + (t + 1) * BK);
         }
         __syncthreads();
     }
+    const int p = p0 + (tid & 127);
+#pragma unroll
+    for (int hh = 0; hh < MH; ++hh) {
+        if (hh) __syncthreads();
+        tile_epilogue(acc[hh], smem, ep, m0 + hh * 128, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Forward, barrier-free variant (ksz % 16 == 0, M % 128 == 0): the bank is stored k-major, bankT[k][c*R + r], so
+// the A fragment of v_mfma_f32_32x32x2_f32 (lane l: row l&31, k = l>>5) is a 128-B coalesced global load per lane
+// half.  Every wave prefetches the 16 A registers of the NEXT k-step while it multiplies the current one; B fragments
+// come from the read-only LDS image with a per-lane base + scalar tap offset + immediate.  Nothing is staged through
+// LDS inside the k-loop, so there is no barrier between the image load and the epilogue: the 16 waves of a CU run
+// independent MFMA streams.  A 16-tap k-step never crosses a tap row (ksz % 16 == 0), so the tap offset is scalar.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 4)
+void conv1_fwd_nb_kernel(const float* __restrict__ bankT, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
+                         int tilesPerImg, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* img = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
+    const int per_m = g.B * tilesPerImg;
+    const int tile_m = blockIdx.x / per_m;
+    const int rest = blockIdx.x - tile_m * per_m;
+    const int b = rest / tilesPerImg;
+    const int p0 = (rest - b * tilesPerImg) * BN;
+    const int m0 = tile_m * BM;
+    const int hmin = p0 / g.Ho;
+    const int plast = min(g.P - 1, p0 + BN - 1);
+    const int hmax = plast / g.Ho;
+    // zero skipping: tap rows that can meet the image for output rows [hmin, hmax]
+    const int ulo = max(0, g.pad - hmax);
+    const int uhi = min(g.ksz - 1, g.pad + g.n - 1 - hmin);
+    const int steps_per_row = g.ksz / BK;
+    const int nrow = max(0, uhi - ulo + 1);
+    const int nk_ci = nrow * steps_per_row;          // k-steps per input channel
+    const int nk = nk_ci * g.Cin;
+
+    load_padded_image(img, y, b, g, hmin, rows, Wp);
+
+    const int khalf = lane >> 5;
+    int boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int p = p0 + wn * 64 + j * 32 + (lane & 31);
+        if (p >= g.P) p = g.P - 1;
+        const int h = p / g.Ho, w = p - h * g.Ho;
+        boff[j] = (h - hmin) * Wp + w + khalf;     // + k parity of this lane half
+    }
+    const float* abase = bankT + (long)khalf * M + m0 + wm * 64 + (lane & 31);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // k-step cursor (wave-uniform, advanced incrementally): vb = 16-tap block in the tap row, ur = tap row, ci
+    struct Cur { int vb, ur, ci; };
+    auto advance = [&](Cur& c) {
+        if (++c.vb == steps_per_row) { c.vb = 0; if (++c.ur == nrow) { c.ur = 0; ++c.ci; } }
+    };
+    auto load_a = [&](float (&a)[BK / 2][2], const Cur& c) {
+        const float* p = abase + (long)((c.ci * g.ksz + ulo + c.ur) * g.ksz + c.vb * BK) * M;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            a[s][0] = p[(long)(2 * s) * M];
+            a[s][1] = p[(long)(2 * s) * M + 32];
+        }
+    };
+    auto compute = [&](const float (&a)[BK / 2][2], const Cur& c) {
+        const int kb = (c.ci * rows + ulo + c.ur) * Wp + c.vb * BK;
+        const float* i0 = img + boff[0] + kb;
+        const float* i1 = img + boff[1] + kb;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float b0 = i0[2 * s];
+            const float b1 = i1[2 * s];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b1, acc[1][1], 0, 0, 0);
+        }
+    };
+
+    // Two register sets, each reloaded right after it has been consumed: while set X is multiplied, the loads of
+    // the other set (issued one whole k-step earlier) are already complete and X's reload has a k-step to land.
+    // Reloads are UNCONDITIONAL (the cursor just stops at the last step), so that the compiler's vmcnt scoreboard is
+    // exact: at every compute() exactly 16 newer loads are in flight and the wait is vmcnt(16 + ...), never vmcnt(0).
+    float A0[BK / 2][2], A1[BK / 2][2];
+    Cur c0{0, 0, 0}, c1{0, 0, 0}, cl{0, 0, 0};       // cursors of A0, A1 and of the next step to load
+    int tl = 0;
+    auto next_load = [&](float (&a)[BK / 2][2], Cur& cdst) {
+        load_a(a, cl);
+        cdst = cl;
+        if (tl + 1 < nk) advance(cl);
+        ++tl;
+    };
+    next_load(A0, c0);
+    next_load(A1, c1);
+    __syncthreads();                                  // image resident
+    for (int t = 0; t < nk; t += 2) {
+        compute(A0, c0);
+        next_load(A0, c0);
+        if (t + 1 < nk) compute(A1, c1);
+        next_load(A1, c1);
+    }
+    __syncthreads();                                  // all waves done with the image before it is reused as staging
     const int p = p0 + (tid & 127);
     tile_epilogue(acc, smem, ep, m0, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
 }

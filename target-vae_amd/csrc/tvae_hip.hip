@@ -1,6 +1,8 @@
 // libtvae_hip.so -- C ABI (include/tvae_hip.h) over the gfx950 kernels of the TARGET-VAE hot path.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/tvae_hip.h"
 #include "gemm_f32_mfma.hpp"
 #include "small_kernels.hpp"
@@ -56,10 +58,27 @@ int tvae_set_gemm_mode(int mode) {
 }
 int tvae_get_gemm_mode(void) { return g_gemm_mode; }
 
+// 1 if tvae_conv1_fwd wants the k-major bank bankT[Cin*k*k][C*R] (barrier-free kernel), 0 for bank[C*R][Cin*k*k]
+int tvae_conv1_bank_layout(int Cin, int n, int ksz, int pad, int C, int R) {
+    // The barrier-free kernel on the k-major bank measured 7 % slower than the LDS-staged one at cfg4 (MFMA pipe 72 % vs
+    // 77 % busy, profiles/r01_c_conv_fwd_variants.txt); it stays selectable for experiments with TVAE_CONV1_KMAJOR=1.
+    static const bool enabled = [] { const char* e = getenv("TVAE_CONV1_KMAJOR"); return e && e[0] == '1'; }();
+    if (!enabled || g_gemm_mode != 0) return 0;
+    if (ksz % BK != 0 || (C * R) % BM != 0) return 0;
+    const int rows = conv_fwd_img_rows(n, ksz, pad);
+    return conv_nb_lds_bytes(Cin, rows, n, pad) <= CONV_IMG_LDS_MAX ? 1 : 0;
+}
+
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
-                         int ksz, int R, tvae_stream_t stream) {
+                         int ksz, int R, int transposed, tvae_stream_t stream) {
     const int k2 = ksz * ksz;
     const long total = (long)C * R * Cin * k2;
+    if (transposed) {
+        hipLaunchKernelGGL(rotate_bank_fwd_t_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight,
+                           tap_idx, tap_w, bank, C, Cin, k2, R);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight, tap_idx,
                        tap_w, bank, C, Cin, k2, R);
     TVAE_CHECK_LAUNCH();
@@ -87,7 +106,7 @@ static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
 }
 
 int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
-                   int pad, int C, int R, int act, float slope, tvae_stream_t stream) {
+                   int pad, int C, int R, int act, float slope, int bank_transposed, tvae_stream_t stream) {
     const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const int M = C * R, N = B * g.P, K = Cin * g.K2;
@@ -98,6 +117,20 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
     ep.bias = bias; ep.bias_shift = sh;
     ep.act = act; ep.slope = slope;
     ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
+    if (bank_transposed) {
+        if (!tvae_conv1_bank_layout(Cin, n, ksz, pad, C, R)) return (int)hipErrorInvalidValue;
+        const int rows_nb = conv_fwd_img_rows(n, ksz, pad);
+        const size_t lds_nb = conv_nb_lds_bytes(Cin, rows_nb, n, pad);
+        const int tilesPerImg = cdiv(g.P, BN);
+        const long nblk = (long)(M / BM) * B * tilesPerImg;
+        if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
+        hipError_t e = allow_big_lds(conv1_fwd_nb_kernel, lds_nb);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(conv1_fwd_nb_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds_nb, S(stream), bank, y, g,
+                           ep, M, tilesPerImg, rows_nb);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     if (g_gemm_mode == 1) {
         LoadKContig8 al8{bank, (long)K, M};
         LoadConvPatchFwd bl8{y, g, N};
@@ -111,16 +144,25 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
         const long nblk = (long)cdiv(M, BM) * B * tilesPerImg;
         if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
         const bool vec = (K % BK == 0) && (M % BM == 0);
+        static const bool wide = [] { const char* e = getenv("TVAE_CONV1_WIDE"); return !(e && e[0] == '0'); }();
+        const size_t lds2 = conv_img_lds_bytes(Cin, rows, n, pad, 2);
         hipError_t e;
-        if (vec) {
-            e = allow_big_lds(conv1_fwd_img_kernel<true>, lds);
+        if (vec && wide && M % (2 * BM) == 0 && lds2 <= CONV_IMG_LDS_MAX) {
+            // 256 x 128 tile: each wave 128 x 64 (8 MFMAs per operand wait)
+            const long nblk2 = (long)(M / (2 * BM)) * B * tilesPerImg;
+            e = allow_big_lds(conv1_fwd_img_kernel<true, 2>, lds2);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(conv1_fwd_img_kernel<true>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
+            hipLaunchKernelGGL((conv1_fwd_img_kernel<true, 2>), dim3((unsigned)nblk2), dim3(GEMM_THREADS), lds2,
+                               S(stream), bank, y, g, ep, M, K, tilesPerImg, rows);
+        } else if (vec) {
+            e = allow_big_lds(conv1_fwd_img_kernel<true, 1>, lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((conv1_fwd_img_kernel<true, 1>), dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
                                bank, y, g, ep, M, K, tilesPerImg, rows);
         } else {
-            e = allow_big_lds(conv1_fwd_img_kernel<false>, lds);
+            e = allow_big_lds(conv1_fwd_img_kernel<false, 1>, lds);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(conv1_fwd_img_kernel<false>, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
+            hipLaunchKernelGGL((conv1_fwd_img_kernel<false, 1>), dim3((unsigned)nblk), dim3(GEMM_THREADS), lds, S(stream),
                                bank, y, g, ep, M, K, tilesPerImg, rows);
         }
         TVAE_CHECK_LAUNCH();

@@ -126,15 +126,22 @@ def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # rotated bank + lifting convolution
 # ---------------------------------------------------------------------------------------------
-def rotate_bank(weight: torch.Tensor, R: int) -> torch.Tensor:
-    """GroupConv.trans_filter (src/models.py:174-197): (C,Cin,1,k,k) -> bank [C*R][Cin*k*k]."""
+def rotate_bank(weight: torch.Tensor, R: int, transposed: bool = False) -> torch.Tensor:
+    """GroupConv.trans_filter (src/models.py:174-197): (C,Cin,1,k,k) -> bank [C*R][Cin*k*k]
+    (or the k-major bank [Cin*k*k][C*R] consumed by the barrier-free forward convolution)."""
     C, Cin, D, k, _ = weight.shape
     if D != 1:
         raise NotImplementedError('input_rot_dim != 1 is never used by the reference (models.py:290,346)')
     idx, w = tap_tables(k, R, weight.device)
-    bank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=weight.device)
-    call('tvae_rotate_bank_fwd', weight.contiguous(), idx, w, bank, C, Cin, k, R)
+    shape = (Cin * k * k, C * R) if transposed else (C * R, Cin * k * k)
+    bank = torch.empty(*shape, dtype=torch.float32, device=weight.device)
+    call('tvae_rotate_bank_fwd', weight.contiguous(), idx, w, bank, C, Cin, k, R, int(transposed))
     return bank
+
+
+def conv1_wants_transposed_bank(Cin, n, k, pad, C, R) -> bool:
+    from ._lib import lib
+    return bool(lib().tvae_conv1_bank_layout(Cin, n, k, pad, C, R))
 
 
 def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> torch.Tensor:
@@ -144,12 +151,15 @@ def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> to
     return dW
 
 
-def conv1_forward(y, bank, bias, C, R, k, pad, act):
+def conv1_forward(y, weight, bias, C, R, k, pad, act):
+    """Rotated bank (in the layout the geometry's kernel prefers) + lifting convolution."""
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
+    tr = conv1_wants_transposed_bank(Cin, n, k, pad, C, R)
+    bank = rotate_bank(weight, R, transposed=tr)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
     with _timed('tvae_conv1_fwd'):
-        call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
+        call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE, int(tr))
     return out
 
 
@@ -186,8 +196,7 @@ class GroupConvFn(torch.autograd.Function):
         y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
         B, n = y.shape[0], y.shape[-1]
         Ho = n + 2 * pad - k + 1
-        bank = rotate_bank(weight, R)
-        out = conv1_forward(y, bank, bias, C, R, k, pad, ACT_NONE)
+        out = conv1_forward(y, weight, bias, C, R, k, pad, ACT_NONE)
         ctx.save_for_backward(y)
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, bias is not None)
         return out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
@@ -219,8 +228,7 @@ class EncoderFn(torch.autograd.Function):
         Ho = n + 2 * pad - k + 1
         N = B * R * Ho * Ho
         C2, nh = W2.shape[0], Wh.shape[0]
-        bank = rotate_bank(w1, R)
-        A1 = conv1_forward(y, bank, b1, C, R, k, pad, act)
+        A1 = conv1_forward(y, w1, b1, C, R, k, pad, act)
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)

@@ -125,7 +125,9 @@ def test_rotate_bank(k, R, Cin, C):
 
 
 @pytest.mark.parametrize('B,Cin,n,k,pad,C,R,act', [(2, 1, 28, 28, 8, 8, 8, 1), (3, 3, 12, 9, 3, 4, 4, 0),
-                                                   (2, 1, 64, 64, 16, 4, 8, 1), (5, 2, 20, 7, 0, 3, 16, 0)])
+                                                   (2, 1, 64, 64, 16, 4, 8, 1), (5, 2, 20, 7, 0, 3, 16, 0),
+                                                   (3, 1, 64, 64, 16, 16, 8, 1), (2, 2, 40, 32, 6, 32, 4, 0),
+                                                   (2, 1, 20, 16, 3, 8, 16, 1)])
 def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act, gemm_mode):
     y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
     bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
@@ -135,9 +137,15 @@ def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act, gemm_mode):
         + bias.double().view(1, C, 1, 1, 1)
     ref = act_ref(ref, act)
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
-    call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE)
+    call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE, 0)
     got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
     assert rel_err(got, ref) < GEMM_TOL[gemm_mode]
+    from tvae._lib import lib
+    if lib().tvae_conv1_bank_layout(Cin, n, k, pad, C, R):      # barrier-free kernel on the k-major bank
+        out2 = torch.empty_like(out)
+        call('tvae_conv1_fwd', y.to(dev()), bank.t().contiguous().to(dev()), bias.to(dev()), out2, B, Cin, n, k, pad,
+             C, R, act, SLOPE, 1)
+        assert rel_err(out2.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4), ref) < GEMM_TOL[gemm_mode]
     # weight gradient
     g = rnd(B, C, R, Ho, Ho, seed=4)
     ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
