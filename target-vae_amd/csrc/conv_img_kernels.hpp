@@ -115,17 +115,22 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
         boff[j] = (h - hmin) * Wp + w;
     }
 
-    // tap-offset table for one k-step: ktab[buf][kk] = (ci*Hp + u)*Wp + v  (0 beyond K: the A tile is zero there)
-    auto fill_ktab = [&](int* tab, int k0) {
+    // tap-offset table for one k-step: entry kk = (ci*rows + u)*Wp + v  (0 beyond K: the A tile is zero there).
+    // Thread tid < 16 owns entry kk = tid and walks its (ci,u,v) INCREMENTALLY (k advances by 16 per fill), so wave 0
+    // carries no integer divisions in the k-loop -- every barrier waits for the slowest wave.
+    int tk = kbeg + (tid & 15), tci, tu, tv;
+    {
+        tci = tk / g.K2;
+        const int rem = tk - tci * g.K2;
+        tu = rem / g.ksz;
+        tv = rem - tu * g.ksz;
+    }
+    auto fill_ktab = [&](int* tab, int /*k0*/) {
         if (tid < BK) {
-            const int k = k0 + tid;
-            int off = 0;
-            if (k < K) {
-                const int ci = k / g.K2, rem = k - ci * g.K2;
-                const int u = rem / g.ksz, v = rem - u * g.ksz;
-                off = (ci * rows + u) * Wp + v;
-            }
-            tab[(tid & 1) * 8 + (tid >> 1)] = off;     // [half][sub-step]: one lane half reads 8 consecutive ints
+            tab[(tid & 1) * 8 + (tid >> 1)] = (tk < K) ? (tci * rows + tu) * Wp + tv : 0;
+            tk += BK;
+            tv += BK;
+            while (tv >= g.ksz) { tv -= g.ksz; if (++tu == g.ksz) { tu = 0; ++tci; } }
         }
     };
 
@@ -352,18 +357,23 @@ void conv1_fwd_nb_kernel(const float* __restrict__ bankT, const float* __restric
 // Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)
 // grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 3)
+template <int MH>
+__global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
 void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
                             Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows) {
+    // MH = 128-row halves per workgroup tile (1: 128 x 128, 2: 256 x 128 with 128 x 64 per wave)
+    constexpr int ALD = MH * 128 + 4;
+    constexpr int AFL = 2 * BK * ALD;
+    constexpr int NJ = 8 * MH;                      // A rows per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    int* ptab = reinterpret_cast<int*>(smem + CONV_A_FLOATS);
-    float* img = smem + CONV_A_FLOATS + CONV_TAB_INTS;
+    int* ptab = reinterpret_cast<int*>(smem + AFL);
+    float* img = smem + AFL + CONV_TAB_INTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
     const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * (BM * MH), n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int ib = split * imgs_per_split;
     const int ie = min(g.B, ib + imgs_per_split);
@@ -379,6 +389,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         pend = max(pbeg, (hhi + 1) * g.Ho);
     }
     const int nk = (pend - pbeg + BK - 1) / BK;
+
     int noff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -390,44 +401,54 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     }
     // A rows (mapping K: kk = tid&15, rows xb + 16 j)
     const int kkA = tid & 15, xb = tid >> 4;
-    long rowoff[8];
+    long rowoff[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         int m = m0 + xb + 16 * j;
         if (m >= M) m = M - 1;                      // clamped rows are never stored
         const int c = m / g.R, rr = m - c * g.R;
         rowoff[j] = (long)c * lddy + (long)rr * g.P;
     }
-    auto fill_ptab = [&](int* tab, int pfrom) {
+    // position-offset table: thread tid < 16 owns entry tid and walks (h, w) incrementally (no divisions in the loop)
+    int tp, th, tw;
+    auto reset_ptab = [&]() {
+        tp = pbeg + (tid & 15);
+        th = tp / g.Ho;
+        tw = tp - th * g.Ho;
+    };
+    auto fill_ptab = [&](int* tab, int /*pfrom*/) {
         if (tid < BK) {
-            const int p = pfrom + tid;
-            int off = 0;
-            if (p < pend) { const int h = p / g.Ho; off = h * Wp + (p - h * g.Ho); }
-            tab[(tid & 1) * 8 + (tid >> 1)] = off;
+            tab[(tid & 1) * 8 + (tid >> 1)] = (tp < pend) ? th * Wp + tw : 0;
+            tp += BK;
+            tw += BK;
+            while (tw >= g.Ho) { tw -= g.Ho; ++th; }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MH][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int hh = 0; hh < MH; ++hh)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[hh][i][j][r] = 0.f;
 
     const int arow = wm * 64 + (lane & 31);
     const int khalf = lane >> 5;
-    float ra[8];
+    float ra[NJ];
     for (int b = ib; b < ie; ++b) {
         __syncthreads();                             // previous image fully consumed
         load_padded_image(img, y, b, g, ulo, rows, Wp);
+        reset_ptab();
         const float* dyb = dy + (long)b * g.R * g.P + pbeg + kkA;
         {
             const bool kok = (pbeg + kkA) < pend;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j]] : 0.f;
+            for (int j = 0; j < NJ; ++j) ra[j] = kok ? dyb[rowoff[j]] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) As[kkA * LDS_LD + xb + 16 * j] = ra[j];
+            for (int j = 0; j < NJ; ++j) As[kkA * ALD + xb + 16 * j] = ra[j];
         }
         fill_ptab(ptab, pbeg);
         __syncthreads();
@@ -438,32 +459,31 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
                 const int pk = (t + 1) * BK;
                 const bool kok = (pbeg + pk + kkA) < pend;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
+                for (int j = 0; j < NJ; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
             }
-            const float* as = As + cur * (BK * LDS_LD);
+            const float* as = As + cur * (BK * ALD);
             const int4* pt4 = reinterpret_cast<const int4*>(ptab + cur * BK + khalf * 8);
             const int4 t0 = pt4[0], t1 = pt4[1];
             const int pos[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            float af[BK / 2][2], bf[BK / 2][2];
 #pragma unroll
             for (int s = 0; s < BK / 2; ++s) {
                 const int kk = 2 * s + khalf;
-                af[s][0] = as[kk * LDS_LD + arow];
-                af[s][1] = as[kk * LDS_LD + arow + 32];
-                bf[s][0] = img[noff[0] + pos[s]];
-                bf[s][1] = img[noff[1] + pos[s]];
-            }
+                const float b0 = img[noff[0] + pos[s]];
+                const float b1 = img[noff[1] + pos[s]];
 #pragma unroll
-            for (int s = 0; s < BK / 2; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][0], bf[s][1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][1], bf[s][1], acc[1][1], 0, 0, 0);
+                for (int hh = 0; hh < MH; ++hh) {
+                    const float a0 = as[kk * ALD + hh * 128 + arow];
+                    const float a1 = as[kk * ALD + hh * 128 + arow + 32];
+                    acc[hh][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[hh][0][0], 0, 0, 0);
+                    acc[hh][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[hh][0][1], 0, 0, 0);
+                    acc[hh][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[hh][1][0], 0, 0, 0);
+                    acc[hh][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[hh][1][1], 0, 0, 0);
+                }
             }
             if (more) {
-                float* an = As + (cur ^ 1) * (BK * LDS_LD);
+                float* an = As + (cur ^ 1) * (BK * ALD);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) an[kkA * LDS_LD + xb + 16 * j] = ra[j];
+                for (int j = 0; j < NJ; ++j) an[kkA * ALD + xb + 16 * j] = ra[j];
                 fill_ptab(ptab + (cur ^ 1) * BK, pbeg + (t + 1) * BK);
             }
             __syncthreads();
@@ -471,7 +491,11 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     }
     __syncthreads();
     const int n = n0 + (tid & 127);
-    tile_epilogue(acc, smem, ep, m0, M, n, n < N, ws, split, N);
+#pragma unroll
+    for (int hh = 0; hh < MH; ++hh) {
+        if (hh) __syncthreads();
+        tile_epilogue(acc[hh], smem, ep, m0 + hh * 128, M, n, n < N, ws, split, N);
+    }
 }
 
 }  // namespace tvae

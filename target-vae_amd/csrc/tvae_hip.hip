@@ -194,7 +194,15 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
     const int rows = conv_wgrad_img_rows(Cin, n, ksz, pad);
     const size_t lds = conv_img_lds_bytes(Cin, rows, n, pad);
     if (lds <= CONV_IMG_LDS_MAX) {
-        int splits = (1024 + tiles - 1) / tiles;
+        static const bool wide_env = [] { const char* e = getenv("TVAE_CONV1_WIDE"); return e && e[0] == '1'; }();
+        const size_t lds2w = conv_img_lds_bytes(Cin, rows, n, pad, 2);
+        const bool use_wide = wide_env && M % (2 * BM) == 0 && lds2w <= CONV_IMG_LDS_MAX;
+        // split the image reduction so that the grid is ONE full wave of resident workgroups (256 CUs x 3 or 2 per CU):
+        // 256 tiles x 4 slices = 1024 workgroups on 768 slots ran as 1.33 waves (the second one a third full)
+        const int out_tiles = use_wide ? (M / (2 * BM)) * tilesN : tiles;
+        const int capacity = 256 * (use_wide ? 2 : 3);
+        int splits = (capacity + out_tiles / 2) / out_tiles;
+        if (splits < 1) splits = 1;
         if (splits > B) splits = B;
         const long per = (long)M * N;
         const long cap = ws ? ws_floats / per : 0;
@@ -202,11 +210,21 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         if (splits < 1) splits = 1;
         const int ips = cdiv(B, splits);
         splits = cdiv(B, ips);
-        hipError_t e = allow_big_lds(conv1_wgrad_img_kernel, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(conv1_wgrad_img_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(GEMM_THREADS), lds,
-                           S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips, splits > 1 ? ws : nullptr, tilesN,
-                           rows);
+        const size_t lds2 = lds2w;
+        if (use_wide) {
+            const int tiles2 = out_tiles;
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<2>, lds2);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(conv1_wgrad_img_kernel<2>, dim3((unsigned)tiles2, (unsigned)splits), dim3(GEMM_THREADS),
+                               lds2, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
+                               splits > 1 ? ws : nullptr, tilesN, rows);
+        } else {
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1>, lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(conv1_wgrad_img_kernel<1>, dim3((unsigned)tiles, (unsigned)splits), dim3(GEMM_THREADS),
+                               lds, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
+                               splits > 1 ? ws : nullptr, tilesN, rows);
+        }
         TVAE_CHECK_LAUNCH();
         if (splits > 1) {
             int blocks = cdiv(per, 256);
