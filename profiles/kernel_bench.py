@@ -4,6 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'target-vae_amd')]
 import torch
+import tvae._lib as _L
+if os.environ.get('TVAE_LIB'):
+    _L.LIB_PATH = os.path.abspath(os.environ['TVAE_LIB'])
 from tvae._lib import call, set_gemm_mode
 set_gemm_mode(os.environ.get('MODE', 'f32'))
 print('mode', os.environ.get('MODE', 'f32'))

@@ -40,9 +40,9 @@ static inline size_t conv_nb_lds_bytes(int Cin, int rows, int n, int pad) {
     if (tot < 64 * 128) tot = 64 * 128;
     return (size_t)tot * sizeof(float);
 }
-static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad, int mh = 1) {
+static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad, int mh = 1, int kb = BK) {
     const int Wp = n + 2 * pad + 1;
-    long tot = 2 * BK * (mh * 128 + 4) + CONV_TAB_INTS + (long)Cin * rows * Wp;
+    long tot = 2 * kb * (mh * 128 + 4) + 2 * kb + (long)Cin * rows * Wp;
     if (tot < 64 * 128) tot = 64 * 128;            // the epilogue staging tile aliases the whole region
     return (size_t)tot * sizeof(float);
 }
@@ -357,18 +357,20 @@ void conv1_fwd_nb_kernel(const float* __restrict__ bankT, const float* __restric
 // Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)
 // grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
 // ------------------------------------------------------------------------------------------
-template <int MH>
+template <int MH, int KB>
 __global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
 void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
                             Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows) {
-    // MH = 128-row halves per workgroup tile (1: 128 x 128, 2: 256 x 128 with 128 x 64 per wave)
+    // MH = 128-row halves per workgroup tile (1: 128 x 128, 2: 256 x 128 with 128 x 64 per wave); KB = positions per
+    // k-step (16 or 32: the image rows of a wgrad tile are small, so a 32-deep step halves the barriers at equal occupancy)
     constexpr int ALD = MH * 128 + 4;
-    constexpr int AFL = 2 * BK * ALD;
-    constexpr int NJ = 8 * MH;                      // A rows per thread
+    constexpr int AFL = 2 * KB * ALD;
+    constexpr int RG = GEMM_THREADS / KB;           // row groups of the A staging map
+    constexpr int NJ = (128 * MH) / RG;             // A rows per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     int* ptab = reinterpret_cast<int*>(smem + AFL);
-    float* img = smem + AFL + CONV_TAB_INTS;
+    float* img = smem + AFL + 2 * KB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
@@ -388,7 +390,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         pbeg = hlo * g.Ho;
         pend = max(pbeg, (hhi + 1) * g.Ho);
     }
-    const int nk = (pend - pbeg + BK - 1) / BK;
+    const int nk = (pend - pbeg + KB - 1) / KB;
 
     int noff[2];
 #pragma unroll
@@ -399,12 +401,12 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         const int u = rem / g.ksz, v = rem - u * g.ksz;
         noff[j] = (ci * rows + (u - ulo)) * Wp + v;
     }
-    // A rows (mapping K: kk = tid&15, rows xb + 16 j)
-    const int kkA = tid & 15, xb = tid >> 4;
+    // A rows (mapping K: kk = tid % KB, rows xb + RG j)
+    const int kkA = tid % KB, xb = tid / KB;
     long rowoff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        int m = m0 + xb + 16 * j;
+        int m = m0 + xb + RG * j;
         if (m >= M) m = M - 1;                      // clamped rows are never stored
         const int c = m / g.R, rr = m - c * g.R;
         rowoff[j] = (long)c * lddy + (long)rr * g.P;
@@ -412,15 +414,15 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     // position-offset table: thread tid < 16 owns entry tid and walks (h, w) incrementally (no divisions in the loop)
     int tp, th, tw;
     auto reset_ptab = [&]() {
-        tp = pbeg + (tid & 15);
+        tp = pbeg + (tid % KB);
         th = tp / g.Ho;
         tw = tp - th * g.Ho;
     };
     auto fill_ptab = [&](int* tab, int /*pfrom*/) {
-        if (tid < BK) {
-            tab[(tid & 1) * 8 + (tid >> 1)] = (tp < pend) ? th * Wp + tw : 0;
-            tp += BK;
-            tw += BK;
+        if (tid < KB) {
+            tab[(tid & 1) * (KB / 2) + (tid >> 1)] = (tp < pend) ? th * Wp + tw : 0;
+            tp += KB;
+            tw += KB;
             while (tw >= g.Ho) { tw -= g.Ho; ++th; }
         }
     };
@@ -448,7 +450,7 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
 #pragma unroll
             for (int j = 0; j < NJ; ++j) ra[j] = kok ? dyb[rowoff[j]] : 0.f;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) As[kkA * ALD + xb + 16 * j] = ra[j];
+            for (int j = 0; j < NJ; ++j) As[kkA * ALD + xb + RG * j] = ra[j];
         }
         fill_ptab(ptab, pbeg);
         __syncthreads();
@@ -456,17 +458,21 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
             const int cur = t & 1;
             const bool more = (t + 1) < nk;
             if (more) {
-                const int pk = (t + 1) * BK;
+                const int pk = (t + 1) * KB;
                 const bool kok = (pbeg + pk + kkA) < pend;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) ra[j] = kok ? dyb[rowoff[j] + pk] : 0.f;
             }
-            const float* as = As + cur * (BK * ALD);
-            const int4* pt4 = reinterpret_cast<const int4*>(ptab + cur * BK + khalf * 8);
-            const int4 t0 = pt4[0], t1 = pt4[1];
-            const int pos[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const float* as = As + cur * (KB * ALD);
+            const int4* pt4 = reinterpret_cast<const int4*>(ptab + cur * KB + khalf * (KB / 2));
+            int pos[KB / 2];
 #pragma unroll
-            for (int s = 0; s < BK / 2; ++s) {
+            for (int q = 0; q < KB / 8; ++q) {
+                const int4 tq = pt4[q];
+                pos[4 * q] = tq.x; pos[4 * q + 1] = tq.y; pos[4 * q + 2] = tq.z; pos[4 * q + 3] = tq.w;
+            }
+#pragma unroll
+            for (int s = 0; s < KB / 2; ++s) {
                 const int kk = 2 * s + khalf;
                 const float b0 = img[noff[0] + pos[s]];
                 const float b1 = img[noff[1] + pos[s]];
@@ -481,10 +487,10 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
                 }
             }
             if (more) {
-                float* an = As + (cur ^ 1) * (BK * ALD);
+                float* an = As + (cur ^ 1) * (KB * ALD);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) an[kkA * ALD + xb + 16 * j] = ra[j];
-                fill_ptab(ptab + (cur ^ 1) * BK, pbeg + (t + 1) * BK);
+                for (int j = 0; j < NJ; ++j) an[kkA * ALD + xb + RG * j] = ra[j];
+                fill_ptab(ptab + (cur ^ 1) * KB, pbeg + (t + 1) * KB);
             }
             __syncthreads();
         }

@@ -197,11 +197,14 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         static const bool wide_env = [] { const char* e = getenv("TVAE_CONV1_WIDE"); return e && e[0] == '1'; }();
         const size_t lds2w = conv_img_lds_bytes(Cin, rows, n, pad, 2);
         const bool use_wide = wide_env && M % (2 * BM) == 0 && lds2w <= CONV_IMG_LDS_MAX;
-        // split the image reduction so that the grid is ONE full wave of resident workgroups (256 CUs x 3 or 2 per CU):
-        // 256 tiles x 4 slices = 1024 workgroups on 768 slots ran as 1.33 waves (the second one a third full)
+        // split the image reduction into ~4 waves of resident workgroups (256 CUs x 3 or 2 per CU): zero skipping makes
+        // edge-tap tiles up to 2x lighter, and many smaller slices let the dispatcher balance that (sweep at cfg4:
+        // 3 / 6 / 12 / 32 slices -> 20.4 / 20.1 / 19.65 / 19.7 ms)
         const int out_tiles = use_wide ? (M / (2 * BM)) * tilesN : tiles;
-        const int capacity = 256 * (use_wide ? 2 : 3);
+        const int capacity = 4 * 256 * (use_wide ? 2 : 3);
         int splits = (capacity + out_tiles / 2) / out_tiles;
+        static const int splits_env = [] { const char* e = getenv("TVAE_CONV1_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+        if (splits_env > 0) splits = splits_env;
         if (splits < 1) splits = 1;
         if (splits > B) splits = B;
         const long per = (long)M * N;
@@ -211,18 +214,27 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         const int ips = cdiv(B, splits);
         splits = cdiv(B, ips);
         const size_t lds2 = lds2w;
+        static const int kb_env = [] { const char* e = getenv("TVAE_CONV1_WGRAD_KB"); return e ? atoi(e) : 32; }();
+        const size_t lds32 = conv_img_lds_bytes(Cin, rows, n, pad, 1, 32);
         if (use_wide) {
             const int tiles2 = out_tiles;
-            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<2>, lds2);
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<2, 16>, lds2);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(conv1_wgrad_img_kernel<2>, dim3((unsigned)tiles2, (unsigned)splits), dim3(GEMM_THREADS),
-                               lds2, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<2, 16>), dim3((unsigned)tiles2, (unsigned)splits),
+                               dim3(GEMM_THREADS), lds2, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
+                               splits > 1 ? ws : nullptr, tilesN, rows);
+        } else if (kb_env == 32 && lds32 * 3 <= 160 * 1024) {
+            // 32 positions per k-step: half the barriers, still 3 workgroups per CU
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 32>, lds32);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 32>), dim3((unsigned)tiles, (unsigned)splits),
+                               dim3(GEMM_THREADS), lds32, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
                                splits > 1 ? ws : nullptr, tilesN, rows);
         } else {
-            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1>, lds);
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 16>, lds);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(conv1_wgrad_img_kernel<1>, dim3((unsigned)tiles, (unsigned)splits), dim3(GEMM_THREADS),
-                               lds, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 16>), dim3((unsigned)tiles, (unsigned)splits),
+                               dim3(GEMM_THREADS), lds, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
                                splits > 1 ? ws : nullptr, tilesN, rows);
         }
         TVAE_CHECK_LAUNCH();

@@ -166,7 +166,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act):
 def conv1_wgrad(y, dpre, C, R, k, pad):
     B, Cin, n, _ = y.shape
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
-    ws = workspace(y.device, max(1 << 24, 8 * dbank.numel()))
+    ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     with _timed('tvae_conv1_wgrad'):
         call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
     return dbank
