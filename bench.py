@@ -28,6 +28,18 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+KERNEL_OF = {'tvae_conv1_fwd': 'conv1_fwd_img_kernel<true,2>', 'tvae_conv1_wgrad': 'conv1_wgrad_img_kernel<1,32>'}
+
+
+def pmc_traffic(entry):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/pmc_traffic.json: FETCH_SIZE x2 -- gfx950 reports half the fetched bytes, calibrated on outer_mask --
+    plus WRITE_SIZE).  Counters cannot be collected inside the timed run, so this is the committed measurement."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        return d[entry]['hbm_bytes_per_launch']
+    except Exception:
+        return None
 CFG = dict(n=64, cin=1, zd=2, C=128, k=64, pad=16, R=8, hidden=512, layers=2, n_out=1)
 
 
@@ -48,7 +60,7 @@ def build_models(device):
     return gen.to(device), enc.to(device)
 
 
-def cpu_baseline(batch=16, steps=2):
+def cpu_baseline(batch=32, steps=4):
     """The CPU oracle (a port of the reference step onto the same ATen CPU operators) timed on this host's
     cores on a bounded sample of the same workload: `batch` images per step, 1 warm-up + `steps` timed steps."""
     from oracle import tvae_oracle as O
@@ -62,7 +74,8 @@ def cpu_baseline(batch=16, steps=2):
     encp = {k_: v.detach().clone().requires_grad_(True) for k_, v in enc.state_dict().items()}
     genp = {k_: v.detach().clone().requires_grad_(True) for k_, v in gen.state_dict().items()}
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = int(os.environ.get('TVAE_CPU_THREADS', min(avail, 32)))   # >32 threads oversubscribe this small job
+    # thread sweep on the GPU box's host (profiles/cpu_sweep.py): 8/16/32/64 threads -> 15/22/17/11 img/s
+    cores = int(os.environ.get('TVAE_CPU_THREADS', min(avail, 16)))
     torch.set_num_threads(cores)
     st = O.new_opt_state(encp, genp)
     x = O.image_coords(c['n'])
@@ -166,9 +179,9 @@ def main():
                                    'k=64 p=16 C=128, z=2, t-inf attention, r-inf attention+offsets, decoder '
                                    '2->512->512->1, Gaussian likelihood, Adam lr 2e-4',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}'},
-            'roofline': {'kernel': dom + ' (gemm_f32_kernel, v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
+            'roofline': {'kernel': dom + ' (' + KERNEL_OF[dom] + ', v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom),
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
                          'other': {'kernel': other, 'mean_launch_ms': kev.get(other, {}).get('mean_ms'),

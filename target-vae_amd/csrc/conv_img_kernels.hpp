@@ -28,10 +28,10 @@ static inline int conv_fwd_img_rows(int n, int ksz, int pad) {
 }
 // Rows a weight-gradient tile needs (single input channel): BN consecutive taps span at most (BN-1)/ksz + 2 tap rows,
 // each combined with Ho output rows.  With several input channels the whole padded image is kept.
-static inline int conv_wgrad_img_rows(int Cin, int n, int ksz, int pad) {
+static inline int conv_wgrad_img_rows(int Cin, int n, int ksz, int pad, int nh = 1) {
     const int Hp = n + 2 * pad, Ho = Hp - ksz + 1;
     if (Cin != 1) return Hp;
-    const int rows = (BN - 1) / ksz + 2 + Ho - 1;
+    const int rows = (BN * nh - 1) / ksz + 2 + Ho - 1;
     return rows < Hp ? rows : Hp;
 }
 static inline size_t conv_nb_lds_bytes(int Cin, int rows, int n, int pad) {
@@ -357,11 +357,13 @@ void conv1_fwd_nb_kernel(const float* __restrict__ bankT, const float* __restric
 // Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)
 // grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
 // ------------------------------------------------------------------------------------------
-template <int MH, int KB>
-__global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
+template <int MH, int KB, int NH>
+__global__ __launch_bounds__(GEMM_THREADS, ((MH == 1 && NH == 1) ? 3 : 2))
 void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
-                            Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows) {
-    // MH = 128-row halves per workgroup tile (1: 128 x 128, 2: 256 x 128 with 128 x 64 per wave); KB = positions per
+                            Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows, int nsplits,
+                            int ngroups) {
+    // NH = 128-column (tap) halves per workgroup tile: NH = 2 halves how often a dY panel is re-read and the A reads
+    // per MFMA.  MH = 128-row halves per workgroup tile (1: 128 x 128, 2: 256 x 128 with 128 x 64 per wave); KB = positions per
     // k-step (16 or 32: the image rows of a wgrad tile are small, so a 32-deep step halves the barriers at equal occupancy)
     constexpr int ALD = MH * 128 + 4;
     constexpr int AFL = 2 * KB * ALD;
@@ -374,9 +376,23 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
-    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
-    const int m0 = tile_m * (BM * MH), n0 = tile_n * BN;
-    const int split = blockIdx.y;
+    // XCD-aware mapping (1-D grid): the tilesN tap-tiles of one group g = (row-tile, image-slice) all read the same dY
+    // panel, and workgroup ids are dealt round-robin over the 8 XCDs, so group g takes the ids congruent to g mod 8:
+    // the panel is then fetched into ONE L2 instead of eight (only speed depends on the placement, never results).
+    int tile_n, gidx;
+    {
+        const int bid = blockIdx.x;
+        if ((ngroups & 7) == 0) {
+            const int x = bid & 7, q = bid >> 3;
+            tile_n = q % tilesN;
+            gidx = (q / tilesN) * 8 + x;
+        } else {
+            tile_n = bid % tilesN;
+            gidx = bid / tilesN;
+        }
+    }
+    const int split = gidx % nsplits, tile_m = gidx / nsplits;
+    const int m0 = tile_m * (BM * MH), n0 = tile_n * (BN * NH);
     const int ib = split * imgs_per_split;
     const int ie = min(g.B, ib + imgs_per_split);
     // rows == Hp: whole padded image(s) resident; otherwise (single channel) only rows [ulo, ulo + rows)
@@ -385,22 +401,24 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
     // pad <= h+u <= pad+n-1 for some such u, i.e. h in [pad-ub, pad+n-1-ua] -- a contiguous position range.
     int pbeg = 0, pend = g.P;
     if (g.Cin == 1) {
-        const int ua = n0 / g.ksz, ub = min(N - 1, n0 + BN - 1) / g.ksz;
+        const int ua = n0 / g.ksz, ub = min(N - 1, n0 + BN * NH - 1) / g.ksz;
         const int hlo = max(0, g.pad - ub), hhi = min(g.Ho - 1, g.pad + g.n - 1 - ua);
         pbeg = hlo * g.Ho;
         pend = max(pbeg, (hhi + 1) * g.Ho);
     }
     const int nk = (pend - pbeg + KB - 1) / KB;
 
-    int noff[2];
+    int noff[NH][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int nn = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (nn >= N) nn = N - 1;
-        const int ci = nn / g.K2, rem = nn - ci * g.K2;
-        const int u = rem / g.ksz, v = rem - u * g.ksz;
-        noff[j] = (ci * rows + (u - ulo)) * Wp + v;
-    }
+    for (int hn = 0; hn < NH; ++hn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int nn = n0 + hn * 128 + wn * 64 + j * 32 + (lane & 31);
+            if (nn >= N) nn = N - 1;
+            const int ci = nn / g.K2, rem = nn - ci * g.K2;
+            const int u = rem / g.ksz, v = rem - u * g.ksz;
+            noff[hn][j] = (ci * rows + (u - ulo)) * Wp + v;
+        }
     // A rows (mapping K: kk = tid % KB, rows xb + RG j)
     const int kkA = tid % KB, xb = tid / KB;
     long rowoff[NJ];
@@ -427,9 +445,9 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         }
     };
 
-    f32x16 acc[MH][2][2];
+    f32x16 acc[MH * NH][2][2];
 #pragma unroll
-    for (int hh = 0; hh < MH; ++hh)
+    for (int hh = 0; hh < MH * NH; ++hh)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -474,16 +492,24 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
 #pragma unroll
             for (int s = 0; s < KB / 2; ++s) {
                 const int kk = 2 * s + khalf;
-                const float b0 = img[noff[0] + pos[s]];
-                const float b1 = img[noff[1] + pos[s]];
+                float bq[NH][2];
+#pragma unroll
+                for (int hn = 0; hn < NH; ++hn) {
+                    bq[hn][0] = img[noff[hn][0] + pos[s]];
+                    bq[hn][1] = img[noff[hn][1] + pos[s]];
+                }
 #pragma unroll
                 for (int hh = 0; hh < MH; ++hh) {
                     const float a0 = as[kk * ALD + hh * 128 + arow];
                     const float a1 = as[kk * ALD + hh * 128 + arow + 32];
-                    acc[hh][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[hh][0][0], 0, 0, 0);
-                    acc[hh][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[hh][0][1], 0, 0, 0);
-                    acc[hh][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[hh][1][0], 0, 0, 0);
-                    acc[hh][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[hh][1][1], 0, 0, 0);
+#pragma unroll
+                    for (int hn = 0; hn < NH; ++hn) {
+                        f32x16 (&ac)[2][2] = acc[hh * NH + hn];
+                        ac[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[hn][0], ac[0][0], 0, 0, 0);
+                        ac[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[hn][1], ac[0][1], 0, 0, 0);
+                        ac[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[hn][0], ac[1][0], 0, 0, 0);
+                        ac[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[hn][1], ac[1][1], 0, 0, 0);
+                    }
                 }
             }
             if (more) {
@@ -496,12 +522,14 @@ void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float
         }
     }
     __syncthreads();
-    const int n = n0 + (tid & 127);
 #pragma unroll
-    for (int hh = 0; hh < MH; ++hh) {
-        if (hh) __syncthreads();
-        tile_epilogue(acc[hh], smem, ep, m0 + hh * 128, M, n, n < N, ws, split, N);
-    }
+    for (int hh = 0; hh < MH; ++hh)
+#pragma unroll
+        for (int hn = 0; hn < NH; ++hn) {
+            if (hh + hn) __syncthreads();
+            const int n = n0 + hn * 128 + (tid & 127);
+            tile_epilogue(acc[hh * NH + hn], smem, ep, m0 + hh * 128, M, n, n < N, ws, split, N);
+        }
 }
 
 }  // namespace tvae

@@ -214,28 +214,59 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         const int ips = cdiv(B, splits);
         splits = cdiv(B, ips);
         const size_t lds2 = lds2w;
+        static const int nh_env = [] { const char* e = getenv("TVAE_CONV1_WGRAD_NH"); return e ? atoi(e) : 2; }();
+        {
+            // 128 x 256 tile (wave 64 x 128): every dY panel is re-read by half as many tap-tiles
+            const int rows2 = conv_wgrad_img_rows(Cin, n, ksz, pad, 2);
+            const size_t ldsn = conv_img_lds_bytes(Cin, rows2, n, pad, 1, 32);
+            if (nh_env == 2 && !use_wide && N % (2 * BN) == 0 && ldsn * 2 <= 160 * 1024) {
+                const int tilesN2 = N / (2 * BN);
+                const int otiles = tilesM * tilesN2;
+                int sp = (4 * 256 * 2 + otiles / 2) / otiles;
+                if (splits_env > 0) sp = splits_env;
+                if (sp > B) sp = B;
+                if (cap < 2) sp = 1; else if (sp > cap) sp = (int)cap;
+                if (sp < 1) sp = 1;
+                const int ips2 = cdiv(B, sp);
+                sp = cdiv(B, ips2);
+                hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 32, 2>, ldsn);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 32, 2>), dim3((unsigned)(otiles * sp)), dim3(GEMM_THREADS),
+                                   ldsn, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips2, sp > 1 ? ws : nullptr,
+                                   tilesN2, rows2, sp, tilesM * sp);
+                TVAE_CHECK_LAUNCH();
+                if (sp > 1) {
+                    int blocks = cdiv(per, 256);
+                    if (blocks > 4096) blocks = 4096;
+                    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, sp,
+                                       M, N, ep);
+                    TVAE_CHECK_LAUNCH();
+                }
+                return 0;
+            }
+        }
         static const int kb_env = [] { const char* e = getenv("TVAE_CONV1_WGRAD_KB"); return e ? atoi(e) : 32; }();
         const size_t lds32 = conv_img_lds_bytes(Cin, rows, n, pad, 1, 32);
         if (use_wide) {
             const int tiles2 = out_tiles;
-            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<2, 16>, lds2);
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<2, 16, 1>, lds2);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((conv1_wgrad_img_kernel<2, 16>), dim3((unsigned)tiles2, (unsigned)splits),
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<2, 16, 1>), dim3((unsigned)(tiles2 * splits)),
                                dim3(GEMM_THREADS), lds2, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
-                               splits > 1 ? ws : nullptr, tilesN, rows);
+                               splits > 1 ? ws : nullptr, tilesN, rows, splits, (tiles2 / tilesN) * splits);
         } else if (kb_env == 32 && lds32 * 3 <= 160 * 1024) {
             // 32 positions per k-step: half the barriers, still 3 workgroups per CU
-            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 32>, lds32);
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 32, 1>, lds32);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 32>), dim3((unsigned)tiles, (unsigned)splits),
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 32, 1>), dim3((unsigned)(tiles * splits)),
                                dim3(GEMM_THREADS), lds32, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
-                               splits > 1 ? ws : nullptr, tilesN, rows);
+                               splits > 1 ? ws : nullptr, tilesN, rows, splits, tilesM * splits);
         } else {
-            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 16>, lds);
+            hipError_t e = allow_big_lds(conv1_wgrad_img_kernel<1, 16, 1>, lds);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 16>), dim3((unsigned)tiles, (unsigned)splits),
+            hipLaunchKernelGGL((conv1_wgrad_img_kernel<1, 16, 1>), dim3((unsigned)(tiles * splits)),
                                dim3(GEMM_THREADS), lds, S(stream), dpre, (long)B * R * g.P, y, g, ep, M, N, ips,
-                               splits > 1 ? ws : nullptr, tilesN, rows);
+                               splits > 1 ? ws : nullptr, tilesN, rows, splits, tilesM * splits);
         }
         TVAE_CHECK_LAUNCH();
         if (splits > 1) {
