@@ -214,7 +214,9 @@ class InferenceNetwork_AttentionTranslation_UnimodalRotation(nn.Module):
         self.conv_r = nn.Conv2d(kernels_num, 2, 1)
         self.conv_z = nn.Conv2d(kernels_num, 2 * latent_dim, 1)
 
-    def forward(self, x, device):
+    def forward(self, x, device, E=None):
+        """Reference 4-tuple (attn, a_sampled, theta, z).  `E` optionally injects the Exp(1) draws of the
+        Gumbel-softmax (reference: F.gumbel_softmax, models.py:311)."""
         if self.groupconv > 0:
             x = self.activation(self.conv1(x, device))
             x = self.fc_r(x.permute(0, 1, 3, 4, 2)).squeeze(4)
@@ -222,7 +224,10 @@ class InferenceNetwork_AttentionTranslation_UnimodalRotation(nn.Module):
             x = self.activation(self.conv1(x))
         h = self.activation(self.conv2(x))
         attn = self.conv_a(h)
-        a = torch.nn.functional.gumbel_softmax(attn.view(attn.shape[0], -1), dim=-1)
+        logits = attn.reshape(attn.shape[0], -1)
+        if E is None:
+            E = torch.empty_like(logits).exponential_()
+        a = torch.softmax(logits - torch.log(E.reshape(logits.shape)), dim=-1)
         return attn, a.view(h.shape[0], h.shape[2], h.shape[3]), self.conv_r(h), self.conv_z(h)
 
 

@@ -212,16 +212,26 @@ def run(kind: str, argv=None):
         theta_prior, normal_prior_over_r = np.pi / 4, True          # train_mnist.py:538-543
     else:
         theta_prior, normal_prior_over_r = np.pi, False
-    if not (t_inf == 'attention' and r_inf in ('attention', 'attention+offsets')):
-        raise SystemExit(f'--t-inf {t_inf} --r-inf {r_inf}: only the TARGET-VAE attention/attention(+offsets) '
-                         'configuration is built on the MI355X hot path')
-    if group_conv == 0:
-        raise SystemExit('--groupconv 0 is not valid with attention over rotations (needs 4, 8 or 16)')
-    encoder_model = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
-        image_dim, in_channels, z_dim, kernels_num=args.encoder_kernel_number, kernels_size=args.encoder_kernel_size,
-        padding=args.encoder_padding, activation=activation, groupconv=group_conv,
-        rot_refinement=(r_inf == 'attention+offsets'), theta_prior=theta_prior,
-        normal_prior_over_r=normal_prior_over_r)
+    if t_inf == 'unimodal' and r_inf == 'unimodal':                 # secondary encoders (train_mnist.py:546-557)
+        encoder_model = models.InferenceNetwork_UnimodalTranslation_UnimodalRotation(
+            image_dim * image_dim * in_channels, z_dim + 3, args.encoder_kernel_number,
+            num_layers=args.encoder_num_layers, activation=activation)
+    elif t_inf == 'attention' and r_inf == 'unimodal':
+        encoder_model = models.InferenceNetwork_AttentionTranslation_UnimodalRotation(
+            image_dim, in_channels, z_dim, kernels_num=args.encoder_kernel_number, activation=activation,
+            groupconv=group_conv)
+    elif t_inf == 'attention':
+        if group_conv == 0:
+            raise SystemExit('--groupconv 0 is not valid with attention over rotations (needs 4, 8 or 16)')
+        encoder_model = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+            image_dim, in_channels, z_dim, kernels_num=args.encoder_kernel_number,
+            kernels_size=args.encoder_kernel_size, padding=args.encoder_padding, activation=activation,
+            groupconv=group_conv, rot_refinement=(r_inf == 'attention+offsets'), theta_prior=theta_prior,
+            normal_prior_over_r=normal_prior_over_r)
+    else:
+        raise SystemExit(f'--t-inf {t_inf} --r-inf {r_inf} is not a combination the reference supports')
+    if kind == 'particles' and not (t_inf == 'attention' and r_inf != 'unimodal'):
+        raise SystemExit('train_particles: the secondary inference branches are only wired for the BCE datasets')
     generator_model.to(device)
     encoder_model.to(device)
     if is_main:

@@ -85,10 +85,24 @@ def _check_branch(t_inf, r_inf):
             '(train_mnist.py:187-282) runs on the HIP hot path')
 
 
+def _secondary(x, y, generator_model, encoder_model, t_inf, r_inf, theta_prior, likelihood, noise):
+    """The two secondary branches (train_mnist.py:35-185) on the generic path of tvae/secondary.py."""
+    from . import secondary
+    if t_inf == 'unimodal' and r_inf == 'unimodal':
+        return secondary.unimodal_unimodal(x, y, generator_model, encoder_model, theta_prior, likelihood, eps=noise)
+    if t_inf == 'attention' and r_inf == 'unimodal':
+        return secondary.attention_unimodal(x, y, generator_model, encoder_model, theta_prior, pixel_spacing(x),
+                                            likelihood, noise=noise)
+    raise NotImplementedError(f'--t-inf {t_inf} --r-inf {r_inf} is not a combination the reference supports '
+                              '(train_mnist.py:35,86,187)')
+
+
 def eval_minibatch(x, y, generator_model, encoder_model, t_inf, r_inf, epoch, device, theta_prior, groupconv,
                    image_dim, likelihood='bce', noise=None):
     """Reference signature train_mnist.py:26-27 (+ optional `likelihood`, `noise` keywords)."""
-    _check_branch(t_inf, r_inf)
+    if not (t_inf == 'attention' and r_inf in ('attention', 'attention+offsets')):
+        return _secondary(x.to(device), y.to(device), generator_model, encoder_model, t_inf, r_inf, theta_prior,
+                          likelihood, noise)
     return elbo_terms(x.to(device), y.to(device), generator_model, encoder_model, likelihood, noise)
 
 

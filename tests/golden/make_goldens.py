@@ -364,6 +364,51 @@ def gen_mrc():
     print('wrote mrc fixtures')
 
 
+def gen_secondary():
+    """The two secondary branches of eval_minibatch (train_mnist.py:35-185): unimodal/unimodal (MLP encoder) and
+    attention/unimodal (translation attention, rotation pooled by fc_r or plain conv)."""
+    n, zd, B = 20, 2, 3
+    x_coord = coords(n)
+    torch.manual_seed(0)
+    y = torch.rand(B, 1, n, n)
+    cases = [('step_unimodal_unimodal', 'unimodal', 'unimodal', 0), ('step_attention_unimodal_gc4', 'attention', 'unimodal', 4),
+             ('step_attention_unimodal_gc0', 'attention', 'unimodal', 0)]
+    for name, t_inf, r_inf, gc in cases:
+        torch.manual_seed(1)
+        gen = models.SpatialGenerator(zd, 32, num_layers=2)
+        if t_inf == 'unimodal':
+            enc = models.InferenceNetwork_UnimodalTranslation_UnimodalRotation(n * n, zd + 3, 32, num_layers=2)
+        else:
+            enc = models.InferenceNetwork_AttentionTranslation_UnimodalRotation(n, 1, zd, kernels_num=8, groupconv=gc)
+            with torch.no_grad():
+                for nm in ('conv_a', 'conv_r', 'conv_z'):
+                    getattr(enc, nm).weight.mul_(10.0)
+        torch.manual_seed(77)
+        state = torch.get_rng_state()
+        elbo, logp, kl = train_mnist.eval_minibatch(x_coord, y, gen, enc, t_inf, r_inf, 0, 'cpu', np.pi, gc, n)
+        (-elbo).backward()
+        out = dict(y=y, elbo=elbo, log_p=logp, kl=kl, rng_seed=np.int64(77), cfg=np.array([n, zd, gc]))
+        for k_, v in enc.state_dict().items():
+            out['e.' + k_] = v
+        for k_, v in gen.state_dict().items():
+            out['d.' + k_] = v
+        for k_, v in enc.named_parameters():
+            out['ge.' + k_] = v.grad
+        for k_, v in gen.named_parameters():
+            out['gd.' + k_] = v.grad
+        # replay of the reference's random draws under the same seed, in its order
+        torch.manual_seed(77)
+        if t_inf == 'unimodal':
+            out['eps'] = y.new(B, zd + 3).normal_()
+        else:
+            Ho = n + 2 * (n // 2) - n + 1
+            out['E'] = torch.empty(B, Ho * Ho).exponential_()
+            out['eps_z'] = torch.normal(torch.zeros(B, zd, 1), torch.ones(B, zd, 1)).view(B, zd)
+            out['eps_theta'] = torch.normal(torch.zeros(B, 1, 1), torch.ones(B, 1, 1)).view(B)
+        save(name, **out)
+        print('   ', name, float(elbo), float(logp), float(kl), elbo.dtype)
+
+
 def gen_epoch():
     """train_epoch over 2 minibatches (train_mnist.py:300-346): running means + post-Adam params."""
     torch.manual_seed(0)
@@ -446,7 +491,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc', 'secondary']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc, 'secondary': gen_secondary}[w]()

@@ -229,13 +229,14 @@ def test_epoch_two_steps_golden(gemm_mode):
 
 
 def test_full_size_properties():
-    """BASELINE size (64x64, P8, z=2, B=256 reduced to B=32 here for memory/time): size-independent properties --
+    """BASELINE.json metric configuration at FULL size (64x64, P8, z=2, k=64 p=16, C=128, hidden 512, B=256) --
+    size-independent properties:
     exp(q) sums to 1, a sums to 1, KL >= 0 finite, determinism (bitwise equal on a second run), and the encoder's
     batch independence (image b's outputs do not depend on its neighbours)."""
     import src.models as M
     from tvae import step
     torch.manual_seed(0)
-    n, R, B = 64, 8, 32
+    n, R, B = 64, 8, 256
     gen = M.SpatialGenerator(2, 512, num_layers=2).to(dev())
     enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
         n, 1, 2, kernels_num=128, kernels_size=64, padding=16, groupconv=R, rot_refinement=True,
@@ -322,3 +323,35 @@ def test_get_latent_golden(name):
     assert rel_err(zc, fx['z_content']) < OUT_TOL
     assert rel_err(th, fx['theta_mu']) < OUT_TOL
     assert rel_err(dx, fx['dx']) < OUT_TOL
+
+
+@pytest.mark.parametrize('name,t_inf,r_inf', [('step_unimodal_unimodal', 'unimodal', 'unimodal'),
+                                              ('step_attention_unimodal_gc4', 'attention', 'unimodal'),
+                                              ('step_attention_unimodal_gc0', 'attention', 'unimodal')])
+def test_secondary_branches_golden(name, t_inf, r_inf):
+    """--t-inf/--r-inf unimodal branches of eval_minibatch (train_mnist.py:35-185) against the reference."""
+    import src.models as M
+    from tvae import step
+    fx = load_golden(name)
+    n, zd, gc = [int(v) for v in fx['cfg']]
+    gen = M.SpatialGenerator(zd, 32, num_layers=2)
+    if t_inf == 'unimodal':
+        enc = M.InferenceNetwork_UnimodalTranslation_UnimodalRotation(n * n, zd + 3, 32, num_layers=2)
+        noise = torch.from_numpy(fx['eps']).to(dev())
+    else:
+        enc = M.InferenceNetwork_AttentionTranslation_UnimodalRotation(n, 1, zd, kernels_num=8, groupconv=gc)
+        noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    enc.load_state_dict(tdict(fx, 'e.'))
+    gen.load_state_dict(tdict(fx, 'd.'))
+    enc, gen = enc.to(dev()), gen.to(dev())
+    elbo, logp, kl = step.eval_minibatch(O.image_coords(n).to(dev()), torch.from_numpy(fx['y']).to(dev()), gen, enc,
+                                         t_inf, r_inf, 0, dev(), np.pi, gc, n, noise=noise)
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
+    assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    (-elbo).backward()
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.named_parameters():
+        assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
