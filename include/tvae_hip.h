@@ -28,12 +28,10 @@ int tvae_get_gemm_mode(void);
 
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
- * rotations (idx < 0 = outside, zero padding).  transposed = 1 writes the k-major layout bank[ci*k*k + d][c*R + r]
- * that tvae_conv1_fwd's barrier-free kernel reads (ask tvae_conv1_bank_layout which one a geometry wants).
- * bwd applies the transposed operator through a CSR table
+ * rotations (idx < 0 = outside, zero padding).  bwd applies the transposed operator through a CSR table
  * (csr_ptr [k*k+1], entries r / dst / w), writing (or accumulating into) dweight. */
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
-                         int ksz, int R, int transposed, tvae_stream_t stream);
+                         int ksz, int R, tvae_stream_t stream);
 int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_r, const int* csr_dst,
                          const float* csr_w, float* dweight, int C, int Cin, int ksz, int R, int accumulate,
                          tvae_stream_t stream);
@@ -41,9 +39,8 @@ int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_
 /* ---- lifting convolution: GroupConv.forward, src/models.py:202-225 (F.conv2d + bias) fused with the following
  * activation (models.py:355).  y [B][Cin][n][n]; bank [C*R][Cin*k*k]; bias [C] (may be NULL);
  * out feature-major [C][B][R][Ho*Ho] (ld = B*R*Ho*Ho), Ho = n + 2*pad - k + 1, stride 1. */
-int tvae_conv1_bank_layout(int Cin, int n, int ksz, int pad, int C, int R);   /* 1: k-major bank preferred, else 0 */
 int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
-                   int pad, int C, int R, int act, float slope, int bank_transposed, tvae_stream_t stream);
+                   int pad, int C, int R, int act, float slope, tvae_stream_t stream);
 /* weight gradient of the same convolution (autograd of F.conv2d, models.py:215): dbank [C*R][Cin*k*k] =
  * sum over (img, position) of dpre[c][img][r][p] * window(y).  dpre is the PRE-activation gradient in the layout
  * of `out`.  ws: split-K workspace of ws_floats floats (>= 2*C*R*Cin*k*k recommended; fewer disables split-K). */

@@ -39,11 +39,7 @@ bias = torch.randn(C, device=dev)
 A1 = torch.empty(C, N, device=dev)
 ws = torch.empty(1 << 26, device=dev)
 fl_conv = 2.0 * C * R * Cin * k * k * P * B
-timeit('conv1_fwd (staged A, wide=%s)' % os.environ.get('TVAE_CONV1_WIDE', '1'), fl_conv, lambda: call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01, 0))
-bankT = bank.t().contiguous()
-from tvae._lib import lib
-if lib().tvae_conv1_bank_layout(Cin, n, k, pad, C, R):
-    timeit('conv1_fwd (barrier-free)', fl_conv, lambda: call('tvae_conv1_fwd', y, bankT, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01, 1))
+timeit('conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01))
 dA1 = torch.randn(C, N, device=dev)
 dbank = torch.empty_like(bank)
 timeit('conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R))

@@ -34,12 +34,6 @@ static inline int conv_wgrad_img_rows(int Cin, int n, int ksz, int pad, int nh =
     const int rows = (BN * nh - 1) / ksz + 2 + Ho - 1;
     return rows < Hp ? rows : Hp;
 }
-static inline size_t conv_nb_lds_bytes(int Cin, int rows, int n, int pad) {
-    const int Wp = n + 2 * pad + 1;
-    long tot = (long)Cin * rows * Wp;
-    if (tot < 64 * 128) tot = 64 * 128;
-    return (size_t)tot * sizeof(float);
-}
 static inline size_t conv_img_lds_bytes(int Cin, int rows, int n, int pad, int mh = 1, int kb = BK) {
     const int Wp = n + 2 * pad + 1;
     long tot = 2 * kb * (mh * 128 + 4) + 2 * kb + (long)Cin * rows * Wp;
@@ -243,115 +237,6 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Forward, barrier-free variant (ksz % 16 == 0, M % 128 == 0): the bank is stored k-major, bankT[k][c*R + r], so
-// the A fragment of v_mfma_f32_32x32x2_f32 (lane l: row l&31, k = l>>5) is a 128-B coalesced global load per lane
-// half.  Every wave prefetches the 16 A registers of the NEXT k-step while it multiplies the current one; B fragments
-// come from the read-only LDS image with a per-lane base + scalar tap offset + immediate.  Nothing is staged through
-// LDS inside the k-loop, so there is no barrier between the image load and the epilogue: the 16 waves of a CU run
-// independent MFMA streams.  A 16-tap k-step never crosses a tap row (ksz % 16 == 0), so the tap offset is scalar.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 4)
-void conv1_fwd_nb_kernel(const float* __restrict__ bankT, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
-                         int tilesPerImg, int rows) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* img = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int Hp = g.n + 2 * g.pad, Wp = Hp + 1;
-    const int per_m = g.B * tilesPerImg;
-    const int tile_m = blockIdx.x / per_m;
-    const int rest = blockIdx.x - tile_m * per_m;
-    const int b = rest / tilesPerImg;
-    const int p0 = (rest - b * tilesPerImg) * BN;
-    const int m0 = tile_m * BM;
-    const int hmin = p0 / g.Ho;
-    const int plast = min(g.P - 1, p0 + BN - 1);
-    const int hmax = plast / g.Ho;
-    // zero skipping: tap rows that can meet the image for output rows [hmin, hmax]
-    const int ulo = max(0, g.pad - hmax);
-    const int uhi = min(g.ksz - 1, g.pad + g.n - 1 - hmin);
-    const int steps_per_row = g.ksz / BK;
-    const int nrow = max(0, uhi - ulo + 1);
-    const int nk_ci = nrow * steps_per_row;          // k-steps per input channel
-    const int nk = nk_ci * g.Cin;
-
-    load_padded_image(img, y, b, g, hmin, rows, Wp);
-
-    const int khalf = lane >> 5;
-    int boff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int p = p0 + wn * 64 + j * 32 + (lane & 31);
-        if (p >= g.P) p = g.P - 1;
-        const int h = p / g.Ho, w = p - h * g.Ho;
-        boff[j] = (h - hmin) * Wp + w + khalf;     // + k parity of this lane half
-    }
-    const float* abase = bankT + (long)khalf * M + m0 + wm * 64 + (lane & 31);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // k-step cursor (wave-uniform, advanced incrementally): vb = 16-tap block in the tap row, ur = tap row, ci
-    struct Cur { int vb, ur, ci; };
-    auto advance = [&](Cur& c) {
-        if (++c.vb == steps_per_row) { c.vb = 0; if (++c.ur == nrow) { c.ur = 0; ++c.ci; } }
-    };
-    auto load_a = [&](float (&a)[BK / 2][2], const Cur& c) {
-        const float* p = abase + (long)((c.ci * g.ksz + ulo + c.ur) * g.ksz + c.vb * BK) * M;
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            a[s][0] = p[(long)(2 * s) * M];
-            a[s][1] = p[(long)(2 * s) * M + 32];
-        }
-    };
-    auto compute = [&](const float (&a)[BK / 2][2], const Cur& c) {
-        const int kb = (c.ci * rows + ulo + c.ur) * Wp + c.vb * BK;
-        const float* i0 = img + boff[0] + kb;
-        const float* i1 = img + boff[1] + kb;
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const float b0 = i0[2 * s];
-            const float b1 = i1[2 * s];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b1, acc[1][1], 0, 0, 0);
-        }
-    };
-
-    // Two register sets, each reloaded right after it has been consumed: while set X is multiplied, the loads of
-    // the other set (issued one whole k-step earlier) are already complete and X's reload has a k-step to land.
-    // Reloads are UNCONDITIONAL (the cursor just stops at the last step), so that the compiler's vmcnt scoreboard is
-    // exact: at every compute() exactly 16 newer loads are in flight and the wait is vmcnt(16 + ...), never vmcnt(0).
-    float A0[BK / 2][2], A1[BK / 2][2];
-    Cur c0{0, 0, 0}, c1{0, 0, 0}, cl{0, 0, 0};       // cursors of A0, A1 and of the next step to load
-    int tl = 0;
-    auto next_load = [&](float (&a)[BK / 2][2], Cur& cdst) {
-        load_a(a, cl);
-        cdst = cl;
-        if (tl + 1 < nk) advance(cl);
-        ++tl;
-    };
-    next_load(A0, c0);
-    next_load(A1, c1);
-    __syncthreads();                                  // image resident
-    for (int t = 0; t < nk; t += 2) {
-        compute(A0, c0);
-        next_load(A0, c0);
-        if (t + 1 < nk) compute(A1, c1);
-        next_load(A1, c1);
-    }
-    __syncthreads();                                  // all waves done with the image before it is reused as staging
-    const int p = p0 + (tid & 127);
-    tile_epilogue(acc, smem, ep, m0, M, b * g.P + p, p < g.P, nullptr, 0, g.B * g.P);
-}
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient:  dbank[cr][n = (ci,u,v)] = sum_{img, p} dY[cr][img, p] * patch(n, p)

@@ -427,6 +427,175 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
     tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, ws, split, N);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the aligned fast path: the B operand X[k][n] (n contiguous) is staged with
+// global_load_lds_dwordx4 (16 B per lane straight into LDS: no VGPR round trip, no ds_write, no address VALU in
+// the loop) into an UNPADDED [BK][128] tile -- the DMA destination is wave-uniform base + lane*16, i.e. lane-linear,
+// and the k-major unpadded tile is already conflict-free for the fragment reads (32 consecutive columns per
+// half-wave).  One wave instruction moves 2 k-rows x 128 columns; 4 waves x 2 instructions cover the tile.
+// The A operand keeps the register-staged loader (weights are k-contiguous and must be transposed on the way in).
+// ------------------------------------------------------------------------------------------
+template <class AL>
+__global__ __launch_bounds__(GEMM_THREADS, 4)
+void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue ep, int M, int N, int K, int tilesN) {
+    constexpr int AT = BK * LDS_LD, BT = BK * BN;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AT + BT) > 64 * 128 ? 2 * (AT + BT) : 64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane DMA source: chunk c = i*4 + wave covers k rows 2c, 2c+1 of the tile; lane -> (row 2c + lane>>5, col (lane&31)*4)
+    const float* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * 4 + wave;
+        bsrc[i] = X + (long)(2 * c + (lane >> 5)) * ldx + n0 + (lane & 31) * 4;
+    }
+    auto dma_b = [&](float* Bs) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* dst = Bs + (i * 4 + wave) * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc[i],
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            bsrc[i] += (long)BK * ldx;
+        }
+    };
+    al.begin(m0, tid, 0, K);
+    if (nk > 0) {
+        dma_b(lds + AT);
+        al.fetch();
+        al.commit(lds);
+    }
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31);
+    const int bcol = wn * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1) < nk;
+        float* nxt = lds + (cur ^ 1) * (AT + BT);
+        if (more) {
+            dma_b(nxt + AT);
+            al.fetch();
+        }
+        const float* as = lds + cur * (AT + BT);
+        const float* bs = as + AT;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + khalf;
+            const float a0 = as[kk * LDS_LD + arow];
+            const float a1 = as[kk * LDS_LD + arow + 32];
+            const float b0 = bs[kk * BN + bcol];
+            const float b1 = bs[kk * BN + bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) al.commit(nxt);
+        __syncthreads();
+    }
+    tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
+}
+
+
+// Both operands by LDS-DMA: A(row x, red k) at At[k*lda + x] (x contiguous: W^T for forward, W itself for dgrad),
+// B(k, n) at X[k*ldx + n].  No register staging at all: per k-step a wave issues 4 DMA instructions, reads 32
+// fragments and issues 32 MFMAs.  Both LDS tiles are unpadded [BK][128].
+__global__ __launch_bounds__(GEMM_THREADS, 4)
+void gemm_f32_glds2_kernel(const float* __restrict__ At, long lda, const float* __restrict__ X, long ldx, Epilogue ep,
+                           int M, int N, int K, int tilesN) {
+    constexpr int TT = BK * BN;                      // one operand tile (floats)
+    __shared__ __attribute__((aligned(16))) float lds[4 * TT > 64 * 128 ? 4 * TT : 64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* asrc[2];
+    const float* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * 4 + wave;                  // chunk c = k rows 2c, 2c+1 of a tile
+        asrc[i] = At + (long)(2 * c + (lane >> 5)) * lda + m0 + (lane & 31) * 4;
+        bsrc[i] = X + (long)(2 * c + (lane >> 5)) * ldx + n0 + (lane & 31) * 4;
+    }
+    auto dma = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 4 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc[i],
+                                             (__attribute__((address_space(3))) void*)(buf + c * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc[i],
+                                             (__attribute__((address_space(3))) void*)(buf + TT + c * 256), 16, 0, 0);
+            asrc[i] += (long)BK * lda;
+            bsrc[i] += (long)BK * ldx;
+        }
+    };
+    if (nk > 0) dma(lds);
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31);
+    const int bcol = wn * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) dma(lds + (cur ^ 1) * (2 * TT));
+        const float* as = lds + cur * (2 * TT);
+        const float* bs = as + TT;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + khalf;
+            const float a0 = as[kk * BN + arow];
+            const float a1 = as[kk * BN + arow + 32];
+            const float b0 = bs[kk * BN + bcol];
+            const float b1 = bs[kk * BN + bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
+}
+
+// out[c][r] = in[r][c]   (small weight transposes feeding the DMA forward GEMM)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) t[j][threadIdx.x] = in[(long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(long)c * rows + r] = t[threadIdx.x][j];
+    }
+}
+
 __global__ void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
     const long total = (long)M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

@@ -93,30 +93,6 @@ __global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const i
     }
 }
 
-// Same bank in k-major layout bankT[(ci*k2 + d)][c*R + r] (A operand of the barrier-free forward convolution).
-__global__ void rotate_bank_fwd_t_kernel(const float* __restrict__ weight, const int* __restrict__ tap_idx,
-                                         const float* __restrict__ tap_w, float* __restrict__ bankT, int C, int Cin,
-                                         int k2, int R) {
-    const int CR = C * R;
-    const long total = (long)CR * Cin * k2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cr = (int)(i % CR);
-        const int k = (int)(i / CR);
-        const int c = cr / R, r = cr - c * R;
-        const int ci = k / k2, d = k - ci * k2;
-        const float* wsrc = weight + ((long)c * Cin + ci) * k2;
-        const int* ti = tap_idx + ((long)r * k2 + d) * 4;
-        const float* tw = tap_w + ((long)r * k2 + d) * 4;
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int id = ti[q];
-            if (id >= 0) s += tw[q] * wsrc[id];
-        }
-        bankT[i] = s;
-    }
-}
-
 // Transposed operator in gather (CSR) form: deterministic, no atomics.
 // dweight[(c*Cin+ci)*k2 + s] = sum_{e in [ptr[s],ptr[s+1])} w[e] * dbank[(c*R + r[e])][ci*k2 + dst[e]]
 __global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const int* __restrict__ csr_ptr,

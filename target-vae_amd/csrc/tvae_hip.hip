@@ -19,6 +19,11 @@ using namespace tvae;
 
 static inline hipStream_t S(tvae_stream_t s) { return (hipStream_t)s; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+// LDS-DMA (global_load_lds) staging of the aligned dense GEMMs; TVAE_GLDS=0 falls back to register staging
+static inline bool use_glds() {
+    static const bool on = [] { const char* e = getenv("TVAE_GLDS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static inline int grid1d(long total, int block, int cap = 8192) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -59,26 +64,10 @@ int tvae_set_gemm_mode(int mode) {
 int tvae_get_gemm_mode(void) { return g_gemm_mode; }
 
 // 1 if tvae_conv1_fwd wants the k-major bank bankT[Cin*k*k][C*R] (barrier-free kernel), 0 for bank[C*R][Cin*k*k]
-int tvae_conv1_bank_layout(int Cin, int n, int ksz, int pad, int C, int R) {
-    // The barrier-free kernel on the k-major bank measured 7 % slower than the LDS-staged one at cfg4 (MFMA pipe 72 % vs
-    // 77 % busy, profiles/r01_c_conv_fwd_variants.txt); it stays selectable for experiments with TVAE_CONV1_KMAJOR=1.
-    static const bool enabled = [] { const char* e = getenv("TVAE_CONV1_KMAJOR"); return e && e[0] == '1'; }();
-    if (!enabled || g_gemm_mode != 0) return 0;
-    if (ksz % BK != 0 || (C * R) % BM != 0) return 0;
-    const int rows = conv_fwd_img_rows(n, ksz, pad);
-    return conv_nb_lds_bytes(Cin, rows, n, pad) <= CONV_IMG_LDS_MAX ? 1 : 0;
-}
-
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
-                         int ksz, int R, int transposed, tvae_stream_t stream) {
+                         int ksz, int R, tvae_stream_t stream) {
     const int k2 = ksz * ksz;
     const long total = (long)C * R * Cin * k2;
-    if (transposed) {
-        hipLaunchKernelGGL(rotate_bank_fwd_t_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight,
-                           tap_idx, tap_w, bank, C, Cin, k2, R);
-        TVAE_CHECK_LAUNCH();
-        return 0;
-    }
     hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight, tap_idx,
                        tap_w, bank, C, Cin, k2, R);
     TVAE_CHECK_LAUNCH();
@@ -106,7 +95,7 @@ static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
 }
 
 int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
-                   int pad, int C, int R, int act, float slope, int bank_transposed, tvae_stream_t stream) {
+                   int pad, int C, int R, int act, float slope, tvae_stream_t stream) {
     const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const int M = C * R, N = B * g.P, K = Cin * g.K2;
@@ -117,20 +106,6 @@ int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* 
     ep.bias = bias; ep.bias_shift = sh;
     ep.act = act; ep.slope = slope;
     ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
-    if (bank_transposed) {
-        if (!tvae_conv1_bank_layout(Cin, n, ksz, pad, C, R)) return (int)hipErrorInvalidValue;
-        const int rows_nb = conv_fwd_img_rows(n, ksz, pad);
-        const size_t lds_nb = conv_nb_lds_bytes(Cin, rows_nb, n, pad);
-        const int tilesPerImg = cdiv(g.P, BN);
-        const long nblk = (long)(M / BM) * B * tilesPerImg;
-        if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
-        hipError_t e = allow_big_lds(conv1_fwd_nb_kernel, lds_nb);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(conv1_fwd_nb_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), lds_nb, S(stream), bank, y, g,
-                           ep, M, tilesPerImg, rows_nb);
-        TVAE_CHECK_LAUNCH();
-        return 0;
-    }
     if (g_gemm_mode == 1) {
         LoadKContig8 al8{bank, (long)K, M};
         LoadConvPatchFwd bl8{y, g, N};
@@ -300,6 +275,13 @@ int tvae_linear_fwd(const float* W, const float* X, const float* bias, const flo
     }
     if (M % BM == 0 && N % BN == 0 && K % BK == 0 && ldx % 4 == 0 && aligned16(W) && aligned16(X)) {
         LoadKContigV4 af{W, (long)K, M};
+        if (use_glds()) {
+            const int tilesN = N / BN;
+            hipLaunchKernelGGL((gemm_f32_glds_kernel<LoadKContigV4>), dim3((unsigned)((M / BM) * tilesN)),
+                               dim3(GEMM_THREADS), 0, S(stream), af, X, ldx, ep, M, N, K, tilesN);
+            TVAE_CHECK_LAUNCH();
+            return 0;
+        }
         LoadXContigV4 bf{X, ldx, N};
         return (int)launch_gemm(af, bf, ep, M, N, K, 1, nullptr, 0, S(stream));
     }
@@ -317,6 +299,14 @@ int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const
     ep.aux = aux; ep.ldaux = ldx;
     ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
     if (g_gemm_mode == 1) return (int)launch_gemm_bf16x3(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
+    if (use_glds() && K % BM == 0 && N % BN == 0 && M % BK == 0 && ldd % 4 == 0 && aligned16(W) && aligned16(dpre)) {
+        // both operands are row-contiguous along their tile dimension: A(kout, m) = W[m][kout], B = dpre[m][n]
+        const int tilesN = N / BN;
+        hipLaunchKernelGGL(gemm_f32_glds2_kernel, dim3((unsigned)((K / BM) * tilesN)), dim3(GEMM_THREADS), 0, S(stream),
+                           W, (long)K, dpre, ldd, ep, K, N, M, tilesN);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     if (K % BM == 0 && N % BN == 0 && M % BK == 0 && ldd % 4 == 0 && K % 4 == 0 && aligned16(W) && aligned16(dpre)) {
         LoadXContigV4 af{W, (long)K, K};
         LoadXContigV4 bf{dpre, ldd, N};

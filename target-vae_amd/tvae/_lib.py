@@ -16,9 +16,9 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libtvae_hip.so
 # signature codes: p = device pointer (tensor or None), i = int, l = long, f = float; the trailing
 # stream argument is appended automatically (torch.cuda.current_stream()).
 SIGNATURES = {
-    'tvae_rotate_bank_fwd': 'ppppiiiii',
+    'tvae_rotate_bank_fwd': 'ppppiiii',
     'tvae_rotate_bank_bwd': 'ppppppiiiii',
-    'tvae_conv1_fwd': 'ppppiiiiiiiifi',
+    'tvae_conv1_fwd': 'ppppiiiiiiiif',
     'tvae_conv1_wgrad': 'ppppl iiiiiii'.replace(' ', ''),
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
@@ -71,8 +71,6 @@ def lib():
         L.tvae_set_gemm_mode.restype = ctypes.c_int
         L.tvae_set_gemm_mode.argtypes = [ctypes.c_int]
         L.tvae_get_gemm_mode.restype = ctypes.c_int
-        L.tvae_conv1_bank_layout.restype = ctypes.c_int
-        L.tvae_conv1_bank_layout.argtypes = [ctypes.c_int] * 6
         _lib = L
         mode = os.environ.get('TVAE_GEMM', DEFAULT_GEMM_MODE)
         set_gemm_mode(mode)
@@ -98,7 +96,7 @@ def get_gemm_mode() -> str:
 
 
 def exported_symbols():
-    return ['tvae_abi_version', 'tvae_conv1_bank_layout', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES)
+    return ['tvae_abi_version', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES)
 
 
 def _ptr(t, name, pos):

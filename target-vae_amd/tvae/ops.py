@@ -126,22 +126,15 @@ def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # rotated bank + lifting convolution
 # ---------------------------------------------------------------------------------------------
-def rotate_bank(weight: torch.Tensor, R: int, transposed: bool = False) -> torch.Tensor:
-    """GroupConv.trans_filter (src/models.py:174-197): (C,Cin,1,k,k) -> bank [C*R][Cin*k*k]
-    (or the k-major bank [Cin*k*k][C*R] consumed by the barrier-free forward convolution)."""
+def rotate_bank(weight: torch.Tensor, R: int) -> torch.Tensor:
+    """GroupConv.trans_filter (src/models.py:174-197): (C,Cin,1,k,k) -> bank [C*R][Cin*k*k]."""
     C, Cin, D, k, _ = weight.shape
     if D != 1:
         raise NotImplementedError('input_rot_dim != 1 is never used by the reference (models.py:290,346)')
     idx, w = tap_tables(k, R, weight.device)
-    shape = (Cin * k * k, C * R) if transposed else (C * R, Cin * k * k)
-    bank = torch.empty(*shape, dtype=torch.float32, device=weight.device)
-    call('tvae_rotate_bank_fwd', weight.contiguous(), idx, w, bank, C, Cin, k, R, int(transposed))
+    bank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=weight.device)
+    call('tvae_rotate_bank_fwd', weight.contiguous(), idx, w, bank, C, Cin, k, R)
     return bank
-
-
-def conv1_wants_transposed_bank(Cin, n, k, pad, C, R) -> bool:
-    from ._lib import lib
-    return bool(lib().tvae_conv1_bank_layout(Cin, n, k, pad, C, R))
 
 
 def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> torch.Tensor:
@@ -152,14 +145,13 @@ def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> to
 
 
 def conv1_forward(y, weight, bias, C, R, k, pad, act):
-    """Rotated bank (in the layout the geometry's kernel prefers) + lifting convolution."""
+    """Rotated bank + lifting convolution."""
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
-    tr = conv1_wants_transposed_bank(Cin, n, k, pad, C, R)
-    bank = rotate_bank(weight, R, transposed=tr)
+    bank = rotate_bank(weight, R)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
     with _timed('tvae_conv1_fwd'):
-        call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE, int(tr))
+        call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
     return out
 
 

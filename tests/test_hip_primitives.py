@@ -53,7 +53,8 @@ def dact_ref(y, act):
 
 @pytest.mark.parametrize('M,N,K,act,use_g,use_res', [
     (128, 8712, 128, 1, False, False), (7, 300, 128, 0, False, False), (512, 1000, 1024, 1, True, False),
-    (64, 517, 64, 1, False, True), (130, 129, 17, 2, True, True), (103, 2000, 128, 0, False, False)])
+    (64, 517, 64, 1, False, True), (130, 129, 17, 2, True, True), (103, 2000, 128, 0, False, False),
+    (128, 1024, 128, 1, True, True), (256, 512, 64, 0, False, False), (512, 2048, 512, 1, True, False)])
 def test_linear_fwd(M, N, K, act, use_g, use_res, gemm_mode):
     W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
     group = 100
@@ -74,7 +75,8 @@ def test_linear_fwd(M, N, K, act, use_g, use_res, gemm_mode):
 
 @pytest.mark.parametrize('M,N,K,mask,use_add', [(7, 3000, 128, 1, False), (128, 1111, 128, 1, False),
                                                 (64, 300, 64, 1, True), (512, 700, 1024, 0, False),
-                                                (33, 257, 65, 2, True)])
+                                                (33, 257, 65, 2, True), (128, 1024, 128, 1, True), (64, 512, 256, 1, False),
+                                                (512, 1024, 512, 0, False)])
 def test_linear_dgrad(M, N, K, mask, use_add, gemm_mode):
     W, d = rnd(M, K, seed=1, scale=M ** -0.5), rnd(M, N, seed=2)
     aux = rnd(K, N, seed=3).clamp(-0.9, 0.9)
@@ -90,7 +92,7 @@ def test_linear_dgrad(M, N, K, mask, use_add, gemm_mode):
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(7, 50000, 128, 0), (128, 8712 * 3, 128, 0), (64, 1000, 2, 1),
-                                       (512, 20000, 512, 0), (130, 777, 1024, 0)])
+                                       (512, 20000, 512, 0), (130, 777, 1024, 0), (128, 8192, 128, 0), (256, 4096, 512, 1)])
 def test_linear_wgrad(M, N, K, acc, gemm_mode):
     d, X = rnd(M, N, seed=1), rnd(K, N, seed=2)
     init = rnd(M, K, seed=3)
@@ -137,15 +139,9 @@ def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act, gemm_mode):
         + bias.double().view(1, C, 1, 1, 1)
     ref = act_ref(ref, act)
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
-    call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE, 0)
+    call('tvae_conv1_fwd', y.to(dev()), bank.to(dev()), bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE)
     got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
     assert rel_err(got, ref) < GEMM_TOL[gemm_mode]
-    from tvae._lib import lib
-    if lib().tvae_conv1_bank_layout(Cin, n, k, pad, C, R):      # barrier-free kernel on the k-major bank
-        out2 = torch.empty_like(out)
-        call('tvae_conv1_fwd', y.to(dev()), bank.t().contiguous().to(dev()), bias.to(dev()), out2, B, Cin, n, k, pad,
-             C, R, act, SLOPE, 1)
-        assert rel_err(out2.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4), ref) < GEMM_TOL[gemm_mode]
     # weight gradient
     g = rnd(B, C, R, Ho, Ho, seed=4)
     ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
