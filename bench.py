@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
-KERNEL_OF = {'tvae_conv1_fwd': 'conv1_fwd_img_kernel<true,2>', 'tvae_conv1_wgrad': 'conv1_wgrad_img_kernel<1,32>'}
+KERNEL_OF = {'tvae_conv1_fwd': 'conv1_fwd_img_kernel<true,2>', 'tvae_conv1_wgrad': 'conv1_wgrad_img_kernel<1,32,2>'}
 
 
 def pmc_traffic(entry):
@@ -41,6 +41,18 @@ def pmc_traffic(entry):
     except Exception:
         return None
 CFG = dict(n=64, cin=1, zd=2, C=128, k=64, pad=16, R=8, hidden=512, layers=2, n_out=1)
+# optional extra workloads (BASELINE.json configs[1], configs[2]); the default S64 is the metric's configuration
+WORKLOADS = {
+    'S64': dict(CFG, fourier=False, lik='gauss', data='randn',
+                desc='S64: synthetic 64x64 particle stack (torch.randn), P8 group-conv encoder k=64 p=16 C=128, z=2, '
+                     't-inf attention, r-inf attention+offsets, decoder 2->512->512->1, Gaussian likelihood, Adam lr 2e-4'),
+    'S28': dict(n=28, cin=1, zd=2, C=128, k=28, pad=8, R=8, hidden=512, layers=2, n_out=1, fourier=False, lik='bce',
+                data='rand', desc='S28: synthetic 28x28 MNIST-shape stack (torch.rand), P8 k=28 p=8 C=128, z=2, '
+                                  'decoder 2->512->512->1, BCE likelihood'),
+    'S28F': dict(n=28, cin=1, zd=2, C=128, k=28, pad=8, R=16, hidden=512, layers=2, n_out=1, fourier=True, lik='bce',
+                 data='rand', desc='S28F: synthetic 28x28, P16 k=28 p=8 C=128, z=2, Fourier decoder '
+                                   'cos1024->512->512->1, BCE likelihood'),
+}
 
 
 def conv1_flops_per_image(c=CFG):
@@ -49,11 +61,12 @@ def conv1_flops_per_image(c=CFG):
     return 2.0 * c['C'] * c['R'] * c['cin'] * c['k'] ** 2 * ho ** 2
 
 
-def build_models(device):
+def build_models(device, c=None):
     import src.models as M
     torch.manual_seed(0)            # reference default init; generator constructed first (train_mnist.py:522,551)
-    c = CFG
-    gen = M.SpatialGenerator(c['zd'], c['hidden'], n_out=c['n_out'], num_layers=c['layers'])
+    c = c or WORKLOADS['S64']
+    gen = M.SpatialGenerator(c['zd'], c['hidden'], n_out=c['n_out'], num_layers=c['layers'],
+                             fourier_expansion=c.get('fourier', False), sigma=2.0 / (c['n'] - 1))
     enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
         c['n'], c['cin'], c['zd'], kernels_num=c['C'], kernels_size=c['k'], padding=c['pad'], groupconv=c['R'],
         rot_refinement=True, theta_prior=np.pi, normal_prior_over_r=False)
@@ -103,6 +116,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step (BASELINE: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='S64',
+                    help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
     args = ap.parse_args()
 
     from tvae import dp, ops, optim, step
@@ -114,27 +129,29 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    gen, enc = build_models(dev)
+    wl = WORKLOADS[args.workload]
+    gen, enc = build_models(dev, wl)
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
     opt = optim.FlatAdam(params, lr=2e-4, reducer=reducer)
     if world > 1:                                   # identical replicas: broadcast rank 0's flat parameters
         dist.broadcast(opt.flat_p, src=0)
 
-    B, c = args.batch, CFG
+    B, c = args.batch, wl
     total_steps = args.steps + args.warmup
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     # synthetic dataset resident in HBM: torch.randn matches --normalize'd particles (SURVEY 8d "S64")
     n_img = B * min(total_steps, 8)
-    data = torch.randn(n_img, c['cin'], c['n'], c['n'], device=dev, generator=g)
+    mk = torch.randn if c['data'] == 'randn' else torch.rand
+    data = mk(n_img, c['cin'], c['n'], c['n'], device=dev, generator=g)
     x = torch.from_numpy(__import__('tvae.tables', fromlist=['x']).image_coords(c['n'])).to(dev)
     step.pixel_spacing(x)                           # cached once (the reference syncs for it every step)
 
     def one_step(i):
         lo = (i % (n_img // B)) * B
         y = data[lo:lo + B]
-        elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, 'gauss')
+        elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, c['lik'])
         (-elbo).backward()
         opt.step()
         opt.zero_grad()
@@ -165,30 +182,30 @@ def main():
 
     if rank == 0:
         imgs = world * B * args.steps
-        flops = conv1_flops_per_image() * B
+        flops = conv1_flops_per_image(c) * B
         dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
         ach = flops / (kev[dom]['mean_ms'] * 1e-3) / 1e12
         other = 'tvae_conv1_wgrad' if dom == 'tvae_conv1_fwd' else 'tvae_conv1_fwd'
         out = {
-            'metric': 'training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU',
+            'metric': 'training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU' if args.workload == 'S64' else
+                      'training images/sec (fwd+bwd+Adam), extra workload ' + args.workload,
             'value': imgs / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'elbo': elbo_last,
-            'config': {'workload': 'S64: synthetic 64x64 particle stack (torch.randn), P8 group-conv encoder '
-                                   'k=64 p=16 C=128, z=2, t-inf attention, r-inf attention+offsets, decoder '
-                                   '2->512->512->1, Gaussian likelihood, Adam lr 2e-4',
+            'config': {'workload': c['desc'],
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}'},
             'roofline': {'kernel': dom + ' (' + KERNEL_OF[dom] + ', v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom),
+                         'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': pmc_traffic(dom) if args.workload == 'S64' else None,
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
                          'other': {'kernel': other, 'mean_launch_ms': kev.get(other, {}).get('mean_ms'),
                                    'achieved': (flops / (kev[other]['mean_ms'] * 1e-3) / 1e12) if other in kev
                                    else None}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'S64':
             out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None

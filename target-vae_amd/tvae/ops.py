@@ -19,6 +19,13 @@ ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 LRELU_SLOPE = 0.01
 
 
+def _expect(cond: bool, what: str) -> None:
+    """Operand shapes are validated on the host before any launch: a kernel must never see a buffer smaller than
+    its grid assumes (an out-of-bounds access can reset the GPU)."""
+    if not cond:
+        raise ValueError('tvae.ops: ' + what)
+
+
 def act_code(activation) -> int:
     """Map an nn activation class/instance (reference ctor argument `activation`) to the kernel code."""
     import torch.nn as nn
@@ -215,11 +222,17 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, w1, b1, W2, b2, Wh, bh, R, pad, act):
         C, Cin, _, k, _ = w1.shape
+        _expect(y.numel() == y.shape[0] * Cin * y.shape[-1] * y.shape[-2] and y.shape[-1] == y.shape[-2],
+                f'encoder input {tuple(y.shape)} is not (B, {Cin}, n, n)')
         y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
         B, n = y.shape[0], y.shape[-1]
         Ho = n + 2 * pad - k + 1
+        _expect(Ho >= 1, f'kernel {k} with padding {pad} does not fit a {n}x{n} image')
+        _expect(R in (4, 8, 16), f'groupconv must be 4, 8 or 16 (got {R})')
         N = B * R * Ho * Ho
         C2, nh = W2.shape[0], Wh.shape[0]
+        _expect(tuple(W2.shape) == (C2, C) and tuple(Wh.shape) == (nh, C2) and b1.numel() == C and
+                b2.numel() == C2 and bh.numel() == nh, 'encoder parameter shapes are inconsistent')
         A1 = conv1_forward(y, w1, b1, C, R, k, pad, act)
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
@@ -281,6 +294,8 @@ class HeadFn(torch.autograd.Function):
     def forward(ctx, heads, E, eps_z, eps_t, tb: HeadTables, B, zd):
         RP = tb.R * tb.P
         dev = heads.device
+        _expect(tuple(heads.shape) == (3 + 2 * zd, B * RP), f'heads {tuple(heads.shape)} != ({3 + 2 * zd}, {B * RP})')
+        _expect(E.numel() == B * RP and eps_z.numel() == B * zd and eps_t.numel() == B, 'noise shapes do not match')
         attn = torch.empty(B, RP, dtype=torch.float32, device=dev)
         q = torch.empty_like(attn)
         a = torch.empty_like(attn)
@@ -322,6 +337,7 @@ class CoordFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xc, dx, theta):
         B, Np = theta.shape[0], xc.shape[0]
+        _expect(tuple(xc.shape) == (Np, 2) and tuple(dx.shape) == (B, 2) and theta.dim() == 1, 'coordinate shapes')
         xc, dx, theta = xc.contiguous(), dx.contiguous(), theta.contiguous()
         xr = torch.empty(B, Np, 2, dtype=torch.float32, device=xc.device)
         call('tvae_coord_fwd', xc, dx, theta, xr, B, Np)
@@ -351,9 +367,14 @@ class DecoderFn(torch.autograd.Function):
         Wo, bo = params[3 + 2 * n_hidden], params[4 + 2 * n_hidden]
         Wf, bf = params[5 + 2 * n_hidden], params[6 + 2 * n_hidden]
         xr = xr.contiguous()
+        _expect(xr.dim() == 3 and xr.shape[2] == 2, f'decoder coordinates {tuple(xr.shape)} are not (B, N, 2)')
         B, Np = xr.shape[0], xr.shape[1]
         Nt = B * Np
         F_, n_out = Wc.shape[0], Wo.shape[0]
+        _expect(1 <= n_out <= 4, f'n_out = {n_out} (the skinny output kernels handle 1..4)')
+        _expect(Wc.shape[1] == (Wf.shape[0] if Wf is not None else 2) and Wo.shape[1] == F_ and
+                all(tuple(W.shape) == (F_, F_) for W, _ in hidden), 'decoder parameter shapes are inconsistent')
+        _expect(Wl is None or (z is not None and tuple(z.shape) == (B, Wl.shape[1])), 'latent z does not match latent_linear')
         dev = xr.device
         LB = None
         if Wl is not None:
@@ -491,6 +512,8 @@ class CtfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y_mu, ctf, n):
         B, kc = ctf.shape[0], ctf.shape[-1]
+        _expect(kc % 2 == 1 and ctf.numel() == B * kc * kc and y_mu.numel() == B * n * n,
+                f'CTF filters {tuple(ctf.shape)} / reconstruction {tuple(y_mu.shape)} do not match n = {n}')
         y_mu = y_mu.contiguous()
         ctf = ctf.contiguous()
         out = torch.empty_like(y_mu)
@@ -517,6 +540,7 @@ class MaskedLogLikFn(torch.autograd.Function):
     def forward(ctx, yh, y, dx, spacing, radius, n):
         B = y.shape[0]
         ctx.shape = tuple(yh.shape)
+        _expect(yh.numel() == B * n * n and y.numel() == B * n * n and tuple(dx.shape) == (B, 2), 'masked likelihood shapes')
         yh = yh.contiguous().view(B, -1)
         y = y.contiguous().view(B, -1)
         dx = dx.detach().contiguous()

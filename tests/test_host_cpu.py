@@ -259,3 +259,17 @@ def test_mrc_codec_against_reference_written_files(tmp_path):
     parts = [mrc.read_shard(os.path.join(gdir, 'stack_ref.mrcs'), r, 2) for r in range(2)]
     assert np.array_equal(np.concatenate([p[0] for p in parts]), fx['stack'])
     assert [p[1][:2] for p in parts] == [(0, 3), (3, 5)]
+
+
+def test_shape_validation_happens_before_any_launch():
+    """Mis-shaped operands raise on the host (ValueError) without touching the GPU library."""
+    from tvae import ops
+    with pytest.raises(ValueError):
+        ops.EncoderFn.apply(torch.zeros(2, 1, 8, 9), torch.zeros(4, 1, 1, 5, 5), torch.zeros(4), torch.zeros(4, 4),
+                            torch.zeros(4), torch.zeros(7, 4), torch.zeros(7), 8, 1, 1)
+    with pytest.raises(ValueError):
+        ops.EncoderFn.apply(torch.zeros(2, 1, 8, 8), torch.zeros(4, 1, 1, 5, 5), torch.zeros(4), torch.zeros(4, 4),
+                            torch.zeros(4), torch.zeros(7, 4), torch.zeros(7), 5, 1, 1)       # R not in {4,8,16}
+    tb = type('T', (), dict(R=4, P=9))()
+    with pytest.raises(ValueError):
+        ops.HeadFn.apply(torch.zeros(7, 10), torch.zeros(2, 36), torch.zeros(2, 2), torch.zeros(2), tb, 2, 2)
