@@ -53,9 +53,10 @@ timeit('conv2_wgrad', 2.0 * C * C * N, lambda: call('tvae_linear_wgrad', dA1, A1
 F_, Nt = 512, B * n * n
 h1 = torch.randn(F_, Nt, device=dev)
 h2 = torch.empty(F_, Nt, device=dev)
+h3 = torch.randn(F_, Nt, device=dev)          # distinct operands: sharing one tensor would halve the HBM traffic
 W = torch.randn(F_, F_, device=dev) * 0.05
 bb = torch.randn(F_, device=dev)
 timeit('dec_fwd 512x512', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd', W, h1, bb, None, 1, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
-timeit('dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad', W, h1, None, h1, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
+timeit('dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad', W, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
 dW = torch.empty(F_, F_, device=dev)
-timeit('dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad', h1, h1, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))
+timeit('dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))

@@ -98,14 +98,14 @@ struct LoadConvDY8 {
 
 template <class AL, class BL>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
-void gemm_bf16x3_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, int tilesN) {
+void gemm_bf16x3_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, TileMap tm) {
     // [buf 2][operand 2][part 2][k-octet 4][x 128] 16-B cells = 64 KiB
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * 2 * 2 * X3_CELLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    int tile_m, tile_n, split;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split)) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * kchunk;
     const int kend = min(K, kbeg + kchunk);
     const int nk = (kend - kbeg + BK3 - 1) / BK3;
@@ -194,10 +194,10 @@ static hipError_t launch_gemm_bf16x3(AL al, BL bl, const Epilogue& ep, int M, in
     }
     int kchunk = cdiv(cdiv(K > 0 ? K : 1, splits), BK3) * BK3;
     splits = cdiv(K > 0 ? K : 1, kchunk);
-    dim3 grid((unsigned)(tilesM * tilesN), (unsigned)splits);
+    const TileMap tm{tilesM, tilesN, splits};
     float* wsp = splits > 1 ? ws : nullptr;
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<AL, BL>), grid, dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, kchunk,
-                       wsp, tilesN);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<AL, BL>), dim3(tm.grid()), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N,
+                       K, kchunk, wsp, tm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (splits > 1) {

@@ -352,23 +352,120 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[2][2], float* ct, co
 }
 
 // ------------------------------------------------------------------------------------------
-// The kernel.  grid.x = tilesM*tilesN (n fastest, so concurrently running workgroups share the
-// A/weight panel of one m-tile in their XCD's L2), grid.y = split-K slices.
+// Vector epilogue of the aligned fast path (M % 128 == 0, N % 128 == 0, every pointer 16-B aligned, leading
+// dimensions % 4 == 0, plain row-major C: no conv remap, no per-image bias, no accumulate).  The tile is staged
+// 64 rows at a time through LDS with a 136-float row pitch (lanes 32..63 of the accumulator layout sit 4 rows
+// lower = +544 floats = bank +32: conflict-free ds_write_b32), then every thread moves float4s: 32 lanes cover one
+// 512-B output row, so bias / residual / mask / store are one instruction per 4 elements instead of per element.
+// `ct` needs 64*136 floats.
+// ------------------------------------------------------------------------------------------
+constexpr int EP_LD = 136;
+
+__device__ __forceinline__ float4 act_mask4(const Epilogue& ep, float4 x, const float* __restrict__ auxp) {
+    if (ep.act == ACT_LRELU) {
+        x.x = x.x > 0.f ? x.x : x.x * ep.slope; x.y = x.y > 0.f ? x.y : x.y * ep.slope;
+        x.z = x.z > 0.f ? x.z : x.z * ep.slope; x.w = x.w > 0.f ? x.w : x.w * ep.slope;
+    } else if (ep.act == ACT_TANH) {
+        x.x = tanhf(x.x); x.y = tanhf(x.y); x.z = tanhf(x.z); x.w = tanhf(x.w);
+    }
+    if (ep.mask != ACT_NONE) {
+        const float4 a = *reinterpret_cast<const float4*>(auxp);
+        if (ep.mask == ACT_LRELU) {
+            x.x *= a.x > 0.f ? 1.f : ep.slope; x.y *= a.y > 0.f ? 1.f : ep.slope;
+            x.z *= a.z > 0.f ? 1.f : ep.slope; x.w *= a.w > 0.f ? 1.f : ep.slope;
+        } else {
+            x.x *= 1.f - a.x * a.x; x.y *= 1.f - a.y * a.y; x.z *= 1.f - a.z * a.z; x.w *= 1.f - a.w * a.w;
+        }
+    }
+    return x;
+}
+
+__device__ __forceinline__ void tile_epilogue_v4(f32x16 (&acc)[2][2], float* ct, const Epilogue& ep, int m0, int n0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c4 = (tid & 31) * 4;
+    const int r8 = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * EP_LD + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 8 + r8;                                   // staged row 0..63
+            const int m = m0 + (rl >> 5) * 64 + i * 32 + (rl & 31);
+            float4 x = *reinterpret_cast<const float4*>(ct + rl * EP_LD + c4);
+            if (ep.bias) {
+                const float b = ep.bias[m >> ep.bias_shift];
+                x.x += b; x.y += b; x.z += b; x.w += b;
+            }
+            if (ep.res) {
+                const float4 q = *reinterpret_cast<const float4*>(ep.res + (long)m * ep.ldres + n0 + c4);
+                x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+            }
+            x = act_mask4(ep, x, ep.aux + (long)m * ep.ldaux + n0 + c4);
+            *reinterpret_cast<float4*>(ep.C + (long)m * ep.ldc + n0 + c4) = x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup id b runs on XCD b & 7) and each
+// XCD has a private L2, so tiles that share an HBM operand panel must (a) carry ids congruent mod 8 and (b) be
+// adjacent in that XCD's dispatch order so that they are resident together and the panel is fetched from HBM once:
+//   no split-K : the tilesM tiles of one column panel X[:, n-tile] form a group (the weight operand is tiny and
+//                L2-resident everywhere);
+//   split-K    : all tilesM*tilesN tiles of one K-slice form a group (each A / B panel of the slice is shared by
+//                tilesN / tilesM of them).
+// Group g lives on XCD g & 7.  The 1-D grid is padded to 8*ceil(groups/8)*group_size; padded ids return false.
+// Measured on the 512x512 decoder layers (FETCH_SIZE): fwd 8.9 -> GB, wgrad 22.9 -> GB per launch.
+// ------------------------------------------------------------------------------------------
+struct TileMap {
+    int tilesM, tilesN, splits;
+    __host__ __device__ int groups() const { return splits > 1 ? splits : tilesN; }
+    __host__ __device__ int group_size() const { return splits > 1 ? tilesM * tilesN : tilesM; }
+    __host__ __device__ unsigned grid() const { return (unsigned)(8 * ((groups() + 7) / 8) * group_size()); }
+    __device__ __forceinline__ bool decode(int bid, int& tile_m, int& tile_n, int& split) const {
+        const int xcd = bid & 7, j = bid >> 3;
+        if (splits > 1) {
+            const int T = tilesM * tilesN;
+            const int tile = j % T;
+            split = (j / T) * 8 + xcd;
+            tile_m = tile / tilesN;
+            tile_n = tile - tile_m * tilesN;
+            return split < splits;
+        }
+        split = 0;
+        tile_m = j % tilesM;
+        tile_n = (j / tilesM) * 8 + xcd;
+        return tile_n < tilesN;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// The kernel.  1-D grid in TileMap order (XCD-aware), covering tiles x split-K slices.
 // With ws != nullptr the raw partial tile is written to ws[split][M][N]; the epilogue then runs in
 // splitk_finalize_kernel (deterministic reduction order).
 // ------------------------------------------------------------------------------------------
 template <class AL, class BL>
 __global__ __launch_bounds__(GEMM_THREADS, 3)
-void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, int tilesN) {
+void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, TileMap tm) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDS_LD];   // [buf][A|B][BK][LDS_LD]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x % tilesN;
-    const int tile_m = blockIdx.x / tilesN;
+    int tile_m, tile_n, split;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split)) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * kchunk;
     const int kend = min(K, kbeg + kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -438,13 +535,15 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
 // ------------------------------------------------------------------------------------------
 template <class AL>
 __global__ __launch_bounds__(GEMM_THREADS, 4)
-void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue ep, int M, int N, int K, int tilesN) {
+void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue ep, int M, int N, int K, TileMap tm,
+                          int vec_ep) {
     constexpr int AT = BK * LDS_LD, BT = BK * BN;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (AT + BT) > 64 * 128 ? 2 * (AT + BT) : 64 * 128];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AT + BT) > 64 * EP_LD ? 2 * (AT + BT) : 64 * EP_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    int tile_m, tile_n, split_unused;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = K / BK;
 
@@ -507,7 +606,8 @@ void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue
         if (more) al.commit(nxt);
         __syncthreads();
     }
-    tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
+    if (vec_ep) tile_epilogue_v4(acc, lds, ep, m0, n0);
+    else tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
 }
 
 
@@ -516,13 +616,14 @@ void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue
 // fragments and issues 32 MFMAs.  Both LDS tiles are unpadded [BK][128].
 __global__ __launch_bounds__(GEMM_THREADS, 4)
 void gemm_f32_glds2_kernel(const float* __restrict__ At, long lda, const float* __restrict__ X, long ldx, Epilogue ep,
-                           int M, int N, int K, int tilesN) {
+                           int M, int N, int K, TileMap tm, int vec_ep) {
     constexpr int TT = BK * BN;                      // one operand tile (floats)
-    __shared__ __attribute__((aligned(16))) float lds[4 * TT > 64 * 128 ? 4 * TT : 64 * 128];
+    __shared__ __attribute__((aligned(16))) float lds[4 * TT > 64 * EP_LD ? 4 * TT : 64 * EP_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    int tile_m, tile_n, split_unused;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = K / BK;
 
@@ -578,7 +679,8 @@ void gemm_f32_glds2_kernel(const float* __restrict__ At, long lda, const float* 
         }
         __syncthreads();
     }
-    tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
+    if (vec_ep) tile_epilogue_v4(acc, lds, ep, m0, n0);
+    else tile_epilogue(acc, lds, ep, m0, M, n0 + (tid & 127), (n0 + (tid & 127)) < N, nullptr, 0, N);
 }
 
 // out[c][r] = in[r][c]   (small weight transposes feeding the DMA forward GEMM)
@@ -621,10 +723,10 @@ static hipError_t launch_gemm(AL al, BL bl, const Epilogue& ep, int M, int N, in
     }
     int kchunk = cdiv(cdiv(K > 0 ? K : 1, splits), BK) * BK;
     splits = cdiv(K > 0 ? K : 1, kchunk);
-    dim3 grid((unsigned)(tilesM * tilesN), (unsigned)splits);
+    const TileMap tm{tilesM, tilesN, splits};
     float* wsp = splits > 1 ? ws : nullptr;
-    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, kchunk,
-                       wsp, tilesN);
+    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), dim3(tm.grid()), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K,
+                       kchunk, wsp, tm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (splits > 1) {

@@ -24,6 +24,14 @@ static inline bool use_glds() {
     static const bool on = [] { const char* e = getenv("TVAE_GLDS"); return !(e && e[0] == '0'); }();
     return on;
 }
+// the float4 epilogue needs plain row-major C and 16-B aligned C / residual / aux rows
+static inline int vec_epilogue_ok(const Epilogue& ep) {
+    const bool plain = ep.convP == 0 && ep.gbias == nullptr && ep.accumulate == 0;
+    const bool c_ok = aligned16(ep.C) && ep.ldc % 4 == 0;
+    const bool r_ok = !ep.res || (aligned16(ep.res) && ep.ldres % 4 == 0);
+    const bool a_ok = ep.mask == ACT_NONE || (aligned16(ep.aux) && ep.ldaux % 4 == 0);
+    return (plain && c_ok && r_ok && a_ok) ? 1 : 0;
+}
 static inline int grid1d(long total, int block, int cap = 8192) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -276,9 +284,9 @@ int tvae_linear_fwd(const float* W, const float* X, const float* bias, const flo
     if (M % BM == 0 && N % BN == 0 && K % BK == 0 && ldx % 4 == 0 && aligned16(W) && aligned16(X)) {
         LoadKContigV4 af{W, (long)K, M};
         if (use_glds()) {
-            const int tilesN = N / BN;
-            hipLaunchKernelGGL((gemm_f32_glds_kernel<LoadKContigV4>), dim3((unsigned)((M / BM) * tilesN)),
-                               dim3(GEMM_THREADS), 0, S(stream), af, X, ldx, ep, M, N, K, tilesN);
+            const TileMap tm{M / BM, N / BN, 1};
+            hipLaunchKernelGGL((gemm_f32_glds_kernel<LoadKContigV4>), dim3(tm.grid()), dim3(GEMM_THREADS), 0, S(stream),
+                               af, X, ldx, ep, M, N, K, tm, vec_epilogue_ok(ep));
             TVAE_CHECK_LAUNCH();
             return 0;
         }
@@ -301,9 +309,9 @@ int tvae_linear_dgrad(const float* W, const float* dpre, const float* add, const
     if (g_gemm_mode == 1) return (int)launch_gemm_bf16x3(al, bl, ep, K, N, M, 1, nullptr, 0, S(stream));
     if (use_glds() && K % BM == 0 && N % BN == 0 && M % BK == 0 && ldd % 4 == 0 && aligned16(W) && aligned16(dpre)) {
         // both operands are row-contiguous along their tile dimension: A(kout, m) = W[m][kout], B = dpre[m][n]
-        const int tilesN = N / BN;
-        hipLaunchKernelGGL(gemm_f32_glds2_kernel, dim3((unsigned)((K / BM) * tilesN)), dim3(GEMM_THREADS), 0, S(stream),
-                           W, (long)K, dpre, ldd, ep, K, N, M, tilesN);
+        const TileMap tm{K / BM, N / BN, 1};
+        hipLaunchKernelGGL(gemm_f32_glds2_kernel, dim3(tm.grid()), dim3(GEMM_THREADS), 0, S(stream), W, (long)K, dpre,
+                           ldd, ep, K, N, M, tm, vec_epilogue_ok(ep));
         TVAE_CHECK_LAUNCH();
         return 0;
     }

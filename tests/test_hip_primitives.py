@@ -54,7 +54,8 @@ def dact_ref(y, act):
 @pytest.mark.parametrize('M,N,K,act,use_g,use_res', [
     (128, 8712, 128, 1, False, False), (7, 300, 128, 0, False, False), (512, 1000, 1024, 1, True, False),
     (64, 517, 64, 1, False, True), (130, 129, 17, 2, True, True), (103, 2000, 128, 0, False, False),
-    (128, 1024, 128, 1, True, True), (256, 512, 64, 0, False, False), (512, 2048, 512, 1, True, False)])
+    (128, 1024, 128, 1, True, True), (256, 512, 64, 0, False, False), (512, 2048, 512, 1, True, False),
+    (128, 1024, 128, 1, False, True), (256, 1152, 32, 2, False, True), (384, 128, 16, 1, False, False)])
 def test_linear_fwd(M, N, K, act, use_g, use_res, gemm_mode):
     W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
     group = 100
@@ -76,7 +77,7 @@ def test_linear_fwd(M, N, K, act, use_g, use_res, gemm_mode):
 @pytest.mark.parametrize('M,N,K,mask,use_add', [(7, 3000, 128, 1, False), (128, 1111, 128, 1, False),
                                                 (64, 300, 64, 1, True), (512, 700, 1024, 0, False),
                                                 (33, 257, 65, 2, True), (128, 1024, 128, 1, True), (64, 512, 256, 1, False),
-                                                (512, 1024, 512, 0, False)])
+                                                (512, 1024, 512, 0, False), (128, 512, 256, 2, True), (16, 1280, 384, 1, False)])
 def test_linear_dgrad(M, N, K, mask, use_add, gemm_mode):
     W, d = rnd(M, K, seed=1, scale=M ** -0.5), rnd(M, N, seed=2)
     aux = rnd(K, N, seed=3).clamp(-0.9, 0.9)
