@@ -74,6 +74,35 @@ int tvae_outer_mask(const float* dy, int no, const float* W, int wsm, int wso, c
                     long ldd, int M, int N, int act, float slope, tvae_stream_t stream);
 int tvae_act_bwd(const float* dY, const float* Y, float* dpre, long n, int act, float slope, tvae_stream_t stream);
 
+/* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
+ * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),
+ *              replaces outer_mask + two rowdot passes:
+ *                D[f][n] = (sum_o Wo[o*F+f] gy[n*n_out+o]) * act'(H[f][n]);
+ *                tot[0][f] = sum_n D[f][n]  (bias gradient of the layer that produced h);
+ *                tot[1+o][f] = sum_n H[f][n] gy[n*n_out+o]  (= dWo[o][f]).          n_out <= 4
+ *              part: workspace >= ceil(N/1024)*F*(1+n_out) floats; tot: (1+n_out)*F floats.
+ * dec_in_bwd:  backward of the first decoder layer h = act(Wc x' + bc + Wl z) without Fourier features
+ *              (src/models.py:107-118), d = pre-activation gradient [F][B*Np]:
+ *                gxr[n][j] = sum_f Wc[2f+j] d[f][n];  Simg[b][f] = sum_{n in image b} d[f][n];
+ *                dbc[f] = sum_n d[f][n];  dWc[f][j] = sum_n d[f][n] x'[n][j].
+ *              part: workspace >= B*ceil(Np/1024)*F*3 floats.
+ * heads_fwd:   conv_a / conv_r / conv_z (src/models.py:390-392) as ONE stacked projection with nh = 3+2*z_dim <= 8
+ *              rows: Y[j][n] = b[j] + sum_c W[j*C+c] X[c][n].
+ * heads_bwd:   its backward, fused with the activation mask of X and the row reductions:
+ *                dX[c][n] = act'(X[c][n]) sum_j W[j*C+c] dY[j][n];
+ *                tot[j][c] = sum_n dY[j][n] X[c][n] (= dW[j][c], j < nh);  tot[nh][c] = sum_n dX[c][n].
+ *              part: workspace >= ceil(N/512)*C*(nh+1) floats; tot: (nh+1)*C floats.
+ * All return hipErrorInvalidValue when n_out / nh is out of range or the workspace is too small. */
+int tvae_dec_out_bwd(const float* gy, int n_out, const float* Wo, const float* H, long ldh, float* D, long ldd, int F,
+                     long N, int act, float slope, float* part, long part_floats, float* tot, tvae_stream_t stream);
+int tvae_dec_in_bwd(const float* d, long ldd, const float* xr, const float* Wc, int F, int B, int Np, float* gxr,
+                    float* Simg, float* dbc, float* dWc, float* part, long part_floats, tvae_stream_t stream);
+int tvae_heads_fwd(const float* W, const float* X, long ldx, const float* bias, float* Y, long ldy, int nh, int C,
+                   long N, tvae_stream_t stream);
+int tvae_heads_bwd(const float* W, const float* dY, long ldy, const float* X, long ldx, float* dX, long lddx, int nh,
+                   int C, long N, int act, float slope, float* part, long part_floats, float* tot,
+                   tvae_stream_t stream);
+
 /* ---- attention head: src/models.py:358-401 (prior add, log_softmax, gumbel_softmax, offsets) fused with the
  * pooling / sampling / KL block of eval_minibatch, train_mnist.py:192-231,242-282.
  * heads [3+2*zd][ldh] rows: 0 logit, 1 theta_mu, 2 theta_logstd, 3.. z_mu, 3+zd.. z_logstd (column = img*R*P + j).

@@ -1,0 +1,293 @@
+// Fused HBM-bound kernels around the skinny ends of the two MLPs (decoder last / first layer, encoder head
+// projection).  Every [feature][batch*position] activation touched here is 1-2 GB at the headline batch, so the
+// cost of this part of the step is the number of passes over those arrays; each kernel below replaces 2-3 separate
+// passes (a skinny product, an activation mask and one or two row reductions) by a single one.
+//
+// Shared structure ("panel kernel"): a 256-thread workgroup owns a panel of CW consecutive columns x all rows.
+// Wave w walks rows w, w+4, ...; lane l owns CPL columns of the panel as CPL/4 float4 groups (group q = columns
+// q*256 + 4*l .. +3), so every global access is a 1-KiB contiguous wave segment.  Column-direction sums stay in
+// registers across the row loop; row-direction sums are wave64 shuffle reductions amortised over CPL columns and
+// written as per-panel partials part[panel][row][v], which a second tiny kernel adds up in a fixed order (bitwise
+// reproducible, no atomics).  Out-of-range columns are loaded as zero and never stored.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "small_kernels.hpp"
+
+namespace tvae {
+
+constexpr int PANEL16 = 1024;   // 64 lanes x 16 columns
+constexpr int PANEL8 = 512;     // 64 lanes x 8 columns
+
+__device__ __forceinline__ float4 load4(const float* __restrict__ row, long col, long cend, bool vec) {
+    if (vec && col + 3 < cend) return *reinterpret_cast<const float4*>(row + col);
+    float4 v;
+    v.x = col < cend ? row[col] : 0.f;
+    v.y = col + 1 < cend ? row[col + 1] : 0.f;
+    v.z = col + 2 < cend ? row[col + 2] : 0.f;
+    v.w = col + 3 < cend ? row[col + 3] : 0.f;
+    return v;
+}
+__device__ __forceinline__ void store4(float* __restrict__ row, long col, long cend, bool vec, float4 v) {
+    if (vec && col + 3 < cend) { *reinterpret_cast<float4*>(row + col) = v; return; }
+    if (col < cend) row[col] = v.x;
+    if (col + 1 < cend) row[col + 1] = v.y;
+    if (col + 2 < cend) row[col + 2] = v.z;
+    if (col + 3 < cend) row[col + 3] = v.w;
+}
+__device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// out[v*M + m] = sum_panel part[(panel*M + m)*NV + v]      (one workgroup per row m)
+__global__ void part_total_kernel(const float* __restrict__ part, int npanels, int M, int NV, float* __restrict__ out) {
+    __shared__ float sm[16];
+    const int m = blockIdx.x;
+    for (int v = 0; v < NV; ++v) {
+        float s[1] = {0.f};
+        for (int p = threadIdx.x; p < npanels; p += blockDim.x) s[0] += part[((long)p * M + m) * NV + v];
+        block_sum<1>(s, sm);
+        if (threadIdx.x == 0) out[(long)v * M + m] = s[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Last decoder layer, backward (reference SpatialGenerator.forward src/models.py:121-123, y = Wo h + bo):
+//   D[f][n]         = (sum_o Wo[o*F + f] * gy[n*NO + o]) * act'(H[f][n])       gradient w.r.t. the pre-activation of h
+//   part[p][f][0]   = sum_{n in panel p} D[f][n]                               -> bias gradient of the layer producing h
+//   part[p][f][1+o] = sum_{n in panel p} H[f][n] * gy[n*NO + o]                -> dWo[o][f]
+// ------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ Wo,
+                                                          const float* __restrict__ H, long ldh, float* __restrict__ D,
+                                                          long ldd, int F, long N, int act, float slope,
+                                                          float* __restrict__ part, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long c0 = (long)blockIdx.x * PANEL16;
+    const long cend = min(N, c0 + PANEL16);
+    float g[4][4][NO];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long n = c0 + q * 256 + lane * 4 + e;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) g[q][e][o] = n < cend ? gy[n * NO + o] : 0.f;
+        }
+    for (int f = wave; f < F; f += 4) {
+        float w[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) w[o] = Wo[(long)o * F + f];
+        const float* hrow = H + (long)f * ldh;
+        float* drow = D + (long)f * ldd;
+        float acc[1 + NO];
+#pragma unroll
+        for (int v = 0; v <= NO; ++v) acc[v] = 0.f;
+        float4 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = load4(hrow, c0 + q * 256 + lane * 4, cend, vec);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float he = f4get(h[q], e);
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    s += w[o] * g[q][e][o];
+                    acc[1 + o] += he * g[q][e][o];
+                }
+                dv[e] = s * act_deriv_from_out(he, act, slope);
+                acc[0] += dv[e];
+            }
+            store4(drow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
+        }
+#pragma unroll
+        for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v <= NO; ++v) part[((long)blockIdx.x * F + f) * (1 + NO) + v] = acc[v];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// First decoder layer without Fourier features, backward (reference src/models.py:107-118: h = act(Wc x' + bc + Wl z)):
+// d[f][n] is the pre-activation gradient.  One panel = up to 1024 pixels of ONE image (cpi panels per image).
+//   gxr[n][j]          = sum_f Wc[2f + j] * d[f][n]                              gradient w.r.t. the coordinates
+//   part[p][f][0..2]   = sum_{n in panel p} d[f][n] * (1, x'_0[n], x'_1[n])      -> per-image sums (latent path),
+//                                                                                   bias and coordinate-weight grads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_in_bwd_kernel(const float* __restrict__ d, long ldd,
+                                                         const float* __restrict__ xr, const float* __restrict__ Wc,
+                                                         int F, int Np, int cpi, float* __restrict__ gxr,
+                                                         float* __restrict__ part, int vec) {
+    __shared__ float sm[4 * PANEL16 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int img = blockIdx.x / cpi, ch = blockIdx.x - img * cpi;
+    const long c0 = (long)img * Np + (long)ch * PANEL16;
+    const long cend = min((long)(img + 1) * Np, c0 + PANEL16);
+    float x0[4][4], x1[4][4], gx0[4][4], gx1[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long n = c0 + q * 256 + lane * 4 + e;
+            x0[q][e] = n < cend ? xr[2 * n] : 0.f;
+            x1[q][e] = n < cend ? xr[2 * n + 1] : 0.f;
+            gx0[q][e] = 0.f;
+            gx1[q][e] = 0.f;
+        }
+    for (int f = wave; f < F; f += 4) {
+        const float wc0 = Wc[2 * f], wc1 = Wc[2 * f + 1];
+        const float* drow = d + (long)f * ldd;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = load4(drow, c0 + q * 256 + lane * 4, cend, vec);
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float de = f4get(v[q], e);
+                gx0[q][e] += wc0 * de;
+                gx1[q][e] += wc1 * de;
+                acc[0] += de;
+                acc[1] += de * x0[q][e];
+                acc[2] += de * x1[q][e];
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) part[((long)blockIdx.x * F + f) * 3 + k] = acc[k];
+        }
+    }
+    // combine the four waves' column sums (each wave saw a quarter of the rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cl = q * 256 + lane * 4 + e;
+            sm[(wave * PANEL16 + cl) * 2] = gx0[q][e];
+            sm[(wave * PANEL16 + cl) * 2 + 1] = gx1[q][e];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PANEL16 * 2; i += 256) {
+        const long n = c0 + (i >> 1);
+        if (n < cend) gxr[2 * n + (i & 1)] = sm[i] + sm[PANEL16 * 2 + i] + sm[2 * PANEL16 * 2 + i] + sm[3 * PANEL16 * 2 + i];
+    }
+}
+
+// Simg[b][f] = sum_c part[b*cpi + c][f][0];  dbc[f] = sum_b Simg[b][f];  dWc[f][j] = sum_{b,c} part[..][f][1+j]
+__global__ void dec_in_total_kernel(const float* __restrict__ part, int B, int cpi, int F, float* __restrict__ Simg,
+                                    float* __restrict__ dbc, float* __restrict__ dWc) {
+    __shared__ float sm[3 * 16];
+    const int f = blockIdx.x;
+    float tot[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < cpi; ++c) {
+            const float* p = part + (((long)b * cpi + c) * F + f) * 3;
+            s[0] += p[0]; s[1] += p[1]; s[2] += p[2];
+        }
+        Simg[(long)b * F + f] = s[0];
+        tot[0] += s[0]; tot[1] += s[1]; tot[2] += s[2];
+    }
+    block_sum<3>(tot, sm);
+    if (threadIdx.x == 0) {
+        dbc[f] = tot[0];
+        dWc[2 * f] = tot[1];
+        dWc[2 * f + 1] = tot[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder head projection (conv_a / conv_r / conv_z as ONE stacked 1x1x1 convolution, reference
+// src/models.py:390-392): NO = 3 + 2*z_dim output rows, far below an MFMA tile, so it is a streaming product.
+//   Y[j][n] = b[j] + sum_c W[j*C + c] * X[c][n]            thread = 4 columns, all C rows
+// ------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                        long ldx, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, long ldy, int C, long N, int vec) {
+    const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= N) return;
+    float acc[NO][4];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const float b = bias ? bias[j] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = b;
+    }
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float4 x = load4(X + (long)c * ldx, col, N, vec);
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const float w = W[(long)j * C + c];
+            acc[j][0] += w * x.x; acc[j][1] += w * x.y; acc[j][2] += w * x.z; acc[j][3] += w * x.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+        store4(Y + (long)j * ldy, col, N, vec, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+}
+
+// Backward of the head projection fused with the activation mask of its input and all row reductions:
+//   dX[c][n]        = act'(X[c][n]) * sum_j W[j*C + c] * dY[j][n]
+//   part[p][c][j]   = sum_{n in panel p} dY[j][n] * X[c][n]        -> dW[j][c]
+//   part[p][c][NO]  = sum_{n in panel p} dX[c][n]                  -> bias gradient of the layer producing X
+template <int NO>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ W, const float* __restrict__ dY,
+                                                        long ldy, const float* __restrict__ X, long ldx,
+                                                        float* __restrict__ dX, long lddx, int C, long N, int act,
+                                                        float slope, float* __restrict__ part, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long c0 = (long)blockIdx.x * PANEL8;
+    const long cend = min(N, c0 + PANEL8);
+    float g[2][4][NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 t = load4(dY + (long)j * ldy, c0 + q * 256 + lane * 4, cend, vec);
+            g[q][0][j] = t.x; g[q][1][j] = t.y; g[q][2][j] = t.z; g[q][3][j] = t.w;
+        }
+    for (int c = wave; c < C; c += 4) {
+        float w[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) w[j] = W[(long)j * C + c];
+        const float* xrow = X + (long)c * ldx;
+        float* orow = dX + (long)c * lddx;
+        float4 x[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) x[q] = load4(xrow, c0 + q * 256 + lane * 4, cend, vec);
+        float acc[NO + 1];
+#pragma unroll
+        for (int v = 0; v <= NO; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xe = f4get(x[q], e);
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    s += w[j] * g[q][e][j];
+                    acc[j] += g[q][e][j] * xe;
+                }
+                dv[e] = s * act_deriv_from_out(xe, act, slope);
+                acc[NO] += dv[e];
+            }
+            store4(orow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
+        }
+#pragma unroll
+        for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v <= NO; ++v) part[((long)blockIdx.x * C + c) * (NO + 1) + v] = acc[v];
+        }
+    }
+}
+
+}  // namespace tvae

@@ -6,6 +6,7 @@
 #include "../../include/tvae_hip.h"
 #include "gemm_f32_mfma.hpp"
 #include "small_kernels.hpp"
+#include "fused_tail_kernels.hpp"
 #include "conv_img_kernels.hpp"
 #include "gemm_bf16x3.hpp"
 
@@ -60,6 +61,21 @@ static hipError_t allow_big_lds(KernelT kernel, size_t bytes) {
 
 // GEMM arithmetic mode: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 x3 (fp32-level accuracy).
 static int g_gemm_mode = 0;
+
+static inline int panels_of(long N, int width) { return (int)((N + width - 1) / width); }
+template <int NO>
+static void launch_heads_fwd(const float* W, const float* X, long ldx, const float* bias, float* Y, long ldy, int C,
+                             long N, int vec, hipStream_t st) {
+    hipLaunchKernelGGL(heads_fwd_kernel<NO>, dim3(panels_of(N, 1024)), dim3(256), 0, st, W, X, ldx, bias, Y, ldy, C, N,
+                       vec);
+}
+template <int NO>
+static void launch_heads_bwd(const float* W, const float* dY, long ldy, const float* X, long ldx, float* dX, long lddx,
+                             int C, long N, int act, float slope, float* part, int vec, hipStream_t st) {
+    hipLaunchKernelGGL(heads_bwd_kernel<NO>, dim3(panels_of(N, PANEL8)), dim3(256), 0, st, W, dY, ldy, X, ldx, dX, lddx,
+                       C, N, act, slope, part, vec);
+}
+
 
 extern "C" {
 
@@ -396,6 +412,84 @@ int tvae_outer_mask(const float* dy, int no, const float* W, int wsm, int wso, c
         case 4: hipLaunchKernelGGL(outer_mask_kernel<4>, grid, block, 0, S(stream), dy, W, wsm, wso, H, ldh, D, ldd, M, N, act, slope); break;
         default: return (int)hipErrorInvalidValue;
     }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- fused tails of the two MLPs (fused_tail_kernels.hpp) --------------------------------------------------
+
+int tvae_dec_out_bwd(const float* gy, int n_out, const float* Wo, const float* H, long ldh, float* D, long ldd, int F,
+                     long N, int act, float slope, float* part, long part_floats, float* tot, tvae_stream_t stream) {
+    if (F <= 0 || N <= 0) return 0;
+    const int np = panels_of(N, PANEL16);
+    if (n_out < 1 || n_out > 4 || part_floats < (long)np * F * (1 + n_out)) return (int)hipErrorInvalidValue;
+    const int vec = (aligned16(H) && aligned16(D) && ldh % 4 == 0 && ldd % 4 == 0) ? 1 : 0;
+    dim3 grid(np), block(256);
+    switch (n_out) {
+        case 1: hipLaunchKernelGGL(dec_out_bwd_kernel<1>, grid, block, 0, S(stream), gy, Wo, H, ldh, D, ldd, F, N, act, slope, part, vec); break;
+        case 2: hipLaunchKernelGGL(dec_out_bwd_kernel<2>, grid, block, 0, S(stream), gy, Wo, H, ldh, D, ldd, F, N, act, slope, part, vec); break;
+        case 3: hipLaunchKernelGGL(dec_out_bwd_kernel<3>, grid, block, 0, S(stream), gy, Wo, H, ldh, D, ldd, F, N, act, slope, part, vec); break;
+        default: hipLaunchKernelGGL(dec_out_bwd_kernel<4>, grid, block, 0, S(stream), gy, Wo, H, ldh, D, ldd, F, N, act, slope, part, vec); break;
+    }
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(part_total_kernel, dim3(F), dim3(256), 0, S(stream), (const float*)part, np, F, 1 + n_out, tot);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_dec_in_bwd(const float* d, long ldd, const float* xr, const float* Wc, int F, int B, int Np, float* gxr,
+                    float* Simg, float* dbc, float* dWc, float* part, long part_floats, tvae_stream_t stream) {
+    if (F <= 0 || B <= 0 || Np <= 0) return 0;
+    const int cpi = panels_of(Np, PANEL16);
+    if (part_floats < (long)B * cpi * F * 3) return (int)hipErrorInvalidValue;
+    const int vec = (aligned16(d) && ldd % 4 == 0 && Np % 4 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(dec_in_bwd_kernel, dim3(B * cpi), dim3(256), 0, S(stream), d, ldd, xr, Wc, F, Np, cpi, gxr, part,
+                       vec);
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dec_in_total_kernel, dim3(F), dim3(256), 0, S(stream), (const float*)part, B, cpi, F, Simg, dbc,
+                       dWc);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_heads_fwd(const float* W, const float* X, long ldx, const float* bias, float* Y, long ldy, int nh, int C,
+                   long N, tvae_stream_t stream) {
+    if (N <= 0 || C <= 0) return 0;
+    if (nh < 1 || nh > 8) return (int)hipErrorInvalidValue;
+    const int vec = (aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy % 4 == 0) ? 1 : 0;
+    switch (nh) {
+        case 1: launch_heads_fwd<1>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 2: launch_heads_fwd<2>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 3: launch_heads_fwd<3>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 4: launch_heads_fwd<4>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 5: launch_heads_fwd<5>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 6: launch_heads_fwd<6>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        case 7: launch_heads_fwd<7>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+        default: launch_heads_fwd<8>(W, X, ldx, bias, Y, ldy, C, N, vec, S(stream)); break;
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_heads_bwd(const float* W, const float* dY, long ldy, const float* X, long ldx, float* dX, long lddx, int nh,
+                   int C, long N, int act, float slope, float* part, long part_floats, float* tot,
+                   tvae_stream_t stream) {
+    if (N <= 0 || C <= 0) return 0;
+    const int np = panels_of(N, PANEL8);
+    if (nh < 1 || nh > 8 || part_floats < (long)np * C * (nh + 1)) return (int)hipErrorInvalidValue;
+    const int vec = (aligned16(X) && aligned16(dX) && aligned16(dY) && ldx % 4 == 0 && lddx % 4 == 0 && ldy % 4 == 0) ? 1 : 0;
+    switch (nh) {
+        case 1: launch_heads_bwd<1>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 2: launch_heads_bwd<2>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 3: launch_heads_bwd<3>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 4: launch_heads_bwd<4>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 5: launch_heads_bwd<5>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 6: launch_heads_bwd<6>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        case 7: launch_heads_bwd<7>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+        default: launch_heads_bwd<8>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
+    }
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(part_total_kernel, dim3(C), dim3(256), 0, S(stream), (const float*)part, np, C, nh + 1, tot);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

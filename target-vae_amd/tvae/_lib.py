@@ -28,6 +28,10 @@ SIGNATURES = {
     'tvae_coldot': 'pliipiipip',
     'tvae_outer_mask': 'pipiiplpliiif',
     'tvae_act_bwd': 'ppplif',
+    'tvae_dec_out_bwd': 'pipplplilifplp',
+    'tvae_dec_in_bwd': 'plppiiipppppl',
+    'tvae_heads_fwd': 'pplppliil',
+    'tvae_heads_bwd': 'pplplpliilifplp',
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppp',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppp',
     'tvae_get_latent': 'plpppiiiifppp',

@@ -106,6 +106,9 @@ def tap_tables_csr(k: int, R: int, device):
     return _dev_table(('csr', k, R), device, lambda: tables.rotation_taps_csr(k, R))
 
 
+SKINNY_MAX = 8          # head projections with <= 8 output rows use the streaming kernels, wider ones the MFMA GEMM
+
+
 def _seglen(N: int) -> int:
     return max(2048, (N + 255) // 256)
 
@@ -237,7 +240,10 @@ class EncoderFn(torch.autograd.Function):
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
-        call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
+        if nh <= SKINNY_MAX:
+            call('tvae_heads_fwd', Wh.contiguous(), H, N, bh, heads, N, nh, C2, N)
+        else:
+            call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
@@ -249,12 +255,21 @@ class EncoderFn(torch.autograd.Function):
         N = B * R * Ho * Ho
         C2, nh = W2.shape[0], Wh.shape[0]
         dheads = dheads.contiguous()
-        dWh = _wgrad(dheads, H, nh, N, C2)
         dbh = _rowsum(dheads, nh, N)
         dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
-        call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
+        if nh <= SKINNY_MAX:
+            # one pass over H: masked dgrad + dWh + the row sums of dH (= db2)
+            npan = (N + 511) // 512
+            part = workspace(y.device, npan * C2 * (nh + 1))
+            tot = torch.empty(nh + 1, C2, dtype=torch.float32, device=y.device)
+            call('tvae_heads_bwd', Wh.contiguous(), dheads, N, H, N, dH, N, nh, C2, N, act, LRELU_SLOPE, part,
+                 part.numel(), tot)
+            dWh, db2 = tot[:nh], tot[nh]
+        else:
+            dWh = _wgrad(dheads, H, nh, N, C2)
+            call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
+            db2 = _rowsum(dH, C2, N)
         dW2 = _wgrad(dH, A1, C2, N, C)
-        db2 = _rowsum(dH, C2, N)
         dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
         del dH
@@ -420,24 +435,22 @@ class DecoderFn(torch.autograd.Function):
         F_, n_out = Wc.shape[0], Wo.shape[0]
         dev = xr.device
         gy = gy.contiguous().view(Nt, n_out)
-        sl = _seglen(Nt)
-        nseg = (Nt + sl - 1) // sl
-        # last layer
-        tmp = torch.empty(nseg, F_, n_out, dtype=torch.float32, device=dev)
-        call('tvae_rowdot_seg', hs[-1], Nt, gy, n_out, F_, Nt, sl, tmp)
-        dWoT = torch.empty(F_, n_out, dtype=torch.float32, device=dev)
-        call('tvae_seg_sum', tmp, nseg, F_ * n_out, dWoT, 1.0, 0)
-        dWo = dWoT.t().contiguous()
+        # last layer: one pass over h gives d (pre-activation gradient), its row sums and dWo
         gyT = gy.t().contiguous()
         dbo = _rowsum(gyT, n_out, Nt)
         d = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
-        call('tvae_outer_mask', gy, n_out, Wo.contiguous(), 1, F_, hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE)
+        part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
+        tot = torch.empty(1 + n_out, F_, dtype=torch.float32, device=dev)
+        call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
+             part.numel(), tot)
+        dWo, drow = tot[1:], tot[0]
         grads_hidden = []
         for li in range(n_hidden - 1, -1, -1):
             W, b = hidden[li]
             hprev = hs[li]
             dW = _wgrad(d, hprev, F_, Nt, F_)
-            db = _rowsum(d, F_, Nt)
+            db = drow if drow is not None else _rowsum(d, F_, Nt)
+            drow = None
             dprev = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                  LRELU_SLOPE)
@@ -446,28 +459,29 @@ class DecoderFn(torch.autograd.Function):
         grads_hidden.reverse()
         # first layer: d is the pre-activation gradient [F][Nt]
         Simg = torch.empty(B, F_, dtype=torch.float32, device=dev)
-        call('tvae_rowdot_seg', d, Nt, None, 1, F_, Nt, Np, Simg)
         dbc = torch.empty(F_, dtype=torch.float32, device=dev)
-        call('tvae_seg_sum', Simg, B, F_, dbc, 1.0, 0)
+        gxr = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
+        if has_f:
+            call('tvae_rowdot_seg', d, Nt, None, 1, F_, Nt, Np, Simg)
+            call('tvae_seg_sum', Simg, B, F_, dbc, 1.0, 0)
+        else:
+            # one pass over d: coordinate gradient, per-image sums, bias and coordinate-weight gradients
+            dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
+            part = workspace(dev, B * ((Np + 1023) // 1024) * F_ * 3)
+            call('tvae_dec_in_bwd', d, Nt, xr.view(Nt, 2), Wc.contiguous(), F_, B, Np, gxr, Simg, dbc, dWc, part,
+                 part.numel())
         dWl = dz = None
         if has_l:
             zd = Wl.shape[1]
             dWl = torch.empty(F_, zd, dtype=torch.float32, device=dev)
             dz = torch.empty(B, zd, dtype=torch.float32, device=dev)
             call('tvae_latent_bwd', Simg, Wl.contiguous(), z, dWl, dz, B, F_, zd)
-        gxr = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
         if has_f:
             Ff = Wf.shape[0]
             dWc = _wgrad(d, feat, F_, Nt, Ff)
             dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
             call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
-        else:
-            tmp2 = torch.empty(nseg, F_, 2, dtype=torch.float32, device=dev)
-            call('tvae_rowdot_seg', d, Nt, xr.view(Nt, 2), 2, F_, Nt, sl, tmp2)
-            dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
-            call('tvae_seg_sum', tmp2, nseg, F_ * 2, dWc, 1.0, 0)
-            call('tvae_coldot', d, Nt, F_, Nt, Wc.contiguous(), 2, 1, None, 2, gxr)
         out = [gxr, dz, None, None, None, None, dWc, dbc, dWl]
         for (dW, db) in grads_hidden:
             out += [dW, db]

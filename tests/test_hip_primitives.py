@@ -189,6 +189,67 @@ def test_coldot_outer_mask(no):
     assert rel_err(pre, ref * dact_ref(X.double(), 1)) < TOL
 
 
+@pytest.mark.parametrize('F_,N,no,act', [(64, 3000, 1, 1), (37, 2051, 2, 1), (130, 1024, 3, 2), (16, 5000, 4, 0)])
+def test_dec_out_bwd(F_, N, no, act):
+    gy, Wo = rnd(N, no, seed=1), rnd(no, F_, seed=2)
+    H = rnd(F_, N, seed=3).clamp(-0.9, 0.9)
+    D = torch.empty(F_, N, device=dev())
+    npan = (N + 1023) // 1024
+    part = torch.empty(npan * F_ * (1 + no), device=dev())
+    tot = torch.empty(1 + no, F_, device=dev())
+    call('tvae_dec_out_bwd', gy.to(dev()), no, Wo.to(dev()), H.to(dev()), N, D, N, F_, N, act, SLOPE, part,
+         part.numel(), tot)
+    ref = (Wo.double().t() @ gy.double().t()) * dact_ref(H.double(), act)
+    assert rel_err(D, ref) < TOL
+    assert rel_err(tot[0], ref.sum(1)) < TOL
+    assert rel_err(tot[1:], (H.double() @ gy.double()).t()) < TOL
+    small = torch.empty(4, device=dev())
+    with pytest.raises(Exception):
+        call('tvae_dec_out_bwd', gy.to(dev()), no, Wo.to(dev()), H.to(dev()), N, D, N, F_, N, act, SLOPE, small, 4, tot)
+
+
+@pytest.mark.parametrize('F_,B,Np', [(64, 3, 784), (33, 2, 1089), (128, 2, 4096), (8, 5, 2500)])
+def test_dec_in_bwd(F_, B, Np):
+    Nt = B * Np
+    d, xr, Wc = rnd(F_, Nt, seed=1), rnd(Nt, 2, seed=2), rnd(F_, 2, seed=3)
+    cpi = (Np + 1023) // 1024
+    part = torch.empty(B * cpi * F_ * 3, device=dev())
+    gxr = torch.empty(Nt, 2, device=dev())
+    Simg = torch.empty(B, F_, device=dev())
+    dbc = torch.empty(F_, device=dev())
+    dWc = torch.empty(F_, 2, device=dev())
+    call('tvae_dec_in_bwd', d.to(dev()), Nt, xr.to(dev()), Wc.to(dev()), F_, B, Np, gxr, Simg, dbc, dWc, part,
+         part.numel())
+    dd = d.double()
+    assert rel_err(gxr, dd.t() @ Wc.double()) < TOL
+    assert rel_err(Simg, dd.view(F_, B, Np).sum(2).t()) < TOL
+    assert rel_err(dbc, dd.sum(1)) < TOL
+    assert rel_err(dWc, dd @ xr.double()) < TOL
+
+
+@pytest.mark.parametrize('nh,C,N,act', [(7, 128, 8712, 1), (3, 33, 1001, 1), (8, 64, 2048, 2), (1, 16, 515, 0),
+                                        (5, 128, 4356, 1)])
+def test_heads_fwd_bwd(nh, C, N, act):
+    W, b = rnd(nh, C, seed=1, scale=C ** -0.5), rnd(nh, seed=2)
+    X = rnd(C, N, seed=3).clamp(-0.9, 0.9)
+    Y = torch.empty(nh, N, device=dev())
+    call('tvae_heads_fwd', W.to(dev()), X.to(dev()), N, b.to(dev()), Y, N, nh, C, N)
+    assert rel_err(Y, W.double() @ X.double() + b.double()[:, None]) < TOL
+    dY = rnd(nh, N, seed=4)
+    dX = torch.empty(C, N, device=dev())
+    npan = (N + 511) // 512
+    part = torch.empty(npan * C * (nh + 1), device=dev())
+    tot = torch.empty(nh + 1, C, device=dev())
+    call('tvae_heads_bwd', W.to(dev()), dY.to(dev()), N, X.to(dev()), N, dX, N, nh, C, N, act, SLOPE, part,
+         part.numel(), tot)
+    ref = (W.double().t() @ dY.double()) * dact_ref(X.double(), act)
+    assert rel_err(dX, ref) < TOL
+    assert rel_err(tot[:nh], dY.double() @ X.double().t()) < TOL
+    assert rel_err(tot[nh], ref.sum(1)) < TOL
+    with pytest.raises(Exception):
+        call('tvae_heads_fwd', W.to(dev()), X.to(dev()), N, b.to(dev()), Y, N, 9, C, N)
+
+
 def test_coord():
     B, n = 3, 9
     xc = O.image_coords(n)
