@@ -74,6 +74,26 @@ int tvae_outer_mask(const float* dy, int no, const float* W, int wsm, int wso, c
                     long ldd, int M, int N, int act, float slope, tvae_stream_t stream);
 int tvae_act_bwd(const float* dY, const float* Y, float* dpre, long n, int act, float slope, tvae_stream_t stream);
 
+/* ---- lifting convolution on the bf16 matrix pipe with fp32-equivalent results ("x6") ------------------------------
+ * Same operator as tvae_conv1_fwd / tvae_conv1_wgrad (F.conv2d in GroupConv.forward, src/models.py:215, and its
+ * weight gradient), evaluated with every fp32 operand split EXACTLY into three bf16 numbers and six bf16 MFMAs per
+ * product block (fp32 accumulate; the dropped cross terms are < 2^-23 relative, below fp32 FMA-chain rounding).
+ * 2.67x the matrix rate of the fp32 MFMA.  The operands are pre-split into 16-byte k-octet cells:
+ *   tvae_bank_split3     bank [C*R][Cin*ksz*ksz] -> a3 (tvae_conv1_x6_bank_bytes bytes), once per step;
+ *   tvae_conv1_fwd_x6    same arguments as tvae_conv1_fwd with a3 instead of bank;
+ *   tvae_conv1_wgrad_x6  same as tvae_conv1_wgrad plus d3, a scratch of tvae_conv1_x6_dy_bytes bytes that receives
+ *                        the split dY; ws must hold at least C*R*Cin*ksz*ksz floats (one partial slab).
+ * tvae_conv1_x6_supported: 1 when both kernels fit the 160 KiB LDS for this geometry (else use the fp32 entry
+ * points); the three query functions are pure host functions (no stream, no GPU work). */
+int tvae_conv1_x6_supported(int Cin, int n, int ksz, int pad);
+long tvae_conv1_x6_bank_bytes(int C, int R, int Cin, int ksz);
+long tvae_conv1_x6_dy_bytes(int B, int C, int R, int n, int ksz, int pad);
+int tvae_bank_split3(const float* bank, void* a3, long a3_bytes, int C, int R, int Cin, int ksz, tvae_stream_t stream);
+int tvae_conv1_fwd_x6(const float* y, const void* a3, const float* bias, float* out, int B, int Cin, int n, int ksz,
+                      int pad, int C, int R, int act, float slope, tvae_stream_t stream);
+int tvae_conv1_wgrad_x6(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, void* d3,
+                        long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
+
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),
  *              replaces outer_mask + two rowdot passes:

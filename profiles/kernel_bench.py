@@ -7,7 +7,7 @@ import torch
 import tvae._lib as _L
 if os.environ.get('TVAE_LIB'):
     _L.LIB_PATH = os.path.abspath(os.environ['TVAE_LIB'])
-from tvae._lib import call, set_gemm_mode
+from tvae._lib import call, set_gemm_mode, query
 set_gemm_mode(os.environ.get('MODE', 'f32'))
 print('mode', os.environ.get('MODE', 'f32'))
 dev = torch.device('cuda:0')
@@ -43,6 +43,23 @@ timeit('conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd', y, bank, bias, A1, B
 dA1 = torch.randn(C, N, device=dev)
 dbank = torch.empty_like(bank)
 timeit('conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R))
+if query('tvae_conv1_x6_supported', Cin, n, k, pad):
+    a3 = torch.empty(query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4, device=dev)
+    d3 = torch.empty(query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4, device=dev)
+    call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k)      # always: the x6 kernels below need real operands
+    timeit('x6_bank_split', 0.0, lambda: call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k))
+    A1x = torch.empty(C, N, device=dev)
+    timeit('x6_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_x6', y, a3, bias, A1x, B, Cin, n, k, pad, C, R, 1, 0.01))
+    dbx = torch.empty_like(bank)
+    timeit('x6_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_x6', y, dA1, dbx, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R))
+    if not only or 'x6' in only:
+        call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
+        call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+        ref = torch.nn.functional.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho) + bias.double().view(1, C, 1, 1, 1)
+        ref = torch.nn.functional.leaky_relu(ref, 0.01).permute(1, 0, 2, 3, 4).reshape(C, -1)
+        e = lambda a: float((a.double() - ref).norm() / ref.norm())
+        print('fwd rel err vs fp64: f32 %.3e  x6 %.3e' % (e(A1), e(A1x)))
+        print('wgrad x6 vs f32 rel diff %.3e' % float((dbx - dbank).norm() / dbank.norm()))
 W2 = torch.randn(C, C, device=dev) * 0.1
 b2 = torch.randn(C, device=dev)
 H = torch.empty(C, N, device=dev)

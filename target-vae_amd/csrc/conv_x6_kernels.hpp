@@ -1,0 +1,566 @@
+// Lifting convolution (forward + weight gradient) on the bf16 matrix pipe with fp32-equivalent results:
+// "x6" = every fp32 operand is written EXACTLY as the sum of three bf16 numbers  x = h + m + l  (8+8+8 significand
+// bits, round-to-nearest residuals) and a product a*b is evaluated as the six partial products
+//     ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh                      (fp32 accumulation inside the MFMA)
+// dropping am*bl + al*bm + al*bl <= ~2^-23 |a*b|, i.e. below the rounding of an fp32 FMA chain (measured: 1.3e-7
+// relative on K = 4096 dot products vs 3.0e-7 for a plain fp32 matmul; the 3-product variant is 4.4e-6).
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 on gfx950, so six of them per product
+// block are still 2.67x faster than the exact-fp32 pipe -- if the operands reach the MFMAs already split:
+//   * filter bank / dY: split ONCE per step by a streaming pre-pass into fragment-ready 16-byte cells
+//       cell(part, octet, row) = 8 consecutive-k bf16 of one row          [part][octet][row]  (row fastest)
+//     so that a workgroup stages its A tile with global_load_lds_dwordx4 (64 consecutive cells per wave instruction,
+//     lane-linear on both sides) and an MFMA A fragment is ONE conflict-free ds_read_b128 per part;
+//   * image: split when it is loaded into LDS (once per workgroup).  The im2col operand needs, per lane, 8 consecutive
+//     pixels of one padded-image row starting at an arbitrary pixel; a 16-byte LDS read must be 16-byte aligned
+//     (misaligned b128 is replayed at 64 cycles), so every part is kept in TWO copies, the second shifted by one
+//     pixel: a lane whose start pixel is odd reads the shifted copy, every read is then 4-byte aligned and a fragment
+//     is two ds_read2_b32 per part.  The parity of the start pixel is a per-lane constant in both kernels (forward:
+//     parity of the lane's output column; wgrad: parity of the lane's tap column) because the row pitch, the octet
+//     starts and the position octets are all even.
+// K ordering: forward  k = (ci, u, v) with every kernel row padded to a whole number of octets (zero weights);
+//             wgrad    k = (image, h, w) with every output row padded to a whole number of octets (zero dY).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_f32_mfma.hpp"
+#include "gemm_bf16x3.hpp"
+#include "conv_img_kernels.hpp"
+
+namespace tvae {
+
+constexpr int X6_STAGE_CELLS_FWD = 3 * 2 * 256;      // [part][octet half][256 rows]
+constexpr int X6_STAGE_CELLS_WG = 3 * 2 * 128;       // [part][octet half][128 rows]
+constexpr int X6_TAB_BYTES = 64;
+
+static inline int x6_round_up(int v, int q) { return (v + q - 1) / q * q; }
+// per-array element count of the LDS image: >= elems + 16 slack, and == 32 (mod 64), i.e. 16 dwords (mod 32): the
+// 4-byte reads use 32 banks, and consecutive arrays -- hence also the two parity copies of one part, 3 arrays apart --
+// then start 16 banks apart, so the even lanes (copy 0) and odd lanes (copy 1) of a fragment read never collide
+static inline int x6_arr_elems(int elems) { return x6_round_up(elems + 16, 64) + 32; }
+
+// exact three-way bf16 split of one fp32 value (RNE residuals); returns the raw bf16 bit patterns
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)x;
+    const float r1 = x - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+__device__ __forceinline__ void split3x8(const float (&r)[8], Cell16& h, Cell16& m, Cell16& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned short h0, m0, l0, h1, m1, l1;
+        split3(r[2 * q], h0, m0, l0);
+        split3(r[2 * q + 1], h1, m1, l1);
+        h.w[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+        m.w[q] = (unsigned)m0 | ((unsigned)m1 << 16);
+        l.w[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+}
+
+// six partial products, in the order the A parts arrive from LDS (h, m, l): the first MFMA of a fragment then waits
+// for ONE read, not three (the running sum already dwarfs every term, so the order is irrelevant for accuracy)
+__device__ __forceinline__ void mfma6(f32x16& acc, const Cell16 (&a)[3], const Cell16 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[1].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[2].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[0].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[1].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[0].v, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pre-pass 1: filter bank fp32 [M][Cin*ksz*ksz] -> cells [part][octet o = (ci*ksz + u)*opr + vo][row m < Mpad]
+// (v = 8*vo + j; zero beyond ksz, beyond M and in the octets o >= Cin*ksz*opr that pad the count to K8pad).
+// ------------------------------------------------------------------------------------------
+__global__ void bank_split3_kernel(const float* __restrict__ bank, uint4* __restrict__ A3, int M, int Mpad, int Cin,
+                                   int ksz, int opr, int K8pad) {
+    const long total = (long)K8pad * Mpad;
+    const int K = Cin * ksz * ksz;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mpad);
+        const int o = (int)(i / Mpad);
+        const int cu = o / opr, vo = o - cu * opr;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int v = vo * 8 + j;
+            r[j] = (m < M && cu < Cin * ksz && v < ksz) ? bank[(long)m * K + (long)cu * ksz + v] : 0.f;
+        }
+        Cell16 h, mm, l;
+        split3x8(r, h, mm, l);
+        A3[i] = h.u;
+        A3[total + i] = mm.u;
+        A3[2 * total + i] = l.u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pre-pass 2: dY fp32 feature-major [c][img][r][p = h*Ho + w] (row stride lddy) ->
+// cells [part][img][q = h*opw + wo (< QP)][row m = c*R + r < Mpad], 8 consecutive w per cell, zero for w >= Ho,
+// q >= Ho*opw, m >= M.  One workgroup per (img, c): coalesced reads of R*P floats, 16*R-byte write runs.
+// ------------------------------------------------------------------------------------------
+__global__ void dy_split3_kernel(const float* __restrict__ dy, long lddy, uint4* __restrict__ D3, int B, int C, int R,
+                                 int Ho, int opw, int QP, int Mpad) {
+    const int img = blockIdx.x, c = blockIdx.y;
+    const int P = Ho * Ho;
+    const long part_stride = (long)B * QP * Mpad;
+    const int cells = QP * R;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        const int r = i % R, q = i / R;
+        const int h = q / opw, wo = q - h * opw;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = wo * 8 + j;
+            v[j] = (c < C && h < Ho && w < Ho) ? dy[(long)c * lddy + ((long)img * R + r) * P + h * Ho + w] : 0.f;
+        }
+        Cell16 hh, mm, ll;
+        split3x8(v, hh, mm, ll);
+        const long at = ((long)img * QP + q) * Mpad + c * R + r;
+        D3[at] = hh.u;
+        D3[part_stride + at] = mm.u;
+        D3[2 * part_stride + at] = ll.u;
+    }
+}
+
+// rows [row0, row0+rows) of the zero-padded image, split, into the six LDS arrays (copy c, part p) at
+// img + (c*3 + p)*arr:  copy0[e] = x[e], copy1[e] = x[e+1].  Everything is zeroed with 16-byte stores first; then only
+// the pixels that exist are fetched, eight global loads in flight per thread before the first is consumed (with one
+// workgroup per CU nothing else hides that latency).  Ends with a barrier.
+__device__ __forceinline__ void load_split_image(unsigned short* img, int arr, const float* __restrict__ y, int b,
+                                                 const ConvGeom& g, int row0, int rows, int Wp) {
+    uint4* z = reinterpret_cast<uint4*>(img);
+    const int n16 = (6 * arr * 2) >> 4;                 // arr is a multiple of 64 elements
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int iy0 = max(0, row0 - g.pad), iy1 = min(g.n, row0 + rows - g.pad);
+    const int vrows = max(0, iy1 - iy0);
+    const int per_c = vrows * g.n;
+    const int count = g.Cin * per_c;
+    const float* yb = y + (long)b * g.Cin * g.n * g.n;
+    for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
+        float v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+            at[u] = -1;
+            v[u] = 0.f;
+            if (idx < count) {
+                const int ci = idx / per_c;
+                const int rem = idx - ci * per_c;
+                const int ry = rem / g.n, ix = rem - ry * g.n;
+                const int iy = iy0 + ry;
+                v[u] = yb[((long)ci * g.n + iy) * g.n + ix];
+                at[u] = (ci * rows + (iy + g.pad - row0)) * Wp + ix + g.pad;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (at[u] >= 0) {
+                unsigned short h, m, l;
+                split3(v[u], h, m, l);
+                const int e = at[u];
+                img[0 * arr + e] = h;
+                img[1 * arr + e] = m;
+                img[2 * arr + e] = l;
+                if (e > 0) {
+                    img[3 * arr + e - 1] = h;
+                    img[4 * arr + e - 1] = m;
+                    img[5 * arr + e - 1] = l;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// one B fragment (3 parts) from the LDS image: 4 consecutive dwords per part at dword index `at`
+__device__ __forceinline__ void read_b_frag(const unsigned* __restrict__ imgdw, int at, int part_stride_dw,
+                                            Cell16 (&b)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const unsigned* q = imgdw + at + p * part_stride_dw;
+        b[p].w[0] = q[0];
+        b[p].w[1] = q[1];
+        b[p].w[2] = q[2];
+        b[p].w[3] = q[3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward.  Tile 256 (rows c*R+r) x 128 (positions of ONE image); four waves STACKED along the rows: wave w owns rows
+// [64w, 64w+64) x all 128 positions = 2 x 4 MFMA tiles, 48 MFMAs per k-step (2 octets = 16 taps of one kernel row).
+// Because a wave's A rows are read by nobody else, each wave runs a PRIVATE A pipeline: it DMAs its own 64 rows of
+// the split bank (6 global_load_lds per step) into its own three-slot ring, two steps ahead, waits on its own vmcnt,
+// and never meets a barrier inside the k-loop -- the four waves drift apart, so their LDS bursts, DMA waits and
+// bookkeeping overlap each other's MFMAs (with one workgroup per CU nothing else would).  The B operand is the
+// static LDS image.  Measured steps of the barrier version: 2300 cycles for 1536 cycles of MFMA (s_memtime).
+// The global_load_lds are issued through inline asm so that the compiler does NOT track them: it would put
+// s_waitcnt vmcnt(0) in front of every later LDS read (it cannot tell the ring slots apart) and expose the full
+// L2 / Infinity-Cache latency in every step.  The waits are placed by hand (vmcnt(6) = all but the youngest stage
+// have landed); compiler-generated vmcnt waits elsewhere can only become stricter.
+// LDS: [A rings 4 waves x 3 slots x 6 KiB][bias table 1 KiB][6 image arrays].
+// ------------------------------------------------------------------------------------------
+constexpr int X6_FWD_SLOT_CELLS = 3 * 2 * 64;        // one wave's stage: [part][octet half][64 rows]
+constexpr int X6_FWD_RING_BYTES = 4 * 3 * X6_FWD_SLOT_CELLS * 16;
+constexpr int X6_FWD_BIAS_BYTES = 1024;
+
+__global__ __launch_bounds__(GEMM_THREADS, 1)
+void conv1_fwd_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
+                         int Mpad, int K8pad, int opr, int tilesPerImg, int rows, int Wp, int arr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* bsm = reinterpret_cast<float*>(smem_raw + X6_FWD_RING_BYTES);
+    unsigned short* img = reinterpret_cast<unsigned short*>(smem_raw + X6_FWD_RING_BYTES + X6_FWD_BIAS_BYTES);
+    const unsigned* imgdw = reinterpret_cast<const unsigned*>(img);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint4* ring = reinterpret_cast<const uint4*>(smem_raw) + wave * 3 * X6_FWD_SLOT_CELLS;
+    const int per_m = g.B * tilesPerImg;
+    const int tile_m = blockIdx.x / per_m;
+    const int rest = blockIdx.x - tile_m * per_m;
+    const int b = rest / tilesPerImg;
+    const int p0 = (rest - b * tilesPerImg) * BN;
+    const int m0 = tile_m * 256;
+    const int hmin = p0 / g.Ho;
+    // zero skipping (single channel): kernel rows whose image rows are pure padding for every output row of the tile
+    int obeg = 0, oend = K8pad;
+    if (g.Cin == 1) {
+        const int plast = min(g.P - 1, p0 + BN - 1);
+        const int hmax = plast / g.Ho;
+        const int ulo = max(0, g.pad - hmax);
+        const int uhi = min(g.ksz - 1, g.pad + g.n - 1 - hmin);
+        obeg = (ulo * opr) & ~1;
+        oend = min(K8pad, ((uhi + 1) * opr + 1) & ~1);
+        if (oend < obeg) oend = obeg;
+    }
+    const int nk = (oend - obeg) >> 1;
+    bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+
+    load_split_image(img, arr, y, b, g, hmin, rows, Wp);      // ends with a barrier (also publishes bsm)
+
+    const int psd = arr >> 1;                          // part stride in dwords
+    int bdw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int p = p0 + j * 32 + (lane & 31);
+        if (p >= g.P) p = g.P - 1;                     // padded columns read valid data; never stored
+        const int h = p / g.Ho, w = p - h * g.Ho;
+        const int boff = (h - hmin) * Wp + w;
+        const int c = boff & 1;
+        bdw[j] = ((c * 3) * arr + boff - c) >> 1;
+    }
+    // this lane half's octet o = obeg + 2t + khalf = (ci*ksz + u)*opr + vo, walked incrementally in registers (no
+    // divisions in the loop):  dword offset ((ci*rows + u)*Wp + 8*vo) / 2, 0 for the padding octets
+    const int khalf = lane >> 5;
+    int o_ci, o_u, o_vo;
+    {
+        const int oo = obeg + khalf;
+        const int cu = oo / opr;
+        o_vo = oo - cu * opr;
+        o_ci = cu / g.ksz;
+        o_u = cu - o_ci * g.ksz;
+    }
+    auto tap_dw = [&]() -> int { return (o_ci < g.Cin) ? (((o_ci * rows + o_u) * Wp + 8 * o_vo) >> 1) : 0; };
+    auto tap_next = [&]() {                            // branch-free: +2 octets wrap at most twice (opr >= 1)
+        o_vo += 2;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const bool wrap = o_vo >= opr;
+            o_vo -= wrap ? opr : 0;
+            o_u += wrap ? 1 : 0;
+            const bool wrap_u = o_u == g.ksz;
+            o_u = wrap_u ? 0 : o_u;
+            o_ci += wrap_u ? 1 : 0;
+        }
+    };
+    // the wave's DMA: rows [64w, 64w+64) of the six (part, octet half) cell rows of octets o, o+1 -> ring slot
+    const long part_cells = (long)K8pad * Mpad;
+    const uint4* a_src = A3 + m0 + 64 * wave + lane;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem_raw +
+                              (unsigned)(wave * 3 * X6_FWD_SLOT_CELLS * 16);
+    auto dma_a = [&](int slot, int o) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh) {
+                const uint4* src = a_src + p * part_cells + (long)(o + oh) * Mpad;
+                const unsigned dst = ring_lds + (unsigned)((slot * 6 + p * 2 + oh) * 64 * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(dst), "v"(src) : "memory");
+            }
+    };
+    auto read_a = [&](int slot, Cell16 (&a)[2][3]) {
+        const uint4* as = ring + slot * X6_FWD_SLOT_CELLS + khalf * 64 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[i][p].u = as[p * 128 + i * 32];
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int olast = K8pad - 2;
+    Cell16 bf[4][3];
+    {
+        const int kt = tap_dw();
+        tap_next();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) read_b_frag(imgdw, bdw[j] + kt, psd, bf[j]);
+        dma_a(0, min(obeg, olast));
+        dma_a(1, min(obeg + 2, olast));
+    }
+    int s_cur = 0, s_dma = 2;
+    for (int t = 0; t < nk; ++t) {
+        // stage t (issued two steps ago) has landed once at most the 6 DMAs of stage t+1 are still in flight
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        Cell16 af[2][3], bn[4][3];
+        read_a(s_cur, af);
+        // bookkeeping of the coming steps: B fragments of step t+1 from the static image, DMA of stage t+2 into the
+        // slot step t-1 used
+        const int ktn = tap_dw();
+        tap_next();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) read_b_frag(imgdw, bdw[j] + ktn, psd, bn[j]);
+        dma_a(s_dma, min(obeg + 2 * (t + 2), olast));   // unconditional (clamped): uniform vmcnt bookkeeping
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mfma6(acc[i][j], af[i], bf[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = bn[j][p];
+        // Issue order (one wave per SIMD issues in order, and an MFMA occupies the pipe for 32 cycles): the 6 A reads,
+        // then every MFMA followed by at most one LDS read and two ALU instructions, so that the 24 B reads and the
+        // address / DMA bookkeeping sit in the shadows of the MFMAs instead of in front of them (a wave can only have
+        // 15 LDS operations outstanding: a burst of 24 reads stalls the in-order issue, MFMAs included).
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int k = 0; k < 48; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        s_cur = (s_cur == 2) ? 0 : s_cur + 1;
+        s_dma = (s_dma == 2) ? 0 : s_dma + 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Direct epilogue (nothing overlaps it with one workgroup per CU, so it must be short): the accumulator layout
+    // already gives 32 consecutive positions (128 contiguous bytes) per row and instruction; no LDS staging.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs still target this wave's ring
+    int pc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc[j] = p0 + j * 32 + (lane & 31);
+    const long imgoff = (long)b * g.R * g.P;
+    const int rmask = (1 << ep.conv_shift) - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + row;
+            const float bv = bsm[row];
+            float* crow = ep.C + (long)(m >> ep.conv_shift) * ep.ldc + imgoff + (long)(m & rmask) * g.P;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[i][j][r] + bv;
+                if (ep.act == ACT_LRELU) v = v > 0.f ? v : v * ep.slope;
+                else if (ep.act == ACT_TANH) v = tanhf(v);
+                if (m < M && pc[j] < g.P) crow[pc[j]] = v;
+            }
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient.  Tile 128 (rows) x 256 (taps), 2x2 waves, wave 64 x 128 = 2 x 4 MFMA tiles; k-step = 2 position
+// octets of one image; split over images as in the fp32 kernel (slab partials + deterministic finalize).
+// 1-D grid, XCD-aware: the tilesN tap tiles of one (row tile, image slice) group share their dY cells in one L2.
+// LDS: [A stages 2 x 12 KiB][position table][6 image arrays].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 1)
+void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict__ y, ConvGeom g, int M, int Mpad,
+                           int N, int opw, int QP, int imgs_per_split, float* ws, int tilesN, int rows, int Wp, int arr,
+                           int nsplits, int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* As = reinterpret_cast<uint4*>(smem_raw);
+    unsigned short* img = reinterpret_cast<unsigned short*>(smem_raw + 2 * X6_STAGE_CELLS_WG * 16 + X6_TAB_BYTES);
+    const unsigned* imgdw = reinterpret_cast<const unsigned*>(img);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_n, gidx;
+    {
+        const int bid = blockIdx.x;
+        if ((ngroups & 7) == 0) {
+            const int x = bid & 7, q = bid >> 3;
+            tile_n = q % tilesN;
+            gidx = (q / tilesN) * 8 + x;
+        } else {
+            tile_n = bid % tilesN;
+            gidx = bid / tilesN;
+        }
+    }
+    const int split = gidx % nsplits, tile_m = gidx / nsplits;
+    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int ib = split * imgs_per_split;
+    const int ie = min(g.B, ib + imgs_per_split);
+    const int Hp = g.n + 2 * g.pad;
+    // kept image rows and zero skipping exactly as in conv1_wgrad_img_kernel (single channel)
+    const int ulo = (rows == Hp) ? 0 : (n0 / g.ksz);
+    int hlo = 0, hhi = g.Ho - 1;
+    if (g.Cin == 1) {
+        const int ua = n0 / g.ksz, ub = min(N - 1, n0 + 255) / g.ksz;
+        hlo = max(0, g.pad - ub);
+        hhi = min(g.Ho - 1, g.pad + g.n - 1 - ua);
+    }
+    const int qbeg = (hlo * opw) & ~1;
+    const int qend = (hhi >= hlo) ? min(QP, (((hhi + 1) * opw) + 1) & ~1) : qbeg;
+    const int nk = (qend - qbeg) >> 1;
+
+    const int psd = arr >> 1;
+    int ndw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int nn = n0 + wn * 128 + j * 32 + (lane & 31);
+        if (nn >= N) nn = N - 1;
+        const int ci = nn / g.K2, rem = nn - ci * g.K2;
+        const int u = rem / g.ksz, v = rem - u * g.ksz;
+        const int noff = (ci * rows + (u - ulo)) * Wp + v;
+        const int c = noff & 1;
+        ndw[j] = ((c * 3) * arr + noff - c) >> 1;
+    }
+    // this lane half's position octet q = qbeg + 2t + khalf = h*opw + wo, walked in registers:
+    // dword offset (h*Wp + 8*wo) / 2   (0 for the octets that pad the count to QP)
+    const int khalf = lane >> 5;
+    int q_h, q_wo;
+    auto pos_reset = [&]() {
+        const int qq = qbeg + khalf;
+        q_h = qq / opw;
+        q_wo = qq - q_h * opw;
+    };
+    auto pos_dw = [&]() -> int { return (q_h < g.Ho) ? ((q_h * Wp + 8 * q_wo) >> 1) : 0; };
+    auto pos_next = [&]() {                            // branch-free
+        q_wo += 2;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const bool wrap = q_wo >= opw;
+            q_wo -= wrap ? opw : 0;
+            q_h += wrap ? 1 : 0;
+        }
+    };
+    const long part_cells = (long)g.B * QP * Mpad;
+    auto dma_a = [&](uint4* stage, int b, int q) {
+        // 6 cell rows of 128 cells = 12 instructions of 64 cells: wave w takes (part, octet half, 64-row half) ids w, w+4, w+8
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int id = wave + 4 * s;               // 0..11
+            const int p = id >> 2, oh = (id >> 1) & 1, mh = id & 1;
+            const uint4* src = D3 + p * part_cells + ((long)b * QP + q + oh) * Mpad + m0 + 64 * mh + lane;
+            uint4* dst = stage + (p * 2 + oh) * 128 + 64 * mh;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2][2];                                // [tap half hn][row tile i][tap tile j within the half]
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[hn][i][j][r] = 0.f;
+
+    const int arow = wm * 64 + (lane & 31);
+    for (int b = ib; b < ie; ++b) {
+        __syncthreads();                                // previous image fully consumed
+        load_split_image(img, arr, y, b, g, ulo, rows, Wp);
+        Cell16 bf[4][3];
+        pos_reset();
+        if (nk > 0) {
+            dma_a(As, b, qbeg);
+            const int pt = pos_dw();
+            pos_next();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) read_b_frag(imgdw, ndw[jj] + pt, psd, bf[jj]);
+        }
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            const bool more = (t + 1) < nk;
+            // all LDS reads of this step first, then the DMA of the next stage (see conv1_fwd_x6_kernel)
+            const int ptn = pos_dw();
+            pos_next();
+            const uint4* as = As + cur * X6_STAGE_CELLS_WG + khalf * 128 + arow;
+            Cell16 af[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[i][p].u = as[p * 256 + i * 32];
+            Cell16 bn[4][3];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) read_b_frag(imgdw, ndw[jj] + ptn, psd, bn[jj]);
+            if (more) dma_a(As + (cur ^ 1) * X6_STAGE_CELLS_WG, b, qbeg + 2 * (t + 1));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                mfma6(acc[jj >> 1][0][jj & 1], af[0], bf[jj]);
+                mfma6(acc[jj >> 1][1][jj & 1], af[1], bf[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[jj][p] = bn[jj][p];
+            __builtin_amdgcn_sched_barrier(0);          // see conv1_fwd_x6_kernel
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // wave (wm, wn) holds rows wm*64 + i*32 and taps wn*128 + hn*64 + j*32: as two 128-column epilogue tiles the
+    // column half is hn' = wn and the wave-in-tile column index is hn -- stage each 128-tap half separately
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        // columns of this pass: n0 + half*128 + [0,128); contributed by the waves with wn == half, whose tiles
+        // (hn, j) sit at column hn*64 + j*32 -- exactly tile_epilogue's (wn' = hn) layout, so every wave stages
+        // its hn-th pair when ITS wn equals `half`, the other waves stage nothing.
+        float* ct = reinterpret_cast<float*>(smem_raw);
+        const int ecol = tid & 127;
+        const int n = n0 + half * 128 + ecol;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i) __syncthreads();
+            if (wn == half) {
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            ct[rl * 128 + hn * 64 + j * 32 + (lane & 31)] = acc[hn][i][j][r];
+                        }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int rl = (tid >> 7) + 2 * it;
+                const int m = m0 + (rl >> 5) * 64 + i * 32 + (rl & 31);
+                if (n < N && m < M) ws[((long)split * M + m) * N + n] = ct[rl * 128 + ecol];
+            }
+        }
+    }
+}
+
+}  // namespace tvae

@@ -7,6 +7,7 @@
 #include "gemm_f32_mfma.hpp"
 #include "small_kernels.hpp"
 #include "fused_tail_kernels.hpp"
+#include "conv_x6_kernels.hpp"
 #include "conv_img_kernels.hpp"
 #include "gemm_bf16x3.hpp"
 
@@ -51,6 +52,7 @@ static inline int pick_splits(int tiles, long K) {
 
 // LDS budget for the image-resident conv kernels (160 KiB per CU on gfx950; keep room for 1 workgroup).
 static const size_t CONV_IMG_LDS_MAX = 150 * 1024;
+static const size_t X6_LDS_MAX = 160 * 1024;       // whole LDS of a CU (one workgroup per CU by design)
 
 template <class KernelT>
 static hipError_t allow_big_lds(KernelT kernel, size_t bytes) {
@@ -77,17 +79,144 @@ static void launch_heads_bwd(const float* W, const float* dY, long ldy, const fl
 }
 
 
+static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
+    ConvGeom g;
+    g.B = B; g.Cin = Cin; g.n = n; g.ksz = ksz; g.pad = pad; g.R = R;
+    g.Ho = n + 2 * pad - ksz + 1;
+    g.P = g.Ho * g.Ho;
+    g.K2 = ksz * ksz;
+    return g;
+}
+
+// Geometry of the 3xbf16-split ("x6") lifting-convolution path (conv_x6_kernels.hpp).
+struct X6Plan {
+    int M, Mpad, opr, K8pad, opw, QP, Wp;
+    int rows_f, arr_f, rows_w, arr_w;
+    size_t lds_f, lds_w;
+    long bank_cells, dy_cells;
+};
+static X6Plan x6_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    X6Plan q;
+    const int Hp = n + 2 * pad, Ho = Hp - ksz + 1;
+    q.M = C * R;
+    q.Mpad = x6_round_up(q.M, 256);
+    q.opr = (ksz + 7) / 8;
+    q.K8pad = x6_round_up(Cin * ksz * q.opr, 2);
+    q.opw = (Ho + 7) / 8;
+    q.QP = x6_round_up(Ho * q.opw, 2);
+    q.Wp = x6_round_up(Hp, 2);
+    q.rows_f = conv_fwd_img_rows(n, ksz, pad);
+    q.arr_f = x6_arr_elems(Cin * q.rows_f * q.Wp);
+    q.lds_f = (size_t)X6_FWD_RING_BYTES + X6_FWD_BIAS_BYTES + (size_t)6 * q.arr_f * 2;
+    q.rows_w = conv_wgrad_img_rows(Cin, n, ksz, pad, 2);
+    q.arr_w = x6_arr_elems(Cin * q.rows_w * q.Wp);
+    q.lds_w = (size_t)2 * X6_STAGE_CELLS_WG * 16 + X6_TAB_BYTES + (size_t)6 * q.arr_w * 2;
+    if (q.lds_w < 64 * 128 * 4) q.lds_w = 64 * 128 * 4;       // epilogue staging tile
+    q.bank_cells = (long)3 * q.K8pad * q.Mpad;
+    q.dy_cells = (long)3 * B * q.QP * q.Mpad;
+    return q;
+}
+
 extern "C" {
 
 int tvae_abi_version(void) { return 1; }
 int tvae_set_gemm_mode(int mode) {
-    if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+    // 0 = exact fp32 MFMA everywhere, 1 = split-bf16 x3 everywhere (lower accuracy), 2 = "x6": the caller routes the
+    // lifting convolution through tvae_conv1_*_x6 (3 x bf16 exact split, fp32-equivalent); the dense entry points here
+    // keep the exact fp32 MFMA
+    if (mode != 0 && mode != 1 && mode != 2) return (int)hipErrorInvalidValue;
     g_gemm_mode = mode;
     return 0;
 }
 int tvae_get_gemm_mode(void) { return g_gemm_mode; }
 
 // 1 if tvae_conv1_fwd wants the k-major bank bankT[Cin*k*k][C*R] (barrier-free kernel), 0 for bank[C*R][Cin*k*k]
+// ---- lifting convolution on the bf16 matrix pipe with fp32-equivalent results (3xbf16 split, 6 products) ----------
+int tvae_conv1_x6_supported(int Cin, int n, int ksz, int pad) {
+    const X6Plan q = x6_plan(1, Cin, n, ksz, pad, 1, 4);
+    return (n + 2 * pad - ksz + 1 > 0 && q.lds_f <= X6_LDS_MAX && q.lds_w <= X6_LDS_MAX) ? 1 : 0;
+}
+long tvae_conv1_x6_bank_bytes(int C, int R, int Cin, int ksz) {
+    return x6_plan(1, Cin, ksz, ksz, 0, C, R).bank_cells * 16;
+}
+long tvae_conv1_x6_dy_bytes(int B, int C, int R, int n, int ksz, int pad) {
+    return x6_plan(B, 1, n, ksz, pad, C, R).dy_cells * 16;
+}
+
+int tvae_bank_split3(const float* bank, void* a3, long a3_bytes, int C, int R, int Cin, int ksz,
+                     tvae_stream_t stream) {
+    const X6Plan q = x6_plan(1, Cin, ksz, ksz, 0, C, R);
+    if (a3_bytes < q.bank_cells * 16 || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    const long total = (long)q.K8pad * q.Mpad;
+    hipLaunchKernelGGL(bank_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), bank, (uint4*)a3, q.M,
+                       q.Mpad, Cin, ksz, q.opr, q.K8pad);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_conv1_fwd_x6(const float* y, const void* a3, const float* bias, float* out, int B, int Cin, int n, int ksz,
+                      int pad, int C, int R, int act, float slope, tvae_stream_t stream) {
+    const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
+    if (g.Ho <= 0) return (int)hipErrorInvalidValue;
+    const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
+    if (q.lds_f > X6_LDS_MAX || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    Epilogue ep;
+    ep.C = out; ep.ldc = (long)B * R * g.P;
+    int sh = 0; while ((1 << sh) < R) ++sh;
+    if ((1 << sh) != R) return (int)hipErrorInvalidValue;
+    ep.bias = bias; ep.bias_shift = sh;
+    ep.act = act; ep.slope = slope;
+    ep.convR = R; ep.conv_shift = sh; ep.convP = g.P;
+    const int tilesPerImg = cdiv(g.P, BN);
+    const long nblk = (long)(q.Mpad / 256) * B * tilesPerImg;
+    if (nblk > 2147483647L) return (int)hipErrorInvalidValue;
+    hipError_t e = allow_big_lds(conv1_fwd_x6_kernel, q.lds_f);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv1_fwd_x6_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), q.lds_f, S(stream),
+                       (const uint4*)a3, y, g, ep, q.M, q.Mpad, q.K8pad, q.opr, tilesPerImg, q.rows_f, q.Wp, q.arr_f);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_conv1_wgrad_x6(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, void* d3,
+                        long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+    const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
+    if (g.Ho <= 0) return (int)hipErrorInvalidValue;
+    const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
+    const int M = q.M, N = Cin * g.K2;
+    if (q.lds_w > X6_LDS_MAX || d3_bytes < q.dy_cells * 16 || !aligned16(d3)) return (int)hipErrorInvalidValue;
+    const long per = (long)M * N;
+    if (!ws || ws_floats < per) return (int)hipErrorInvalidValue;
+    // pre-pass: dY -> split cells
+    hipLaunchKernelGGL(dy_split3_kernel, dim3(B, q.Mpad / R), dim3(256), 0, S(stream), dpre, (long)B * R * g.P,
+                       (uint4*)d3, B, C, R, g.Ho, q.opw, q.QP, q.Mpad);
+    TVAE_CHECK_LAUNCH();
+    const int tilesM = cdiv(M, 128), tilesN = cdiv(N, 256);
+    const int otiles = tilesM * tilesN;
+    int sp = (4 * 256 * 2 + otiles / 2) / otiles;
+    static const int splits_env = [] { const char* e = getenv("TVAE_CONV1_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+    if (splits_env > 0) sp = splits_env;
+    if (sp > B) sp = B;
+    const long cap = ws_floats / per;
+    if (sp > cap) sp = (int)cap;
+    if (sp < 1) sp = 1;
+    const int ips = cdiv(B, sp);
+    sp = cdiv(B, ips);
+    hipError_t e = allow_big_lds(conv1_wgrad_x6_kernel, q.lds_w);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv1_wgrad_x6_kernel, dim3((unsigned)(otiles * sp)), dim3(GEMM_THREADS), q.lds_w, S(stream),
+                       (const uint4*)d3, y, g, M, q.Mpad, N, q.opw, q.QP, ips, ws, tilesN, q.rows_w, q.Wp, q.arr_w, sp,
+                       tilesM * sp);
+    TVAE_CHECK_LAUNCH();
+    Epilogue ep;
+    ep.C = dbank; ep.ldc = N;
+    int blocks = cdiv(per, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, sp, M, N, ep);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
                          int ksz, int R, tvae_stream_t stream) {
     const int k2 = ksz * ksz;
@@ -109,14 +238,6 @@ int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_
     return 0;
 }
 
-static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
-    ConvGeom g;
-    g.B = B; g.Cin = Cin; g.n = n; g.ksz = ksz; g.pad = pad; g.R = R;
-    g.Ho = n + 2 * pad - ksz + 1;
-    g.P = g.Ho * g.Ho;
-    g.K2 = ksz * ksz;
-    return g;
-}
 
 int tvae_conv1_fwd(const float* y, const float* bank, const float* bias, float* out, int B, int Cin, int n, int ksz,
                    int pad, int C, int R, int act, float slope, tvae_stream_t stream) {

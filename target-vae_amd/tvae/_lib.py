@@ -20,6 +20,9 @@ SIGNATURES = {
     'tvae_rotate_bank_bwd': 'ppppppiiiii',
     'tvae_conv1_fwd': 'ppppiiiiiiiif',
     'tvae_conv1_wgrad': 'ppppl iiiiiii'.replace(' ', ''),
+    'tvae_bank_split3': 'ppliiii',
+    'tvae_conv1_fwd_x6': 'ppppiiiiiiiif',
+    'tvae_conv1_wgrad_x6': 'pppplpliiiiiii',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -50,6 +53,13 @@ SIGNATURES = {
     'tvae_adam_flat': 'pppplfffffff',
 }
 
+# pure host queries (no stream argument): name -> (argument codes, return code)
+QUERIES = {
+    'tvae_conv1_x6_supported': ('iiii', 'i'),
+    'tvae_conv1_x6_bank_bytes': ('iiii', 'l'),
+    'tvae_conv1_x6_dy_bytes': ('iiiiii', 'l'),
+}
+
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None
 
@@ -71,6 +81,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [_CT[c] for c in sig] + [ctypes.c_void_p]
+        for name, (sig, ret) in QUERIES.items():
+            fn = getattr(L, name)
+            fn.restype = _CT[ret]
+            fn.argtypes = [_CT[c] for c in sig]
         L.tvae_abi_version.restype = ctypes.c_int
         L.tvae_set_gemm_mode.restype = ctypes.c_int
         L.tvae_set_gemm_mode.argtypes = [ctypes.c_int]
@@ -81,12 +95,14 @@ def lib():
     return _lib
 
 
-GEMM_MODES = {'f32': 0, 'bf16x3': 1}
+GEMM_MODES = {'f32': 0, 'bf16x3': 1, 'x6': 2}
 DEFAULT_GEMM_MODE = 'f32'      # exact fp32 MFMA; 'bf16x3' is opt-in (TVAE_GEMM=bf16x3)
 
 
 def set_gemm_mode(mode: str) -> None:
-    """'f32' = exact fp32 MFMA; 'bf16x3' = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)."""
+    """'f32' = exact fp32 MFMA; 'x6' = lifting convolution on the bf16 matrix pipe with every operand split EXACTLY into
+    three bf16 numbers and six products (fp32-equivalent results, dense layers stay on the fp32 MFMA);
+    'bf16x3' = two-part split, three products everywhere (about 1e-5 relative, opt-in only)."""
     if mode not in GEMM_MODES:
         raise TvaeHipError(f'unknown GEMM mode {mode!r}; choose from {sorted(GEMM_MODES)}')
     rc = lib().tvae_set_gemm_mode(GEMM_MODES[mode])
@@ -100,7 +116,15 @@ def get_gemm_mode() -> str:
 
 
 def exported_symbols():
-    return ['tvae_abi_version', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES)
+    return ['tvae_abi_version', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES) + sorted(QUERIES)
+
+
+def query(name, *args) -> int:
+    """Pure host query of the library (geometry / workspace sizes); no GPU work."""
+    sig, _ = QUERIES[name]
+    if len(args) != len(sig):
+        raise TvaeHipError(f'{name}: expected {len(sig)} arguments, got {len(args)}')
+    return int(getattr(lib(), name)(*[int(a) for a in args]))
 
 
 def _ptr(t, name, pos):

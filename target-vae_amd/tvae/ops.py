@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import tables
-from ._lib import call
+from ._lib import call, get_gemm_mode, query
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 LRELU_SLOPE = 0.01
@@ -154,12 +154,33 @@ def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> to
     return dW
 
 
+def _use_x6(Cin, n, k, pad) -> bool:
+    """Lifting convolution on the bf16 matrix pipe (exact 3 x bf16 operand split, six products; fp32-equivalent)."""
+    return get_gemm_mode() == 'x6' and bool(query('tvae_conv1_x6_supported', Cin, n, k, pad))
+
+
+def _scratch(device, key, floats: int) -> torch.Tensor:
+    """Named persistent scratch buffers (split operands of the x6 convolution)."""
+    k_ = (key, device.type, device.index)
+    t = _WS.get(k_)
+    if t is None or t.numel() < floats:
+        t = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _WS[k_] = t
+    return t
+
+
 def conv1_forward(y, weight, bias, C, R, k, pad, act):
     """Rotated bank + lifting convolution."""
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
     bank = rotate_bank(weight, R)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
+    if _use_x6(Cin, n, k, pad):
+        a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
+        call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k)
+        with _timed('tvae_conv1_fwd'):
+            call('tvae_conv1_fwd_x6', y, a3, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
+        return out
     with _timed('tvae_conv1_fwd'):
         call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
     return out
@@ -169,6 +190,11 @@ def conv1_wgrad(y, dpre, C, R, k, pad):
     B, Cin, n, _ = y.shape
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
+    if _use_x6(Cin, n, k, pad):
+        d3 = _scratch(y.device, 'x6_dy', query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4)
+        with _timed('tvae_conv1_wgrad'):
+            call('tvae_conv1_wgrad_x6', y, dpre, dbank, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+        return dbank
     with _timed('tvae_conv1_wgrad'):
         call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
     return dbank

@@ -153,6 +153,38 @@ def test_conv1_fwd_wgrad(B, Cin, n, k, pad, C, R, act, gemm_mode):
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL[gemm_mode]
 
 
+@pytest.mark.parametrize('B,Cin,n,k,pad,C,R,act', [(2, 1, 28, 28, 8, 8, 8, 1), (3, 3, 12, 9, 3, 4, 4, 0),
+                                                   (2, 1, 64, 64, 16, 4, 8, 1), (5, 2, 20, 7, 0, 3, 16, 0),
+                                                   (3, 1, 64, 64, 16, 16, 8, 1), (2, 1, 40, 32, 6, 32, 4, 0),
+                                                   (2, 1, 20, 16, 3, 8, 16, 1), (17, 1, 64, 64, 16, 48, 8, 1)])
+def test_conv1_x6_matches_fp64_at_fp32_tolerance(B, Cin, n, k, pad, C, R, act):
+    """3xbf16-split conv kernels: same tolerance as the exact-fp32 MFMA path (GEMM_TOL['f32'])."""
+    from tvae._lib import query
+    if not query('tvae_conv1_x6_supported', Cin, n, k, pad):
+        pytest.skip('geometry does not fit the LDS-resident x6 kernels')
+    y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
+    bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(C, seed=3, scale=0.1)
+    Ho = n + 2 * pad - k + 1
+    ref = F.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho) \
+        + bias.double().view(1, C, 1, 1, 1)
+    ref = act_ref(ref, act)
+    a3 = torch.empty(query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4, device=dev())
+    call('tvae_bank_split3', bank.to(dev()), a3, a3.numel() * 4, C, R, Cin, k)
+    out = torch.empty(C, B * R * Ho * Ho, device=dev())
+    call('tvae_conv1_fwd_x6', y.to(dev()), a3, bias.to(dev()), out, B, Cin, n, k, pad, C, R, act, SLOPE)
+    got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+    assert rel_err(got, ref) < GEMM_TOL['f32']
+    g = rnd(B, C, R, Ho, Ho, seed=4)
+    ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
+    dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
+    dbank = torch.empty(C * R, Cin * k * k, device=dev())
+    ws = torch.empty(1 << 22, device=dev())
+    d3 = torch.empty(query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4, device=dev())
+    call('tvae_conv1_wgrad_x6', y.to(dev()), dpre, dbank, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
+
+
 def test_reductions():
     M, N = 37, 10007
     X = rnd(M, N, seed=1)

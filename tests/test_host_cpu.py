@@ -17,7 +17,7 @@ from oracle import tvae_oracle as O
 def test_library_exports_every_declared_symbol():
     from tvae import _lib
     hdr = open(os.path.join(ROOT, 'include', 'tvae_hip.h')).read()
-    declared = sorted(set(re.findall(r'\bint\s+(tvae_\w+)\s*\(', hdr)))
+    declared = sorted(set(re.findall(r'\b(?:int|long)\s+(tvae_\w+)\s*\(', hdr)))
     assert declared == sorted(_lib.exported_symbols())
     L = _lib.lib()
     for name in declared:
