@@ -27,8 +27,21 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
-KERNEL_OF = {'tvae_conv1_fwd': 'conv1_fwd_img_kernel<true,2>', 'tvae_conv1_wgrad': 'conv1_wgrad_img_kernel<1,32,2>'}
+# /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks.  In the default 'x6' arithmetic the lifting convolution
+# runs SIX v_mfma_f32_32x32x16_bf16 per algorithmic product block (exact 3 x bf16 operand split, fp32-equivalent
+# result), so its speed of light in algorithmic FLOP/s is the bf16 peak / 6.
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+MODE_INFO = {
+    'f32': dict(peak=PEAK_F32_MFMA_TFLOPS, insn='v_mfma_f32_32x32x2_f32', suffix='',
+                kernels={'tvae_conv1_fwd': 'conv1_fwd_img_kernel<true,2>',
+                         'tvae_conv1_wgrad': 'conv1_wgrad_img_kernel<1,32,2>'},
+                dtype='f32'),
+    'x6': dict(peak=PEAK_BF16_MFMA_TFLOPS / 6.0, insn='6 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
+               kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
+               dtype='f32 (lifting conv: operands split exactly into 3 x bf16, 6 bf16 MFMAs per product, fp32 '
+                     'accumulate -- fp32-equivalent, same parity tolerances; dense layers: fp32 MFMA)'),
+}
 
 
 def pmc_traffic(entry):
@@ -116,11 +129,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step (BASELINE: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-companion', action='store_true',
+                    help="skip the extra measurement of the same steps in the all-fp32-MFMA mode (TVAE_GEMM=f32)")
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='S64',
                     help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
     args = ap.parse_args()
 
     from tvae import dp, ops, optim, step
+    from tvae import _lib
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -162,6 +178,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mode = _lib.get_gemm_mode()
+    if mode not in MODE_INFO:
+        mode = 'f32' if mode == 'bf16x3' else mode
     for i in range(args.warmup):
         one_step(i)
     barrier()
@@ -174,6 +193,30 @@ def main():
     dt = time.perf_counter() - t0
     kev = ops.kernel_event_ms()
     ops.KERNEL_EVENTS = None
+    # companion measurement: the same number of steps with every matrix product on the exact fp32 MFMA
+    companion = None
+    if world == 1 and mode == 'x6' and not args.no_f32_companion:
+        _lib.set_gemm_mode('f32')
+        for i in range(2):
+            one_step(i)
+        barrier()
+        ops.KERNEL_EVENTS = {}
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        kev1 = ops.kernel_event_ms()
+        ops.KERNEL_EVENTS = None
+        _lib.set_gemm_mode('x6')
+        fl1 = conv1_flops_per_image(c) * B
+        companion = {'value': B * args.steps / dt1, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt1 / args.steps,
+                     'arithmetic': 'TVAE_GEMM=f32: every matrix product on v_mfma_f32_32x32x2_f32',
+                     'conv1_fwd_ms': kev1.get('tvae_conv1_fwd', {}).get('mean_ms'),
+                     'conv1_wgrad_ms': kev1.get('tvae_conv1_wgrad', {}).get('mean_ms'),
+                     'conv1_wgrad_frac_of_f32_peak':
+                         fl1 / (kev1['tvae_conv1_wgrad']['mean_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                         if 'tvae_conv1_wgrad' in kev1 else None}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -191,20 +234,28 @@ def main():
                       'training images/sec (fwd+bwd+Adam), extra workload ' + args.workload,
             'value': imgs / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': MODE_INFO[mode]['dtype'], 'data': 'synthetic',
             'elbo': elbo_last,
             'config': {'workload': c['desc'],
-                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}'},
-            'roofline': {'kernel': dom + ' (' + KERNEL_OF[dom] + ', v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
-                         'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                         'traffic': pmc_traffic(dom) if args.workload == 'S64' else None,
+                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
+                       'arithmetic_mode': mode},
+            'roofline': {'kernel': dom + MODE_INFO[mode]['suffix'] + ' (' + MODE_INFO[mode]['kernels'][dom] + ', ' +
+                                   MODE_INFO[mode]['insn'] + ')', 'bound': 'mfma',
+                         'achieved': ach, 'peak': MODE_INFO[mode]['peak'], 'unit': 'TFLOP/s',
+                         'frac': ach / MODE_INFO[mode]['peak'],
+                         'peak_note': 'algorithmic (fp32-equivalent) FLOP/s; x6 peak = 2500 TFLOP/s dense bf16 / 6 '
+                                      'products per block' if mode == 'x6' else 'dense f32 MFMA peak',
+                         'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': pmc_traffic(dom + MODE_INFO[mode]['suffix']) if args.workload == 'S64' else None,
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
-                         'other': {'kernel': other, 'mean_launch_ms': kev.get(other, {}).get('mean_ms'),
+                         'other': {'kernel': other + MODE_INFO[mode]['suffix'],
+                                   'mean_launch_ms': kev.get(other, {}).get('mean_ms'),
                                    'achieved': (flops / (kev[other]['mean_ms'] * 1e-3) / 1e12) if other in kev
                                    else None}},
         }
+        if companion is not None:
+            out['exact_f32_mode'] = companion
         if world == 1 and not args.no_cpu_baseline and args.workload == 'S64':
             out['cpu_baseline'] = cpu_baseline()
         else:

@@ -81,8 +81,9 @@ int tvae_act_bwd(const float* dY, const float* Y, float* dpre, long n, int act, 
  * 2.67x the matrix rate of the fp32 MFMA.  The operands are pre-split into 16-byte k-octet cells:
  *   tvae_bank_split3     bank [C*R][Cin*ksz*ksz] -> a3 (tvae_conv1_x6_bank_bytes bytes), once per step;
  *   tvae_conv1_fwd_x6    same arguments as tvae_conv1_fwd with a3 instead of bank;
- *   tvae_conv1_wgrad_x6  same as tvae_conv1_wgrad plus d3, a scratch of tvae_conv1_x6_dy_bytes bytes that receives
- *                        the split dY; ws must hold at least C*R*Cin*ksz*ksz floats (one partial slab).
+ *   tvae_dy_split3       dY [C][B*R*Ho*Ho] (the dpre of tvae_conv1_wgrad) -> d3 (tvae_conv1_x6_dy_bytes bytes);
+ *   tvae_conv1_wgrad_x6  same as tvae_conv1_wgrad with d3 instead of dpre; ws must hold at least C*R*Cin*ksz*ksz
+ *                        floats (one partial slab).
  * tvae_conv1_x6_supported: 1 when both kernels fit the 160 KiB LDS for this geometry (else use the fp32 entry
  * points); the three query functions are pure host functions (no stream, no GPU work). */
 int tvae_conv1_x6_supported(int Cin, int n, int ksz, int pad);
@@ -91,8 +92,10 @@ long tvae_conv1_x6_dy_bytes(int B, int C, int R, int n, int ksz, int pad);
 int tvae_bank_split3(const float* bank, void* a3, long a3_bytes, int C, int R, int Cin, int ksz, tvae_stream_t stream);
 int tvae_conv1_fwd_x6(const float* y, const void* a3, const float* bias, float* out, int B, int Cin, int n, int ksz,
                       int pad, int C, int R, int act, float slope, tvae_stream_t stream);
-int tvae_conv1_wgrad_x6(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, void* d3,
-                        long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
+int tvae_dy_split3(const float* dpre, void* d3, long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R,
+                   tvae_stream_t stream);
+int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws, long ws_floats, int B, int Cin, int n,
+                        int ksz, int pad, int C, int R, tvae_stream_t stream);
 
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),

@@ -51,7 +51,9 @@ if query('tvae_conv1_x6_supported', Cin, n, k, pad):
     A1x = torch.empty(C, N, device=dev)
     timeit('x6_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_x6', y, a3, bias, A1x, B, Cin, n, k, pad, C, R, 1, 0.01))
     dbx = torch.empty_like(bank)
-    timeit('x6_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_x6', y, dA1, dbx, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R))
+    call('tvae_dy_split3', dA1, d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+    timeit('x6_dy_split', 0.0, lambda: call('tvae_dy_split3', dA1, d3, d3.numel() * 4, B, Cin, n, k, pad, C, R))
+    timeit('x6_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_x6', y, d3, dbx, ws, ws.numel(), B, Cin, n, k, pad, C, R))
     if not only or 'x6' in only:
         call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
         call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)

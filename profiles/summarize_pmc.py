@@ -6,7 +6,7 @@
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): counters are collected in separate --pmc passes together with
 --kernel-trace only; FETCH_SIZE / WRITE_SIZE are in KiB (x1024 -> bytes here); on gfx950 FETCH_SIZE under-reports
 streamed reads by 2x, which this script re-checks on every run with a kernel whose read volume is known exactly
-(outer_mask_kernel<1> reads the 2.147e9-byte hidden activation H once and writes as much): the `calibration` entry
+(dec_out_bwd_kernel<1> / outer_mask_kernel<1> read the 2.147e9-byte hidden activation H once and write as much): the `calibration` entry
 shows raw and corrected figures side by side.  hbm_bytes_per_launch = 2 * FETCH + WRITE, mean over launches.
 """
 import csv
@@ -15,7 +15,9 @@ import sys
 from collections import defaultdict
 
 ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tvae_conv1_wgrad',
-         'outer_mask_kernel<1>': 'calibration_outer_mask'}
+         'conv1_fwd_x6_kernel': 'tvae_conv1_fwd_x6', 'conv1_wgrad_x6_kernel': 'tvae_conv1_wgrad_x6',
+         'dy_split3_kernel': 'tvae_dy_split3',
+         'outer_mask_kernel<1>': 'calibration_outer_mask', 'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
 def per_kernel(path, counter):

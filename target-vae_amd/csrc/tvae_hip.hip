@@ -178,19 +178,27 @@ int tvae_conv1_fwd_x6(const float* y, const void* a3, const float* bias, float* 
     return 0;
 }
 
-int tvae_conv1_wgrad_x6(const float* y, const float* dpre, float* dbank, float* ws, long ws_floats, void* d3,
-                        long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+int tvae_dy_split3(const float* dpre, void* d3, long d3_bytes, int B, int Cin, int n, int ksz, int pad, int C, int R,
+                   tvae_stream_t stream) {
+    const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
+    if (g.Ho <= 0) return (int)hipErrorInvalidValue;
+    const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
+    if (d3_bytes < q.dy_cells * 16 || !aligned16(d3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dy_split3_kernel, dim3(B, q.Mpad / R), dim3(256), 0, S(stream), dpre, (long)B * R * g.P,
+                       (uint4*)d3, B, C, R, g.Ho, q.opw, q.QP, q.Mpad);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws, long ws_floats, int B, int Cin, int n,
+                        int ksz, int pad, int C, int R, tvae_stream_t stream) {
     const ConvGeom g = make_geom(B, Cin, n, ksz, pad, R);
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
     const int M = q.M, N = Cin * g.K2;
-    if (q.lds_w > X6_LDS_MAX || d3_bytes < q.dy_cells * 16 || !aligned16(d3)) return (int)hipErrorInvalidValue;
+    if (q.lds_w > X6_LDS_MAX || !aligned16(d3)) return (int)hipErrorInvalidValue;
     const long per = (long)M * N;
     if (!ws || ws_floats < per) return (int)hipErrorInvalidValue;
-    // pre-pass: dY -> split cells
-    hipLaunchKernelGGL(dy_split3_kernel, dim3(B, q.Mpad / R), dim3(256), 0, S(stream), dpre, (long)B * R * g.P,
-                       (uint4*)d3, B, C, R, g.Ho, q.opw, q.QP, q.Mpad);
-    TVAE_CHECK_LAUNCH();
     const int tilesM = cdiv(M, 128), tilesN = cdiv(N, 256);
     const int otiles = tilesM * tilesN;
     int sp = (4 * 256 * 2 + otiles / 2) / otiles;

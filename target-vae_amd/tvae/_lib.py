@@ -22,7 +22,8 @@ SIGNATURES = {
     'tvae_conv1_wgrad': 'ppppl iiiiiii'.replace(' ', ''),
     'tvae_bank_split3': 'ppliiii',
     'tvae_conv1_fwd_x6': 'ppppiiiiiiiif',
-    'tvae_conv1_wgrad_x6': 'pppplpliiiiiii',
+    'tvae_dy_split3': 'ppliiiiiii',
+    'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -96,7 +97,7 @@ def lib():
 
 
 GEMM_MODES = {'f32': 0, 'bf16x3': 1, 'x6': 2}
-DEFAULT_GEMM_MODE = 'f32'      # exact fp32 MFMA; 'bf16x3' is opt-in (TVAE_GEMM=bf16x3)
+DEFAULT_GEMM_MODE = 'x6'       # fp32-equivalent split convolution + fp32 MFMA dense layers; TVAE_GEMM=f32 for all-fp32 MFMA
 
 
 def set_gemm_mode(mode: str) -> None:

@@ -192,8 +192,9 @@ def conv1_wgrad(y, dpre, C, R, k, pad):
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     if _use_x6(Cin, n, k, pad):
         d3 = _scratch(y.device, 'x6_dy', query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4)
+        call('tvae_dy_split3', dpre, d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
         with _timed('tvae_conv1_wgrad'):
-            call('tvae_conv1_wgrad_x6', y, dpre, dbank, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+            call('tvae_conv1_wgrad_x6', y, d3, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
         return dbank
     with _timed('tvae_conv1_wgrad'):
         call('tvae_conv1_wgrad', y, dpre, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)

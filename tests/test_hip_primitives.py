@@ -181,7 +181,8 @@ def test_conv1_x6_matches_fp64_at_fp32_tolerance(B, Cin, n, k, pad, C, R, act):
     dbank = torch.empty(C * R, Cin * k * k, device=dev())
     ws = torch.empty(1 << 22, device=dev())
     d3 = torch.empty(query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4, device=dev())
-    call('tvae_conv1_wgrad_x6', y.to(dev()), dpre, dbank, ws, ws.numel(), d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+    call('tvae_dy_split3', dpre, d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
+    call('tvae_conv1_wgrad_x6', y.to(dev()), d3, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
 
