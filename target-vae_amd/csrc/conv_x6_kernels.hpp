@@ -99,24 +99,45 @@ __global__ void bank_split3_kernel(const float* __restrict__ bank, uint4* __rest
 
 // ------------------------------------------------------------------------------------------
 // Pre-pass 2: dY fp32 feature-major [c][img][r][p = h*Ho + w] (row stride lddy) ->
-// cells [part][img][q = h*opw + wo (< QP)][row m = c*R + r < Mpad], 8 consecutive w per cell, zero for w >= Ho,
-// q >= Ho*opw, m >= M.  One workgroup per (img, c): coalesced reads of R*P floats, 16*R-byte write runs.
+// cells [part][img][q < QP][row m = c*R + r < Mpad] in the K order of conv1_wgrad_x6_kernel (X6WgK below):
+//   q <  row_cells : h = q / opwf, 8 consecutive w = 8*(q % opwf) + j
+//   q <  cells     : leftover column w = 8*opwf + (q - row_cells) / opc, 8 consecutive h = 8*((q - row_cells) % opc) + j
+//   q >= cells     : zero (pads the count to an even number)
+// Zero for h >= Ho, m >= M.  One workgroup per (img, c): coalesced reads of R*P floats, 16*R-byte write runs.
 // ------------------------------------------------------------------------------------------
 __global__ void dy_split3_kernel(const float* __restrict__ dy, long lddy, uint4* __restrict__ D3, int B, int C, int R,
-                                 int Ho, int opw, int QP, int Mpad) {
+                                 int Ho, int opwf, int opc, int row_cells, int ncells, int QP, int Mpad) {
+    // the R*P floats of (c, img) are contiguous: stage them through LDS with coalesced loads, gather cells from LDS
+    extern __shared__ float tile[];
     const int img = blockIdx.x, c = blockIdx.y;
     const int P = Ho * Ho;
     const long part_stride = (long)B * QP * Mpad;
+    if (c < C) {
+        const float* src = dy + (long)c * lddy + (long)img * R * P;
+        for (int i = threadIdx.x; i < R * P; i += blockDim.x) tile[i] = src[i];
+    }
+    __syncthreads();
     const int cells = QP * R;
     for (int i = threadIdx.x; i < cells; i += blockDim.x) {
         const int r = i % R, q = i / R;
-        const int h = q / opw, wo = q - h * opw;
         float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int w = wo * 8 + j;
-            v[j] = (c < C && h < Ho && w < Ho) ? dy[(long)c * lddy + ((long)img * R + r) * P + h * Ho + w] : 0.f;
+        int h0, w0, step;                              // first position of the cell and its stride in p
+        if (q < row_cells) {
+            h0 = q / opwf;
+            w0 = 8 * (q - h0 * opwf);
+            step = 1;
+        } else {
+            const int qc = q - row_cells;
+            const int wr = qc / opc;
+            w0 = 8 * opwf + wr;
+            h0 = 8 * (qc - wr * opc);
+            step = Ho;
         }
+        const bool ok = c < C && q < ncells;
+        const int nvalid = ok ? (step == 1 ? 8 : min(8, Ho - h0)) : 0;
+        const float* s0 = tile + r * P + h0 * Ho + w0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (j < nvalid) ? s0[j * step] : 0.f;
         Cell16 hh, mm, ll;
         split3x8(v, hh, mm, ll);
         const long at = ((long)img * QP + q) * Mpad + c * R + r;
@@ -127,13 +148,18 @@ __global__ void dy_split3_kernel(const float* __restrict__ dy, long lddy, uint4*
 }
 
 // rows [row0, row0+rows) of the zero-padded image, split, into the six LDS arrays (copy c, part p) at
-// img + (c*3 + p)*arr:  copy0[e] = x[e], copy1[e] = x[e+1].  Everything is zeroed with 16-byte stores first; then only
-// the pixels that exist are fetched, eight global loads in flight per thread before the first is consumed (with one
-// workgroup per CU nothing else hides that latency).  Ends with a barrier.
+// img + (c*3 + p)*arr:  copy0[e] = x[e], copy1[e] = x[e+1].  With imgT != nullptr the padded columns
+// [tcol0, tcol0 + nct) are ALSO stored transposed (element (ci*nct + col - tcol0)*PT + row) in six more arrays at
+// imgT + (c*3 + p)*arrT (imgT must directly follow the six image arrays: one zero fill covers both).
+// Everything is zeroed with 16-byte stores first; then only the pixels that exist are fetched, eight global loads in
+// flight per thread before the first is consumed (with one workgroup per CU nothing else hides that latency).
+// Ends with a barrier.
 __device__ __forceinline__ void load_split_image(unsigned short* img, int arr, const float* __restrict__ y, int b,
-                                                 const ConvGeom& g, int row0, int rows, int Wp) {
+                                                 const ConvGeom& g, int row0, int rows, int Wp,
+                                                 unsigned short* imgT = nullptr, int arrT = 0, int PT = 0,
+                                                 int tcol0 = 0, int nct = 0) {
     uint4* z = reinterpret_cast<uint4*>(img);
-    const int n16 = (6 * arr * 2) >> 4;                 // arr is a multiple of 64 elements
+    const int n16 = (6 * (arr + (imgT ? arrT : 0)) * 2) >> 4;      // arr, arrT are multiples of 32 elements
     for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const int iy0 = max(0, row0 - g.pad), iy1 = min(g.n, row0 + rows - g.pad);
@@ -143,11 +169,12 @@ __device__ __forceinline__ void load_split_image(unsigned short* img, int arr, c
     const float* yb = y + (long)b * g.Cin * g.n * g.n;
     for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
         float v[8];
-        int at[8];
+        int at[8], att[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
             at[u] = -1;
+            att[u] = -1;
             v[u] = 0.f;
             if (idx < count) {
                 const int ci = idx / per_c;
@@ -155,7 +182,9 @@ __device__ __forceinline__ void load_split_image(unsigned short* img, int arr, c
                 const int ry = rem / g.n, ix = rem - ry * g.n;
                 const int iy = iy0 + ry;
                 v[u] = yb[((long)ci * g.n + iy) * g.n + ix];
-                at[u] = (ci * rows + (iy + g.pad - row0)) * Wp + ix + g.pad;
+                const int rl = iy + g.pad - row0, cp = ix + g.pad;
+                at[u] = (ci * rows + rl) * Wp + cp;
+                if (imgT && cp >= tcol0 && cp < tcol0 + nct) att[u] = (ci * nct + cp - tcol0) * PT + rl;
             }
         }
 #pragma unroll
@@ -171,6 +200,17 @@ __device__ __forceinline__ void load_split_image(unsigned short* img, int arr, c
                     img[3 * arr + e - 1] = h;
                     img[4 * arr + e - 1] = m;
                     img[5 * arr + e - 1] = l;
+                }
+                const int et = att[u];
+                if (et >= 0) {
+                    imgT[0 * arrT + et] = h;
+                    imgT[1 * arrT + et] = m;
+                    imgT[2 * arrT + et] = l;
+                    if (et > 0) {
+                        imgT[3 * arrT + et - 1] = h;
+                        imgT[4 * arrT + et - 1] = m;
+                        imgT[5 * arrT + et - 1] = l;
+                    }
                 }
             }
         }
@@ -386,15 +426,46 @@ void conv1_fwd_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__
 // Weight gradient.  Tile 128 (rows) x 256 (taps), 2x2 waves, wave 64 x 128 = 2 x 4 MFMA tiles; k-step = 2 position
 // octets of one image; split over images as in the fp32 kernel (slab partials + deterministic finalize).
 // 1-D grid, XCD-aware: the tilesN tap tiles of one (row tile, image slice) group share their dY cells in one L2.
-// LDS: [A stages 2 x 12 KiB][position table][6 image arrays].
+//
+// K order of one image (X6WgK): the Ho x Ho output positions are covered WITHOUT padding every row to whole octets:
+//   row cells   q <  Ho*opwf           : 8 consecutive w of one output row h (w < 8*opwf = the whole octets of a row);
+//   column cells q >= Ho*opwf          : the rem = Ho - 8*opwf leftover columns, 8 consecutive h of one column w.
+// (Ho = 33: 132 + 5 cells instead of 165, i.e. 0.6 % instead of 21 % of the MFMAs multiply padding.)  A column cell
+// needs 8 vertically adjacent pixels of the padded image per lane, so the columns that the leftover positions can
+// touch (8*opwf .. 8*opwf+rem-1+ksz-1) are ALSO kept transposed in LDS, again in two parity copies; the parity of a
+// column-cell start is the parity of the lane's tap row u (the transposed pitch and the cell starts are even).
+// The per-step cell ids and image offsets come from a small LDS table built once per workgroup.
+// LDS: [A stages 2 x 12 KiB][cell table][6 image arrays][6 transposed arrays].
 // ------------------------------------------------------------------------------------------
+struct X6WgK {
+    int opwf;      // whole octets per output row
+    int rem;       // leftover columns per row (0..7)
+    int opc;       // octets per leftover column = ceil(Ho / 8)
+    int row_cells; // Ho * opwf
+    int cells;     // row_cells + rem * opc
+    int QP;        // cells + 1 zero cell, rounded up to even (cell index `cells` is all zero)
+};
+static inline X6WgK x6_wg_k(int Ho) {
+    X6WgK k;
+    k.opwf = Ho / 8;
+    k.rem = Ho - 8 * k.opwf;
+    k.opc = (Ho + 7) / 8;
+    k.row_cells = Ho * k.opwf;
+    k.cells = k.row_cells + k.rem * k.opc;
+    k.QP = (k.cells + 2) & ~1;
+    return k;
+}
+constexpr int X6_WG_TAB_INTS = 2 * 256;            // (cell id, packed offset) per octet of the tile's k range, <= 256
+
 __global__ __launch_bounds__(GEMM_THREADS, 1)
 void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict__ y, ConvGeom g, int M, int Mpad,
-                           int N, int opw, int QP, int imgs_per_split, float* ws, int tilesN, int rows, int Wp, int arr,
-                           int nsplits, int ngroups) {
+                           int N, X6WgK kk, int imgs_per_split, float* ws, int tilesN, int rows, int Wp, int arr,
+                           int PT, int arrT, int nsplits, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* As = reinterpret_cast<uint4*>(smem_raw);
-    unsigned short* img = reinterpret_cast<unsigned short*>(smem_raw + 2 * X6_STAGE_CELLS_WG * 16 + X6_TAB_BYTES);
+    int* tab = reinterpret_cast<int*>(smem_raw + 2 * X6_STAGE_CELLS_WG * 16);
+    unsigned short* img = reinterpret_cast<unsigned short*>(smem_raw + 2 * X6_STAGE_CELLS_WG * 16 + X6_WG_TAB_INTS * 4);
+    unsigned short* imgT = img + 6 * arr;
     const unsigned* imgdw = reinterpret_cast<const unsigned*>(img);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,12 +495,35 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
         hlo = max(0, g.pad - ub);
         hhi = min(g.Ho - 1, g.pad + g.n - 1 - ua);
     }
-    const int qbeg = (hlo * opw) & ~1;
-    const int qend = (hhi >= hlo) ? min(QP, (((hhi + 1) * opw) + 1) & ~1) : qbeg;
-    const int nk = (qend - qbeg) >> 1;
+    // octet sequence of this tile: row cells of rows hlo..hhi, then column cells covering hlo..hhi of each leftover
+    // column; padded to an even count with the all-zero cell.  tab[2s] = cell id, tab[2s+1] = dword offset | phase<<24
+    const int nh = max(0, hhi - hlo + 1);
+    const int n_row = nh * kk.opwf;
+    const int ho_lo = hlo >> 3, ho_hi = hhi >> 3;
+    const int n_colh = (nh > 0) ? (ho_hi - ho_lo + 1) : 0;
+    const int n_oct = n_row + kk.rem * n_colh;
+    const int nk = (n_oct + 1) >> 1;
+    const int c0 = 8 * kk.opwf;                        // first leftover column (in output coordinates)
+    for (int s = tid; s < 2 * nk; s += GEMM_THREADS) {
+        int cell = kk.cells, packed = 0;               // padding octet: zero dY cell, any valid image offset
+        if (s < n_row) {
+            const int hr = s / kk.opwf, wo = s - hr * kk.opwf;
+            const int h = hlo + hr;
+            cell = h * kk.opwf + wo;
+            packed = (h * Wp + 8 * wo) >> 1;
+        } else if (s < n_oct) {
+            const int sc = s - n_row;
+            const int wr = sc / n_colh, ho = ho_lo + (sc - wr * n_colh);
+            cell = kk.row_cells + wr * kk.opc + ho;
+            packed = ((wr * PT + 8 * ho) >> 1) | (1 << 24);
+        }
+        tab[2 * s] = cell;
+        tab[2 * s + 1] = packed;
+    }
 
-    const int psd = arr >> 1;
-    int ndw[4];
+    const int psd = arr >> 1, psdT = arrT >> 1;
+    const int tbase = (6 * arr) >> 1;                  // dword index of the transposed arrays
+    int ndw[4], ndwT[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int nn = n0 + wn * 128 + j * 32 + (lane & 31);
@@ -439,38 +533,35 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
         const int noff = (ci * rows + (u - ulo)) * Wp + v;
         const int c = noff & 1;
         ndw[j] = ((c * 3) * arr + noff - c) >> 1;
+        // transposed: element (column v [+ leftover index wr*PT from the table], row u - ulo [+ 8*ho + j])
+        const int toff = (ci * (g.ksz + 7) + v) * PT + (u - ulo);
+        const int ct = toff & 1;
+        ndwT[j] = tbase + (((ct * 3) * arrT + toff - ct) >> 1);
     }
-    // this lane half's position octet q = qbeg + 2t + khalf = h*opw + wo, walked in registers:
-    // dword offset (h*Wp + 8*wo) / 2   (0 for the octets that pad the count to QP)
     const int khalf = lane >> 5;
-    int q_h, q_wo;
-    auto pos_reset = [&]() {
-        const int qq = qbeg + khalf;
-        q_h = qq / opw;
-        q_wo = qq - q_h * opw;
-    };
-    auto pos_dw = [&]() -> int { return (q_h < g.Ho) ? ((q_h * Wp + 8 * q_wo) >> 1) : 0; };
-    auto pos_next = [&]() {                            // branch-free
-        q_wo += 2;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const bool wrap = q_wo >= opw;
-            q_wo -= wrap ? opw : 0;
-            q_h += wrap ? 1 : 0;
-        }
-    };
-    const long part_cells = (long)g.B * QP * Mpad;
-    auto dma_a = [&](uint4* stage, int b, int q) {
+    const long part_cells = (long)g.B * kk.QP * Mpad;
+    auto dma_a = [&](uint4* stage, int b, int s2) {
         // 6 cell rows of 128 cells = 12 instructions of 64 cells: wave w takes (part, octet half, 64-row half) ids w, w+4, w+8
+        const int q0 = __builtin_amdgcn_readfirstlane(tab[2 * s2]);
+        const int q1 = __builtin_amdgcn_readfirstlane(tab[2 * s2 + 2]);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int id = wave + 4 * s;               // 0..11
             const int p = id >> 2, oh = (id >> 1) & 1, mh = id & 1;
-            const uint4* src = D3 + p * part_cells + ((long)b * QP + q + oh) * Mpad + m0 + 64 * mh + lane;
+            const uint4* src = D3 + p * part_cells + ((long)b * kk.QP + (oh ? q1 : q0)) * Mpad + m0 + 64 * mh + lane;
             uint4* dst = stage + (p * 2 + oh) * 128 + 64 * mh;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+    };
+    // B fragments of octet s (this lane half): row cells from the image copies, column cells from the transposed ones
+    auto read_b_all = [&](int s, Cell16 (&bf)[4][3]) {
+        const int packed = tab[2 * s + 1];
+        const bool col = (packed >> 24) != 0;
+        const int off = packed & 0xffffff;
+        const int ps = col ? psdT : psd;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) read_b_frag(imgdw, (col ? ndwT[jj] : ndw[jj]) + off, ps, bf[jj]);
     };
 
     f32x16 acc[2][2][2];                                // [tap half hn][row tile i][tap tile j within the half]
@@ -485,24 +576,18 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
 
     const int arow = wm * 64 + (lane & 31);
     for (int b = ib; b < ie; ++b) {
-        __syncthreads();                                // previous image fully consumed
-        load_split_image(img, arr, y, b, g, ulo, rows, Wp);
+        __syncthreads();                                // previous image fully consumed (and the table is visible)
+        load_split_image(img, arr, y, b, g, ulo, rows, Wp, imgT, arrT, PT, c0, g.ksz + 7);
         Cell16 bf[4][3];
-        pos_reset();
         if (nk > 0) {
-            dma_a(As, b, qbeg);
-            const int pt = pos_dw();
-            pos_next();
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) read_b_frag(imgdw, ndw[jj] + pt, psd, bf[jj]);
+            dma_a(As, b, 0);
+            read_b_all(khalf, bf);
         }
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const bool more = (t + 1) < nk;
             // all LDS reads of this step first, then the DMA of the next stage (see conv1_fwd_x6_kernel)
-            const int ptn = pos_dw();
-            pos_next();
             const uint4* as = As + cur * X6_STAGE_CELLS_WG + khalf * 128 + arow;
             Cell16 af[2][3];
 #pragma unroll
@@ -510,9 +595,8 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[i][p].u = as[p * 256 + i * 32];
             Cell16 bn[4][3];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) read_b_frag(imgdw, ndw[jj] + ptn, psd, bn[jj]);
-            if (more) dma_a(As + (cur ^ 1) * X6_STAGE_CELLS_WG, b, qbeg + 2 * (t + 1));
+            read_b_all(more ? 2 * (t + 1) + khalf : khalf, bn);
+            if (more) dma_a(As + (cur ^ 1) * X6_STAGE_CELLS_WG, b, 2 * (t + 1));
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 mfma6(acc[jj >> 1][0][jj & 1], af[0], bf[jj]);
@@ -527,14 +611,10 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
         }
     }
     __syncthreads();
-    // wave (wm, wn) holds rows wm*64 + i*32 and taps wn*128 + hn*64 + j*32: as two 128-column epilogue tiles the
-    // column half is hn' = wn and the wave-in-tile column index is hn -- stage each 128-tap half separately
+    // wave (wm, wn) holds rows wm*64 + i*32 and taps wn*128 + hn*64 + j*32: stage each 128-tap half separately
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
-        // columns of this pass: n0 + half*128 + [0,128); contributed by the waves with wn == half, whose tiles
-        // (hn, j) sit at column hn*64 + j*32 -- exactly tile_epilogue's (wn' = hn) layout, so every wave stages
-        // its hn-th pair when ITS wn equals `half`, the other waves stage nothing.
         float* ct = reinterpret_cast<float*>(smem_raw);
         const int ecol = tid & 127;
         const int n = n0 + half * 128 + ecol;
@@ -562,5 +642,6 @@ void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict
         }
     }
 }
+
 
 }  // namespace tvae

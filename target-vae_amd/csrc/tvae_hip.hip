@@ -90,8 +90,9 @@ static ConvGeom make_geom(int B, int Cin, int n, int ksz, int pad, int R) {
 
 // Geometry of the 3xbf16-split ("x6") lifting-convolution path (conv_x6_kernels.hpp).
 struct X6Plan {
-    int M, Mpad, opr, K8pad, opw, QP, Wp;
-    int rows_f, arr_f, rows_w, arr_w;
+    int M, Mpad, opr, K8pad, Wp;
+    int rows_f, arr_f, rows_w, arr_w, PT, arr_t;
+    X6WgK kk;
     size_t lds_f, lds_w;
     long bank_cells, dy_cells;
 };
@@ -102,18 +103,20 @@ static X6Plan x6_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.Mpad = x6_round_up(q.M, 256);
     q.opr = (ksz + 7) / 8;
     q.K8pad = x6_round_up(Cin * ksz * q.opr, 2);
-    q.opw = (Ho + 7) / 8;
-    q.QP = x6_round_up(Ho * q.opw, 2);
+    q.kk = x6_wg_k(Ho > 0 ? Ho : 1);
     q.Wp = x6_round_up(Hp, 2);
     q.rows_f = conv_fwd_img_rows(n, ksz, pad);
     q.arr_f = x6_arr_elems(Cin * q.rows_f * q.Wp);
     q.lds_f = (size_t)X6_FWD_RING_BYTES + X6_FWD_BIAS_BYTES + (size_t)6 * q.arr_f * 2;
     q.rows_w = conv_wgrad_img_rows(Cin, n, ksz, pad, 2);
     q.arr_w = x6_arr_elems(Cin * q.rows_w * q.Wp);
-    q.lds_w = (size_t)2 * X6_STAGE_CELLS_WG * 16 + X6_TAB_BYTES + (size_t)6 * q.arr_w * 2;
+    // transposed copies of the leftover columns: pitch covers 8*opc rows of cells plus the tap-row spread of a tile
+    q.PT = x6_round_up(8 * q.kk.opc + (q.rows_w - Ho) + 2, 2);
+    q.arr_t = q.kk.rem > 0 ? x6_arr_elems(Cin * (ksz + 7) * q.PT) : 0;
+    q.lds_w = (size_t)2 * X6_STAGE_CELLS_WG * 16 + X6_WG_TAB_INTS * 4 + (size_t)6 * (q.arr_w + q.arr_t) * 2;
     if (q.lds_w < 64 * 128 * 4) q.lds_w = 64 * 128 * 4;       // epilogue staging tile
     q.bank_cells = (long)3 * q.K8pad * q.Mpad;
-    q.dy_cells = (long)3 * B * q.QP * q.Mpad;
+    q.dy_cells = (long)3 * B * q.kk.QP * q.Mpad;
     return q;
 }
 
@@ -134,7 +137,8 @@ int tvae_get_gemm_mode(void) { return g_gemm_mode; }
 // ---- lifting convolution on the bf16 matrix pipe with fp32-equivalent results (3xbf16 split, 6 products) ----------
 int tvae_conv1_x6_supported(int Cin, int n, int ksz, int pad) {
     const X6Plan q = x6_plan(1, Cin, n, ksz, pad, 1, 4);
-    return (n + 2 * pad - ksz + 1 > 0 && q.lds_f <= X6_LDS_MAX && q.lds_w <= X6_LDS_MAX) ? 1 : 0;
+    return (n + 2 * pad - ksz + 1 > 0 && q.lds_f <= X6_LDS_MAX && q.lds_w <= X6_LDS_MAX &&
+            q.kk.cells + 2 <= X6_WG_TAB_INTS / 2) ? 1 : 0;
 }
 long tvae_conv1_x6_bank_bytes(int C, int R, int Cin, int ksz) {
     return x6_plan(1, Cin, ksz, ksz, 0, C, R).bank_cells * 16;
@@ -184,8 +188,12 @@ int tvae_dy_split3(const float* dpre, void* d3, long d3_bytes, int B, int Cin, i
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
     if (d3_bytes < q.dy_cells * 16 || !aligned16(d3)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(dy_split3_kernel, dim3(B, q.Mpad / R), dim3(256), 0, S(stream), dpre, (long)B * R * g.P,
-                       (uint4*)d3, B, C, R, g.Ho, q.opw, q.QP, q.Mpad);
+    const size_t tile_bytes = (size_t)R * g.P * sizeof(float);
+    if (tile_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
+    hipError_t e0 = allow_big_lds(dy_split3_kernel, tile_bytes);
+    if (e0 != hipSuccess) return (int)e0;
+    hipLaunchKernelGGL(dy_split3_kernel, dim3(B, q.Mpad / R), dim3(256), tile_bytes, S(stream), dpre, (long)B * R * g.P,
+                       (uint4*)d3, B, C, R, g.Ho, q.kk.opwf, q.kk.opc, q.kk.row_cells, q.kk.cells, q.kk.QP, q.Mpad);
     TVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -196,7 +204,7 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
     if (g.Ho <= 0) return (int)hipErrorInvalidValue;
     const X6Plan q = x6_plan(B, Cin, n, ksz, pad, C, R);
     const int M = q.M, N = Cin * g.K2;
-    if (q.lds_w > X6_LDS_MAX || !aligned16(d3)) return (int)hipErrorInvalidValue;
+    if (q.lds_w > X6_LDS_MAX || !aligned16(d3) || q.kk.cells + 2 > X6_WG_TAB_INTS / 2) return (int)hipErrorInvalidValue;
     const long per = (long)M * N;
     if (!ws || ws_floats < per) return (int)hipErrorInvalidValue;
     const int tilesM = cdiv(M, 128), tilesN = cdiv(N, 256);
@@ -213,8 +221,8 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
     hipError_t e = allow_big_lds(conv1_wgrad_x6_kernel, q.lds_w);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(conv1_wgrad_x6_kernel, dim3((unsigned)(otiles * sp)), dim3(GEMM_THREADS), q.lds_w, S(stream),
-                       (const uint4*)d3, y, g, M, q.Mpad, N, q.opw, q.QP, ips, ws, tilesN, q.rows_w, q.Wp, q.arr_w, sp,
-                       tilesM * sp);
+                       (const uint4*)d3, y, g, M, q.Mpad, N, q.kk, ips, ws, tilesN, q.rows_w, q.Wp, q.arr_w, q.PT,
+                       q.arr_t, sp, tilesM * sp);
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dbank; ep.ldc = N;
