@@ -97,6 +97,20 @@ int tvae_dy_split3(const float* dpre, void* d3, long d3_bytes, int B, int Cin, i
 int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws, long ws_floats, int B, int Cin, int n,
                         int ksz, int pad, int C, int R, tvae_stream_t stream);
 
+/* ---- dense layers in the same "x6" arithmetic (nn.Linear of SpatialGenerator, src/models.py:78-93,119-120) -----------
+ * tvae_dense_split3: W (row stride ldw) -> cells for A(row, k) = W[row][k] (transpose = 0: forward, rows = out
+ *                    features) or A(row, k) = W[k][row] (transpose = 1: data gradient, rows = in features);
+ *                    a3 needs tvae_dense_x6_bytes(rows, K) bytes (host query).
+ * tvae_linear_fwd_x6 / tvae_linear_dgrad_x6: as tvae_linear_fwd / tvae_linear_dgrad with the split weight instead of
+ *                    W (no per-image bias); N must be a multiple of 128 (else hipErrorInvalidValue: use the fp32 entry). */
+long tvae_dense_x6_bytes(int rows, int K);
+int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                      tvae_stream_t stream);
+int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
+                       int K, long ldx, long ldy, int act, float slope, tvae_stream_t stream);
+int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
+                         int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream);
+
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),
  *              replaces outer_mask + two rowdot passes:

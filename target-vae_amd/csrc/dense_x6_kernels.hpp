@@ -1,0 +1,210 @@
+// Dense layers  Y[m][n] = sum_k A(m,k) X[k][n]  on the bf16 matrix pipe with fp32-equivalent results (the "x6"
+// arithmetic of conv_x6_kernels.hpp: every operand split EXACTLY into three bf16 numbers, six partial products,
+// fp32 accumulation).  Used for the 512x512 decoder layers: forward (A = W) and data gradient (A = W^T, X = dY).
+//
+//   * A (the weight, <= 1.5 MB) is split once per call by a tiny pre-pass into fragment-ready cells
+//     [part][k-octet][row]; it stays L2 resident, and every wave loads the cells of its own 64 rows straight into
+//     registers (one 16-byte load per fragment part, 64 consecutive cells per wave instruction), one step ahead.
+//   * X is feature-major [k][n] (n contiguous), i.e. the 8 consecutive k an MFMA B fragment needs per lane are strided
+//     in memory.  The workgroup transposes on the fly: thread (octet, n) loads its 8 k-values with 8 coalesced dword
+//     loads (two steps ahead), splits them (split3x8) in the shadow of the MFMAs and writes the three 16-byte cells to
+//     the [part][octet][n] LDS stage of the NEXT step; B fragments are conflict-free ds_read_b128.
+//   * Tile 512 x 128, eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step),
+//     two per SIMD; one barrier per step (the B stage is shared), double-buffered B stage, XCD-aware tile order.
+//   * Direct epilogue from the accumulator layout (32 consecutive n = 128 contiguous bytes per row and instruction):
+//     bias, residual, activation, activation-derivative mask.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_x6_kernels.hpp"
+
+namespace tvae {
+
+// Pre-pass: W fp32 -> cells [part][octet][row < Rpad].
+//   transpose == 0: A(row, k) = W[row*ldw + k]        (forward: rows = out features, k = in features)
+//   transpose == 1: A(row, k) = W[k*ldw + row]        (data gradient: rows = in features, k = out features)
+// Rows >= Rrows and k >= K are zero; K8pad octets (even).
+__global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
+                                    int K, int K8pad, int transpose) {
+    const long total = (long)K8pad * Rpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i % Rpad);
+        const int o = (int)(i / Rpad);
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * o + j;
+            r[j] = (row < Rrows && k < K) ? (transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k]) : 0.f;
+        }
+        Cell16 h, m, l;
+        split3x8(r, h, m, l);
+        A3[i] = h.u;
+        A3[total + i] = m.u;
+        A3[2 * total + i] = l.u;
+    }
+}
+
+constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
+constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
+
+template <int ACT, int MASK, bool RES>
+__device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
+                                                  int n0, int M, int wave, int lane) {
+    // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
+    // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
+    // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
+    // waves per SIMD.
+    const long off = n0 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            float av[8][4], rv[8][4];
+            long mrow[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rh * 8 + q;
+                mrow[q] = (long)min(m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+            }
+            if (MASK != ACT_NONE) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[q][j] = ep.aux[mrow[q] * ep.ldaux + off + j * 32];
+            }
+            if (RES) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[q][j] = ep.res[mrow[q] * ep.ldres + off + j * 32];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rh * 8 + q;
+                const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + row;
+                const float bv = bsm[row];
+                float* crow = ep.C + mrow[q] * ep.ldc + off;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[i][j][r] + bv;
+                    if (RES) v += rv[q][j];
+                    if (ACT == ACT_LRELU) v = v > 0.f ? v : v * ep.slope;
+                    else if (ACT == ACT_TANH) v = tanhf(v);
+                    if (MASK == ACT_LRELU) v *= av[q][j] > 0.f ? 1.f : ep.slope;
+                    else if (MASK == ACT_TANH) v *= 1.f - av[q][j] * av[q][j];
+                    if (m < M) crow[j * 32] = v;
+                }
+            }
+        }
+}
+
+// Tile 512 x 128: eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step), two per
+// SIMD, so one wave's split arithmetic, LDS traffic and load waits run under the other's MFMAs.  Every k-value of X is
+// split once per 512 output rows (4 per thread per step).
+__global__ __launch_bounds__(DX6_THREADS, 2)
+void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
+                     int N, int K, int K8pad, TileMap tm) {
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
+    __shared__ float bsm[DX6_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n, split_unused;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
+    const int m0 = tile_m * DX6_ROWS, n0 = tile_n * 128;
+    const int khalf = lane >> 5;
+    const int nk = K8pad >> 1;
+    bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+
+    // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
+    const long part_cells = (long)K8pad * Mpad;
+    const uint4* a_ptr = A3 + (long)khalf * Mpad + m0 + 64 * wave + (lane & 31);
+    auto load_a = [&](int t, Cell16 (&a)[2][3]) {
+        const uint4* q = a_ptr + (long)(2 * t) * Mpad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[i][p].u = q[p * part_cells + i * 32];
+    };
+    // B build role: k-quad kq (4 consecutive k = half a cell), column nb
+    const int kq = tid >> 7, nb = tid & 127;
+    const float* x_ptr = X + (long)(4 * kq) * ldx + n0 + nb;
+    auto load_x = [&](int t, float (&x)[4]) {
+        const float* q = x_ptr + (long)(16 * t) * ldx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (16 * t + 4 * kq + j < K) ? q[(long)j * ldx] : 0.f;
+    };
+    auto store_b = [&](int stage, const float (&x)[4]) {
+        unsigned hw[2], mw[2], lw[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned short h0, m0_, l0, h1, m1, l1;
+            split3(x[2 * q], h0, m0_, l0);
+            split3(x[2 * q + 1], h1, m1, l1);
+            hw[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+            mw[q] = (unsigned)m0_ | ((unsigned)m1 << 16);
+            lw[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
+        dst[0] = make_uint2(hw[0], hw[1]);
+        dst[2 * 256] = make_uint2(mw[0], mw[1]);
+        dst[2 * 512] = make_uint2(lw[0], lw[1]);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Cell16 af[2][3];
+    float x1[4], x2[4];
+    {
+        float x0[4];
+        load_x(0, x0);
+        load_a(0, af);
+        load_x(nk > 1 ? 1 : 0, x1);
+        store_b(0, x0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        Cell16 an[2][3];
+        load_a(t + 1 < nk ? t + 1 : t, an);             // A cells of the next step, X values two steps ahead
+        load_x(t + 2 < nk ? t + 2 : t, x2);
+        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Cell16 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
+            mfma6(acc[0][j], af[0], bf);
+            mfma6(acc[1][j], af[1], bf);
+            if (j == 1) store_b(cur ^ 1, x1);           // cells of step t+1
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x1[j] = x2[j];
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // epilogue specialised on (activation, mask, residual): no per-element branches
+    const bool res = ep.res != nullptr;
+#define TVAE_DX6_EPI(A_, M_, R_) dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane)
+    if (ep.mask == ACT_NONE) {
+        if (ep.act == ACT_LRELU) { if (res) TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, true); else TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, false); }
+        else if (ep.act == ACT_TANH) { if (res) TVAE_DX6_EPI(ACT_TANH, ACT_NONE, true); else TVAE_DX6_EPI(ACT_TANH, ACT_NONE, false); }
+        else { if (res) TVAE_DX6_EPI(ACT_NONE, ACT_NONE, true); else TVAE_DX6_EPI(ACT_NONE, ACT_NONE, false); }
+    } else if (ep.mask == ACT_LRELU) {
+        if (res) TVAE_DX6_EPI(ACT_NONE, ACT_LRELU, true); else TVAE_DX6_EPI(ACT_NONE, ACT_LRELU, false);
+    } else {
+        if (res) TVAE_DX6_EPI(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI(ACT_NONE, ACT_TANH, false);
+    }
+#undef TVAE_DX6_EPI
+}
+
+}  // namespace tvae

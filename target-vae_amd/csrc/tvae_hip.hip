@@ -8,6 +8,7 @@
 #include "small_kernels.hpp"
 #include "fused_tail_kernels.hpp"
 #include "conv_x6_kernels.hpp"
+#include "dense_x6_kernels.hpp"
 #include "conv_img_kernels.hpp"
 #include "gemm_bf16x3.hpp"
 
@@ -231,6 +232,53 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, sp, M, N, ep);
     TVAE_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
+long tvae_dense_x6_bytes(int rows, int K) {
+    const long Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    return 3 * K8pad * Rpad * 16;
+}
+int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                      tvae_stream_t stream) {
+    if (rows <= 0 || K <= 0) return 0;
+    if (a3_bytes < tvae_dense_x6_bytes(rows, K) || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const long total = (long)K8pad * Rpad;
+    hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
+                       Rpad, K, K8pad, transpose);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
+                           hipStream_t st) {
+    if (rows <= 0 || N <= 0) return 0;
+    if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
+    hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep, rows,
+                       Rpad, N, K, K8pad, tm);
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}
+int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
+                       int K, long ldx, long ldy, int act, float slope, tvae_stream_t stream) {
+    Epilogue ep;
+    ep.C = Y; ep.ldc = ldy;
+    ep.bias = bias;
+    ep.res = res; ep.ldres = ldy;
+    ep.act = act; ep.slope = slope;
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream));
+}
+int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
+                         int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream) {
+    // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
+    Epilogue ep;
+    ep.C = dX; ep.ldc = ldx;
+    ep.res = add; ep.ldres = ldx;
+    ep.aux = aux; ep.ldaux = ldx;
+    ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
+    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream));
 }
 
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,

@@ -24,6 +24,9 @@ SIGNATURES = {
     'tvae_conv1_fwd_x6': 'ppppiiiiiiiif',
     'tvae_dy_split3': 'ppliiiiiii',
     'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
+    'tvae_dense_split3': 'plpliii',
+    'tvae_linear_fwd_x6': 'pppppiiillif',
+    'tvae_linear_dgrad_x6': 'pppppiiillif',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -59,6 +62,7 @@ QUERIES = {
     'tvae_conv1_x6_supported': ('iiii', 'i'),
     'tvae_conv1_x6_bank_bytes': ('iiii', 'l'),
     'tvae_conv1_x6_dy_bytes': ('iiiiii', 'l'),
+    'tvae_dense_x6_bytes': ('ii', 'l'),
 }
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}

@@ -125,6 +125,19 @@ def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None)
     return out
 
 
+def _dense_x6_ok(rows: int, N: int) -> bool:
+    """Dense layers on the split bf16 pipe: wide layers only (the 512-row tile would waste a 128-row layer)."""
+    return get_gemm_mode() == 'x6' and N % 128 == 0 and rows >= 256
+
+
+def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str) -> torch.Tensor:
+    """W (out, in) -> fragment-ready 3 x bf16 cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad)."""
+    W = W.contiguous()
+    w3 = _scratch(W.device, key, query('tvae_dense_x6_bytes', rows, K) // 4)
+    call('tvae_dense_split3', W, W.shape[1], w3, w3.numel() * 4, rows, K, 1 if transpose else 0)
+    return w3
+
+
 def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
@@ -436,8 +449,13 @@ class DecoderFn(torch.autograd.Function):
         hs = [h]
         for (W, b) in hidden:
             hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
-            call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_, Nt,
-                 Nt, act, LRELU_SLOPE)
+            if _dense_x6_ok(F_, Nt):
+                w3 = _split_weight(W, F_, F_, False, 'x6_dense_w')
+                call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
+                     LRELU_SLOPE)
+            else:
+                call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
+                     Nt, Nt, act, LRELU_SLOPE)
             hs.append(hn)
         yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
         call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
@@ -479,8 +497,13 @@ class DecoderFn(torch.autograd.Function):
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             dprev = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
-            call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
-                 LRELU_SLOPE)
+            if _dense_x6_ok(F_, Nt):
+                w3t = _split_weight(W, F_, F_, True, 'x6_dense_wt')
+                call('tvae_linear_dgrad_x6', w3t, d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
+                     LRELU_SLOPE)
+            else:
+                call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
+                     act, LRELU_SLOPE)
             d = dprev
             grads_hidden.append((dW, db))
         grads_hidden.reverse()

@@ -186,6 +186,42 @@ def test_conv1_x6_matches_fp64_at_fp32_tolerance(B, Cin, n, k, pad, C, R, act):
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
 
+@pytest.mark.parametrize('M,N,K,act,use_res', [(512, 2048, 512, 1, False), (128, 1024, 128, 1, True), (300, 384, 40, 2, False),
+                                               (512, 128, 512, 0, True), (64, 256, 1024, 1, False)])
+def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
+    """Dense layers in the exact-split bf16 arithmetic: same tolerance as the fp32 MFMA path."""
+    from tvae._lib import query
+    W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
+    res = rnd(M, N, seed=5) if use_res else None
+    ref = W.double() @ X.double() + b.double()[:, None]
+    if use_res:
+        ref = ref + res.double()
+    ref = act_ref(ref, act)
+    w3 = torch.empty(query('tvae_dense_x6_bytes', M, K) // 4, device=dev())
+    Wd = W.to(dev())
+    call('tvae_dense_split3', Wd, K, w3, w3.numel() * 4, M, K, 0)
+    Y = torch.empty(M, N, device=dev())
+    call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), res.to(dev()) if use_res else None, Y, M, N, K, N, N, act,
+         SLOPE)
+    assert rel_err(Y, ref) < GEMM_TOL['f32']
+    # data gradient: dX[k][n] = act'(aux) * (add + sum_m W[m][k] d[m][n])
+    d = rnd(M, N, seed=6)
+    aux = rnd(K, N, seed=7).clamp(-0.9, 0.9)
+    add = rnd(K, N, seed=8) if use_res else None
+    refg = W.double().t() @ d.double()
+    if use_res:
+        refg = refg + add.double()
+    refg = refg * dact_ref(aux.double(), act)
+    w3t = torch.empty(query('tvae_dense_x6_bytes', K, M) // 4, device=dev())
+    call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1)
+    dX = torch.empty(K, N, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
+         dX, M, N, K, N, N, act, SLOPE)
+    assert rel_err(dX, refg) < GEMM_TOL['f32']
+    with pytest.raises(Exception):
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE)
+
+
 def test_reductions():
     M, N = 37, 10007
     X = rnd(M, N, seed=1)
