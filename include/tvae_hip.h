@@ -110,6 +110,10 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
                        int K, long ldx, long ldy, int act, float slope, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream);
+/* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned
+ * rows and a workspace of at least M*K floats (hipErrorInvalidValue otherwise: use the fp32 entry). */
+int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
+                         long ldd, long ldx, int accumulate, tvae_stream_t stream);
 
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),

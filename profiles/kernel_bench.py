@@ -87,3 +87,4 @@ timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, 
 timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
 timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01))
 timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
+timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))

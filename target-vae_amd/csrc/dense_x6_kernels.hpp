@@ -207,4 +207,135 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #undef TVAE_DX6_EPI
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a dense layer in the same arithmetic:  dW[m][k] = sum_n dY[m][n] X[k][n].
+// Both operands are row-major with the reduction index n contiguous, so a fragment cell (8 consecutive n of one row)
+// is 32 contiguous bytes of its row.  Tile 512 (m) x 128 (k), eight waves stacked along m (64 x 128 each); the
+// reduction is split over n-chunks (slab partials + the deterministic finalize of the fp32 core), 1-D XCD-aware grid
+// (the k-tiles of one chunk share the dY panel in one L2).
+//   * A (dY): every lane loads and splits the cells of its OWN fragments (rows 64w + 32i + lane&31, octet lane>>5)
+//     straight into registers, one step ahead -- no LDS, no barrier dependence;
+//   * B (X): the 128 x 16 tile of a step is split cooperatively (4 values per thread) into the [part][octet][row]
+//     LDS stage of the next step, as in dense_x6_kernel.
+// Requires n-chunks that are multiples of 16 and 16-byte aligned rows (checked on the host).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DX6_THREADS, 2)
+void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
+                           int M, int Kf, int N, int nchunk, TileMap tm) {
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_k, split;
+    if (!tm.decode(blockIdx.x, tile_m, tile_k, split)) return;
+    const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
+    const int nbeg = split * nchunk;
+    const int nend = min(N, nbeg + nchunk);
+    const int nk = (nend - nbeg) >> 4;
+    const int khalf = lane >> 5;
+
+    // A: this lane's two fragment rows
+    const float* a_ptr[2];
+    float a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 64 * wave + 32 * i + (lane & 31);
+        a_ok[i] = m < M ? 1.f : 0.f;
+        a_ptr[i] = dY + (long)min(m, M - 1) * ldd + nbeg + 8 * khalf;
+    }
+    auto load_a = [&](int t, float4 (&r)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4* q = reinterpret_cast<const float4*>(a_ptr[i] + 16 * t);
+            r[i][0] = q[0];
+            r[i][1] = q[1];
+        }
+    };
+    auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
+                                r[i][1].x * a_ok[i], r[i][1].y * a_ok[i], r[i][1].z * a_ok[i], r[i][1].w * a_ok[i]};
+            split3x8(v, a[i][0], a[i][1], a[i][2]);
+        }
+    };
+    // B build role: row kr (of the 128 feature rows), n-quad q (4 consecutive n = half a cell)
+    const int kr = tid >> 2, q4 = tid & 3;
+    const float b_ok = (k0 + kr) < Kf ? 1.f : 0.f;
+    const float* x_ptr = X + (long)min(k0 + kr, Kf - 1) * ldx + nbeg + 4 * q4;
+    auto load_x = [&](int t) -> float4 { return *reinterpret_cast<const float4*>(x_ptr + 16 * t); };
+    auto store_b = [&](int stage, const float4& x) {
+        unsigned hw[2], mw[2], lw[2];
+        const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned short h0, m0_, l0, h1, m1, l1;
+            split3(v[2 * q], h0, m0_, l0);
+            split3(v[2 * q + 1], h1, m1, l1);
+            hw[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+            mw[q] = (unsigned)m0_ | ((unsigned)m1 << 16);
+            lw[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
+        dst[0] = make_uint2(hw[0], hw[1]);
+        dst[2 * 256] = make_uint2(mw[0], mw[1]);
+        dst[2 * 512] = make_uint2(lw[0], lw[1]);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Cell16 af[2][3];
+    float4 ar[2][2], x1;
+    if (nk > 0) {
+        load_a(0, ar);
+        const float4 x0 = load_x(0);
+        x1 = load_x(nk > 1 ? 1 : 0);
+        split_a(ar, af);
+        load_a(nk > 1 ? 1 : 0, ar);
+        store_b(0, x0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const float4 x2 = load_x(t + 2 < nk ? t + 2 : t);   // X values two steps ahead
+        Cell16 an[2][3];
+        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Cell16 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
+            mfma6(acc[0][j], af[0], bf);
+            mfma6(acc[1][j], af[1], bf);
+            if (j == 0) split_a(ar, an);                 // A cells of step t+1 (loaded during step t-1)
+            if (j == 1) store_b(cur ^ 1, x1);            // B cells of step t+1
+            if (j == 2) load_a(t + 2 < nk ? t + 2 : t, ar);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
+        x1 = x2;
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // slab partial: ws[split][M][Kf]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+            float* wrow = ws + ((long)split * M + m) * Kf + k0 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = acc[i][j][r];
+        }
+}
+
 }  // namespace tvae

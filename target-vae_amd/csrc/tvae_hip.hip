@@ -280,6 +280,36 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
     return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream));
 }
+int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
+                         long ldd, long ldx, int accumulate, tvae_stream_t stream) {
+    // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
+    if (M <= 0 || K <= 0) return 0;
+    if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || ldx % 4 != 0 || !aligned16(dpre) || !aligned16(X) || !ws)
+        return (int)hipErrorInvalidValue;
+    const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
+    const long per = (long)M * K;
+    const long cap = ws_floats / per;
+    if (cap < 2 || N < 32) return (int)hipErrorInvalidValue;
+    int splits = (2 * 256 + tilesM * tilesK - 1) / (tilesM * tilesK);     // ~2 workgroups per CU
+    if (splits > cap) splits = (int)cap;
+    if (splits > N / 16) splits = N / 16;
+    if (splits < 2) splits = 2;                        // TileMap groups by reduction slice only when there are >= 2
+    const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
+    splits = cdiv(N, nchunk);
+    if (splits < 2) return (int)hipErrorInvalidValue;
+    const TileMap tmk{tilesM, tilesK, splits};
+    hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx, ws, M,
+                       K, N, nchunk, tmk);
+    TVAE_CHECK_LAUNCH();
+    Epilogue ep;
+    ep.C = dW; ep.ldc = K;
+    ep.accumulate = accumulate;
+    int blocks = cdiv(per, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits, M, K, ep);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
 
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
                          int ksz, int R, tvae_stream_t stream) {

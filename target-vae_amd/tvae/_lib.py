@@ -27,6 +27,7 @@ SIGNATURES = {
     'tvae_dense_split3': 'plpliii',
     'tvae_linear_fwd_x6': 'pppppiiillif',
     'tvae_linear_dgrad_x6': 'pppppiiillif',
+    'tvae_linear_wgrad_x6': 'ppppliiilli',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',

@@ -142,6 +142,9 @@ def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
     ws = workspace(dpre.device, max(need, 1 << 24))
+    if get_gemm_mode() == 'x6' and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
+        call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
+        return dW
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
 

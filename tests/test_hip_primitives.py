@@ -222,6 +222,19 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
         call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE)
 
 
+@pytest.mark.parametrize('M,N,K,acc', [(512, 20000 // 16 * 16, 512, 0), (128, 8192, 128, 0), (300, 1600, 70, 1), (512, 4096, 512, 1)])
+def test_linear_wgrad_x6(M, N, K, acc):
+    d, X = rnd(M, N, seed=1), rnd(K, N, seed=2)
+    init = rnd(M, K, seed=3)
+    ref = d.double() @ X.double().t() + (init.double() if acc else 0)
+    dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
+    ws = torch.empty(1 << 24, device=dev())
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc)
+    assert rel_err(dW, ref) < GEMM_TOL['f32']
+    with pytest.raises(Exception):
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc)
+
+
 def test_reductions():
     M, N = 37, 10007
     X = rnd(M, N, seed=1)
