@@ -39,8 +39,9 @@ MODE_INFO = {
                 dtype='f32'),
     'x6': dict(peak=PEAK_BF16_MFMA_TFLOPS / 6.0, insn='6 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
-               dtype='f32 (lifting conv: operands split exactly into 3 x bf16, 6 bf16 MFMAs per product, fp32 '
-                     'accumulate -- fp32-equivalent, same parity tolerances; dense layers: fp32 MFMA)'),
+               dtype='f32 (matrix products: operands split exactly into 3 x bf16, 6 bf16 MFMAs per product, fp32 '
+                     'accumulate -- fp32-equivalent, same parity tolerances; the 512-wide decoder layers likewise, the '
+                     '128-wide encoder 1x1x1 layers on the fp32 MFMA)'),
 }
 
 
