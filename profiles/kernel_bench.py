@@ -88,3 +88,14 @@ timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', 
 timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01))
 timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01))
 timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))
+if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
+    at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev)
+    wsd = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev)
+    A1d = torch.empty(C, N, device=dev)
+    timeit('dft_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_dft', y, bank, bias, A1d, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 1, 0.01))
+    dbd = torch.empty_like(bank)
+    timeit('dft_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_dft', dA1, at, dbd, wsd, wsd.numel(), B, Cin, n, k, pad, C, R))
+    if not only or 'dft' in only:
+        call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
+        call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+        print('dft fwd vs f32-MFMA rel diff %.3e   wgrad rel diff %.3e' % (float((A1d - A1).norm() / A1.norm()), float((dbd - dbank).norm() / dbank.norm())))

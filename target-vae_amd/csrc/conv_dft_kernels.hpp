@@ -1,0 +1,318 @@
+// Lifting convolution through the frequency domain, with the DFTs and the spectral contraction written as GEMMs.
+//
+// The reference's conv1 correlates a 64x64-tap filter bank with a 96x96 padded image to get 33x33 outputs: 8.9 MFLOP
+// per (image, filter) in the direct form, and the direct kernels sit on the board power limit of the matrix pipe.
+// With the circular-correlation theorem on an L x L frame (L = n + 2*pad; outputs h, w <= L - ksz are alias free)
+//     out[b][m][h][w] = 1/L^2 * Re sum_{fx < Lh} c_fx e^{+2 pi i fx w / L}  T[fx][(b,h)][m]
+//     T[fx][(b,h)][m] = sum_{fy < L} ( Yh[b][fy][fx] e^{+2 pi i fy h / L} ) * conj( Kh[m][fy][fx] )
+// (Lh = L/2 + 1 by Hermitian symmetry, c_fx = 1 for fx = 0 and fx = L/2, else 2) the heavy part is, for every fx,
+// ONE complex GEMM  [(b,h): B*Ho] x [fy: L] x [m: C*R]  = 326 GFLOP per launch instead of 2 339 GFLOP, and it runs
+// on the split-bf16 dense kernels (dense_x6_kernels.hpp) as a real GEMM with the complex structure folded into the
+// operands:  [Tr; Ti] = [[Kr, Ki], [-Ki, Kr]] . [Ar; Ai]   (rows m | M+m, reduction index (re/im, fy)).
+// The weight gradient is the same contraction transposed:
+//     dKh'[m][fy][fx] = sum_{(b,h)} conj(S[fx][m][(b,h)]) * A[fx][(b,h)][fy],   S = DFT over w of dY,
+// followed by a small inverse DFT per filter.  Everything else here is small streaming work:
+//   dft_image_kernel   y -> A^T[fx][(re/im, fy)][(b,h)]           (one workgroup per image, DFT by direct sums in LDS)
+//   dft_bank_kernel    bank -> W[fx][m | M+m][(re/im, fy)]         (one workgroup per filter)
+//   dft_out_kernel     T -> out (+bias, activation)                (contraction over fx on the vector ALU)
+//   dft_dy_kernel      dY -> S'[fx][m | M+m][(b,h)]
+//   dft_dbank_kernel   G[fx][m | M+m][(re/im, fy)] -> dbank        (inverse DFT per filter, cropped to ksz x ksz)
+// Single input channel (Cin = 1: MNIST / particle configurations).  Twiddles: sincospi of exactly reduced angles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "small_kernels.hpp"
+
+namespace tvae {
+
+constexpr int DFT_WMAX = 40;           // output width / height handled by the register accumulators
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// tw[j] = e^{+2 pi i j / L}, j < L, into LDS
+__device__ __forceinline__ void fill_twiddles(float2* tw, int L) {
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        float s, c;
+        sincospif(2.0f * (float)j / (float)L, &s, &c);
+        tw[j] = make_float2(c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per image:  Yh = DFT2(padded image) restricted to fx < Lh, then
+// AT[fx][fy][b*Ho + h] = Re(Yh[fy][fx] e^{+2 pi i fy h / L}),  AT[fx][L + fy][..] = Im(..).
+// LDS: image n*n floats, R n*Lh complex, Yh L*Lh complex, tw L complex.
+// ------------------------------------------------------------------------------------------
+__global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict__ AT, int n, int pad, int L, int Lh,
+                                 int Ho, long NBpad) {
+    extern __shared__ float sm_dft[];
+    float* img = sm_dft;
+    float2* R = reinterpret_cast<float2*>(img + n * n);
+    float2* Yh = R + n * Lh;
+    float2* tw = Yh + L * Lh;
+    const int b = blockIdx.x;
+    fill_twiddles(tw, L);
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) img[i] = y[(long)b * n * n + i];
+    __syncthreads();
+    // R[yy][fx] = sum_x img[yy][x] e^{-2 pi i fx (x+pad) / L}
+    for (int i = threadIdx.x; i < n * Lh; i += blockDim.x) {
+        const int yy = i / Lh, fx = i - yy * Lh;
+        float re = 0.f, im = 0.f;
+        int ph = (fx * pad) % L;
+        for (int x = 0; x < n; ++x) {
+            const float v = img[yy * n + x];
+            const float2 t = tw[ph];
+            re += v * t.x;
+            im -= v * t.y;
+            ph += fx;
+            if (ph >= L) ph -= L;
+        }
+        R[i] = make_float2(re, im);
+    }
+    __syncthreads();
+    // Yh[fy][fx] = sum_y R[y][fx] e^{-2 pi i fy (y+pad) / L}
+    for (int i = threadIdx.x; i < L * Lh; i += blockDim.x) {
+        const int fy = i / Lh, fx = i - fy * Lh;
+        float2 acc = make_float2(0.f, 0.f);
+        int ph = (fy * pad) % L;
+        for (int yy = 0; yy < n; ++yy) {
+            const float2 r = R[yy * Lh + fx];
+            const float2 t = make_float2(tw[ph].x, -tw[ph].y);
+            const float2 p = cmul(r, t);
+            acc.x += p.x;
+            acc.y += p.y;
+            ph += fy;
+            if (ph >= L) ph -= L;
+        }
+        Yh[i] = acc;
+    }
+    __syncthreads();
+    // AT[fx][ri*L + fy][b*Ho + h]
+    const int total = Lh * L * Ho;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int h = i % Ho;
+        const int t2 = i / Ho;
+        const int fy = t2 % L, fx = t2 / L;
+        const float2 v = cmul(Yh[fy * Lh + fx], tw[(fy * h) % L]);
+        float* dst = AT + ((long)fx * 2 * L + fy) * NBpad + (long)b * Ho + h;
+        dst[0] = v.x;
+        dst[(long)L * NBpad] = v.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per filter m:  Kh = DFT2(filter at the origin of the L x L frame), fx < Lh, then the real operand
+// rows of the spectral GEMM:  W[fx][m][fy] = Kr, W[fx][m][L+fy] = Ki;  W[fx][M+m][fy] = -Ki, W[fx][M+m][L+fy] = Kr.
+// ------------------------------------------------------------------------------------------
+__global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M) {
+    extern __shared__ float sm_dft[];
+    float* ker = sm_dft;
+    float2* Q = reinterpret_cast<float2*>(ker + ksz * ksz);
+    float2* Kh = Q + ksz * Lh;
+    float2* tw = Kh + L * Lh;
+    const int m = blockIdx.x;
+    fill_twiddles(tw, L);
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) ker[i] = bank[(long)m * ksz * ksz + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < ksz * Lh; i += blockDim.x) {
+        const int u = i / Lh, fx = i - u * Lh;
+        float re = 0.f, im = 0.f;
+        int ph = 0;
+        for (int v = 0; v < ksz; ++v) {
+            const float k = ker[u * ksz + v];
+            re += k * tw[ph].x;
+            im -= k * tw[ph].y;
+            ph += fx;
+            if (ph >= L) ph -= L;
+        }
+        Q[i] = make_float2(re, im);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * Lh; i += blockDim.x) {
+        const int fy = i / Lh, fx = i - fy * Lh;
+        float2 acc = make_float2(0.f, 0.f);
+        int ph = 0;
+        for (int u = 0; u < ksz; ++u) {
+            const float2 p = cmul(Q[u * Lh + fx], make_float2(tw[ph].x, -tw[ph].y));
+            acc.x += p.x;
+            acc.y += p.y;
+            ph += fy;
+            if (ph >= L) ph -= L;
+        }
+        Kh[i] = acc;
+    }
+    __syncthreads();
+    const long rowlen = 2L * L;
+    for (int i = threadIdx.x; i < Lh * L; i += blockDim.x) {
+        const int fy = i % L, fx = i / L;
+        const float2 k = Kh[fy * Lh + fx];
+        float* r0 = W + ((long)fx * 2 * M + m) * rowlen;
+        float* r1 = W + ((long)fx * 2 * M + M + m) * rowlen;
+        r0[fy] = k.x;
+        r0[L + fy] = k.y;
+        r1[fy] = -k.y;
+        r1[L + fy] = k.x;
+    }
+}
+
+// tables for the contraction over fx: cs[fx][w] = c_fx/L^2 cos(2 pi fx w / L), sn likewise (scaled: forward), and the
+// unscaled pair cw / sw (backward);  4 * Lh * DFT_WMAX floats:  [cs | sn | cw | sw]
+__global__ void dft_tables_kernel(float* __restrict__ tab, int L, int Lh) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Lh * DFT_WMAX; i += gridDim.x * blockDim.x) {
+        const int fx = i / DFT_WMAX, w = i - fx * DFT_WMAX;
+        float s, c;
+        sincospif(2.0f * (float)((fx * w) % L) / (float)L, &s, &c);
+        const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
+        const float sc = cf / ((float)L * (float)L);
+        tab[i] = c * sc;
+        tab[Lh * DFT_WMAX + i] = s * sc;
+        tab[2 * Lh * DFT_WMAX + i] = c;
+        tab[3 * Lh * DFT_WMAX + i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[c][b][r][h][w] = act( bias[c] + sum_fx ( Tr[fx][m][n] cs[fx][w] - Ti[fx][m][n] sn[fx][w] ) ),  m = c*R + r,
+// n = b*Ho + h.  One thread per (m, n); the 2*Lh values of T are coalesced along n, the tables are wave-uniform
+// (scalar loads); results go through LDS so that the stores are contiguous runs.
+// grid (ceil(NB/256), M), block 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ T, const float* __restrict__ tab,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                      int R, int B, int Ho, int Lh, long NBpad, int act, float slope) {
+    __shared__ float st[256 * (DFT_WMAX + 1)];
+    const int m = blockIdx.y;
+    const long n0 = (long)blockIdx.x * 256;
+    const long n = n0 + threadIdx.x;
+    const long NB = (long)B * Ho;
+    const float* cs = tab;
+    const float* sn = tab + Lh * DFT_WMAX;
+    float acc[DFT_WMAX];
+#pragma unroll
+    for (int w = 0; w < DFT_WMAX; ++w) acc[w] = 0.f;
+    const long col = n < NBpad ? n : NBpad - 1;
+    const long plane = 2L * M * NBpad;
+    for (int fx = 0; fx < Lh; ++fx) {
+        const float tr = T[fx * plane + (long)m * NBpad + col];
+        const float ti = T[fx * plane + (long)(M + m) * NBpad + col];
+#pragma unroll
+        for (int w = 0; w < DFT_WMAX; ++w) acc[w] += tr * cs[fx * DFT_WMAX + w] - ti * sn[fx * DFT_WMAX + w];
+    }
+    const int c = m / R, r = m - c * R;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int w = 0; w < DFT_WMAX; ++w) {
+        float v = acc[w] + bv;
+        if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+        else if (act == ACT_TANH) v = tanhf(v);
+        st[threadIdx.x * (DFT_WMAX + 1) + w] = v;
+    }
+    __syncthreads();
+    const int P = Ho * Ho;
+    const int cnt = 256 * Ho;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int t = e / Ho, w = e - t * Ho;
+        const long nn = n0 + t;
+        if (nn < NB) {
+            const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
+            out[(((long)c * B + b) * R + r) * P + h * Ho + w] = st[t * (DFT_WMAX + 1) + w];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// S'[fx][m][n] = sum_w dY[m][n][w] cos(2 pi fx w / L),   S'[fx][M+m][n] = - sum_w dY[m][n][w] sin(2 pi fx w / L)
+// (S = DFT over w of the output gradient).  dY is [c][b][r][h][w]; one thread per (m, n).
+// grid (ceil(NBpad/256), M), block 256: columns n >= NB are written as zeros.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ dY, const float* __restrict__ tab,
+                                                     float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
+                                                     long NBpad) {
+    __shared__ float st[256 * (DFT_WMAX + 1)];
+    const int m = blockIdx.y;
+    const long n0 = (long)blockIdx.x * 256;
+    const long NB = (long)B * Ho;
+    const int c = m / R, r = m - c * R;
+    const int P = Ho * Ho;
+    const int cnt = 256 * Ho;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int t = e / Ho, w = e - t * Ho;
+        const long nn = n0 + t;
+        float v = 0.f;
+        if (nn < NB) {
+            const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
+            v = dY[(((long)c * B + b) * R + r) * P + h * Ho + w];
+        }
+        st[t * (DFT_WMAX + 1) + w] = v;
+    }
+    __syncthreads();
+    float d[DFT_WMAX];
+#pragma unroll
+    for (int w = 0; w < DFT_WMAX; ++w) d[w] = w < Ho ? st[threadIdx.x * (DFT_WMAX + 1) + w] : 0.f;
+    const float* cw = tab + 2 * Lh * DFT_WMAX;
+    const float* sw = tab + 3 * Lh * DFT_WMAX;
+    const long n = n0 + threadIdx.x;
+    if (n >= NBpad) return;
+    const long plane = 2L * M * NBpad;
+    for (int fx = 0; fx < Lh; ++fx) {
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int w = 0; w < DFT_WMAX; ++w) {
+            sr += d[w] * cw[fx * DFT_WMAX + w];
+            si -= d[w] * sw[fx * DFT_WMAX + w];
+        }
+        Sp[fx * plane + (long)m * NBpad + n] = sr;
+        Sp[fx * plane + (long)(M + m) * NBpad + n] = si;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per filter m:  dKh'[fy][fx] from the four real blocks of G[fx][m | M+m][(re/im, fy)]
+//   Re = G[m][fy] + G[M+m][L+fy],  Im = G[m][L+fy] - G[M+m][fy]
+// then dbank[m][u][v] = 1/L^2 sum_fx c_fx Re( e^{2 pi i fx v/L} sum_fy dKh'[fy][fx] e^{2 pi i fy u/L} ),  u, v < ksz.
+// ------------------------------------------------------------------------------------------
+__global__ void dft_dbank_kernel(const float* __restrict__ G, float* __restrict__ dbank, int ksz, int L, int Lh, int M) {
+    extern __shared__ float sm_dft[];
+    float2* Kh = reinterpret_cast<float2*>(sm_dft);
+    float2* Z = Kh + L * Lh;
+    float2* tw = Z + ksz * Lh;
+    const int m = blockIdx.x;
+    fill_twiddles(tw, L);
+    const long rowlen = 2L * L;
+    for (int i = threadIdx.x; i < Lh * L; i += blockDim.x) {
+        const int fy = i % L, fx = i / L;
+        const float* r0 = G + ((long)fx * 2 * M + m) * rowlen;
+        const float* r1 = G + ((long)fx * 2 * M + M + m) * rowlen;
+        Kh[fy * Lh + fx] = make_float2(r0[fy] + r1[L + fy], r0[L + fy] - r1[fy]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ksz * Lh; i += blockDim.x) {
+        const int u = i / Lh, fx = i - u * Lh;
+        float2 acc = make_float2(0.f, 0.f);
+        int ph = 0;
+        for (int fy = 0; fy < L; ++fy) {
+            const float2 p = cmul(Kh[fy * Lh + fx], tw[ph]);
+            acc.x += p.x;
+            acc.y += p.y;
+            ph += u;
+            if (ph >= L) ph -= L;
+        }
+        Z[i] = acc;
+    }
+    __syncthreads();
+    const float inv = 1.f / ((float)L * (float)L);
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) {
+        const int u = i / ksz, v = i - u * ksz;
+        float acc = 0.f;
+        int ph = 0;
+        for (int fx = 0; fx < Lh; ++fx) {
+            const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
+            const float2 z = Z[u * Lh + fx];
+            acc += cf * (z.x * tw[ph].x - z.y * tw[ph].y);
+            ph += v;
+            if (ph >= L) ph -= L;
+        }
+        dbank[(long)m * ksz * ksz + i] = acc * inv;
+    }
+}
+
+}  // namespace tvae

@@ -101,23 +101,39 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
 // Tile 512 x 128: eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step), two per
 // SIMD, so one wave's split arithmetic, LDS traffic and load waits run under the other's MFMAs.  Every k-value of X is
 // split once per 512 output rows (4 per thread per step).
+struct DenseBatch {        // batched launch: row tile t belongs to problem t / tiles_per_batch (0 = not batched)
+    int tiles_per_batch;
+    long x_stride;         // floats between the X operands of consecutive problems
+    long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
+};
+
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
     if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
-    const int m0 = tile_m * DX6_ROWS, n0 = tile_n * 128;
+    // batched: the rows of all problems are stacked in A3 (Mpad = total padded rows, M = rows per problem)
+    int batch = 0;
+    if (bt.tiles_per_batch > 0) {
+        batch = tile_m / bt.tiles_per_batch;
+        X += batch * bt.x_stride;
+        ep.C += batch * bt.c_stride;
+        if (ep.aux) ep.aux += batch * bt.c_stride;
+        if (ep.res) ep.res += batch * bt.c_stride;
+    }
+    const int m0g = tile_m * DX6_ROWS;                                   // row offset inside A3
+    const int m0 = m0g - batch * bt.tiles_per_batch * DX6_ROWS, n0 = tile_n * 128;   // row offset inside the problem
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
 
     // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
     const long part_cells = (long)K8pad * Mpad;
-    const uint4* a_ptr = A3 + (long)khalf * Mpad + m0 + 64 * wave + (lane & 31);
+    const uint4* a_ptr = A3 + (long)khalf * Mpad + m0g + 64 * wave + (lane & 31);
     auto load_a = [&](int t, Cell16 (&a)[2][3]) {
         const uint4* q = a_ptr + (long)(2 * t) * Mpad;
 #pragma unroll
@@ -221,12 +237,21 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
-                           int M, int Kf, int N, int nchunk, TileMap tm) {
+                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_k, split;
     if (!tm.decode(blockIdx.x, tile_m, tile_k, split)) return;
+    // batched: row tile t belongs to problem t / tiles_per_batch; slabs are [split][batch][M][Kf]
+    int batch = 0, nbatch = 1;
+    if (bt.tiles_per_batch > 0) {
+        batch = tile_m / bt.tiles_per_batch;
+        nbatch = tm.tilesM / bt.tiles_per_batch;
+        tile_m -= batch * bt.tiles_per_batch;
+        dY += batch * dy_stride;
+        X += batch * bt.x_stride;
+    }
     const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
     const int nbeg = split * nchunk;
     const int nend = min(N, nbeg + nchunk);
@@ -331,7 +356,7 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= M) continue;
-            float* wrow = ws + ((long)split * M + m) * Kf + k0 + (lane & 31);
+            float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = acc[i][j][r];

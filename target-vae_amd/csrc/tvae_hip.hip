@@ -9,6 +9,7 @@
 #include "fused_tail_kernels.hpp"
 #include "conv_x6_kernels.hpp"
 #include "dense_x6_kernels.hpp"
+#include "conv_dft_kernels.hpp"
 #include "conv_img_kernels.hpp"
 #include "gemm_bf16x3.hpp"
 
@@ -118,6 +119,46 @@ static X6Plan x6_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     if (q.lds_w < 64 * 128 * 4) q.lds_w = 64 * 128 * 4;       // epilogue staging tile
     q.bank_cells = (long)3 * q.K8pad * q.Mpad;
     q.dy_cells = (long)3 * B * q.kk.QP * q.Mpad;
+    return q;
+}
+
+static long tvae_dense_x6_bytes_impl(int rows, int K) {
+    const long Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    return 3 * K8pad * Rpad * 16;
+}
+
+// Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
+constexpr int DFT_WG_SPLITS = 8;
+struct DftPlan {
+    int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
+    long NB, NBpad;            // (image, output row) columns
+    long at_floats;            // A^T [Lh][2L][NBpad]
+    long w_floats;             // W   [Lh][2M][2L]
+    long w3_floats;            // split cells of W
+    long t_floats;             // T / S' [Lh][2M][NBpad]
+    long tab_floats;
+    long g_floats;             // G [Lh][2M][2L] (finalised spectral weight gradient)
+    bool ok;
+};
+static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    DftPlan q;
+    q.L = n + 2 * pad;
+    q.Lh = q.L / 2 + 1;
+    q.Ho = q.L - ksz + 1;
+    q.M = C * R;
+    q.K2 = 2 * q.L;
+    q.NB = (long)B * q.Ho;
+    q.NBpad = (q.NB + 127) / 128 * 128;
+    q.at_floats = (long)q.Lh * q.K2 * q.NBpad;
+    q.w_floats = (long)q.Lh * 2 * q.M * q.K2;
+    q.w3_floats = tvae_dense_x6_bytes_impl(q.Lh * 2 * q.M, q.K2) / 4;
+    q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
+    q.tab_floats = 4L * q.Lh * DFT_WMAX;
+    q.g_floats = q.w_floats;
+    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WMAX && (2 * q.M) % DX6_ROWS == 0 && lds_img <= 150 * 1024 &&
+           lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
     return q;
 }
 
@@ -235,10 +276,7 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
 }
 
 // ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
-long tvae_dense_x6_bytes(int rows, int K) {
-    const long Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
-    return 3 * K8pad * Rpad * 16;
-}
+long tvae_dense_x6_bytes(int rows, int K) { return tvae_dense_x6_bytes_impl(rows, K); }
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                       tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;
@@ -257,7 +295,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep, rows,
-                       Rpad, N, K, K8pad, tm);
+                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0});
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -299,7 +337,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
     hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx, ws, M,
-                       K, N, nchunk, tmk);
+                       K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L);
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dW; ep.ldc = K;
@@ -307,6 +345,111 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     int blocks = cdiv(per, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits, M, K, ep);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- lifting convolution through the frequency domain (conv_dft_kernels.hpp) -------------------------------------
+int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
+}
+long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    return dft_plan(B, Cin, n, ksz, pad, C, R).at_floats;
+}
+long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    // forward: W + W3 + T + tables; backward: S' (= T) + slabs (2 x G) + G + tables
+    const long fwd = q.w_floats + q.w3_floats + q.t_floats + q.tab_floats + 64;
+    const long bwd = q.t_floats + (DFT_WG_SPLITS + 1) * q.g_floats + q.tab_floats + 64;
+    return fwd > bwd ? fwd : bwd;
+}
+
+int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
+                       long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
+                       tvae_stream_t stream) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = S(stream);
+    float* W = ws;
+    float* W3 = W + ((q.w_floats + 3) & ~3L);
+    float* T = W3 + ((q.w3_floats + 3) & ~3L);
+    float* tab = T + ((q.t_floats + 3) & ~3L);
+    if (q.NBpad != q.NB) {
+        hipError_t e = hipMemsetAsync(at, 0, (size_t)q.at_floats * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, tab, q.L, q.Lh);
+    TVAE_CHECK_LAUNCH();
+    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    hipError_t e = allow_big_lds(dft_image_kernel, lds_img);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_image_kernel, dim3(B), dim3(256), lds_img, st, y, at, n, pad, q.L, q.Lh, q.Ho, q.NBpad);
+    TVAE_CHECK_LAUNCH();
+    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    e = allow_big_lds(dft_bank_kernel, lds_bank);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_bank_kernel, dim3(q.M), dim3(256), lds_bank, st, bank, W, ksz, q.L, q.Lh, q.M);
+    TVAE_CHECK_LAUNCH();
+    // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
+    const int rows = q.Lh * 2 * q.M;
+    int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, stream);
+    if (rc) return rc;
+    {
+        Epilogue ep;
+        ep.C = T; ep.ldc = q.NBpad;
+        const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((q.K2 + 7) / 8, 2);
+        const TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
+        const DenseBatch bt{2 * q.M / DX6_ROWS, (long)q.K2 * q.NBpad, 2L * q.M * q.NBpad};
+        hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
+                           q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt);
+        TVAE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(dft_out_kernel, dim3((unsigned)((q.NB + 255) / 256), q.M), dim3(256), 0, st, (const float*)T,
+                       (const float*)tab, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* ws, long ws_floats, int B, int Cin,
+                         int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = S(stream);
+    float* Sp = ws;
+    float* slabs = Sp + ((q.t_floats + 3) & ~3L);
+    float* G = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
+    float* tab = G + ((q.g_floats + 3) & ~3L);
+    hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, tab, q.L, q.Lh);
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dft_dy_kernel, dim3((unsigned)(q.NBpad / 256 + (q.NBpad % 256 ? 1 : 0)), q.M), dim3(256), 0, st,
+                       dpre, (const float*)tab, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad);
+    TVAE_CHECK_LAUNCH();
+    // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
+    {
+        const int M2 = 2 * q.M, tiles_b = M2 / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
+        // 8 reduction slices: TileMap deals the slices round-robin to the 8 XCDs, fewer would leave XCDs idle
+        const int splits = DFT_WG_SPLITS;
+        const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
+        const TileMap tmk{tilesM, tilesK, splits};
+        const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
+        hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp, q.NBpad, at,
+                           q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, (long)M2 * q.NBpad);
+        TVAE_CHECK_LAUNCH();
+        Epilogue ep;
+        ep.C = G; ep.ldc = q.K2;
+        const long per = (long)q.Lh * M2 * q.K2;
+        int blocks = cdiv(per, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, splits,
+                           q.Lh * M2, q.K2, ep);
+        TVAE_CHECK_LAUNCH();
+    }
+    const size_t lds_db = (size_t)q.L * q.Lh * 8 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * 8;
+    hipError_t e = allow_big_lds(dft_dbank_kernel, lds_db);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M), dim3(256), lds_db, st, (const float*)G, dbank, ksz, q.L, q.Lh, q.M);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -24,6 +24,8 @@ SIGNATURES = {
     'tvae_conv1_fwd_x6': 'ppppiiiiiiiif',
     'tvae_dy_split3': 'ppliiiiiii',
     'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
+    'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
+    'tvae_conv1_wgrad_dft': 'ppppliiiiiii',
     'tvae_dense_split3': 'plpliii',
     'tvae_linear_fwd_x6': 'pppppiiillif',
     'tvae_linear_dgrad_x6': 'pppppiiillif',
@@ -64,6 +66,9 @@ QUERIES = {
     'tvae_conv1_x6_bank_bytes': ('iiii', 'l'),
     'tvae_conv1_x6_dy_bytes': ('iiiiii', 'l'),
     'tvae_dense_x6_bytes': ('ii', 'l'),
+    'tvae_conv1_dft_supported': ('iiiiiii', 'i'),
+    'tvae_conv1_dft_at_floats': ('iiiiiii', 'l'),
+    'tvae_conv1_dft_ws_floats': ('iiiiiii', 'l'),
 }
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}

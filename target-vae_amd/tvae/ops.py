@@ -7,6 +7,7 @@ happens in the HIP library on the current torch stream; torch only provides devi
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -185,12 +186,32 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
     return t
 
 
-def conv1_forward(y, weight, bias, C, R, k, pad, act):
-    """Rotated bank + lifting convolution."""
+CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
+
+
+def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
+    """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): 7x fewer matrix FLOPs than the direct
+    form; same arithmetic mode as 'x6' (TVAE_CONV_DFT=0 keeps the direct x6 kernels)."""
+    return CONV_DFT and get_gemm_mode() == 'x6' and bool(query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R))
+
+
+def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
+    """Rotated bank + lifting convolution.  `keep` (a dict) receives what the weight gradient can reuse."""
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
     bank = rotate_bank(weight, R)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
+    if _use_dft(B, Cin, n, k, pad, C, R):
+        # zeros: the columns that pad (image, row) to a multiple of 128 must stay finite
+        at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), dtype=torch.float32,
+                         device=y.device)
+        ws = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
+        with _timed('tvae_conv1_fwd'):
+            call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,
+                 LRELU_SLOPE)
+        if keep is not None:
+            keep['at'] = at
+        return out
     if _use_x6(Cin, n, k, pad):
         a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
         call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k)
@@ -202,9 +223,14 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act):
     return out
 
 
-def conv1_wgrad(y, dpre, C, R, k, pad):
+def conv1_wgrad(y, dpre, C, R, k, pad, at=None):
     B, Cin, n, _ = y.shape
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
+    if at is not None:
+        wsd = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
+        with _timed('tvae_conv1_wgrad'):
+            call('tvae_conv1_wgrad_dft', dpre, at, dbank, wsd, wsd.numel(), B, Cin, n, k, pad, C, R)
+        return dbank
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     if _use_x6(Cin, n, k, pad):
         d3 = _scratch(y.device, 'x6_dy', query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4)
@@ -241,8 +267,10 @@ class GroupConvFn(torch.autograd.Function):
         y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
         B, n = y.shape[0], y.shape[-1]
         Ho = n + 2 * pad - k + 1
-        out = conv1_forward(y, weight, bias, C, R, k, pad, ACT_NONE)
+        keep = {}
+        out = conv1_forward(y, weight, bias, C, R, k, pad, ACT_NONE, keep)
         ctx.save_for_backward(y)
+        ctx.at = keep.get('at')
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, bias is not None)
         return out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
 
@@ -253,7 +281,7 @@ class GroupConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError('GroupConv input gradient is not part of the hot path (input is data)')
         dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, B * R * Ho * Ho)
-        dbank = conv1_wgrad(y, dpre, C, R, k, pad)
+        dbank = conv1_wgrad(y, dpre, C, R, k, pad, ctx.at)
         dW = rotate_bank_bwd(dbank, C, Cin, k, R)
         db = _rowsum(dpre, C, dpre.shape[1]) if has_bias else None
         return None, dW, db, None, None
@@ -279,7 +307,9 @@ class EncoderFn(torch.autograd.Function):
         C2, nh = W2.shape[0], Wh.shape[0]
         _expect(tuple(W2.shape) == (C2, C) and tuple(Wh.shape) == (nh, C2) and b1.numel() == C and
                 b2.numel() == C2 and bh.numel() == nh, 'encoder parameter shapes are inconsistent')
-        A1 = conv1_forward(y, w1, b1, C, R, k, pad, act)
+        keep = {}
+        A1 = conv1_forward(y, w1, b1, C, R, k, pad, act, keep)
+        ctx.at = keep.get('at')
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
@@ -317,7 +347,7 @@ class EncoderFn(torch.autograd.Function):
         call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
         del dH
         db1 = _rowsum(dA1, C, N)
-        dbank = conv1_wgrad(y, dA1, C, R, k, pad)
+        dbank = conv1_wgrad(y, dA1, C, R, k, pad, ctx.at)
         dw1 = rotate_bank_bwd(dbank, C, Cin, k, R)
         return None, dw1, db1, dW2, db2, dWh, dbh, None, None, None
 

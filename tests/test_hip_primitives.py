@@ -235,6 +235,36 @@ def test_linear_wgrad_x6(M, N, K, acc):
         call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc)
 
 
+@pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
+                                               (17, 64, 64, 16, 64, 8, 1)])
+def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
+    """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64."""
+    from tvae._lib import query
+    Cin = 1
+    if not query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
+        pytest.skip('geometry not handled by the frequency-domain path')
+    y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
+    bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(C, seed=3, scale=0.1)
+    Ho = n + 2 * pad - k + 1
+    ref = F.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho) \
+        + bias.double().view(1, C, 1, 1, 1)
+    ref = act_ref(ref, act)
+    at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev())
+    ws = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
+    out = torch.empty(C, B * R * Ho * Ho, device=dev())
+    call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, ws, ws.numel(), B, Cin, n, k, pad,
+         C, R, act, SLOPE)
+    got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+    assert rel_err(got, ref) < GEMM_TOL['f32']
+    g = rnd(B, C, R, Ho, Ho, seed=4)
+    ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
+    dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
+    dbank = torch.empty(C * R, Cin * k * k, device=dev())
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
+
+
 def test_reductions():
     M, N = 37, 10007
     X = rnd(M, N, seed=1)
