@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "small_kernels.hpp"
+#include "conv_x6_kernels.hpp"
 
 namespace tvae {
 
@@ -190,10 +191,9 @@ __global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ 
 #pragma unroll
     for (int w = 0; w < DFT_WMAX; ++w) acc[w] = 0.f;
     const long col = n < NBpad ? n : NBpad - 1;
-    const long plane = 2L * M * NBpad;
     for (int fx = 0; fx < Lh; ++fx) {
-        const float tr = T[fx * plane + (long)m * NBpad + col];
-        const float ti = T[fx * plane + (long)(M + m) * NBpad + col];
+        const float tr = T[((long)m * Lh + fx) * NBpad + col];
+        const float ti = T[((long)(M + m) * Lh + fx) * NBpad + col];
 #pragma unroll
         for (int w = 0; w < DFT_WMAX; ++w) acc[w] += tr * cs[fx * DFT_WMAX + w] - ti * sn[fx * DFT_WMAX + w];
     }
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ d
     const float* sw = tab + 3 * Lh * DFT_WMAX;
     const long n = n0 + threadIdx.x;
     if (n >= NBpad) return;
-    const long plane = 2L * M * NBpad;
     for (int fx = 0; fx < Lh; ++fx) {
         float sr = 0.f, si = 0.f;
 #pragma unroll
@@ -260,8 +259,242 @@ __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ d
             sr += d[w] * cw[fx * DFT_WMAX + w];
             si -= d[w] * sw[fx * DFT_WMAX + w];
         }
-        Sp[fx * plane + (long)m * NBpad + n] = sr;
-        Sp[fx * plane + (long)(M + m) * NBpad + n] = si;
+        Sp[((long)m * Lh + fx) * NBpad + n] = sr;
+        Sp[((long)(M + m) * Lh + fx) * NBpad + n] = si;
+    }
+}
+
+// ==========================================================================================
+// The two transforms along w (33-wide output rows <-> Lh frequencies) on the matrix pipe.  They are tiny GEMMs with
+// a constant operand,  out[w][(m,n)] = sum_k E[w][k] T[k][(m,n)]  and  S'[k][(m,n)] = sum_w E'[k][w] dY[(m,n)][w],
+// in the same exact-split arithmetic: the constant matrix is pre-split into cells once per call, every lane builds the
+// B fragments of its own column in registers (8 strided / contiguous values, split3x8), no workgroup barrier in the
+// loop.  The vector-ALU versions above needed 3 234 FMAs per (m,n); here the ALU only splits 98 (resp. 33) values.
+// k order: k = ri*KH + fx with KH = Lh rounded up to 8 (ri = 0: real plane, 1: imaginary plane).
+// ==========================================================================================
+constexpr int DFT_WROWS = 64;          // padded output width of the forward transform (two 32-row MFMA tiles)
+
+// E cells  [part][octet < 2*KH/8][row w < 64]:   E[w][ri*KH+fx] = ri ? -c_fx/L^2 sin(2 pi fx w/L) : c_fx/L^2 cos(..)
+// E' cells [part][octet < WOCT][row k < 128]:    E'[ri*KH+fx][w] = ri ? -sin(2 pi fx w/L) : cos(2 pi fx w/L)
+__global__ void dft_etab_kernel(uint4* __restrict__ E3, uint4* __restrict__ Ep3, int L, int Lh, int KH, int Ho, int WOCT) {
+    const int KO = 2 * KH / 8;
+    const int nE = KO * DFT_WROWS, nEp = WOCT * 128;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nE + nEp; i += gridDim.x * blockDim.x) {
+        float r[8];
+        uint4* dst;
+        long stride;
+        if (i < nE) {
+            const int w = i % DFT_WROWS, o = i / DFT_WROWS;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * o + j, ri = k / KH, fx = k - ri * KH;
+                float v = 0.f;
+                if (w < Ho && fx < Lh) {
+                    float sn, cs;
+                    sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
+                    const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
+                    v = (ri ? -sn : cs) * cf / ((float)L * (float)L);
+                }
+                r[j] = v;
+            }
+            dst = E3 + i;
+            stride = nE;
+        } else {
+            const int ii = i - nE;
+            const int k = ii % 128, o = ii / 128;
+            const int ri = k / KH, fx = k - ri * KH;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = 8 * o + j;
+                float v = 0.f;
+                if (w < Ho && fx < Lh && ri < 2) {
+                    float sn, cs;
+                    sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
+                    v = ri ? -sn : cs;
+                }
+                r[j] = v;
+            }
+            dst = Ep3 + ii;
+            stride = nEp;
+        }
+        Cell16 h, m, l;
+        split3x8(r, h, m, l);
+        dst[0] = h.u;
+        dst[stride] = m.u;
+        dst[2 * stride] = l.u;
+    }
+}
+
+// out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]).  One wave per tile of 32 columns (m fixed, 32
+// consecutive n); a workgroup of 4 waves walks tiles blockIdx.x*4 + wave, += gridDim.x*4.
+__global__ __launch_bounds__(256) void dft_out_mfma_kernel(const float* __restrict__ T, const uint4* __restrict__ E3,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int M, int R, int B, int Ho, int Lh, int KH, long NBpad,
+                                                           int act, float slope) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_o[];
+    const int KO = 2 * KH / 8;                       // octets
+    uint4* Es = reinterpret_cast<uint4*>(sm_o);      // [part][octet][64 rows]
+    float* stg = reinterpret_cast<float*>(sm_o + (size_t)3 * KO * DFT_WROWS * 16);   // per wave [32 cols][Ho+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * KO * DFT_WROWS; i += 256) Es[i] = E3[i];
+    __syncthreads();
+    float* wst = stg + wave * 32 * (DFT_WROWS + 1);
+    const int khalf = lane >> 5, j = lane & 31;
+    const long tiles_n = NBpad / 32;
+    const long ntiles = (long)M * tiles_n;
+    const long NB = (long)B * Ho;
+    const long plane = (long)M * Lh * NBpad;                      // offset of the imaginary rows
+    const int P = Ho * Ho;
+    const int nsteps = KO / 2;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float* tcol = T + (long)m * Lh * NBpad + n0 + j;          // T is [ri*M + m][fx][n]
+        // all 8*nsteps values of this lane's column first (independent loads in flight), then split + MFMA
+        constexpr int MAXS = 8;                         // nsteps <= 8 (2*KH <= 128)
+        float v[MAXS][8];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = 16 * s + 8 * khalf + q;
+                const int ri = k / KH, fx = k - ri * KH;
+                v[s][q] = (s < nsteps && fx < Lh && ri < 2) ? tcol[(long)fx * NBpad + ri * plane] : 0.f;
+            }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            if (s < nsteps) {
+                Cell16 bf[3];
+                split3x8(v[s], bf[0], bf[1], bf[2]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Cell16 af[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[p].u = Es[(p * KO + 2 * s + khalf) * DFT_WROWS + i * 32 + j];
+                    mfma6(acc[i], af, bf);
+                }
+            }
+        }
+        // stage [col][w] through LDS, then contiguous runs
+        const int c = m / R, rr = m - c * R;
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = acc[i][r] + bv;
+                if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+                else if (act == ACT_TANH) v = tanhf(v);
+                wst[j * (DFT_WROWS + 1) + w] = v;
+            }
+        // two columns per pass (lanes 0..31 / 32..63 take w = lane & 31 and, in a second sweep, w + 32)
+        const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+        for (int t = khalf; t < 32; t += 2) {
+            int h = h0 + t, b = b0;
+            while (h >= Ho) { h -= Ho; ++b; }
+            if (n0 + t < NB) {
+                float* dst = out + (((long)c * B + b) * R + rr) * P + h * Ho;
+                for (int w = j; w < Ho; w += 32) dst[w] = wst[t * (DFT_WROWS + 1) + w];
+            }
+        }
+    }
+}
+
+// S'[fx][ri*M + m][n] = sum_w E'[ri*KH+fx][w] dY[(m,n)][w].  One wave per tile of 32 columns; dY rows are staged
+// through LDS (per wave [32 cols][pitch]) so that every lane finds its 8-value cells 16-byte aligned.
+__global__ __launch_bounds__(256) void dft_dy_mfma_kernel(const float* __restrict__ dY, const uint4* __restrict__ Ep3,
+                                                          float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
+                                                          int KH, int WOCT, long NBpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_o[];
+    uint4* Es = reinterpret_cast<uint4*>(sm_o);      // [part][octet < WOCT][128 rows]
+    const int pitch = 8 * WOCT + 4;                  // floats per staged column (16-byte multiple, odd multiple of 4)
+    float* stg = reinterpret_cast<float*>(sm_o + (size_t)3 * WOCT * 128 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * WOCT * 128; i += 256) Es[i] = Ep3[i];
+    __syncthreads();
+    float* wst = stg + wave * 32 * pitch;
+    const int khalf = lane >> 5, j = lane & 31;
+    const long tiles_n = NBpad / 32;
+    const long ntiles = (long)M * tiles_n;
+    const long NB = (long)B * Ho;
+    const long plane = (long)M * Lh * NBpad;                      // offset of the imaginary rows
+    const int P = Ho * Ho;
+    const int nsteps = (WOCT + 1) / 2;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const int c = m / R, rr = m - c * R;
+        // stage the 32 columns (zeros beyond Ho and beyond NB): lanes 0..31 / 32..63 take alternate columns and
+        // w = lane & 31 (+32); all loads of the tile are issued before the first LDS write
+        {
+            const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+            float sv[16][2];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = 2 * it + khalf;
+                int h = h0 + t, b = b0;
+                while (h >= Ho) { h -= Ho; ++b; }
+                const bool ok = n0 + t < NB;
+                const float* src = dY + (((long)c * B + (ok ? b : 0)) * R + rr) * P + h * Ho;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int w = j + 32 * q;
+                    sv[it][q] = (ok && w < Ho) ? src[w] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = 2 * it + khalf;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int w = j + 32 * q;
+                    if (w < pitch) wst[t * pitch + w] = sv[it][q];
+                }
+            }
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int s = 0; s < nsteps; ++s) {
+            const int o = 2 * s + khalf;
+            float v[8];
+            if (o < WOCT) {
+                const float4 a = *reinterpret_cast<const float4*>(wst + j * pitch + 8 * o);
+                const float4 bq = *reinterpret_cast<const float4*>(wst + j * pitch + 8 * o + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
+            Cell16 bf[3];
+            split3x8(v, bf[0], bf[1], bf[2]);
+            const int oa = o < WOCT ? o : 0;         // padding octet: B is zero, any valid A cell
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Cell16 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p].u = Es[(p * WOCT + oa) * 128 + i * 32 + j];
+                mfma6(acc[i], af, bf);
+            }
+        }
+        // direct stores: row k = (ri, fx), 32 consecutive n per row
+        float* scol = Sp + (long)m * Lh * NBpad + n0 + j;               // S' is [ri*M + m][fx][n]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int ri = k / KH, fx = k - ri * KH;
+                if (ri < 2 && fx < Lh) scol[(long)fx * NBpad + ri * plane] = acc[i][r];
+            }
     }
 }
 

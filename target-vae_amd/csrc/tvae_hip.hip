@@ -131,6 +131,7 @@ static long tvae_dense_x6_bytes_impl(int rows, int K) {
 constexpr int DFT_WG_SPLITS = 8;
 struct DftPlan {
     int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
+    int KH, KO, WOCT;          // padded half spectrum, its octets (x2 planes), octets of an output row
     long NB, NBpad;            // (image, output row) columns
     long at_floats;            // A^T [Lh][2L][NBpad]
     long w_floats;             // W   [Lh][2M][2L]
@@ -153,11 +154,14 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.w_floats = (long)q.Lh * 2 * q.M * q.K2;
     q.w3_floats = tvae_dense_x6_bytes_impl(q.Lh * 2 * q.M, q.K2) / 4;
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
-    q.tab_floats = 4L * q.Lh * DFT_WMAX;
+    q.KH = (q.Lh + 7) / 8 * 8;
+    q.KO = 2 * q.KH / 8;
+    q.WOCT = (q.Ho + 7) / 8;
+    q.tab_floats = 4L * (3L * q.KO * DFT_WROWS + 3L * q.WOCT * 128) + 4L * q.Lh * DFT_WMAX;   // E, E' cells + ALU tables
     q.g_floats = q.w_floats;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WMAX && (2 * q.M) % DX6_ROWS == 0 && lds_img <= 150 * 1024 &&
+    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && 2 * q.KH <= 128 && (2 * q.M) % DX6_ROWS == 0 && lds_img <= 150 * 1024 &&
            lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
     return q;
 }
@@ -379,7 +383,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         hipError_t e = hipMemsetAsync(at, 0, (size_t)q.at_floats * 4, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, tab, q.L, q.Lh);
+    uint4* E3 = reinterpret_cast<uint4*>(tab);
+    uint4* Ep3 = E3 + 3L * q.KO * DFT_WROWS;
+    hipLaunchKernelGGL(dft_etab_kernel, dim3(16), dim3(256), 0, st, E3, Ep3, q.L, q.Lh, q.KH, q.Ho, q.WOCT);
     TVAE_CHECK_LAUNCH();
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     hipError_t e = allow_big_lds(dft_image_kernel, lds_img);
@@ -397,17 +403,33 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     if (rc) return rc;
     {
         Epilogue ep;
-        ep.C = T; ep.ldc = q.NBpad;
+        ep.C = T; ep.ldc = (long)q.Lh * q.NBpad;          // T is [m'][fx][n]: the 2*Lh rows of one (m, .) stay together
         const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((q.K2 + 7) / 8, 2);
         const TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
-        const DenseBatch bt{2 * q.M / DX6_ROWS, (long)q.K2 * q.NBpad, 2L * q.M * q.NBpad};
+        const DenseBatch bt{2 * q.M / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
         hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt);
         TVAE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(dft_out_kernel, dim3((unsigned)((q.NB + 255) / 256), q.M), dim3(256), 0, st, (const float*)T,
-                       (const float*)tab, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
-    TVAE_CHECK_LAUNCH();
+    static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();
+    if (out_mfma || q.Ho > DFT_WMAX) {
+        const size_t lds_o = (size_t)3 * q.KO * DFT_WROWS * 16 + (size_t)4 * 32 * (DFT_WROWS + 1) * 4;
+        e = allow_big_lds(dft_out_mfma_kernel, lds_o);
+        if (e != hipSuccess) return (int)e;
+        const long ntiles = (long)q.M * (q.NBpad / 32);
+        const int grid = (int)(ntiles / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
+        hipLaunchKernelGGL(dft_out_mfma_kernel, dim3(grid), dim3(256), lds_o, st, (const float*)T, (const uint4*)E3, bias,
+                           out, q.M, R, B, q.Ho, q.Lh, q.KH, q.NBpad, act, slope);
+        TVAE_CHECK_LAUNCH();
+    } else {
+        // vector-ALU contraction over fx (measured faster than the MFMA variant for Ho <= 40: 2.2 vs 3.3 ms)
+        float* vtab = reinterpret_cast<float*>(Ep3 + 3L * q.WOCT * 128);
+        hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, vtab, q.L, q.Lh);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dft_out_kernel, dim3((unsigned)((q.NB + 255) / 256), q.M), dim3(256), 0, st, (const float*)T,
+                           (const float*)vtab, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
+        TVAE_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -421,11 +443,20 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
     float* G = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
     float* tab = G + ((q.g_floats + 3) & ~3L);
-    hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, tab, q.L, q.Lh);
+    uint4* E3 = reinterpret_cast<uint4*>(tab);
+    uint4* Ep3 = E3 + 3L * q.KO * DFT_WROWS;
+    hipLaunchKernelGGL(dft_etab_kernel, dim3(16), dim3(256), 0, st, E3, Ep3, q.L, q.Lh, q.KH, q.Ho, q.WOCT);
     TVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dft_dy_kernel, dim3((unsigned)(q.NBpad / 256 + (q.NBpad % 256 ? 1 : 0)), q.M), dim3(256), 0, st,
-                       dpre, (const float*)tab, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad);
-    TVAE_CHECK_LAUNCH();
+    {
+        const size_t lds_d = (size_t)3 * q.WOCT * 128 * 16 + (size_t)4 * 32 * (8 * q.WOCT + 4) * 4;
+        hipError_t e0 = allow_big_lds(dft_dy_mfma_kernel, lds_d);
+        if (e0 != hipSuccess) return (int)e0;
+        const long ntiles = (long)q.M * (q.NBpad / 32);
+        const int grid = (int)(ntiles / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
+        hipLaunchKernelGGL(dft_dy_mfma_kernel, dim3(grid), dim3(256), lds_d, st, dpre, (const uint4*)Ep3, Sp, q.M, R, B,
+                           q.Ho, q.Lh, q.KH, q.WOCT, q.NBpad);
+        TVAE_CHECK_LAUNCH();
+    }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
     {
         const int M2 = 2 * q.M, tiles_b = M2 / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
@@ -434,8 +465,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
-        hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp, q.NBpad, at,
-                           q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, (long)M2 * q.NBpad);
+        hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
+                           (long)q.Lh * q.NBpad, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, q.NBpad);
         TVAE_CHECK_LAUNCH();
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;
