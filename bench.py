@@ -45,12 +45,14 @@ MODE_INFO = {
 }
 
 
-def pmc_traffic(entry):
+def pmc_traffic(entry, grid=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/pmc_traffic.json: FETCH_SIZE x2 -- gfx950 reports half the fetched bytes, calibrated on outer_mask --
     plus WRITE_SIZE).  Counters cannot be collected inside the timed run, so this is the committed measurement."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        if grid is not None and (entry + '@grid%d' % grid) in d:
+            return d[entry + '@grid%d' % grid]['hbm_bytes_per_launch']
         return d[entry]['hbm_bytes_per_launch']
     except Exception:
         return None
@@ -226,34 +228,59 @@ def main():
 
     if rank == 0:
         imgs = world * B * args.steps
-        flops = conv1_flops_per_image(c) * B
-        dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
+        conv_flops = conv1_flops_per_image(c) * B
+        Nt = B * c['n'] * c['n']
+        dense_flops = 2.0 * c['hidden'] * c['hidden'] * Nt
+        info = MODE_INFO[mode]
+        # every timed entry point: (algorithmic FLOPs per launch, kernel, note)
+        conv_dft = mode == 'x6' and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
+        entries = {
+            'tvae_conv1_fwd': (conv_flops, 'dft_image + dft_bank + batched dense_x6_kernel + dft_out_kernel'
+                               if conv_dft else info['kernels']['tvae_conv1_fwd']),
+            'tvae_conv1_wgrad': (conv_flops, 'dft_dy_mfma + batched dense_wgrad_x6_kernel + dft_dbank_kernel'
+                                 if conv_dft else info['kernels']['tvae_conv1_wgrad']),
+            'tvae_linear_fwd_x6': (dense_flops, 'dense_x6_kernel'),
+            'tvae_linear_dgrad_x6': (dense_flops, 'dense_x6_kernel'),
+            'tvae_linear_wgrad_x6': (dense_flops, 'dense_wgrad_x6_kernel'),
+        }
+        timed = {k_: v for k_, v in kev.items() if k_ in entries}
+        # the roofline object describes the dominant KERNEL.  In the default arithmetic that is dense_x6_kernel (the
+        # split-pipe GEMM: decoder layers and the spectral contraction of the convolution); its forward decoder launch
+        # is the measured instance.  In fp32 mode it is the direct lifting-convolution weight gradient.
+        if mode == 'x6' and 'tvae_linear_fwd_x6' in timed:
+            dom = 'tvae_linear_fwd_x6'
+        else:
+            dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
+        flops = entries[dom][0]
         ach = flops / (kev[dom]['mean_ms'] * 1e-3) / 1e12
-        other = 'tvae_conv1_wgrad' if dom == 'tvae_conv1_fwd' else 'tvae_conv1_fwd'
         out = {
             'metric': 'training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU' if args.workload == 'S64' else
                       'training images/sec (fwd+bwd+Adam), extra workload ' + args.workload,
             'value': imgs / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': MODE_INFO[mode]['dtype'], 'data': 'synthetic',
+            'dtype': info['dtype'], 'data': 'synthetic',
             'elbo': elbo_last,
             'config': {'workload': c['desc'],
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
-                       'arithmetic_mode': mode},
-            'roofline': {'kernel': dom + MODE_INFO[mode]['suffix'] + ' (' + MODE_INFO[mode]['kernels'][dom] + ', ' +
-                                   MODE_INFO[mode]['insn'] + ')', 'bound': 'mfma',
-                         'achieved': ach, 'peak': MODE_INFO[mode]['peak'], 'unit': 'TFLOP/s',
-                         'frac': ach / MODE_INFO[mode]['peak'],
+                       'arithmetic_mode': mode,
+                       'lifting_conv': ('frequency domain: DFT + batched split-pipe GEMM (326 GFLOP of matrix work per '
+                                        'launch instead of 2339)' if conv_dft else 'direct implicit GEMM')},
+            'roofline': {'kernel': dom + ' (' + entries[dom][1] + ', ' + info['insn'] + ')', 'bound': 'mfma',
+                         'achieved': ach, 'peak': info['peak'], 'unit': 'TFLOP/s',
+                         'frac': ach / info['peak'],
                          'peak_note': 'algorithmic (fp32-equivalent) FLOP/s; x6 peak = 2500 TFLOP/s dense bf16 / 6 '
                                       'products per block' if mode == 'x6' else 'dense f32 MFMA peak',
                          'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
-                         'traffic': pmc_traffic(dom + MODE_INFO[mode]['suffix']) if args.workload == 'S64' else None,
+                         # dense_x6_kernel is launched with several shapes: pick the decoder-layer launch by its grid
+                         # (512 threads x 8*ceil(tiles_n/8) workgroups; forward and data-gradient launches averaged)
+                         'traffic': pmc_traffic(dom, 512 * 8 * ((Nt // 128 + 7) // 8) * ((c['hidden'] + 511) // 512)
+                                                if dom.startswith('tvae_linear') else None)
+                         if args.workload == 'S64' else None,
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
-                         'other': {'kernel': other + MODE_INFO[mode]['suffix'],
-                                   'mean_launch_ms': kev.get(other, {}).get('mean_ms'),
-                                   'achieved': (flops / (kev[other]['mean_ms'] * 1e-3) / 1e12) if other in kev
-                                   else None}},
+                         'entry_points_ms': {k_: round(v['mean_ms'], 3) for k_, v in sorted(timed.items())},
+                         'conv_direct_form_tflops': {k_: conv_flops / (kev[k_]['mean_ms'] * 1e-3) / 1e12
+                                                     for k_ in ('tvae_conv1_fwd', 'tvae_conv1_wgrad') if k_ in kev}},
         }
         if companion is not None:
             out['exact_f32_mode'] = companion

@@ -16,16 +16,18 @@ from collections import defaultdict
 
 ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tvae_conv1_wgrad',
          'conv1_fwd_x6_kernel': 'tvae_conv1_fwd_x6', 'conv1_wgrad_x6_kernel': 'tvae_conv1_wgrad_x6',
-         'dy_split3_kernel': 'tvae_dy_split3',
+         'dy_split3_kernel': 'tvae_dy_split3', 'dense_x6_kernel': 'tvae_linear_fwd_x6',
+         'dense_wgrad_x6_kernel': 'tvae_linear_wgrad_x6', 'dft_out_kernel': 'tvae_dft_out', 'dft_dy_mfma_kernel': 'tvae_dft_dy',
          'outer_mask_kernel<1>': 'calibration_outer_mask', 'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
 def per_kernel(path, counter):
+    """bytes per launch, grouped by (kernel name, grid size): one kernel can be launched with several shapes per step"""
     acc = defaultdict(list)
     with open(path) as f:
         for row in csv.DictReader(f):
             if row['Counter_Name'] == counter:
-                acc[row['Kernel_Name']].append(float(row['Counter_Value']) * 1024.0)
+                acc[row['Kernel_Name'] + ' @grid' + row['Grid_Size']].append(float(row['Counter_Value']) * 1024.0)
     return acc
 
 
@@ -39,15 +41,20 @@ def main():
                 fb = sum(vals) / len(vals)
                 wv = write.get(name, [0.0])
                 wb = sum(wv) / len(wv)
-                # the largest launch shape of a kernel dominates; keep the entry with the most bytes
-                if entry in out and out[entry]['fetch_size_bytes_raw'] > fb:
+                # several launch shapes per kernel: keep the one with the largest grid (for dense_x6_kernel that is the
+                # decoder layer, forward and data-gradient launches averaged)
+                grid = int(name.rsplit('@grid', 1)[1])
+                out[entry + '@grid%d' % grid] = {'kernel': name[:64], 'grid': grid, 'launches': len(vals),
+                                                 'fetch_size_bytes_raw': fb, 'write_size_bytes': wb,
+                                                 'hbm_bytes_per_launch': 2.0 * fb + wb}
+                if entry in out and out[entry]['grid'] >= grid:
                     continue
-                out[entry] = {'kernel': name[:64], 'launches': len(vals), 'fetch_size_bytes_raw': fb,
+                out[entry] = {'kernel': name[:64], 'grid': grid, 'launches': len(vals), 'fetch_size_bytes_raw': fb,
                               'write_size_bytes': wb, 'hbm_bytes_per_launch': 2.0 * fb + wb,
                               'note': 'FETCH_SIZE doubled (gfx950 reports 1/2 of streamed bytes; see calibration entry)'}
     dst = sys.argv[3] if len(sys.argv) > 3 else 'profiles/pmc_traffic.json'
     json.dump(out, open(dst, 'w'), indent=1)
-    for k, v in out.items():
+    for k, v in sorted(out.items()):
         print(f"{k:26s} fetch_raw {v['fetch_size_bytes_raw']/1e9:8.3f} GB  write {v['write_size_bytes']/1e9:7.3f} GB  "
               f"hbm {v['hbm_bytes_per_launch']/1e9:8.3f} GB  ({v['launches']} launches)")
 

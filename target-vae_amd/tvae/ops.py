@@ -144,7 +144,8 @@ def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
     need = 64 * max(M, 128) * max(K, 128)
     ws = workspace(dpre.device, max(need, 1 << 24))
     if get_gemm_mode() == 'x6' and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
-        call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
+        with _timed('tvae_linear_wgrad_x6'):
+            call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
         return dW
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
@@ -484,8 +485,9 @@ class DecoderFn(torch.autograd.Function):
             hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 w3 = _split_weight(W, F_, F_, False, 'x6_dense_w')
-                call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
-                     LRELU_SLOPE)
+                with _timed('tvae_linear_fwd_x6'):
+                    call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
+                         LRELU_SLOPE)
             else:
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
                      Nt, Nt, act, LRELU_SLOPE)
@@ -532,8 +534,9 @@ class DecoderFn(torch.autograd.Function):
             dprev = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 w3t = _split_weight(W, F_, F_, True, 'x6_dense_wt')
-                call('tvae_linear_dgrad_x6', w3t, d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
-                     LRELU_SLOPE)
+                with _timed('tvae_linear_dgrad_x6'):
+                    call('tvae_linear_dgrad_x6', w3t, d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
+                         LRELU_SLOPE)
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
                      act, LRELU_SLOPE)
