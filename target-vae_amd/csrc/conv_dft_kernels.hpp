@@ -166,8 +166,8 @@ __global__ void dft_tables_kernel(float* __restrict__ tab, int L, int Lh) {
         const float sc = cf / ((float)L * (float)L);
         tab[i] = c * sc;
         tab[Lh * DFT_WMAX + i] = s * sc;
-        tab[2 * Lh * DFT_WMAX + i] = c;
-        tab[3 * Lh * DFT_WMAX + i] = s;
+        tab[2 * Lh * DFT_WMAX + 2 * i] = c;           // (cos, -sin) pairs for the dY transform
+        tab[2 * Lh * DFT_WMAX + 2 * i + 1] = -s;
     }
 }
 
@@ -177,35 +177,50 @@ __global__ void dft_tables_kernel(float* __restrict__ tab, int L, int Lh) {
 // (scalar loads); results go through LDS so that the stores are contiguous runs.
 // grid (ceil(NB/256), M), block 256.
 // ------------------------------------------------------------------------------------------
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+
+// WT = compile-time output width (33 and 17 are the reference configurations; DFT_WMAX is the generic instance):
+// the 2*Lh*WT multiply-adds per (m, n) run as packed v_pk_fma_f32 on pairs of outputs.
+template <int WT>
 __global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ T, const float* __restrict__ tab,
                                                       const float* __restrict__ bias, float* __restrict__ out, int M,
                                                       int R, int B, int Ho, int Lh, long NBpad, int act, float slope) {
-    __shared__ float st[256 * (DFT_WMAX + 1)];
+    constexpr int W2 = (WT + 1) / 2;
+    __shared__ float st[256 * (2 * W2 + 1)];
     const int m = blockIdx.y;
     const long n0 = (long)blockIdx.x * 256;
     const long n = n0 + threadIdx.x;
     const long NB = (long)B * Ho;
-    const float* cs = tab;
-    const float* sn = tab + Lh * DFT_WMAX;
-    float acc[DFT_WMAX];
+    const f32x2p* cs = reinterpret_cast<const f32x2p*>(tab);                       // [Lh][DFT_WMAX/2] pairs
+    const f32x2p* sn = reinterpret_cast<const f32x2p*>(tab + Lh * DFT_WMAX);
+    f32x2p acc[W2];
 #pragma unroll
-    for (int w = 0; w < DFT_WMAX; ++w) acc[w] = 0.f;
+    for (int q = 0; q < W2; ++q) acc[q] = (f32x2p){0.f, 0.f};
     const long col = n < NBpad ? n : NBpad - 1;
+    const float* tr_p = T + (long)m * Lh * NBpad + col;
+    const float* ti_p = T + (long)(M + m) * Lh * NBpad + col;
+#pragma unroll 2
     for (int fx = 0; fx < Lh; ++fx) {
-        const float tr = T[((long)m * Lh + fx) * NBpad + col];
-        const float ti = T[((long)(M + m) * Lh + fx) * NBpad + col];
+        const float tr = tr_p[(long)fx * NBpad];
+        const float ti = ti_p[(long)fx * NBpad];
+        const f32x2p tr2 = {tr, tr}, ti2 = {-ti, -ti};
 #pragma unroll
-        for (int w = 0; w < DFT_WMAX; ++w) acc[w] += tr * cs[fx * DFT_WMAX + w] - ti * sn[fx * DFT_WMAX + w];
+        for (int q = 0; q < W2; ++q) {
+            acc[q] = __builtin_elementwise_fma(tr2, cs[fx * (DFT_WMAX / 2) + q], acc[q]);
+            acc[q] = __builtin_elementwise_fma(ti2, sn[fx * (DFT_WMAX / 2) + q], acc[q]);
+        }
     }
     const int c = m / R, r = m - c * R;
     const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
-    for (int w = 0; w < DFT_WMAX; ++w) {
-        float v = acc[w] + bv;
-        if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
-        else if (act == ACT_TANH) v = tanhf(v);
-        st[threadIdx.x * (DFT_WMAX + 1) + w] = v;
-    }
+    for (int q = 0; q < W2; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = acc[q][e] + bv;
+            if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+            else if (act == ACT_TANH) v = tanhf(v);
+            st[threadIdx.x * (2 * W2 + 1) + 2 * q + e] = v;
+        }
     __syncthreads();
     const int P = Ho * Ho;
     const int cnt = 256 * Ho;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ 
         const long nn = n0 + t;
         if (nn < NB) {
             const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
-            out[(((long)c * B + b) * R + r) * P + h * Ho + w] = st[t * (DFT_WMAX + 1) + w];
+            out[(((long)c * B + b) * R + r) * P + h * Ho + w] = st[t * (2 * W2 + 1) + w];
         }
     }
 }
@@ -224,10 +239,11 @@ __global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ 
 // (S = DFT over w of the output gradient).  dY is [c][b][r][h][w]; one thread per (m, n).
 // grid (ceil(NBpad/256), M), block 256: columns n >= NB are written as zeros.
 // ------------------------------------------------------------------------------------------
+template <int WT>
 __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ dY, const float* __restrict__ tab,
                                                      float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
                                                      long NBpad) {
-    __shared__ float st[256 * (DFT_WMAX + 1)];
+    __shared__ float st[256 * (WT + 1)];
     const int m = blockIdx.y;
     const long n0 = (long)blockIdx.x * 256;
     const long NB = (long)B * Ho;
@@ -242,25 +258,25 @@ __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ d
             const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
             v = dY[(((long)c * B + b) * R + r) * P + h * Ho + w];
         }
-        st[t * (DFT_WMAX + 1) + w] = v;
+        st[t * (WT + 1) + w] = v;
     }
     __syncthreads();
-    float d[DFT_WMAX];
+    float d[WT];
 #pragma unroll
-    for (int w = 0; w < DFT_WMAX; ++w) d[w] = w < Ho ? st[threadIdx.x * (DFT_WMAX + 1) + w] : 0.f;
-    const float* cw = tab + 2 * Lh * DFT_WMAX;
-    const float* sw = tab + 3 * Lh * DFT_WMAX;
+    for (int w = 0; w < WT; ++w) d[w] = w < Ho ? st[threadIdx.x * (WT + 1) + w] : 0.f;
+    // (cos, -sin) pairs: S = sum_w d[w] e^{-2 pi i fx w / L} as ONE packed FMA per w
+    const f32x2p* cm = reinterpret_cast<const f32x2p*>(tab + 2 * Lh * DFT_WMAX);   // [Lh][DFT_WMAX] pairs
     const long n = n0 + threadIdx.x;
     if (n >= NBpad) return;
+    float* sr_p = Sp + (long)m * Lh * NBpad + n;
+    float* si_p = Sp + (long)(M + m) * Lh * NBpad + n;
+#pragma unroll 2
     for (int fx = 0; fx < Lh; ++fx) {
-        float sr = 0.f, si = 0.f;
+        f32x2p s2 = {0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < DFT_WMAX; ++w) {
-            sr += d[w] * cw[fx * DFT_WMAX + w];
-            si -= d[w] * sw[fx * DFT_WMAX + w];
-        }
-        Sp[((long)m * Lh + fx) * NBpad + n] = sr;
-        Sp[((long)(M + m) * Lh + fx) * NBpad + n] = si;
+        for (int w = 0; w < WT; ++w) s2 = __builtin_elementwise_fma((f32x2p){d[w], d[w]}, cm[fx * DFT_WMAX + w], s2);
+        sr_p[(long)fx * NBpad] = s2[0];
+        si_p[(long)fx * NBpad] = s2[1];
     }
 }
 

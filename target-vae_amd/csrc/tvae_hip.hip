@@ -426,8 +426,16 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         float* vtab = reinterpret_cast<float*>(Ep3 + 3L * q.WOCT * 128);
         hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, vtab, q.L, q.Lh);
         TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dft_out_kernel, dim3((unsigned)((q.NB + 255) / 256), q.M), dim3(256), 0, st, (const float*)T,
-                           (const float*)vtab, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
+        const dim3 og((unsigned)((q.NB + 255) / 256), q.M);
+        if (q.Ho == 33)
+            hipLaunchKernelGGL(dft_out_kernel<33>, og, dim3(256), 0, st, (const float*)T, (const float*)vtab, bias, out,
+                               q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
+        else if (q.Ho == 17)
+            hipLaunchKernelGGL(dft_out_kernel<17>, og, dim3(256), 0, st, (const float*)T, (const float*)vtab, bias, out,
+                               q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
+        else
+            hipLaunchKernelGGL(dft_out_kernel<DFT_WMAX>, og, dim3(256), 0, st, (const float*)T, (const float*)vtab, bias,
+                               out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope);
         TVAE_CHECK_LAUNCH();
     }
     return 0;
@@ -447,7 +455,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     uint4* Ep3 = E3 + 3L * q.KO * DFT_WROWS;
     hipLaunchKernelGGL(dft_etab_kernel, dim3(16), dim3(256), 0, st, E3, Ep3, q.L, q.Lh, q.KH, q.Ho, q.WOCT);
     TVAE_CHECK_LAUNCH();
-    {
+    static const bool dy_mfma = [] { const char* e_ = getenv("TVAE_DFT_DY_MFMA"); return e_ && e_[0] == '1'; }();
+    if (dy_mfma || q.Ho > DFT_WMAX) {
         const size_t lds_d = (size_t)3 * q.WOCT * 128 * 16 + (size_t)4 * 32 * (8 * q.WOCT + 4) * 4;
         hipError_t e0 = allow_big_lds(dft_dy_mfma_kernel, lds_d);
         if (e0 != hipSuccess) return (int)e0;
@@ -455,6 +464,21 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const int grid = (int)(ntiles / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
         hipLaunchKernelGGL(dft_dy_mfma_kernel, dim3(grid), dim3(256), lds_d, st, dpre, (const uint4*)Ep3, Sp, q.M, R, B,
                            q.Ho, q.Lh, q.KH, q.WOCT, q.NBpad);
+        TVAE_CHECK_LAUNCH();
+    } else {
+        float* vtab = reinterpret_cast<float*>(Ep3 + 3L * q.WOCT * 128);
+        hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, vtab, q.L, q.Lh);
+        TVAE_CHECK_LAUNCH();
+        const dim3 dg((unsigned)((q.NBpad + 255) / 256), q.M);
+        if (q.Ho == 33)
+            hipLaunchKernelGGL(dft_dy_kernel<33>, dg, dim3(256), 0, st, dpre, (const float*)vtab, Sp, q.M, R, B, q.Ho, q.Lh,
+                               q.NBpad);
+        else if (q.Ho == 17)
+            hipLaunchKernelGGL(dft_dy_kernel<17>, dg, dim3(256), 0, st, dpre, (const float*)vtab, Sp, q.M, R, B, q.Ho, q.Lh,
+                               q.NBpad);
+        else
+            hipLaunchKernelGGL(dft_dy_kernel<DFT_WMAX>, dg, dim3(256), 0, st, dpre, (const float*)vtab, Sp, q.M, R, B, q.Ho,
+                               q.Lh, q.NBpad);
         TVAE_CHECK_LAUNCH();
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
