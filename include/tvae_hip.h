@@ -103,7 +103,8 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
  * one batched GEMM per call on the split-bf16 dense kernels (7x fewer matrix FLOPs than the direct form), inverse
  * transform of the 33-wide output rows on the vector ALU.  `at` (tvae_conv1_dft_at_floats floats) receives the image
  * spectra in GEMM-operand form in the forward call and is consumed again by the weight gradient of the same step;
- * ws is scratch (tvae_conv1_dft_ws_floats floats).  tvae_conv1_dft_supported: 1 if this geometry is handled
+ * ws is scratch (tvae_conv1_dft_ws_floats floats); dbias (C floats, may be NULL) receives the bias gradient
+ * sum over (image, rotation, position) of dpre, read off the zero-frequency row.  tvae_conv1_dft_supported: 1 if this geometry is handled
  * (single channel, output side <= 40, 2*C*R a multiple of 512). */
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R);
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);
@@ -111,8 +112,8 @@ long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, in
 int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
                        long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
                        tvae_stream_t stream);
-int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* ws, long ws_floats, int B, int Cin,
-                         int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
+int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* dbias, float* ws, long ws_floats, int B,
+                         int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
 
 /* ---- dense layers in the same "x6" arithmetic (nn.Linear of SpatialGenerator, src/models.py:78-93,119-120) -----------
  * tvae_dense_split3: W (row stride ldw) -> cells for A(row, k) = W[row][k] (transpose = 0: forward, rows = out

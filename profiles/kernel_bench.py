@@ -94,7 +94,7 @@ if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
     A1d = torch.empty(C, N, device=dev)
     timeit('dft_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_dft', y, bank, bias, A1d, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 1, 0.01))
     dbd = torch.empty_like(bank)
-    timeit('dft_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_dft', dA1, at, dbd, wsd, wsd.numel(), B, Cin, n, k, pad, C, R))
+    timeit('dft_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_dft', dA1, at, dbd, None, wsd, wsd.numel(), B, Cin, n, k, pad, C, R))
     if not only or 'dft' in only:
         call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
         call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)

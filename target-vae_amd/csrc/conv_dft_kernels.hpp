@@ -514,6 +514,20 @@ __global__ __launch_bounds__(256) void dft_dy_mfma_kernel(const float* __restric
     }
 }
 
+// Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
+// db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  One workgroup per channel.
+__global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, long NBpad) {
+    __shared__ float sm[16];
+    const int c = blockIdx.x;
+    float acc[1] = {0.f};
+    for (int r = 0; r < R; ++r) {
+        const float* row = Sp + (long)(c * R + r) * Lh * NBpad;
+        for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += row[n];
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) db[c] = acc[0];
+}
+
 // ------------------------------------------------------------------------------------------
 // One workgroup per filter m:  dKh'[fy][fx] from the four real blocks of G[fx][m | M+m][(re/im, fy)]
 //   Re = G[m][fy] + G[M+m][L+fy],  Im = G[m][L+fy] - G[M+m][fy]

@@ -441,8 +441,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     return 0;
 }
 
-int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* ws, long ws_floats, int B, int Cin,
-                         int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* dbias, float* ws, long ws_floats, int B,
+                         int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
@@ -479,6 +479,10 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         else
             hipLaunchKernelGGL(dft_dy_kernel<DFT_WMAX>, dg, dim3(256), 0, st, dpre, (const float*)vtab, Sp, q.M, R, B, q.Ho,
                                q.Lh, q.NBpad);
+        TVAE_CHECK_LAUNCH();
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(dft_dbias_kernel, dim3(C), dim3(256), 0, st, (const float*)Sp, dbias, R, q.Lh, q.NB, q.NBpad);
         TVAE_CHECK_LAUNCH();
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices

@@ -25,7 +25,7 @@ SIGNATURES = {
     'tvae_dy_split3': 'ppliiiiiii',
     'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
-    'tvae_conv1_wgrad_dft': 'ppppliiiiiii',
+    'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
     'tvae_dense_split3': 'plpliii',
     'tvae_linear_fwd_x6': 'pppppiiillif',
     'tvae_linear_dgrad_x6': 'pppppiiillif',

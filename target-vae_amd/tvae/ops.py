@@ -224,13 +224,15 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
     return out
 
 
-def conv1_wgrad(y, dpre, C, R, k, pad, at=None):
+def conv1_wgrad(y, dpre, C, R, k, pad, at=None, dbias=None):
+    """Weight gradient of the lifting convolution.  With the frequency-domain path (`at` from the forward call) the bias
+    gradient is a by-product: pass `dbias` (C floats) to receive it; returns (dbank, bias_done)."""
     B, Cin, n, _ = y.shape
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
     if at is not None:
         wsd = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
         with _timed('tvae_conv1_wgrad'):
-            call('tvae_conv1_wgrad_dft', dpre, at, dbank, wsd, wsd.numel(), B, Cin, n, k, pad, C, R)
+            call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, wsd, wsd.numel(), B, Cin, n, k, pad, C, R)
         return dbank
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     if _use_x6(Cin, n, k, pad):
@@ -282,9 +284,13 @@ class GroupConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError('GroupConv input gradient is not part of the hot path (input is data)')
         dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, B * R * Ho * Ho)
-        dbank = conv1_wgrad(y, dpre, C, R, k, pad, ctx.at)
+        db = None
+        if has_bias and ctx.at is not None:
+            db = torch.empty(C, dtype=torch.float32, device=y.device)
+        dbank = conv1_wgrad(y, dpre, C, R, k, pad, ctx.at, db)
         dW = rotate_bank_bwd(dbank, C, Cin, k, R)
-        db = _rowsum(dpre, C, dpre.shape[1]) if has_bias else None
+        if has_bias and db is None:
+            db = _rowsum(dpre, C, dpre.shape[1])
         return None, dW, db, None, None
 
 
@@ -347,8 +353,8 @@ class EncoderFn(torch.autograd.Function):
         dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
         call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
         del dH
-        db1 = _rowsum(dA1, C, N)
-        dbank = conv1_wgrad(y, dA1, C, R, k, pad, ctx.at)
+        db1 = torch.empty(C, dtype=torch.float32, device=y.device) if ctx.at is not None else _rowsum(dA1, C, N)
+        dbank = conv1_wgrad(y, dA1, C, R, k, pad, ctx.at, db1 if ctx.at is not None else None)
         dw1 = rotate_bank_bwd(dbank, C, Cin, k, R)
         return None, dw1, db1, dW2, db2, dWh, dbh, None, None, None
 

@@ -261,7 +261,9 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
     ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
     dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
     dbank = torch.empty(C * R, Cin * k * k, device=dev())
-    call('tvae_conv1_wgrad_dft', dpre, at, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    dbias = torch.empty(C, device=dev())
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    assert rel_err(dbias, g.double().sum(dim=(0, 2, 3, 4))) < TOL
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
 
