@@ -202,8 +202,8 @@ static hipError_t launch_gemm_bf16x3(AL al, BL bl, const Epilogue& ep, int M, in
     if (e != hipSuccess) return e;
     if (splits > 1) {
         const long total = (long)M * N;
-        int blocks = cdiv(total, 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = cdiv(total, 64);
+        if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, splits, M, N,
                            ep);
         e = hipGetLastError();

@@ -698,13 +698,33 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
-__global__ void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
+// Deterministic reduction of the split-K slabs: a workgroup owns 64 consecutive outputs, its four thread rows sum
+// every fourth slab (independent loads in flight, 256-byte coalesced rows) and the four partial sums are added in a
+// fixed order.  (A thread per output walking all slabs is latency bound when there are hundreds of small slabs.)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
+    __shared__ float part[4][64];
     const long total = (long)M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long i = base + lane;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(long)k * total + i];
-        const int m = (int)(i / N), n = (int)(i - (long)m * N);
-        ep.store(m, n, ep.prep(n), s);
+        if (i < total) {
+            int k = slice;
+            for (; k + 12 < splits; k += 16) {
+                const float a = ws[(long)k * total + i], b = ws[(long)(k + 4) * total + i];
+                const float c = ws[(long)(k + 8) * total + i], d = ws[(long)(k + 12) * total + i];
+                s += (a + b) + (c + d);
+            }
+            for (; k < splits; k += 4) s += ws[(long)k * total + i];
+        }
+        part[slice][lane] = s;
+        __syncthreads();
+        if (slice == 0 && i < total) {
+            const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            const int m = (int)(i / N), n = (int)(i - (long)m * N);
+            ep.store(m, n, ep.prep(n), v);
+        }
+        __syncthreads();
     }
 }
 
@@ -731,8 +751,8 @@ static hipError_t launch_gemm(AL al, BL bl, const Epilogue& ep, int M, int N, in
     if (e != hipSuccess) return e;
     if (splits > 1) {
         const long total = (long)M * N;
-        int blocks = cdiv(total, 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = cdiv(total, 64);
+        if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, splits, M, N,
                            ep);
         e = hipGetLastError();

@@ -272,8 +272,8 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dbank; ep.ldc = N;
-    int blocks = cdiv(per, 256);
-    if (blocks > 4096) blocks = 4096;
+    int blocks = cdiv(per, 64);
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, sp, M, N, ep);
     TVAE_CHECK_LAUNCH();
     return 0;
@@ -346,8 +346,8 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     Epilogue ep;
     ep.C = dW; ep.ldc = K;
     ep.accumulate = accumulate;
-    int blocks = cdiv(per, 256);
-    if (blocks > 4096) blocks = 4096;
+    int blocks = cdiv(per, 64);
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits, M, K, ep);
     TVAE_CHECK_LAUNCH();
     return 0;
@@ -499,8 +499,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;
         const long per = (long)q.Lh * M2 * q.K2;
-        int blocks = cdiv(per, 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = cdiv(per, 64);
+        if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, splits,
                            q.Lh * M2, q.K2, ep);
         TVAE_CHECK_LAUNCH();
@@ -652,8 +652,8 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
                                    tilesN2, rows2, sp, tilesM * sp);
                 TVAE_CHECK_LAUNCH();
                 if (sp > 1) {
-                    int blocks = cdiv(per, 256);
-                    if (blocks > 4096) blocks = 4096;
+                    int blocks = cdiv(per, 64);
+                    if (blocks > 16384) blocks = 16384;
                     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, sp,
                                        M, N, ep);
                     TVAE_CHECK_LAUNCH();
@@ -686,8 +686,8 @@ int tvae_conv1_wgrad(const float* y, const float* dpre, float* dbank, float* ws,
         }
         TVAE_CHECK_LAUNCH();
         if (splits > 1) {
-            int blocks = cdiv(per, 256);
-            if (blocks > 4096) blocks = 4096;
+            int blocks = cdiv(per, 64);
+            if (blocks > 16384) blocks = 16384;
             hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits,
                                M, N, ep);
             TVAE_CHECK_LAUNCH();
