@@ -430,11 +430,27 @@ __device__ __forceinline__ void tile_epilogue_v4(f32x16 (&acc)[2][2], float* ct,
 // ------------------------------------------------------------------------------------------
 struct TileMap {
     int tilesM, tilesN, splits;
-    __host__ __device__ int groups() const { return splits > 1 ? splits : tilesN; }
-    __host__ __device__ int group_size() const { return splits > 1 ? tilesM * tilesN : tilesM; }
+    // batched GEMMs with per-problem operands (bt = row tiles per problem, nch = column chunks per problem): a group is
+    // (problem, column chunk): the problem's A cells stay in ONE L2 while its column tiles stream, and the bt row tiles
+    // of a column panel are adjacent so the panel is fetched once.
+    int bt = 0, nch = 1;
+    __host__ __device__ int chunk() const { return (tilesN + nch - 1) / nch; }
+    __host__ __device__ int groups() const { return bt > 0 ? (tilesM / bt) * nch : (splits > 1 ? splits : tilesN); }
+    __host__ __device__ int group_size() const {
+        return bt > 0 ? bt * chunk() : (splits > 1 ? tilesM * tilesN : tilesM);
+    }
     __host__ __device__ unsigned grid() const { return (unsigned)(8 * ((groups() + 7) / 8) * group_size()); }
     __device__ __forceinline__ bool decode(int bid, int& tile_m, int& tile_n, int& split) const {
         const int xcd = bid & 7, j = bid >> 3;
+        if (bt > 0) {
+            const int gs = bt * chunk();
+            const int g = (j / gs) * 8 + xcd, r = j % gs;
+            const int batch = g / nch, ch = g - batch * nch;
+            split = 0;
+            tile_n = ch * chunk() + r / bt;
+            tile_m = batch * bt + r % bt;
+            return g < groups() && tile_n < tilesN;
+        }
         if (splits > 1) {
             const int T = tilesM * tilesN;
             const int tile = j % T;

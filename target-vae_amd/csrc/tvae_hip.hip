@@ -405,7 +405,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         Epilogue ep;
         ep.C = T; ep.ldc = (long)q.Lh * q.NBpad;          // T is [m'][fx][n]: the 2*Lh rows of one (m, .) stay together
         const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((q.K2 + 7) / 8, 2);
-        const TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
+        TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
+        tm.bt = 2 * q.M / DX6_ROWS;                    // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
+        tm.nch = 4;
         const DenseBatch bt{2 * q.M / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
         hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt);
