@@ -105,7 +105,7 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
  * spectra in GEMM-operand form in the forward call and is consumed again by the weight gradient of the same step;
  * ws is scratch (tvae_conv1_dft_ws_floats floats); dbias (C floats, may be NULL) receives the bias gradient
  * sum over (image, rotation, position) of dpre, read off the zero-frequency row.  tvae_conv1_dft_supported: 1 if this geometry is handled
- * (single channel, output side <= 40, 2*C*R a multiple of 512). */
+ * (single input channel, output side <= 64, frame side <= 126). */
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R);
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);

@@ -104,7 +104,8 @@ __global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict_
 // One workgroup per filter m:  Kh = DFT2(filter at the origin of the L x L frame), fx < Lh, then the real operand
 // rows of the spectral GEMM:  W[fx][m][fy] = Kr, W[fx][m][L+fy] = Ki;  W[fx][M+m][fy] = -Ki, W[fx][M+m][L+fy] = Kr.
 // ------------------------------------------------------------------------------------------
-__global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M) {
+__global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M,
+                                int Mb) {
     extern __shared__ float sm_dft[];
     float* ker = sm_dft;
     float2* Q = reinterpret_cast<float2*>(ker + ksz * ksz);
@@ -146,8 +147,8 @@ __global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restric
     for (int i = threadIdx.x; i < Lh * L; i += blockDim.x) {
         const int fy = i % L, fx = i / L;
         const float2 k = Kh[fy * Lh + fx];
-        float* r0 = W + ((long)fx * 2 * M + m) * rowlen;
-        float* r1 = W + ((long)fx * 2 * M + M + m) * rowlen;
+        float* r0 = W + ((long)fx * Mb + m) * rowlen;            // Mb >= 2M rows per fx (padding rows stay zero)
+        float* r1 = W + ((long)fx * Mb + M + m) * rowlen;
         r0[fy] = k.x;
         r0[L + fy] = k.y;
         r1[fy] = -k.y;

@@ -132,6 +132,7 @@ constexpr int DFT_WG_SPLITS = 8;
 struct DftPlan {
     int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
     int KH, KO, WOCT;          // padded half spectrum, its octets (x2 planes), octets of an output row
+    int Mb;                    // rows per fx in the stacked spectral weight (2M rounded up to the 512-row tile)
     long NB, NBpad;            // (image, output row) columns
     long at_floats;            // A^T [Lh][2L][NBpad]
     long w_floats;             // W   [Lh][2M][2L]
@@ -150,18 +151,19 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.K2 = 2 * q.L;
     q.NB = (long)B * q.Ho;
     q.NBpad = (q.NB + 127) / 128 * 128;
+    q.Mb = x6_round_up(2 * q.M, DX6_ROWS);
     q.at_floats = (long)q.Lh * q.K2 * q.NBpad;
-    q.w_floats = (long)q.Lh * 2 * q.M * q.K2;
-    q.w3_floats = tvae_dense_x6_bytes_impl(q.Lh * 2 * q.M, q.K2) / 4;
+    q.w_floats = (long)q.Lh * q.Mb * q.K2;
+    q.w3_floats = tvae_dense_x6_bytes_impl(q.Lh * q.Mb, q.K2) / 4;
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
     q.KH = (q.Lh + 7) / 8 * 8;
     q.KO = 2 * q.KH / 8;
     q.WOCT = (q.Ho + 7) / 8;
     q.tab_floats = 4L * (3L * q.KO * DFT_WROWS + 3L * q.WOCT * 128) + 4L * q.Lh * DFT_WMAX;   // E, E' cells + ALU tables
-    q.g_floats = q.w_floats;
+    q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && 2 * q.KH <= 128 && (2 * q.M) % DX6_ROWS == 0 && lds_img <= 150 * 1024 &&
+    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && 2 * q.KH <= 128 && lds_img <= 150 * 1024 &&
            lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
     return q;
 }
@@ -395,10 +397,14 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     e = allow_big_lds(dft_bank_kernel, lds_bank);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_bank_kernel, dim3(q.M), dim3(256), lds_bank, st, bank, W, ksz, q.L, q.Lh, q.M);
+    if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
+        e = hipMemsetAsync(W, 0, (size_t)q.w_floats * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dft_bank_kernel, dim3(q.M), dim3(256), lds_bank, st, bank, W, ksz, q.L, q.Lh, q.M, q.Mb);
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
-    const int rows = q.Lh * 2 * q.M;
+    const int rows = q.Lh * q.Mb;
     int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, stream);
     if (rc) return rc;
     {
@@ -406,9 +412,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         ep.C = T; ep.ldc = (long)q.Lh * q.NBpad;          // T is [m'][fx][n]: the 2*Lh rows of one (m, .) stay together
         const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((q.K2 + 7) / 8, 2);
         TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
-        tm.bt = 2 * q.M / DX6_ROWS;                    // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
+        tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
-        const DenseBatch bt{2 * q.M / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
+        const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
         hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt);
         TVAE_CHECK_LAUNCH();
@@ -489,7 +495,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
     {
-        const int M2 = 2 * q.M, tiles_b = M2 / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
+        const int M2 = 2 * q.M, tiles_b = q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
         // 8 reduction slices: TileMap deals the slices round-robin to the 8 XCDs, fewer would leave XCDs idle
         const int splits = DFT_WG_SPLITS;
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;

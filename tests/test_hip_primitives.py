@@ -236,7 +236,7 @@ def test_linear_wgrad_x6(M, N, K, acc):
 
 
 @pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
-                                               (17, 64, 64, 16, 64, 8, 1)])
+                                               (17, 64, 64, 16, 64, 8, 1), (4, 32, 32, 8, 16, 8, 1), (3, 20, 9, 2, 5, 4, 0)])
 def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
     """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64."""
     from tvae._lib import query
