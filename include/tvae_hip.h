@@ -120,12 +120,16 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
  *                    features) or A(row, k) = W[k][row] (transpose = 1: data gradient, rows = in features);
  *                    a3 needs tvae_dense_x6_bytes(rows, K) bytes (host query).
  * tvae_linear_fwd_x6 / tvae_linear_dgrad_x6: as tvae_linear_fwd / tvae_linear_dgrad with the split weight instead of
- *                    W (no per-image bias); N must be a multiple of 128 (else hipErrorInvalidValue: use the fp32 entry). */
+ *                    W (no per-image bias); N must be a multiple of 128 (else hipErrorInvalidValue: use the fp32 entry).
+ *                    tvae_linear_fwd_x6 can also apply the NEXT layer when that is the single-output Linear
+ *                    (src/models.py:121-123): col_y[n] = col_b[0] + sum_m col_w[m] Y[m][n] (col_w = NULL: off; needs
+ *                    M <= 512), which saves a separate pass over Y. */
 long tvae_dense_x6_bytes(int rows, int K);
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                       tvae_stream_t stream);
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
-                       int K, long ldx, long ldy, int act, float slope, tvae_stream_t stream);
+                       int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
+                       float* col_y, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream);
 /* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned

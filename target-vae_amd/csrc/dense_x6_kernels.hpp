@@ -48,7 +48,8 @@ constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
 
 template <int ACT, int MASK, bool RES>
 __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
-                                                  int n0, int M, int wave, int lane) {
+                                                  int n0, int M, int wave, int lane, const float* wsm,
+                                                  float (&ysum)[4]) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
@@ -92,7 +93,10 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                     else if (ACT == ACT_TANH) v = tanhf(v);
                     if (MASK == ACT_LRELU) v *= av[q][j] > 0.f ? 1.f : ep.slope;
                     else if (MASK == ACT_TANH) v *= 1.f - av[q][j] * av[q][j];
-                    if (m < M) crow[j * 32] = v;
+                    if (m < M) {
+                        crow[j * 32] = v;
+                        if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
+                    }
                 }
             }
         }
@@ -107,11 +111,18 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
     long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
 };
 
+struct ColDot {            // optional fused skinny layer on the OUTPUT of this one (single row tile, one output):
+    const float* w;        //   y[n] = b[0] + sum_m w[m] * Y[m][n]   (SpatialGenerator's last Linear, src/models.py:121-123)
+    const float* b;
+    float* y;
+};
+
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
+    __shared__ float wsm_[DX6_ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
@@ -130,6 +141,8 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+    wsm_[tid] = (cd.w && (m0 + tid) < M) ? cd.w[m0 + tid] : 0.f;
+    const float* wsm = cd.w ? wsm_ : nullptr;
 
     // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
     const long part_cells = (long)K8pad * Mpad;
@@ -210,7 +223,8 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     }
     // epilogue specialised on (activation, mask, residual): no per-element branches
     const bool res = ep.res != nullptr;
-#define TVAE_DX6_EPI(A_, M_, R_) dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane)
+    float ysum[4] = {0.f, 0.f, 0.f, 0.f};
+#define TVAE_DX6_EPI(A_, M_, R_) dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum)
     if (ep.mask == ACT_NONE) {
         if (ep.act == ACT_LRELU) { if (res) TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, true); else TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, false); }
         else if (ep.act == ACT_TANH) { if (res) TVAE_DX6_EPI(ACT_TANH, ACT_NONE, true); else TVAE_DX6_EPI(ACT_TANH, ACT_NONE, false); }
@@ -221,6 +235,22 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         if (res) TVAE_DX6_EPI(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI(ACT_NONE, ACT_TANH, false);
     }
 #undef TVAE_DX6_EPI
+    if (cd.w) {
+        // the eight waves hold disjoint rows of the same 128 columns: lane halves first, then waves through LDS
+        float* cds = reinterpret_cast<float*>(Bs);          // the B stages are free after the k-loop
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = ysum[j] + __shfl_xor(ysum[j], 32, 64);
+            if (lane < 32) cds[wave * 128 + j * 32 + lane] = v;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float y = cd.b ? cd.b[0] : 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) y += cds[w * 128 + tid];
+            cd.y[n0 + tid] = y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

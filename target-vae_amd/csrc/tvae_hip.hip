@@ -295,24 +295,26 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
     return 0;
 }
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
-                           hipStream_t st) {
+                           hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr}) {
+    if (cd.w && rows > DX6_ROWS) return (int)hipErrorInvalidValue;      // the fused column dot needs ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep, rows,
-                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0});
+                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
-                       int K, long ldx, long ldy, int act, float slope, tvae_stream_t stream) {
+                       int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
+                       float* col_y, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
     ep.bias = bias;
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
-    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream));
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y});
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream) {
@@ -416,7 +418,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
         hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
-                           q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt);
+                           q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr});
         TVAE_CHECK_LAUNCH();
     }
     static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();

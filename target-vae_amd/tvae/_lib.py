@@ -27,7 +27,7 @@ SIGNATURES = {
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
     'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
     'tvae_dense_split3': 'plpliii',
-    'tvae_linear_fwd_x6': 'pppppiiillif',
+    'tvae_linear_fwd_x6': 'pppppiiillifppp',
     'tvae_linear_dgrad_x6': 'pppppiiillif',
     'tvae_linear_wgrad_x6': 'ppppliiilli',
     'tvae_linear_fwd': 'ppppippiiillif',

@@ -188,6 +188,7 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
 
 
 CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
+FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -487,19 +488,24 @@ class DecoderFn(torch.autograd.Function):
         else:
             call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
         hs = [h]
-        for (W, b) in hidden:
+        yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
+        fused_out = False
+        for li, (W, b) in enumerate(hidden):
             hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 w3 = _split_weight(W, F_, F_, False, 'x6_dense_w')
+                # the last hidden layer also applies the single-output Linear that follows it (one pass less over h)
+                fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
-                         LRELU_SLOPE)
+                         LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None)
+                fused_out = fuse
             else:
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
                      Nt, Nt, act, LRELU_SLOPE)
             hs.append(hn)
-        yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
-        call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
+        if not fused_out:
+            call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
         ctx.save_for_backward(xr, z if Wl is not None else None, feat, *hs, *[p for p in params if p is not None])
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
         return yh

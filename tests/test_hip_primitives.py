@@ -201,8 +201,13 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     Wd = W.to(dev())
     call('tvae_dense_split3', Wd, K, w3, w3.numel() * 4, M, K, 0)
     Y = torch.empty(M, N, device=dev())
+    cw, cb = rnd(M, seed=11), rnd(1, seed=12)
+    cy = torch.empty(N, device=dev())
+    fuse = M <= 512
     call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), res.to(dev()) if use_res else None, Y, M, N, K, N, N, act,
-         SLOPE)
+         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None)
+    if fuse:
+        assert rel_err(cy, cw.double() @ ref + cb.double()) < GEMM_TOL['f32']
     assert rel_err(Y, ref) < GEMM_TOL['f32']
     # data gradient: dX[k][n] = act'(aux) * (add + sum_m W[m][k] d[m][n])
     d = rnd(M, N, seed=6)
@@ -219,7 +224,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
          dX, M, N, K, N, N, act, SLOPE)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE)
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None)
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(512, 20000 // 16 * 16, 512, 0), (128, 8192, 128, 0), (300, 1600, 70, 1), (512, 4096, 512, 1)])
