@@ -131,7 +131,15 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
-                         int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream);
+                         int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
+                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats,
+                         tvae_stream_t stream);
+/* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
+ * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
+ * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
+ * (never materialised).  tvae_dec_in_total turns the panels into Simg [B][F], dbc [F], dWc [F][2] (cpi panels per image). */
+int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
+                      tvae_stream_t stream);
 /* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned
  * rows and a workspace of at least M*K floats (hipErrorInvalidValue otherwise: use the fp32 entry). */
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,

@@ -46,15 +46,37 @@ __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
 constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
 
+struct InTail {            // optional fused backward of SpatialGenerator's FIRST layer (h0 = act(Wc x' + ..), in_dim 2,
+    const float* xr;       // src/models.py:107-118) on the output dX of a data-gradient launch (single row tile, panels
+    const float* wc;       // inside one image):  gxr[n][j] = sum_f wc[f][j] dX[f][n];
+    float* gxr;            // part[panel][f][0..2] = sum_{n in panel} dX[f][n] * (1, x'_0[n], x'_1[n])
+    float* part;           // xr [N][2], wc [rows][2], gxr [N][2], part [N/128][rows][3]
+};
+
+struct ColDot {            // optional fused skinny layer on the OUTPUT of this one (single row tile, one output):
+    const float* w;        //   y[n] = b[0] + sum_m w[m] * Y[m][n]   (SpatialGenerator's last Linear, src/models.py:121-123)
+    const float* b;
+    float* y;
+};
+
 template <int ACT, int MASK, bool RES>
 __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
                                                   int n0, int M, int wave, int lane, const float* wsm,
-                                                  float (&ysum)[4]) {
+                                                  float (&ysum)[4], const InTail& it, const float* wc2,
+                                                  float (&gsum)[4][2], int tile_n) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
     // waves per SIMD.
     const long off = n0 + (lane & 31);
+    float x0[4], x1[4];
+    if (it.xr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x0[j] = it.xr[2 * (off + j * 32)];
+            x1[j] = it.xr[2 * (off + j * 32) + 1];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,7 +106,8 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int m = m0 + row;
                 const float bv = bsm[row];
-                float* crow = ep.C + mrow[q] * ep.ldc + off;
+                float* crow = ep.C ? ep.C + mrow[q] * ep.ldc + off : nullptr;
+                float rs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[i][j][r] + bv;
@@ -94,8 +117,29 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                     if (MASK == ACT_LRELU) v *= av[q][j] > 0.f ? 1.f : ep.slope;
                     else if (MASK == ACT_TANH) v *= 1.f - av[q][j] * av[q][j];
                     if (m < M) {
-                        crow[j * 32] = v;
+                        if (crow) crow[j * 32] = v;
                         if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
+                        if (it.xr) {                             // fused first-layer backward (see InTail)
+                            rs[0] += v;
+                            rs[1] += v * x0[j];
+                            rs[2] += v * x1[j];
+                            gsum[j][0] += wc2[2 * row] * v;
+                            gsum[j][1] += wc2[2 * row + 1] * v;
+                        }
+                    }
+                }
+                if (it.xr) {
+                    // row sums over this panel's 128 columns: the 32 lanes of a half wave hold the same row
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) rs[k] += __shfl_xor(rs[k], o, 64);
+                    }
+                    if ((lane & 31) == 0 && m < M) {
+                        float* pp = it.part + ((long)tile_n * M + m) * 3;
+                        pp[0] = rs[0];
+                        pp[1] = rs[1];
+                        pp[2] = rs[2];
                     }
                 }
             }
@@ -111,18 +155,12 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
     long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
 };
 
-struct ColDot {            // optional fused skinny layer on the OUTPUT of this one (single row tile, one output):
-    const float* w;        //   y[n] = b[0] + sum_m w[m] * Y[m][n]   (SpatialGenerator's last Linear, src/models.py:121-123)
-    const float* b;
-    float* y;
-};
-
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
-    __shared__ float wsm_[DX6_ROWS];
+    __shared__ float wsm_[2 * DX6_ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
@@ -141,8 +179,13 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
-    wsm_[tid] = (cd.w && (m0 + tid) < M) ? cd.w[m0 + tid] : 0.f;
-    const float* wsm = cd.w ? wsm_ : nullptr;
+    if (it.xr) {
+        wsm_[2 * tid] = (m0 + tid) < M ? it.wc[2 * (m0 + tid)] : 0.f;
+        wsm_[2 * tid + 1] = (m0 + tid) < M ? it.wc[2 * (m0 + tid) + 1] : 0.f;
+    } else {
+        wsm_[tid] = (cd.w && (m0 + tid) < M) ? cd.w[m0 + tid] : 0.f;
+    }
+    const float* wsm = (cd.w && !it.xr) ? wsm_ : nullptr;
 
     // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
     const long part_cells = (long)K8pad * Mpad;
@@ -224,7 +267,9 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // epilogue specialised on (activation, mask, residual): no per-element branches
     const bool res = ep.res != nullptr;
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
-#define TVAE_DX6_EPI(A_, M_, R_) dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum)
+    float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#define TVAE_DX6_EPI(A_, M_, R_) \
+    dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n)
     if (ep.mask == ACT_NONE) {
         if (ep.act == ACT_LRELU) { if (res) TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, true); else TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, false); }
         else if (ep.act == ACT_TANH) { if (res) TVAE_DX6_EPI(ACT_TANH, ACT_NONE, true); else TVAE_DX6_EPI(ACT_TANH, ACT_NONE, false); }
@@ -235,7 +280,23 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         if (res) TVAE_DX6_EPI(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI(ACT_NONE, ACT_TANH, false);
     }
 #undef TVAE_DX6_EPI
-    if (cd.w) {
+    if (it.xr) {
+        float* cds = reinterpret_cast<float*>(Bs);          // [wave][128][2]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v = gsum[j][k] + __shfl_xor(gsum[j][k], 32, 64);
+                if (lane < 32) cds[(wave * 128 + j * 32 + lane) * 2 + k] = v;
+            }
+        __syncthreads();
+        if (tid < 256) {
+            float g = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) g += cds[w * 256 + tid];
+            it.gxr[2 * (long)n0 + tid] = g;
+        }
+    } else if (cd.w) {
         // the eight waves hold disjoint rows of the same 128 columns: lane halves first, then waves through LDS
         float* cds = reinterpret_cast<float*>(Bs);          // the B stages are free after the k-loop
 #pragma unroll

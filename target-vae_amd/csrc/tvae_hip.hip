@@ -295,14 +295,15 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
     return 0;
 }
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
-                           hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr}) {
-    if (cd.w && rows > DX6_ROWS) return (int)hipErrorInvalidValue;      // the fused column dot needs ONE row tile
+                           hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
+                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr}) {
+    if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep, rows,
-                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd);
+                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -317,14 +318,31 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
     return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y});
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
-                         int N, int K, long ldd, long ldx, int mask, float slope, tvae_stream_t stream) {
+                         int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
+                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats,
+                         tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
-    ep.C = dX; ep.ldc = ldx;
+    ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
     ep.res = add; ep.ldres = ldx;
     ep.aux = aux; ep.ldaux = ldx;
     ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
-    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream));
+    if (in_xr) {
+        if (!in_wc || !in_gxr || !in_part || in_part_floats < (long)(N / 128) * K * 3) return (int)hipErrorInvalidValue;
+    } else if (!dX) {
+        return (int)hipErrorInvalidValue;
+    }
+    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
+                           InTail{in_xr, in_wc, in_gxr, in_part});
+}
+
+int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
+                      tvae_stream_t stream) {
+    // second stage of the fused first-layer backward: part[B*cpi panels][F][3] -> per-image sums, bias and weight grads
+    if (B <= 0 || F <= 0) return 0;
+    hipLaunchKernelGGL(dec_in_total_kernel, dim3(F), dim3(256), 0, S(stream), part, B, cpi, F, Simg, dbc, dWc);
+    TVAE_CHECK_LAUNCH();
+    return 0;
 }
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, tvae_stream_t stream) {
@@ -418,7 +436,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
         hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
-                           q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr});
+                           q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr},
+                           InTail{nullptr, nullptr, nullptr, nullptr});
         TVAE_CHECK_LAUNCH();
     }
     static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();

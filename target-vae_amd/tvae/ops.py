@@ -189,6 +189,7 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
 
 CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
 FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
+FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -537,18 +538,28 @@ class DecoderFn(torch.autograd.Function):
              part.numel(), tot)
         dWo, drow = tot[1:], tot[0]
         grads_hidden = []
+        fused_in = False
         for li in range(n_hidden - 1, -1, -1):
             W, b = hidden[li]
             hprev = hs[li]
             dW = _wgrad(d, hprev, F_, Nt, F_)
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
-            dprev = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+            # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
+            # (coordinate gradient + per-panel row sums); its result is then never written
+            fuse_in = (FUSE_IN_TAIL and li == 0 and not has_f and not resid and F_ <= 512 and Np % 128 == 0 and
+                       _dense_x6_ok(F_, Nt))
+            dprev = None if fuse_in else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 w3t = _split_weight(W, F_, F_, True, 'x6_dense_wt')
+                if fuse_in:
+                    gxr_f = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
+                    part_f = workspace(dev, (Nt // 128) * F_ * 3)
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
-                         LRELU_SLOPE)
+                         LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
+                         gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0)
+                fused_in = fuse_in
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
                      act, LRELU_SLOPE)
@@ -558,8 +569,11 @@ class DecoderFn(torch.autograd.Function):
         # first layer: d is the pre-activation gradient [F][Nt]
         Simg = torch.empty(B, F_, dtype=torch.float32, device=dev)
         dbc = torch.empty(F_, dtype=torch.float32, device=dev)
-        gxr = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
-        if has_f:
+        gxr = torch.empty(B, Np, 2, dtype=torch.float32, device=dev) if not fused_in else gxr_f
+        if fused_in:
+            dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
+            call('tvae_dec_in_total', part_f, B, Np // 128, F_, Simg, dbc, dWc)
+        elif has_f:
             call('tvae_rowdot_seg', d, Nt, None, 1, F_, Nt, Np, Simg)
             call('tvae_seg_sum', Simg, B, F_, dbc, 1.0, 0)
         else:

@@ -221,7 +221,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None)
@@ -270,6 +270,31 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
     call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R)
     assert rel_err(dbias, g.double().sum(dim=(0, 2, 3, 4))) < TOL
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
+
+
+@pytest.mark.parametrize('F_,B,Np,M,act', [(512, 3, 256, 512, 1), (300, 2, 384, 512, 1), (64, 2, 128, 200, 2)])
+def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
+    """Data gradient of the first hidden layer fused with the backward of the coordinate layer: dX is never stored."""
+    from tvae._lib import query
+    Nt = B * Np
+    W, d = rnd(M, F_, seed=1, scale=M ** -0.5), rnd(M, Nt, seed=2)
+    aux = rnd(F_, Nt, seed=3).clamp(-0.9, 0.9)
+    xr, Wc = rnd(Nt, 2, seed=4), rnd(F_, 2, seed=5)
+    d0 = (W.double().t() @ d.double()) * dact_ref(aux.double(), act)
+    w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
+    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1)
+    gxr = torch.empty(Nt, 2, device=dev())
+    part = torch.empty((Nt // 128) * F_ * 3, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
+         Wc.to(dev()), gxr, part, part.numel())
+    Simg = torch.empty(B, F_, device=dev())
+    dbc = torch.empty(F_, device=dev())
+    dWc = torch.empty(F_, 2, device=dev())
+    call('tvae_dec_in_total', part, B, Np // 128, F_, Simg, dbc, dWc)
+    assert rel_err(gxr, d0.t() @ Wc.double()) < GEMM_TOL['f32']
+    assert rel_err(Simg, d0.view(F_, B, Np).sum(2).t()) < GEMM_TOL['f32']
+    assert rel_err(dbc, d0.sum(1)) < GEMM_TOL['f32']
+    assert rel_err(dWc, d0 @ xr.double()) < GEMM_TOL['f32']
 
 
 def test_reductions():
