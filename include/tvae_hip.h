@@ -132,8 +132,8 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
                        float* col_y, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
-                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats,
-                         tvae_stream_t stream);
+                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
+                         const float* vg_gy, tvae_stream_t stream);
 /* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
@@ -143,7 +143,13 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
 /* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned
  * rows and a workspace of at least M*K floats (hipErrorInvalidValue otherwise: use the fp32 entry). */
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
-                         long ldd, long ldx, int accumulate, tvae_stream_t stream);
+                         long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
+                         float vg_slope, tvae_stream_t stream);
+/* Implicit gradient operand (vg_wo != NULL, both entries): dpre is then NOT the gradient but the saved activation H of
+ * the layer in front of the single-output last Linear, and the gradient is formed on the fly,
+ * dpre_eff[m][n] = vg_wo[m] * vg_gy[n] * act'(H[m][n])  (act = `mask` for the data gradient, vg_act for the weight
+ * gradient), so the [hid][B*n^2] gradient tensor is never written; tvae_dec_out_bwd with D = NULL then only produces
+ * the row sums. */
 
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),
@@ -151,7 +157,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
  *                D[f][n] = (sum_o Wo[o*F+f] gy[n*n_out+o]) * act'(H[f][n]);
  *                tot[0][f] = sum_n D[f][n]  (bias gradient of the layer that produced h);
  *                tot[1+o][f] = sum_n H[f][n] gy[n*n_out+o]  (= dWo[o][f]).          n_out <= 4
- *              part: workspace >= ceil(N/1024)*F*(1+n_out) floats; tot: (1+n_out)*F floats.
+ *              part: workspace >= ceil(N/1024)*F*(1+n_out) floats; tot: (1+n_out)*F floats.  D may be NULL (sums only).
  * dec_in_bwd:  backward of the first decoder layer h = act(Wc x' + bc + Wl z) without Fourier features
  *              (src/models.py:107-118), d = pre-activation gradient [F][B*Np]:
  *                gxr[n][j] = sum_f Wc[2f+j] d[f][n];  Simg[b][f] = sum_{n in image b} d[f][n];

@@ -84,10 +84,10 @@ call('tvae_dense_split3', W, F_, w3, w3.numel() * 4, F_, F_, 0)
 w3t = torch.empty_like(w3)
 call('tvae_dense_split3', W, F_, w3t, w3t.numel() * 4, F_, F_, 1)
 timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
-timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0))
-timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0))
+timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None))
+timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None))
 timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
-timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0))
+timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01))
 if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
     at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev)
     wsd = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev)

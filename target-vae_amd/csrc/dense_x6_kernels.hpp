@@ -46,6 +46,17 @@ __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
 constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
 
+struct VirtGrad {          // the streamed gradient operand given implicitly (backward of the single-output last Linear,
+    const float* wo;       // src/models.py:121-123, never materialised):  value(m, n) = wo[m] * gy[n] * act'(H[m][n]),
+    const float* gy;       // with the saved activation H passed where the operand pointer is expected
+    int act;
+    float slope;
+};
+__device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
+    const float dv = vg.act == ACT_LRELU ? (h > 0.f ? 1.f : vg.slope) : (vg.act == ACT_TANH ? 1.f - h * h : 1.f);
+    return wo * g * dv;
+}
+
 struct InTail {            // optional fused backward of SpatialGenerator's FIRST layer (h0 = act(Wc x' + ..), in_dim 2,
     const float* xr;       // src/models.py:107-118) on the output dX of a data-gradient launch (single row tile, panels
     const float* wc;       // inside one image):  gxr[n][j] = sum_f wc[f][j] dX[f][n];
@@ -155,9 +166,10 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
     long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
 };
 
+template <bool VIRT>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     __shared__ float wsm_[2 * DX6_ROWS];
@@ -200,10 +212,22 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // B build role: k-quad kq (4 consecutive k = half a cell), column nb
     const int kq = tid >> 7, nb = tid & 127;
     const float* x_ptr = X + (long)(4 * kq) * ldx + n0 + nb;
+    // VIRT (compile time, so that the plain instance keeps its straight-line load stream): the operand is the saved
+    // activation and the gradient wo[k] * gy[n] * act'(h) is formed when the cells are built (store_b)
+    const float vg_g = VIRT ? vg.gy[n0 + nb] : 0.f;
     auto load_x = [&](int t, float (&x)[4]) {
         const float* q = x_ptr + (long)(16 * t) * ldx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[j] = (16 * t + 4 * kq + j < K) ? q[(long)j * ldx] : 0.f;
+    };
+    auto virt_x = [&](int t, float (&x)[4]) {
+        if (VIRT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * t + 4 * kq + j;
+                x[j] = (k < K) ? virt_value(vg, x[j], vg.wo[k], vg_g) : 0.f;
+            }
+        }
     };
     auto store_b = [&](int stage, const float (&x)[4]) {
         unsigned hw[2], mw[2], lw[2];
@@ -237,6 +261,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         load_x(0, x0);
         load_a(0, af);
         load_x(nk > 1 ? 1 : 0, x1);
+        virt_x(0, x0);
         store_b(0, x0);
     }
     __syncthreads();
@@ -253,7 +278,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
             mfma6(acc[0][j], af[0], bf);
             mfma6(acc[1][j], af[1], bf);
-            if (j == 1) store_b(cur ^ 1, x1);           // cells of step t+1
+            if (j == 1) {                                // cells of step t+1
+                virt_x(t + 1 < nk ? t + 1 : t, x1);
+                store_b(cur ^ 1, x1);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -326,9 +354,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 //     LDS stage of the next step, as in dense_x6_kernel.
 // Requires n-chunks that are multiples of 16 and 16-byte aligned rows (checked on the host).
 // ------------------------------------------------------------------------------------------
+template <bool VIRT>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
-                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride) {
+                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,15 +384,32 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + 64 * wave + 32 * i + (lane & 31);
-        a_ok[i] = m < M ? 1.f : 0.f;
+        a_ok[i] = m < M ? (VIRT ? vg.wo[m] : 1.f) : 0.f;          // row validity (and the row's output weight)
         a_ptr[i] = dY + (long)min(m, M - 1) * ldd + nbeg + 8 * khalf;
     }
+    const float* g_ptr = VIRT ? vg.gy + nbeg + 8 * khalf : nullptr;
+    float4 gq[2];                                      // gy of the cell being split (VIRT), loaded with the A values
     auto load_a = [&](int t, float4 (&r)[2][2]) {
+        if (VIRT) {
+            gq[0] = *reinterpret_cast<const float4*>(g_ptr + 16 * t);
+            gq[1] = *reinterpret_cast<const float4*>(g_ptr + 16 * t + 4);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float4* q = reinterpret_cast<const float4*>(a_ptr[i] + 16 * t);
             r[i][0] = q[0];
             r[i][1] = q[1];
+        }
+    };
+    auto virt_a = [&](float4 (&r)[2][2]) {
+        if (VIRT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                r[i][0] = make_float4(virt_value(vg, r[i][0].x, 1.f, gq[0].x), virt_value(vg, r[i][0].y, 1.f, gq[0].y),
+                                      virt_value(vg, r[i][0].z, 1.f, gq[0].z), virt_value(vg, r[i][0].w, 1.f, gq[0].w));
+                r[i][1] = make_float4(virt_value(vg, r[i][1].x, 1.f, gq[1].x), virt_value(vg, r[i][1].y, 1.f, gq[1].y),
+                                      virt_value(vg, r[i][1].z, 1.f, gq[1].z), virt_value(vg, r[i][1].w, 1.f, gq[1].w));
+            }
         }
     };
     auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
@@ -411,6 +457,7 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
         load_a(0, ar);
         const float4 x0 = load_x(0);
         x1 = load_x(nk > 1 ? 1 : 0);
+        virt_a(ar);
         split_a(ar, af);
         load_a(nk > 1 ? 1 : 0, ar);
         store_b(0, x0);
@@ -428,7 +475,10 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
             for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
             mfma6(acc[0][j], af[0], bf);
             mfma6(acc[1][j], af[1], bf);
-            if (j == 0) split_a(ar, an);                 // A cells of step t+1 (loaded during step t-1)
+            if (j == 0) {                                // A cells of step t+1 (loaded during step t-1)
+                virt_a(ar);
+                split_a(ar, an);
+            }
             if (j == 1) store_b(cur ^ 1, x1);            // B cells of step t+1
             if (j == 2) load_a(t + 2 < nk ? t + 2 : t, ar);
         }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
                 dv[e] = s * act_deriv_from_out(he, act, slope);
                 acc[0] += dv[e];
             }
-            store4(drow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
+            if (D) store4(drow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
         }
 #pragma unroll
         for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);

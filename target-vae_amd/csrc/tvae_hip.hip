@@ -296,14 +296,19 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
 }
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
-                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr}) {
+                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr},
+                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f}) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
-    hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep, rows,
-                       Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it);
+    if (vg.wo)
+        hipLaunchKernelGGL(dense_x6_kernel<true>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
+                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg);
+    else
+        hipLaunchKernelGGL(dense_x6_kernel<false>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
+                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -319,8 +324,8 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
-                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats,
-                         tvae_stream_t stream) {
+                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
+                         const float* vg_gy, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -333,7 +338,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
         return (int)hipErrorInvalidValue;
     }
     return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
-                           InTail{in_xr, in_wc, in_gxr, in_part});
+                           InTail{in_xr, in_wc, in_gxr, in_part}, VirtGrad{vg_wo, vg_gy, mask, slope});
 }
 
 int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
@@ -345,7 +350,8 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
     return 0;
 }
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
-                         long ldd, long ldx, int accumulate, tvae_stream_t stream) {
+                         long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
+                         float vg_slope, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
     if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || ldx % 4 != 0 || !aligned16(dpre) || !aligned16(X) || !ws)
@@ -362,8 +368,12 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     splits = cdiv(N, nchunk);
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
-    hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx, ws, M,
-                       K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L);
+    if (vg_wo)
+        hipLaunchKernelGGL(dense_wgrad_x6_kernel<true>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx,
+                           ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, VirtGrad{vg_wo, vg_gy, vg_act, vg_slope});
+    else
+        hipLaunchKernelGGL(dense_wgrad_x6_kernel<false>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx,
+                           ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, VirtGrad{vg_wo, vg_gy, vg_act, vg_slope});
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dW; ep.ldc = K;
@@ -435,9 +445,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
-        hipLaunchKernelGGL(dense_x6_kernel, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
+        hipLaunchKernelGGL(dense_x6_kernel<false>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr},
-                           InTail{nullptr, nullptr, nullptr, nullptr});
+                           InTail{nullptr, nullptr, nullptr, nullptr}, VirtGrad{nullptr, nullptr, 0, 0.f});
         TVAE_CHECK_LAUNCH();
     }
     static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();
@@ -522,8 +532,9 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
-        hipLaunchKernelGGL(dense_wgrad_x6_kernel, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
-                           (long)q.Lh * q.NBpad, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, q.NBpad);
+        hipLaunchKernelGGL(dense_wgrad_x6_kernel<false>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
+                           (long)q.Lh * q.NBpad, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, q.NBpad,
+                           VirtGrad{nullptr, nullptr, 0, 0.f});
         TVAE_CHECK_LAUNCH();
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;
@@ -869,7 +880,7 @@ int tvae_dec_out_bwd(const float* gy, int n_out, const float* Wo, const float* H
     if (F <= 0 || N <= 0) return 0;
     const int np = panels_of(N, PANEL16);
     if (n_out < 1 || n_out > 4 || part_floats < (long)np * F * (1 + n_out)) return (int)hipErrorInvalidValue;
-    const int vec = (aligned16(H) && aligned16(D) && ldh % 4 == 0 && ldd % 4 == 0) ? 1 : 0;
+    const int vec = (aligned16(H) && (!D || aligned16(D)) && ldh % 4 == 0 && ldd % 4 == 0) ? 1 : 0;   // D may be NULL
     dim3 grid(np), block(256);
     switch (n_out) {
         case 1: hipLaunchKernelGGL(dec_out_bwd_kernel<1>, grid, block, 0, S(stream), gy, Wo, H, ldh, D, ldd, F, N, act, slope, part, vec); break;

@@ -28,9 +28,9 @@ SIGNATURES = {
     'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
     'tvae_dense_split3': 'plpliii',
     'tvae_linear_fwd_x6': 'pppppiiillifppp',
-    'tvae_linear_dgrad_x6': 'pppppiiillifppppl',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpp',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiilli',
+    'tvae_linear_wgrad_x6': 'ppppliiillippif',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',

@@ -139,13 +139,16 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str)
     return w3
 
 
-def _wgrad(dpre, X, M, N, K) -> torch.Tensor:
+def _wgrad(dpre, X, M, N, K, virt=None) -> torch.Tensor:
+    """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
+    on the fly (split-pipe path only)."""
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
     ws = workspace(dpre.device, max(need, 1 << 24))
     if get_gemm_mode() == 'x6' and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
         with _timed('tvae_linear_wgrad_x6'):
-            call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
+            call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
+                 virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else 0, LRELU_SLOPE)
         return dW
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
@@ -190,6 +193,7 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
 CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
 FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
 FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
+FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -531,18 +535,25 @@ class DecoderFn(torch.autograd.Function):
         # last layer: one pass over h gives d (pre-activation gradient), its row sums and dWo
         gyT = gy.t().contiguous()
         dbo = _rowsum(gyT, n_out, Nt)
-        d = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        # with a single output the gradient of the last hidden activation, Wo[f] gy[n] act'(h[f][n]), is cheap to
+        # re-form inside the two GEMMs that consume it: it is then never written (dec_out_bwd only produces row sums)
+        virt = (FUSE_VIRT_GRAD and n_out == 1 and n_hidden >= 1 and not resid and _dense_x6_ok(F_, Nt) and F_ >= 256
+                and Nt % 16 == 0)
+        d = None if virt else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
         part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
         tot = torch.empty(1 + n_out, F_, dtype=torch.float32, device=dev)
         call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
              part.numel(), tot)
+        vg = (Wo.contiguous().view(-1), gy.view(-1), act) if virt else None
         dWo, drow = tot[1:], tot[0]
         grads_hidden = []
         fused_in = False
         for li in range(n_hidden - 1, -1, -1):
             W, b = hidden[li]
             hprev = hs[li]
-            dW = _wgrad(d, hprev, F_, Nt, F_)
+            use_vg = vg is not None and li == n_hidden - 1
+            dsrc = hs[-1] if use_vg else d             # implicit operand: pass the saved activation instead
+            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None)
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
@@ -556,9 +567,10 @@ class DecoderFn(torch.autograd.Function):
                     gxr_f = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
                     part_f = workspace(dev, (Nt // 128) * F_ * 3)
                 with _timed('tvae_linear_dgrad_x6'):
-                    call('tvae_linear_dgrad_x6', w3t, d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
+                    call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
-                         gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0)
+                         gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
+                         vg[0] if use_vg else None, vg[1] if use_vg else None)
                 fused_in = fuse_in
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,

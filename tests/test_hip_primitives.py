@@ -221,7 +221,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None)
@@ -234,10 +234,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
-    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc)
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE)
     assert rel_err(dW, ref) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc)
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE)
 
 
 @pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
@@ -286,7 +286,7 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     gxr = torch.empty(Nt, 2, device=dev())
     part = torch.empty((Nt // 128) * F_ * 3, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
-         Wc.to(dev()), gxr, part, part.numel())
+         Wc.to(dev()), gxr, part, part.numel(), None, None)
     Simg = torch.empty(B, F_, device=dev())
     dbc = torch.empty(F_, device=dev())
     dWc = torch.empty(F_, 2, device=dev())
@@ -295,6 +295,34 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     assert rel_err(Simg, d0.view(F_, B, Np).sum(2).t()) < GEMM_TOL['f32']
     assert rel_err(dbc, d0.sum(1)) < GEMM_TOL['f32']
     assert rel_err(dWc, d0 @ xr.double()) < GEMM_TOL['f32']
+
+
+def test_linear_x6_implicit_gradient_operand():
+    """dgrad / wgrad with the gradient operand formed on the fly from (Wo, gy, saved activation)."""
+    from tvae._lib import query
+    M, N, K = 512, 1024, 512
+    W, H = rnd(M, K, seed=1, scale=M ** -0.5), rnd(M, N, seed=2).clamp(-0.9, 0.9)
+    wo, gy = rnd(M, seed=3), rnd(N, seed=4)
+    aux, X = rnd(K, N, seed=5).clamp(-0.9, 0.9), rnd(K, N, seed=6)
+    d = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), 1)
+    w3t = torch.empty(query('tvae_dense_x6_bytes', K, M) // 4, device=dev())
+    call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1)
+    dX = torch.empty(K, N, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX, M, N, K, N, N, 1, SLOPE, None, None, None,
+         None, 0, wo.to(dev()), gy.to(dev()))
+    assert rel_err(dX, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
+    dW = torch.empty(M, K, device=dev())
+    ws = torch.empty(1 << 24, device=dev())
+    call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
+         gy.to(dev()), 1, SLOPE)
+    assert rel_err(dW, d @ X.double().t()) < GEMM_TOL['f32']
+    # dec_out_bwd without the gradient tensor: sums only
+    F_ = M
+    part = torch.empty(((N + 1023) // 1024) * F_ * 2, device=dev())
+    tot = torch.empty(2, F_, device=dev())
+    call('tvae_dec_out_bwd', gy.view(N, 1).to(dev()), 1, wo.view(1, F_).to(dev()), H.to(dev()), N, None, N, F_, N, 1,
+         SLOPE, part, part.numel(), tot)
+    assert rel_err(tot[0], d.sum(1)) < TOL and rel_err(tot[1], H.double() @ gy.double()) < TOL
 
 
 def test_reductions():
