@@ -99,3 +99,9 @@ if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
         call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
         call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
         print('dft fwd vs f32-MFMA rel diff %.3e   wgrad rel diff %.3e' % (float((A1d - A1).norm() / A1.norm()), float((dbd - dbank).norm() / dbank.norm())))
+if only and 'zero' in only:
+    w3z = torch.zeros_like(w3)
+    hz = torch.zeros_like(h1)
+    timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
+    timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
+    timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
