@@ -173,6 +173,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     __shared__ float wsm_[2 * DX6_ROWS];
+    __shared__ float vwo_[VIRT ? 512 : 1];               // output weights of the implicit gradient operand (K <= 512)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
@@ -215,6 +216,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // VIRT (compile time, so that the plain instance keeps its straight-line load stream): the operand is the saved
     // activation and the gradient wo[k] * gy[n] * act'(h) is formed when the cells are built (store_b)
     const float vg_g = VIRT ? vg.gy[n0 + nb] : 0.f;
+    if (VIRT) {
+        if (tid < K && tid < 512) vwo_[tid] = vg.wo[tid];
+    }
+    const bool vwo_lds = K <= 512;
     auto load_x = [&](int t, float (&x)[4]) {
         const float* q = x_ptr + (long)(16 * t) * ldx;
 #pragma unroll
@@ -225,7 +230,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * t + 4 * kq + j;
-                x[j] = (k < K) ? virt_value(vg, x[j], vg.wo[k], vg_g) : 0.f;
+                x[j] = (k < K) ? virt_value(vg, x[j], vwo_lds ? vwo_[k & 511] : vg.wo[k], vg_g) : 0.f;
             }
         }
     };
@@ -256,6 +261,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 
     Cell16 af[2][3];
     float x1[4], x2[4];
+    if (VIRT) __syncthreads();                          // vwo_ is read by the prologue's virt_x
     {
         float x0[4];
         load_x(0, x0);
