@@ -105,3 +105,14 @@ if only and 'zero' in only:
     timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
     timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
     timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None))
+if only and 'tail' in only:
+    xr2 = torch.randn(Nt, 2, device=dev); wc2 = torch.randn(F_, 2, device=dev)
+    gxr = torch.empty(Nt, 2, device=dev); partf = torch.empty((Nt // 128) * F_ * 3, device=dev)
+    wo1 = torch.randn(F_, device=dev); gy1 = torch.randn(Nt, device=dev)
+    fl = 2.0 * F_ * F_ * Nt
+    timeit('tail_dgrad_plain', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None))
+    timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None))
+    timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1))
+    timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1))
+    timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01))
+    timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01))
