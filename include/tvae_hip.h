@@ -129,11 +129,12 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
                       tvae_stream_t stream);
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
-                       float* col_y, tvae_stream_t stream);
+                       float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
+                       int va_np, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
-                         const float* vg_gy, tvae_stream_t stream);
+                         const float* vg_gy, const float* in_bc, const float* in_lb, int in_np, tvae_stream_t stream);
 /* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
@@ -144,12 +145,19 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
  * rows and a workspace of at least M*K floats (hipErrorInvalidValue otherwise: use the fp32 entry). */
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
-                         float vg_slope, tvae_stream_t stream);
+                         float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
+                         int va_np, tvae_stream_t stream);
 /* Implicit gradient operand (vg_wo != NULL, both entries): dpre is then NOT the gradient but the saved activation H of
  * the layer in front of the single-output last Linear, and the gradient is formed on the fly,
  * dpre_eff[m][n] = vg_wo[m] * vg_gy[n] * act'(H[m][n])  (act = `mask` for the data gradient, vg_act for the weight
  * gradient), so the [hid][B*n^2] gradient tensor is never written; tvae_dec_out_bwd with D = NULL then only produces
- * the row sums. */
+ * the row sums.
+ * Recomputed first-layer operand (va_xr != NULL in fwd / wgrad, in_bc != NULL in dgrad): the input of the layer is the
+ * output of SpatialGenerator's coordinate layer without Fourier features (src/models.py:107-118),
+ *   h0[f][n] = act(fma(Wc[f][1], xr[n][1], fma(Wc[f][0], xr[n][0], bc[f])) + LB[n / np][f])
+ * (exactly the expression tvae_dec_l0_fwd evaluates), formed inside the kernel from xr [N][2], Wc [K][2], bc [K] and the
+ * per-image latent term LB [B][K]; X (resp. aux for the mask) may then be NULL and the [hid][B*n^2] tensor is never
+ * stored.  Needs np % 128 == 0 and K <= 512 (fwd / dgrad), np % 4 == 0 (wgrad). */
 
 /* ---- fused skinny ends of the two MLPs: one pass over the 1-2 GB activation instead of 2-3 -------------------------
  * dec_out_bwd: backward of the last decoder layer y = Wo h + bo (SpatialGenerator.forward, src/models.py:121-123),

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_x6_kernels.hpp"
+#include "small_kernels.hpp"
 
 namespace tvae {
 
@@ -57,11 +58,24 @@ __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float w
     return wo * g * dv;
 }
 
+struct VirtAct {           // a streamed ACTIVATION operand given implicitly: the output of SpatialGenerator's first
+    const float* xr;       // layer (no Fourier features), h0[f][n] = act(wc[f][0] x'_0[n] + wc[f][1] x'_1[n] + bc[f] +
+    const float* wc;       // lb[n / Np][f]) (src/models.py:107-118), recomputed where it is consumed instead of being
+    const float* bc;       // stored: xr [N][2], wc [F][2], bc [F], lb [B][F] or NULL.  Column tiles / chunks must not
+    const float* lb;       // straddle images where noted.
+    int Np;
+    int act;
+    float slope;
+};
+
 struct InTail {            // optional fused backward of SpatialGenerator's FIRST layer (h0 = act(Wc x' + ..), in_dim 2,
     const float* xr;       // src/models.py:107-118) on the output dX of a data-gradient launch (single row tile, panels
     const float* wc;       // inside one image):  gxr[n][j] = sum_f wc[f][j] dX[f][n];
     float* gxr;            // part[panel][f][0..2] = sum_{n in panel} dX[f][n] * (1, x'_0[n], x'_1[n])
     float* part;           // xr [N][2], wc [rows][2], gxr [N][2], part [N/128][rows][3]
+    const float* bc;       // bc != NULL: the mask operand (this layer's own output h0) is recomputed from (xr, wc, bc, lb)
+    const float* lb;       //   instead of being read from ep.aux
+    int Np;
 };
 
 struct ColDot {            // optional fused skinny layer on the OUTPUT of this one (single row tile, one output):
@@ -70,11 +84,11 @@ struct ColDot {            // optional fused skinny layer on the OUTPUT of this 
     float* y;
 };
 
-template <int ACT, int MASK, bool RES>
+template <int ACT, int MASK, bool RES, bool AV>
 __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
                                                   int n0, int M, int wave, int lane, const float* wsm,
                                                   float (&ysum)[4], const InTail& it, const float* wc2,
-                                                  float (&gsum)[4][2], int tile_n) {
+                                                  float (&gsum)[4][2], int tile_n, const float* cbm) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
@@ -99,7 +113,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 const int r = rh * 8 + q;
                 mrow[q] = (long)min(m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
             }
-            if (MASK != ACT_NONE) {
+            if (MASK != ACT_NONE && !AV) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -125,8 +139,17 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                     if (RES) v += rv[q][j];
                     if (ACT == ACT_LRELU) v = v > 0.f ? v : v * ep.slope;
                     else if (ACT == ACT_TANH) v = tanhf(v);
-                    if (MASK == ACT_LRELU) v *= av[q][j] > 0.f ? 1.f : ep.slope;
-                    else if (MASK == ACT_TANH) v *= 1.f - av[q][j] * av[q][j];
+                    if (MASK != ACT_NONE) {
+                        float a;
+                        if (AV) {    // recompute the masked layer's output (see VirtAct) instead of loading it
+                            a = dec_l0_pre(wc2[2 * row], wc2[2 * row + 1], cbm[row], cbm[DX6_ROWS + row], x0[j], x1[j]);
+                            if (MASK == ACT_TANH) a = tanhf(a);             // LReLU: only the sign is used
+                        } else {
+                            a = av[q][j];
+                        }
+                        if (MASK == ACT_LRELU) v *= a > 0.f ? 1.f : ep.slope;
+                        else v *= 1.f - a * a;
+                    }
                     if (m < M) {
                         if (crow) crow[j * 32] = v;
                         if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
@@ -166,14 +189,17 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
     long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
 };
 
-template <bool VIRT>
+// XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct)
+template <int XV>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
+    constexpr bool VIRT = XV == 1;
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     __shared__ float wsm_[2 * DX6_ROWS];
-    __shared__ float vwo_[VIRT ? 512 : 1];               // output weights of the implicit gradient operand (K <= 512)
+    __shared__ float vwo_[XV == 1 ? 512 : (XV == 2 ? 2048 : 1)];   // tables of the implicit operand (K <= 512)
+    __shared__ float cbm_[2 * DX6_ROWS];                 // (bc, lb) rows of the recomputed mask operand (InTail.bc)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
@@ -199,6 +225,11 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         wsm_[tid] = (cd.w && (m0 + tid) < M) ? cd.w[m0 + tid] : 0.f;
     }
     const float* wsm = (cd.w && !it.xr) ? wsm_ : nullptr;
+    if (it.bc) {
+        const int img_ = n0 / it.Np;
+        cbm_[tid] = (m0 + tid) < M ? it.bc[m0 + tid] : 0.f;
+        cbm_[DX6_ROWS + tid] = (it.lb && (m0 + tid) < M) ? it.lb[(long)img_ * M + m0 + tid] : 0.f;
+    }
 
     // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
     const long part_cells = (long)K8pad * Mpad;
@@ -219,11 +250,28 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     if (VIRT) {
         if (tid < K && tid < 512) vwo_[tid] = vg.wo[tid];
     }
+    float va_x0 = 0.f, va_x1 = 0.f;
+    if (XV == 2) {                                       // tables (w0, w1, bc, lb) of the recomputed activation, K <= 512
+        const int img_ = n0 / va.Np;
+        if (tid < K) {
+            vwo_[tid] = va.wc[2 * tid];
+            vwo_[512 + tid] = va.wc[2 * tid + 1];
+            vwo_[1024 + tid] = va.bc[tid];
+            vwo_[1536 + tid] = va.lb ? va.lb[(long)img_ * K + tid] : 0.f;
+        }
+        va_x0 = va.xr[2 * (long)(n0 + nb)];
+        va_x1 = va.xr[2 * (long)(n0 + nb) + 1];
+    }
     const bool vwo_lds = K <= 512;
     auto load_x = [&](int t, float (&x)[4]) {
-        const float* q = x_ptr + (long)(16 * t) * ldx;
+        if (XV == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = (16 * t + 4 * kq + j < K) ? q[(long)j * ldx] : 0.f;
+            for (int j = 0; j < 4; ++j) x[j] = 0.f;
+        } else {
+            const float* q = x_ptr + (long)(16 * t) * ldx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (16 * t + 4 * kq + j < K) ? q[(long)j * ldx] : 0.f;
+        }
     };
     auto virt_x = [&](int t, float (&x)[4]) {
         if (VIRT) {
@@ -231,6 +279,14 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * t + 4 * kq + j;
                 x[j] = (k < K) ? virt_value(vg, x[j], vwo_lds ? vwo_[k & 511] : vg.wo[k], vg_g) : 0.f;
+            }
+        }
+        if (XV == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (16 * t + 4 * kq + j) & 511;
+                const float pre = dec_l0_pre(vwo_[k], vwo_[512 + k], vwo_[1024 + k], vwo_[1536 + k], va_x0, va_x1);
+                x[j] = (16 * t + 4 * kq + j < K) ? act_apply(pre, va.act, va.slope) : 0.f;
             }
         }
     };
@@ -261,7 +317,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 
     Cell16 af[2][3];
     float x1[4], x2[4];
-    if (VIRT) __syncthreads();                          // vwo_ is read by the prologue's virt_x
+    if (XV != 0) __syncthreads();                       // vwo_ is read by the prologue's virt_x
     {
         float x0[4];
         load_x(0, x0);
@@ -302,17 +358,20 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const bool res = ep.res != nullptr;
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#define TVAE_DX6_EPI(A_, M_, R_) \
-    dense_x6_epilogue<A_, M_, R_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n)
+#define TVAE_DX6_EPI(A_, M_, R_, V_) \
+    dense_x6_epilogue<A_, M_, R_, V_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_)
+#define TVAE_DX6_EPI_R(A_, M_, V_) \
+    do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
     if (ep.mask == ACT_NONE) {
-        if (ep.act == ACT_LRELU) { if (res) TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, true); else TVAE_DX6_EPI(ACT_LRELU, ACT_NONE, false); }
-        else if (ep.act == ACT_TANH) { if (res) TVAE_DX6_EPI(ACT_TANH, ACT_NONE, true); else TVAE_DX6_EPI(ACT_TANH, ACT_NONE, false); }
-        else { if (res) TVAE_DX6_EPI(ACT_NONE, ACT_NONE, true); else TVAE_DX6_EPI(ACT_NONE, ACT_NONE, false); }
+        if (ep.act == ACT_LRELU) TVAE_DX6_EPI_R(ACT_LRELU, ACT_NONE, false);
+        else if (ep.act == ACT_TANH) TVAE_DX6_EPI_R(ACT_TANH, ACT_NONE, false);
+        else TVAE_DX6_EPI_R(ACT_NONE, ACT_NONE, false);
     } else if (ep.mask == ACT_LRELU) {
-        if (res) TVAE_DX6_EPI(ACT_NONE, ACT_LRELU, true); else TVAE_DX6_EPI(ACT_NONE, ACT_LRELU, false);
+        if (it.bc) TVAE_DX6_EPI_R(ACT_NONE, ACT_LRELU, true); else TVAE_DX6_EPI_R(ACT_NONE, ACT_LRELU, false);
     } else {
-        if (res) TVAE_DX6_EPI(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI(ACT_NONE, ACT_TANH, false);
+        if (it.bc) TVAE_DX6_EPI_R(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI_R(ACT_NONE, ACT_TANH, false);
     }
+#undef TVAE_DX6_EPI_R
 #undef TVAE_DX6_EPI
     if (it.xr) {
         float* cds = reinterpret_cast<float*>(Bs);          // [wave][128][2]
@@ -360,10 +419,12 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 //     LDS stage of the next step, as in dense_x6_kernel.
 // Requires n-chunks that are multiples of 16 and 16-byte aligned rows (checked on the host).
 // ------------------------------------------------------------------------------------------
-template <bool VIRT>
+// VIRT: implicit gradient A operand (VirtGrad); XVA: implicit first-layer activation as the X operand (VirtAct)
+template <bool VIRT, bool XVA>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
-                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg) {
+                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
+                           VirtAct va) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,8 +490,23 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
     // B build role: row kr (of the 128 feature rows), n-quad q (4 consecutive n = half a cell)
     const int kr = tid >> 2, q4 = tid & 3;
     const float b_ok = (k0 + kr) < Kf ? 1.f : 0.f;
-    const float* x_ptr = X + (long)min(k0 + kr, Kf - 1) * ldx + nbeg + 4 * q4;
-    auto load_x = [&](int t) -> float4 { return *reinterpret_cast<const float4*>(x_ptr + 16 * t); };
+    const float* x_ptr = XVA ? nullptr : X + (long)min(k0 + kr, Kf - 1) * ldx + nbeg + 4 * q4;
+    const int kx = min(k0 + kr, Kf - 1);
+    const float va_w0 = XVA ? va.wc[2 * kx] : 0.f, va_w1 = XVA ? va.wc[2 * kx + 1] : 0.f, va_bc = XVA ? va.bc[kx] : 0.f;
+    auto load_x = [&](int t) -> float4 {
+        if (XVA) {
+            // recompute h0[kx][n .. n+3] from the coordinates (8 contiguous floats) and the per-image latent bias
+            const long n = (long)nbeg + 16 * t + 4 * q4;
+            const float4 c0 = *reinterpret_cast<const float4*>(va.xr + 2 * n);
+            const float4 c1 = *reinterpret_cast<const float4*>(va.xr + 2 * n + 4);
+            const float lbv = va.lb ? va.lb[(n / va.Np) * Kf + kx] : 0.f;
+            return make_float4(act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.z, c1.w), va.act, va.slope));
+        }
+        return *reinterpret_cast<const float4*>(x_ptr + 16 * t);
+    };
     auto store_b = [&](int stage, const float4& x) {
         unsigned hw[2], mw[2], lw[2];
         const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};

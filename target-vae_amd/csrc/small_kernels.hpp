@@ -246,6 +246,12 @@ __global__ void coord_bwd_kernel(const float* __restrict__ xc, const float* __re
 // Decoder first layer without Fourier features (reference src/models.py:107-118, in_dim = 2):
 //   h[f][pix] = act( Wc[f][0]*x0 + Wc[f][1]*x1 + bc[f] + LB[img][f] )
 // ------------------------------------------------------------------------------------------
+// pre-activation of the first decoder layer, with a FIXED operation order: the kernels that recompute this layer
+// instead of reading its stored output (dense_x6_kernels.hpp, VirtAct) must reproduce it bit for bit so that the
+// activation masks of forward and backward agree
+__device__ __forceinline__ float dec_l0_pre(float w0, float w1, float bc, float lb, float x0, float x1) {
+    return __fmaf_rn(w1, x1, __fmaf_rn(w0, x0, bc)) + lb;
+}
 __global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wc,
                                   const float* __restrict__ bc, const float* __restrict__ LB, float* __restrict__ h,
                                   long ldh, int F, long Ntot, int Np, int act, float slope) {
@@ -255,8 +261,7 @@ __global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __r
     const int img = (int)(n / Np);
     const int fbeg = blockIdx.y * 16, fend = min(F, fbeg + 16);
     for (int f = fbeg; f < fend; ++f) {
-        float v = Wc[2 * f] * x0 + Wc[2 * f + 1] * x1 + bc[f];
-        if (LB) v += LB[(long)img * F + f];
+        const float v = dec_l0_pre(Wc[2 * f], Wc[2 * f + 1], bc[f], LB ? LB[(long)img * F + f] : 0.f, x0, x1);
         h[(long)f * ldh + n] = act_apply(v, act, slope);
     }
 }

@@ -296,49 +296,61 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
 }
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
-                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr},
-                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f}) {
+                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
+                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
-    if (vg.wo)
-        hipLaunchKernelGGL(dense_x6_kernel<true>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
-                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg);
+    // the recomputed operands need tiles inside one image and tables of <= 512 entries
+    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
+        return (int)hipErrorInvalidValue;
+    if (va.xr)
+        hipLaunchKernelGGL(dense_x6_kernel<2>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
+                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg, va);
+    else if (vg.wo)
+        hipLaunchKernelGGL(dense_x6_kernel<1>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
+                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg, va);
     else
-        hipLaunchKernelGGL(dense_x6_kernel<false>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
-                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg);
+        hipLaunchKernelGGL(dense_x6_kernel<0>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
+                           rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg, va);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
-                       float* col_y, tvae_stream_t stream) {
+                       float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
+                       int va_np, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
     ep.bias = bias;
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
-    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y});
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y},
+                           InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
-                         const float* vg_gy, tvae_stream_t stream) {
+                         const float* vg_gy, const float* in_bc, const float* in_lb, int in_np, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
     ep.res = add; ep.ldres = ldx;
     ep.aux = aux; ep.ldaux = ldx;
-    ep.mask = aux ? mask : ACT_NONE; ep.slope = slope;
+    ep.mask = (aux || in_bc) ? mask : ACT_NONE; ep.slope = slope;
+    if (in_bc && !in_xr) return (int)hipErrorInvalidValue;               // the recomputed mask needs the coordinates
     if (in_xr) {
         if (!in_wc || !in_gxr || !in_part || in_part_floats < (long)(N / 128) * K * 3) return (int)hipErrorInvalidValue;
     } else if (!dX) {
         return (int)hipErrorInvalidValue;
     }
     return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
-                           InTail{in_xr, in_wc, in_gxr, in_part}, VirtGrad{vg_wo, vg_gy, mask, slope});
+                           InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
+                           VirtGrad{vg_wo, vg_gy, mask, slope});
 }
 
 int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
@@ -351,11 +363,15 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
 }
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
-                         float vg_slope, tvae_stream_t stream) {
+                         float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
+                         int va_np, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
-    if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || ldx % 4 != 0 || !aligned16(dpre) || !aligned16(X) || !ws)
+    if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || !aligned16(dpre) || !ws) return (int)hipErrorInvalidValue;
+    if (va_xr ? (va_np % 4 != 0 || !aligned16(va_xr)) : (ldx % 4 != 0 || !X || !aligned16(X)))
         return (int)hipErrorInvalidValue;
+    const VirtGrad vgs{vg_wo, vg_gy, vg_act, vg_slope};
+    const VirtAct vas{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, vg_act, vg_slope};
     const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
     const long per = (long)M * K;
     const long cap = ws_floats / per;
@@ -368,12 +384,12 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     splits = cdiv(N, nchunk);
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
-    if (vg_wo)
-        hipLaunchKernelGGL(dense_wgrad_x6_kernel<true>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx,
-                           ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, VirtGrad{vg_wo, vg_gy, vg_act, vg_slope});
-    else
-        hipLaunchKernelGGL(dense_wgrad_x6_kernel<false>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, ldx,
-                           ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, VirtGrad{vg_wo, vg_gy, vg_act, vg_slope});
+#define TVAE_WG_LAUNCH(V_, X_)                                                                                        \
+    hipLaunchKernelGGL((dense_wgrad_x6_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, \
+                       ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas)
+    if (vg_wo) { if (va_xr) TVAE_WG_LAUNCH(true, true); else TVAE_WG_LAUNCH(true, false); }
+    else { if (va_xr) TVAE_WG_LAUNCH(false, true); else TVAE_WG_LAUNCH(false, false); }
+#undef TVAE_WG_LAUNCH
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dW; ep.ldc = K;
@@ -445,9 +461,10 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
-        hipLaunchKernelGGL(dense_x6_kernel<false>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
+        hipLaunchKernelGGL(dense_x6_kernel<0>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr},
-                           InTail{nullptr, nullptr, nullptr, nullptr}, VirtGrad{nullptr, nullptr, 0, 0.f});
+                           InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f});
         TVAE_CHECK_LAUNCH();
     }
     static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();
@@ -532,9 +549,9 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
-        hipLaunchKernelGGL(dense_wgrad_x6_kernel<false>, dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
+        hipLaunchKernelGGL((dense_wgrad_x6_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
                            (long)q.Lh * q.NBpad, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, q.NBpad,
-                           VirtGrad{nullptr, nullptr, 0, 0.f});
+                           VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f});
         TVAE_CHECK_LAUNCH();
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;

@@ -27,10 +27,10 @@ SIGNATURES = {
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
     'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
     'tvae_dense_split3': 'plpliii',
-    'tvae_linear_fwd_x6': 'pppppiiillifppp',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpp',
+    'tvae_linear_fwd_x6': 'pppppiiillifpppppppi',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplppppi',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippif',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppi',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',

@@ -139,17 +139,19 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str)
     return w3
 
 
-def _wgrad(dpre, X, M, N, K, virt=None) -> torch.Tensor:
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0) -> torch.Tensor:
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
-    on the fly (split-pipe path only)."""
+    on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only)."""
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
     ws = workspace(dpre.device, max(need, 1 << 24))
     if get_gemm_mode() == 'x6' and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
         with _timed('tvae_linear_wgrad_x6'):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
-                 virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else 0, LRELU_SLOPE)
+                 virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
+                 *(va if va else (None, None, None, None, 0)))
         return dW
+    _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
 
@@ -194,6 +196,7 @@ CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
 FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
 FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
 FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
+FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -484,8 +487,16 @@ class DecoderFn(torch.autograd.Function):
             LB = torch.empty(B, F_, dtype=torch.float32, device=dev)
             call('tvae_latent_bias', Wl.contiguous(), z, LB, B, F_, zd)
         feat = None
-        h = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
-        if Wf is not None:
+        # without Fourier features the coordinate layer's output is two FMAs and an activation per element: the layers
+        # that consume it (first hidden layer: forward, mask of the data gradient, weight gradient) recompute it and the
+        # [hid][B*n^2] tensor is never written or read
+        virt_act = (FUSE_VIRT_ACT and FUSE_IN_TAIL and Wf is None and n_hidden >= 1 and not resid and 256 <= F_ <= 512
+                    and Np % 128 == 0 and Nt >= 32 and _dense_x6_ok(F_, Nt))
+        va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if virt_act else None
+        h = None if virt_act else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        if virt_act:
+            pass
+        elif Wf is not None:
             Ff = Wf.shape[0]
             feat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
             call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, Nt, Ff, Nt)
@@ -503,7 +514,8 @@ class DecoderFn(torch.autograd.Function):
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
-                         LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None)
+                         LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
+                         *(va if va and li == 0 else (None, None, None, None, 0)))
                 fused_out = fuse
             else:
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
@@ -511,7 +523,8 @@ class DecoderFn(torch.autograd.Function):
             hs.append(hn)
         if not fused_out:
             call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
-        ctx.save_for_backward(xr, z if Wl is not None else None, feat, *hs, *[p for p in params if p is not None])
+        ctx.save_for_backward(xr, z if Wl is not None else None, feat, LB if virt_act else None, *hs,
+                              *[p for p in params if p is not None])
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
         return yh
 
@@ -519,9 +532,9 @@ class DecoderFn(torch.autograd.Function):
     def backward(ctx, gy):
         act, resid, sigma, n_hidden, has_l, has_f, B, Np = ctx.meta
         sv = list(ctx.saved_tensors)
-        xr, z, feat = sv[0], sv[1], sv[2]
-        hs = sv[3:3 + n_hidden + 1]
-        ps = sv[3 + n_hidden + 1:]
+        xr, z, feat, LB = sv[0], sv[1], sv[2], sv[3]
+        hs = sv[4:4 + n_hidden + 1]
+        ps = sv[4 + n_hidden + 1:]
         it = iter(ps)
         Wc, bc = next(it), next(it)
         Wl = next(it) if has_l else None
@@ -553,7 +566,8 @@ class DecoderFn(torch.autograd.Function):
             hprev = hs[li]
             use_vg = vg is not None and li == n_hidden - 1
             dsrc = hs[-1] if use_vg else d             # implicit operand: pass the saved activation instead
-            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None)
+            va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if hprev is None else None   # recomputed first layer
+            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act)
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
@@ -570,7 +584,8 @@ class DecoderFn(torch.autograd.Function):
                     call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
-                         vg[0] if use_vg else None, vg[1] if use_vg else None)
+                         vg[0] if use_vg else None, vg[1] if use_vg else None,
+                         bc if va else None, LB if va else None, Np if va else 0)
                 fused_in = fuse_in
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,

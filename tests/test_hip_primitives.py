@@ -205,7 +205,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     cy = torch.empty(N, device=dev())
     fuse = M <= 512
     call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), res.to(dev()) if use_res else None, Y, M, N, K, N, N, act,
-         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None)
+         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None, None, None, None, None, 0)
     if fuse:
         assert rel_err(cy, cw.double() @ ref + cb.double()) < GEMM_TOL['f32']
     assert rel_err(Y, ref) < GEMM_TOL['f32']
@@ -221,10 +221,10 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, 0)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None)
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0)
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(512, 20000 // 16 * 16, 512, 0), (128, 8192, 128, 0), (300, 1600, 70, 1), (512, 4096, 512, 1)])
@@ -234,10 +234,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
-    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE)
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0)
     assert rel_err(dW, ref) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE)
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0)
 
 
 @pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
@@ -286,7 +286,7 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     gxr = torch.empty(Nt, 2, device=dev())
     part = torch.empty((Nt // 128) * F_ * 3, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
-         Wc.to(dev()), gxr, part, part.numel(), None, None)
+         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, 0)
     Simg = torch.empty(B, F_, device=dev())
     dbc = torch.empty(F_, device=dev())
     dWc = torch.empty(F_, 2, device=dev())
@@ -309,12 +309,12 @@ def test_linear_x6_implicit_gradient_operand():
     call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, wo.to(dev()), gy.to(dev()))
+         None, 0, wo.to(dev()), gy.to(dev()), None, None, 0)
     assert rel_err(dX, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
     dW = torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
     call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
-         gy.to(dev()), 1, SLOPE)
+         gy.to(dev()), 1, SLOPE, None, None, None, None, 0)
     assert rel_err(dW, d @ X.double().t()) < GEMM_TOL['f32']
     # dec_out_bwd without the gradient tensor: sums only
     F_ = M
@@ -323,6 +323,57 @@ def test_linear_x6_implicit_gradient_operand():
     call('tvae_dec_out_bwd', gy.view(N, 1).to(dev()), 1, wo.view(1, F_).to(dev()), H.to(dev()), N, None, N, F_, N, 1,
          SLOPE, part, part.numel(), tot)
     assert rel_err(tot[0], d.sum(1)) < TOL and rel_err(tot[1], H.double() @ gy.double()) < TOL
+
+
+@pytest.mark.parametrize('F_,B,Np,act,has_lb', [(512, 3, 256, 1, True), (300, 2, 384, 2, True), (256, 2, 128, 1, False)])
+def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
+    """The output of the coordinate layer formed inside its three consumers (forward X, data-gradient mask, weight-gradient
+    X) instead of being read: bitwise the same results as with the tensor written by tvae_dec_l0_fwd."""
+    from tvae._lib import query
+    Nt, M = B * Np, F_
+    xr, Wc, bc = rnd(Nt, 2, seed=1).to(dev()), rnd(F_, 2, seed=2).to(dev()), rnd(F_, seed=3).to(dev())
+    LB = rnd(B, F_, seed=4).to(dev()) if has_lb else None
+    h0 = torch.empty(F_, Nt, device=dev())
+    call('tvae_dec_l0_fwd', xr, Wc, bc, LB, h0, Nt, F_, Nt, Np, act, SLOPE)
+    pre = (Wc.double().cpu() @ xr.double().cpu().t() + bc.double().cpu()[:, None] +
+           (LB.double().cpu().t().repeat_interleave(Np, dim=1) if has_lb else 0.0))
+    assert rel_err(h0, act_ref(pre, act)) < TOL
+    W, b, d = rnd(M, F_, seed=5, scale=F_ ** -0.5), rnd(M, seed=6), rnd(M, Nt, seed=7).to(dev())
+    w3 = torch.empty(query('tvae_dense_x6_bytes', M, F_) // 4, device=dev())
+    w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
+    call('tvae_dense_split3', W.to(dev()), F_, w3, w3.numel() * 4, M, F_, 0)
+    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1)
+    va = (xr, Wc, bc, LB, Np)
+    # forward
+    Y = [torch.empty(M, Nt, device=dev()) for _ in range(2)]
+    call('tvae_linear_fwd_x6', w3, h0, b.to(dev()), None, Y[0], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
+         None, None, None, None, 0)
+    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va)
+    assert torch.equal(Y[0], Y[1])
+    assert rel_err(Y[0], act_ref(W.double() @ h0.double().cpu() + b.double()[:, None], act)) < GEMM_TOL['f32']
+    # data gradient with the fused coordinate-layer backward
+    outs = []
+    for virt in (False, True):
+        gxr = torch.empty(Nt, 2, device=dev())
+        part = torch.empty((Nt // 128) * F_ * 3, device=dev())
+        call('tvae_linear_dgrad_x6', w3t, d, None, None if virt else h0, None, M, Nt, F_, Nt, Nt, act, SLOPE, xr, Wc,
+             gxr, part, part.numel(), None, None, bc if virt else None, LB if virt else None, Np if virt else 0)
+        outs.append((gxr, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    d0 = (W.double().t() @ d.double().cpu()) * dact_ref(h0.double().cpu(), act)
+    assert rel_err(outs[1][0], d0.t() @ Wc.double().cpu()) < GEMM_TOL['f32']
+    # weight gradient
+    ws = torch.empty(1 << 24, device=dev())
+    dW = [torch.empty(M, F_, device=dev()) for _ in range(2)]
+    call('tvae_linear_wgrad_x6', d, h0, dW[0], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE,
+         None, None, None, None, 0)
+    call('tvae_linear_wgrad_x6', d, None, dW[1], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE, *va)
+    assert torch.equal(dW[0], dW[1])
+    assert rel_err(dW[1], d.double().cpu() @ h0.double().cpu().t()) < GEMM_TOL['f32']
+    # images that are not whole column tiles are refused
+    with pytest.raises(Exception):
+        call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
+             xr, Wc, bc, LB, 96)
 
 
 def test_reductions():
