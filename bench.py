@@ -68,6 +68,11 @@ WORKLOADS = {
     'S28F': dict(n=28, cin=1, zd=2, C=128, k=28, pad=8, R=16, hidden=512, layers=2, n_out=1, fourier=True, lik='bce',
                  data='rand', desc='S28F: synthetic 28x28, P16 k=28 p=8 C=128, z=2, Fourier decoder '
                                    'cos1024->512->512->1, BCE likelihood'),
+    # BASELINE.json configs[4] (galaxy shape): 136 MB of lifted activations per image, so 8 images per step
+    'S128G': dict(n=128, cin=3, zd=50, C=128, k=64, pad=32, R=16, hidden=512, layers=4, n_out=3, fourier=True, lik='bce3',
+                  data='rand', batch=8,
+                  desc='S128G: synthetic 128x128x3 galaxy-shape stack (torch.rand), P16 k=64 p=32 C=128, z=50, Fourier '
+                       'decoder cos1024->512->512->512->512->3, 3-channel BCE likelihood'),
 }
 
 
@@ -130,7 +135,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step (BASELINE: 256)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (BASELINE: 256; S128G: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-companion', action='store_true',
                     help="skip the extra measurement of the same steps in the all-fp32-MFMA mode (TVAE_GEMM=f32)")
@@ -149,6 +154,8 @@ def main():
     dev = torch.device('cuda', local)
 
     wl = WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = wl.get('batch', 256)
     gen, enc = build_models(dev, wl)
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None

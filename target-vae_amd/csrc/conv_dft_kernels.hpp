@@ -27,6 +27,13 @@ namespace tvae {
 
 constexpr int DFT_WMAX = 40;           // output width / height handled by the register accumulators
 
+// T / S' layout: [n >> 7][row m' < 2M][fx < Lh][n & 127] -- the 2*Lh frequency rows of one (m, 128 columns) are one
+// contiguous run for the transforms along w, and a GEMM tile (512 rows x 128 columns of one fx) touches 512-byte runs
+// 512*Lh bytes apart instead of Lh*NBpad*4 bytes apart.
+__device__ __forceinline__ long dft_t_off(long n, int row, int rows2, int Lh) {
+    return (((n >> 7) * rows2 + row) * Lh) * 128 + (n & 127);            // + fx * 128
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // tw[j] = e^{+2 pi i j / L}, j < L, into LDS
@@ -198,12 +205,12 @@ __global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < W2; ++q) acc[q] = (f32x2p){0.f, 0.f};
     const long col = n < NBpad ? n : NBpad - 1;
-    const float* tr_p = T + (long)m * Lh * NBpad + col;
-    const float* ti_p = T + (long)(M + m) * Lh * NBpad + col;
+    const float* tr_p = T + dft_t_off(col, m, 2 * M, Lh);
+    const float* ti_p = T + dft_t_off(col, M + m, 2 * M, Lh);
 #pragma unroll 2
     for (int fx = 0; fx < Lh; ++fx) {
-        const float tr = tr_p[(long)fx * NBpad];
-        const float ti = ti_p[(long)fx * NBpad];
+        const float tr = tr_p[fx * 128];
+        const float ti = ti_p[fx * 128];
         const f32x2p tr2 = {tr, tr}, ti2 = {-ti, -ti};
 #pragma unroll
         for (int q = 0; q < W2; ++q) {
@@ -269,15 +276,15 @@ __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ d
     const f32x2p* cm = reinterpret_cast<const f32x2p*>(tab + 2 * Lh * DFT_WMAX);   // [Lh][DFT_WMAX] pairs
     const long n = n0 + threadIdx.x;
     if (n >= NBpad) return;
-    float* sr_p = Sp + (long)m * Lh * NBpad + n;
-    float* si_p = Sp + (long)(M + m) * Lh * NBpad + n;
+    float* sr_p = Sp + dft_t_off(n, m, 2 * M, Lh);
+    float* si_p = Sp + dft_t_off(n, M + m, 2 * M, Lh);
 #pragma unroll 2
     for (int fx = 0; fx < Lh; ++fx) {
         f32x2p s2 = {0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < WT; ++w) s2 = __builtin_elementwise_fma((f32x2p){d[w], d[w]}, cm[fx * DFT_WMAX + w], s2);
-        sr_p[(long)fx * NBpad] = s2[0];
-        si_p[(long)fx * NBpad] = s2[1];
+        sr_p[fx * 128] = s2[0];
+        si_p[fx * 128] = s2[1];
     }
 }
 
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void dft_out_mfma_kernel(const float* __restri
     const long tiles_n = NBpad / 32;
     const long ntiles = (long)M * tiles_n;
     const long NB = (long)B * Ho;
-    const long plane = (long)M * Lh * NBpad;                      // offset of the imaginary rows
+    const long plane = (long)M * Lh * 128;                        // offset of the imaginary rows
     const int P = Ho * Ho;
     const int nsteps = KO / 2;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256) void dft_out_mfma_kernel(const float* __restri
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        const float* tcol = T + (long)m * Lh * NBpad + n0 + j;          // T is [ri*M + m][fx][n]
+        const float* tcol = T + dft_t_off(n0 + j, m, 2 * M, Lh);        // T is [n >> 7][ri*M + m][fx][n & 127]
         // all 8*nsteps values of this lane's column first (independent loads in flight), then split + MFMA
         constexpr int MAXS = 8;                         // nsteps <= 8 (2*KH <= 128)
         float v[MAXS][8];
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void dft_out_mfma_kernel(const float* __restri
             for (int q = 0; q < 8; ++q) {
                 const int k = 16 * s + 8 * khalf + q;
                 const int ri = k / KH, fx = k - ri * KH;
-                v[s][q] = (s < nsteps && fx < Lh && ri < 2) ? tcol[(long)fx * NBpad + ri * plane] : 0.f;
+                v[s][q] = (s < nsteps && fx < Lh && ri < 2) ? tcol[fx * 128 + ri * plane] : 0.f;
             }
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void dft_dy_mfma_kernel(const float* __restric
     const long tiles_n = NBpad / 32;
     const long ntiles = (long)M * tiles_n;
     const long NB = (long)B * Ho;
-    const long plane = (long)M * Lh * NBpad;                      // offset of the imaginary rows
+    const long plane = (long)M * Lh * 128;                        // offset of the imaginary rows
     const int P = Ho * Ho;
     const int nsteps = (WOCT + 1) / 2;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -503,28 +510,26 @@ __global__ __launch_bounds__(256) void dft_dy_mfma_kernel(const float* __restric
             }
         }
         // direct stores: row k = (ri, fx), 32 consecutive n per row
-        float* scol = Sp + (long)m * Lh * NBpad + n0 + j;               // S' is [ri*M + m][fx][n]
+        float* scol = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);             // S' is [n >> 7][ri*M + m][fx][n & 127]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int ri = k / KH, fx = k - ri * KH;
-                if (ri < 2 && fx < Lh) scol[(long)fx * NBpad + ri * plane] = acc[i][r];
+                if (ri < 2 && fx < Lh) scol[fx * 128 + ri * plane] = acc[i][r];
             }
     }
 }
 
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
 // db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  One workgroup per channel.
-__global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, long NBpad) {
+__global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, int M) {
     __shared__ float sm[16];
     const int c = blockIdx.x;
     float acc[1] = {0.f};
-    for (int r = 0; r < R; ++r) {
-        const float* row = Sp + (long)(c * R + r) * Lh * NBpad;
-        for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += row[n];
-    }
+    for (int r = 0; r < R; ++r)
+        for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += Sp[dft_t_off(n, c * R + r, 2 * M, Lh)];
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) db[c] = acc[0];
 }

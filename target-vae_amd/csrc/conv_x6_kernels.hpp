@@ -48,16 +48,24 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     m = __builtin_bit_cast(unsigned short, bm);
     l = __builtin_bit_cast(unsigned short, bl);
 }
+// the same split for two values at once, results packed (x0 in the low half): v_cvt_pk_bf16_f32 rounds both, the parts
+// are widened again with a shift / a mask and the residuals come from one packed subtraction -- 9 VALU instructions
+// per pair instead of ~9 per value, bitwise the same parts as split3
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hw, unsigned& mw, unsigned& lw) {
+    const f32x2v x = {x0, x1};
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
+    const f32x2v hf = {__uint_as_float(hw << 16), __uint_as_float(hw & 0xffff0000u)};
+    const f32x2v r1 = x - hf;
+    mw = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2v));
+    const f32x2v mf = {__uint_as_float(mw << 16), __uint_as_float(mw & 0xffff0000u)};
+    const f32x2v r2 = r1 - mf;
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2v));
+}
 __device__ __forceinline__ void split3x8(const float (&r)[8], Cell16& h, Cell16& m, Cell16& l) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        unsigned short h0, m0, l0, h1, m1, l1;
-        split3(r[2 * q], h0, m0, l0);
-        split3(r[2 * q + 1], h1, m1, l1);
-        h.w[q] = (unsigned)h0 | ((unsigned)h1 << 16);
-        m.w[q] = (unsigned)m0 | ((unsigned)m1 << 16);
-        l.w[q] = (unsigned)l0 | ((unsigned)l1 << 16);
-    }
+    for (int q = 0; q < 4; ++q) split3_pair(r[2 * q], r[2 * q + 1], h.w[q], m.w[q], l.w[q]);
 }
 
 // six partial products, in the order the A parts arrive from LDS (h, m, l): the first MFMA of a fragment then waits

@@ -94,6 +94,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
     // waves per SIMD.
     const long off = n0 + (lane & 31);
+    const long coff = ep.ctile ? (long)tile_n * ep.ctile + (lane & 31) : off;     // column-tiled output (see Epilogue)
     float x0[4], x1[4];
     if (it.xr) {
 #pragma unroll
@@ -131,7 +132,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int m = m0 + row;
                 const float bv = bsm[row];
-                float* crow = ep.C ? ep.C + mrow[q] * ep.ldc + off : nullptr;
+                float* crow = ep.C ? ep.C + mrow[q] * ep.ldc + coff : nullptr;
                 float rs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -293,14 +294,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     auto store_b = [&](int stage, const float (&x)[4]) {
         unsigned hw[2], mw[2], lw[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            unsigned short h0, m0_, l0, h1, m1, l1;
-            split3(x[2 * q], h0, m0_, l0);
-            split3(x[2 * q + 1], h1, m1, l1);
-            hw[q] = (unsigned)h0 | ((unsigned)h1 << 16);
-            mw[q] = (unsigned)m0_ | ((unsigned)m1 << 16);
-            lw[q] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
+        for (int q = 0; q < 2; ++q) split3_pair(x[2 * q], x[2 * q + 1], hw[q], mw[q], lw[q]);
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
         dst[0] = make_uint2(hw[0], hw[1]);
         dst[2 * 256] = make_uint2(mw[0], mw[1]);
@@ -420,11 +414,18 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 // Requires n-chunks that are multiples of 16 and 16-byte aligned rows (checked on the host).
 // ------------------------------------------------------------------------------------------
 // VIRT: implicit gradient A operand (VirtGrad); XVA: implicit first-layer activation as the X operand (VirtAct)
+struct ATile {             // column addressing of the streamed A operand: element (row, n) lives at
+    int sh;                //   row * ldd + (n >> sh) * ts + (n & mask)
+    int mask;              // plain row-major rows: {30, 0x3fffffff, 0}; the column-tiled T / S' layout of the
+    long ts;               // frequency-domain convolution (conv_dft_kernels.hpp): {7, 127, tile stride}
+};
+constexpr ATile ATILE_PLAIN = {30, 0x3fffffff, 0};
+
 template <bool VIRT, bool XVA>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                            int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
-                           VirtAct va) {
+                           VirtAct va, ATile atile) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,7 +453,7 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + 64 * wave + 32 * i + (lane & 31);
         a_ok[i] = m < M ? (VIRT ? vg.wo[m] : 1.f) : 0.f;          // row validity (and the row's output weight)
-        a_ptr[i] = dY + (long)min(m, M - 1) * ldd + nbeg + 8 * khalf;
+        a_ptr[i] = dY + (long)min(m, M - 1) * ldd;
     }
     const float* g_ptr = VIRT ? vg.gy + nbeg + 8 * khalf : nullptr;
     float4 gq[2];                                      // gy of the cell being split (VIRT), loaded with the A values
@@ -461,9 +462,11 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
             gq[0] = *reinterpret_cast<const float4*>(g_ptr + 16 * t);
             gq[1] = *reinterpret_cast<const float4*>(g_ptr + 16 * t + 4);
         }
+        const int na = nbeg + 8 * khalf + 16 * t;        // the 8 values of a cell never straddle a column tile
+        const long aoff = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float4* q = reinterpret_cast<const float4*>(a_ptr[i] + 16 * t);
+            const float4* q = reinterpret_cast<const float4*>(a_ptr[i] + aoff);
             r[i][0] = q[0];
             r[i][1] = q[1];
         }
@@ -511,14 +514,7 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
         unsigned hw[2], mw[2], lw[2];
         const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            unsigned short h0, m0_, l0, h1, m1, l1;
-            split3(v[2 * q], h0, m0_, l0);
-            split3(v[2 * q + 1], h1, m1, l1);
-            hw[q] = (unsigned)h0 | ((unsigned)h1 << 16);
-            mw[q] = (unsigned)m0_ | ((unsigned)m1 << 16);
-            lw[q] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
+        for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
         dst[0] = make_uint2(hw[0], hw[1]);
         dst[2 * 256] = make_uint2(mw[0], mw[1]);

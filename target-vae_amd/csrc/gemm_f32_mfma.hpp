@@ -54,6 +54,7 @@ struct Epilogue {
     int mask = ACT_NONE;           // multiply by act'(aux): lrelu -> (aux>0 ? 1 : slope), tanh -> 1-aux^2
     float slope = 0.01f;
     int accumulate = 0;            // C += instead of C =
+    long ctile = 0;                // dense_x6_kernel only: != 0 -> column tile t (128 columns) starts at C + t*ctile
     // conv1 output remap: column n = img*convP + p, row m = c*convR + r  ->  C[c*ldc + img*convR*convP + r*convP + p]
     int convR = 0;                 // power of two (reference allows R in {4,8,16})
     int conv_shift = 0;            // log2(convR)

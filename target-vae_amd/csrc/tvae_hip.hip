@@ -386,7 +386,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     const TileMap tmk{tilesM, tilesK, splits};
 #define TVAE_WG_LAUNCH(V_, X_)                                                                                        \
     hipLaunchKernelGGL((dense_wgrad_x6_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, \
-                       ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas)
+                       ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN)
     if (vg_wo) { if (va_xr) TVAE_WG_LAUNCH(true, true); else TVAE_WG_LAUNCH(true, false); }
     else { if (va_xr) TVAE_WG_LAUNCH(false, true); else TVAE_WG_LAUNCH(false, false); }
 #undef TVAE_WG_LAUNCH
@@ -455,12 +455,13 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     if (rc) return rc;
     {
         Epilogue ep;
-        ep.C = T; ep.ldc = (long)q.Lh * q.NBpad;          // T is [m'][fx][n]: the 2*Lh rows of one (m, .) stay together
+        ep.C = T; ep.ldc = (long)q.Lh * 128;              // T is [n >> 7][m'][fx][n & 127] (dft_t_off)
+        ep.ctile = (long)2 * q.M * q.Lh * 128;
         const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((q.K2 + 7) / 8, 2);
         TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
         tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
-        const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, q.NBpad};
+        const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, 128};
         hipLaunchKernelGGL(dense_x6_kernel<0>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr},
                            InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
@@ -538,7 +539,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         TVAE_CHECK_LAUNCH();
     }
     if (dbias) {
-        hipLaunchKernelGGL(dft_dbias_kernel, dim3(C), dim3(256), 0, st, (const float*)Sp, dbias, R, q.Lh, q.NB, q.NBpad);
+        hipLaunchKernelGGL(dft_dbias_kernel, dim3(C), dim3(256), 0, st, (const float*)Sp, dbias, R, q.Lh, q.NB, q.M);
         TVAE_CHECK_LAUNCH();
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
@@ -550,8 +551,9 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         hipLaunchKernelGGL((dense_wgrad_x6_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
-                           (long)q.Lh * q.NBpad, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, q.NBpad,
-                           VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f});
+                           (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, 128L,
+                           VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f},
+                           ATile{7, 127, (long)M2 * q.Lh * 128});
         TVAE_CHECK_LAUNCH();
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;
