@@ -1,0 +1,18 @@
+#!/bin/bash
+# Per-kernel averages of the default bench step: gpurun -- 'bash profiles/quick_stats.sh <tag>'
+set -u
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/qs_${1:-x}
+mkdir -p "$OUT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion > "$OUT/stats.log" 2>&1
+S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
+cp "$S" "$OUT/kernel_stats.csv"
+rm -rf "$OUT/stats"
+python3 - "$OUT/kernel_stats.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print('kernel time per step %.3f ms' % (tot / 7 / 1e6))
+for r in rows[:int(20)]:
+    print('%-84s n %4s avg %9.1f us %5.1f%%' % (r['Name'][:84], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+PY

@@ -289,236 +289,250 @@ __global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ d
 }
 
 // ==========================================================================================
-// The two transforms along w (33-wide output rows <-> Lh frequencies) on the matrix pipe.  They are tiny GEMMs with
-// a constant operand,  out[w][(m,n)] = sum_k E[w][k] T[k][(m,n)]  and  S'[k][(m,n)] = sum_w E'[k][w] dY[(m,n)][w],
-// in the same exact-split arithmetic: the constant matrix is pre-split into cells once per call, every lane builds the
-// B fragments of its own column in registers (8 strided / contiguous values, split3x8), no workgroup barrier in the
-// loop.  The vector-ALU versions above needed 3 234 FMAs per (m,n); here the ALU only splits 98 (resp. 33) values.
-// k order: k = ri*KH + fx with KH = Lh rounded up to 8 (ri = 0: real plane, 1: imaginary plane).
+// The two transforms along w on the matrix pipe, in plain fp32 (v_mfma_f32_32x32x2_f32: exact products, fp32
+// accumulate -- no operand splitting, so the vector ALU only moves data).  They are small GEMMs with a constant operand,
+//     out[w][(m,n)] = sum_{(fx,ri)} E[w][(fx,ri)] T[(fx,ri)][(m,n)]      (K = 2*Lh, 32 output rows per MFMA tile)
+//     S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]              (K = Ho)
+// and one wave owns a tile of 32 consecutive columns n of one filter row m.  The vector-ALU versions above issue
+// 3 234 FMAs per (m,n) with one scalar table load per FMA pair and wait on the scalar cache 60 % of the time; here a
+// tile costs 49 (resp. 68) MFMAs and the constant operand comes from LDS (one ds_read_b32 per 64-cycle MFMA).
+// The values of the NEXT tile are loaded into registers while the current one is on the matrix pipe.
 // ==========================================================================================
-constexpr int DFT_WROWS = 64;          // padded output width of the forward transform (two 32-row MFMA tiles)
+constexpr int DFT_WROWS = 64;          // largest output width of the matrix-pipe transforms (two 32-row tiles)
 
-// E cells  [part][octet < 2*KH/8][row w < 64]:   E[w][ri*KH+fx] = ri ? -c_fx/L^2 sin(2 pi fx w/L) : c_fx/L^2 cos(..)
-// E' cells [part][octet < WOCT][row k < 128]:    E'[ri*KH+fx][w] = ri ? -sin(2 pi fx w/L) : cos(2 pi fx w/L)
-__global__ void dft_etab_kernel(uint4* __restrict__ E3, uint4* __restrict__ Ep3, int L, int Lh, int KH, int Ho, int WOCT) {
-    const int KO = 2 * KH / 8;
-    const int nE = KO * DFT_WROWS, nEp = WOCT * 128;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nE + nEp; i += gridDim.x * blockDim.x) {
-        float r[8];
-        uint4* dst;
-        long stride;
-        if (i < nE) {
-            const int w = i % DFT_WROWS, o = i / DFT_WROWS;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * o + j, ri = k / KH, fx = k - ri * KH;
-                float v = 0.f;
-                if (w < Ho && fx < Lh) {
-                    float sn, cs;
-                    sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
-                    const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
-                    v = (ri ? -sn : cs) * cf / ((float)L * (float)L);
-                }
-                r[j] = v;
-            }
-            dst = E3 + i;
-            stride = nE;
+// EO[fx < LHP][t < NTT][lane]: t < NT:  E[w = 32t + (lane & 31)][(fx, ri = lane >> 5)] = c_fx/L^2 * (ri ? -sin : cos)(2 pi fx w / L)
+//                              t == NT (REM1 only): the same for the single extra row w = 32*NT, identical in all 32 lanes
+// ED[s < NS][rt < NRT][lane]:  E'[kk = 32 rt + (lane & 31)][w = 2s + (lane >> 5)], kk = 2 fx + ri: ri ? -sin : cos
+// Entries outside fx < Lh, w < Ho are zero (they pad the loops of the kernels).
+__global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict__ ED, int L, int Lh, int Ho, int LHP, int NT,
+                                int NTT, int NS, int NRT) {
+    const int nEO = LHP * NTT * 64, nED = NS * NRT * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nEO + nED; i += gridDim.x * blockDim.x) {
+        int fx, w, ri;
+        bool fwd;
+        if (i < nEO) {
+            const int lane = i & 63, t = (i >> 6) % NTT;
+            fx = (i >> 6) / NTT;
+            ri = lane >> 5;
+            w = t < NT ? 32 * t + (lane & 31) : 32 * NT;
+            fwd = true;
         } else {
-            const int ii = i - nE;
-            const int k = ii % 128, o = ii / 128;
-            const int ri = k / KH, fx = k - ri * KH;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int w = 8 * o + j;
-                float v = 0.f;
-                if (w < Ho && fx < Lh && ri < 2) {
-                    float sn, cs;
-                    sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
-                    v = ri ? -sn : cs;
-                }
-                r[j] = v;
-            }
-            dst = Ep3 + ii;
-            stride = nEp;
+            const int ii = i - nEO, lane = ii & 63, rt = (ii >> 6) % NRT, s = (ii >> 6) / NRT;
+            const int kk = 32 * rt + (lane & 31);
+            fx = kk >> 1;
+            ri = kk & 1;
+            w = 2 * s + (lane >> 5);
+            fwd = false;
         }
-        Cell16 h, m, l;
-        split3x8(r, h, m, l);
-        dst[0] = h.u;
-        dst[stride] = m.u;
-        dst[2 * stride] = l.u;
+        float v = 0.f;
+        if (fx < Lh && w < Ho) {
+            float sn, cs;
+            sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
+            v = ri ? -sn : cs;
+            if (fwd) v *= (((fx == 0) || (2 * fx == L)) ? 1.f : 2.f) / ((float)L * (float)L);
+        }
+        if (i < nEO) EO[i] = v; else ED[i - nEO] = v;
     }
 }
 
-// out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]).  One wave per tile of 32 columns (m fixed, 32
-// consecutive n); a workgroup of 4 waves walks tiles blockIdx.x*4 + wave, += gridDim.x*4.
-__global__ __launch_bounds__(256) void dft_out_mfma_kernel(const float* __restrict__ T, const uint4* __restrict__ E3,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           int M, int R, int B, int Ho, int Lh, int KH, long NBpad,
-                                                           int act, float slope) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_o[];
-    const int KO = 2 * KH / 8;                       // octets
-    uint4* Es = reinterpret_cast<uint4*>(sm_o);      // [part][octet][64 rows]
-    float* stg = reinterpret_cast<float*>(sm_o + (size_t)3 * KO * DFT_WROWS * 16);   // per wave [32 cols][Ho+1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * KO * DFT_WROWS; i += 256) Es[i] = E3[i];
+// out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]).  Block of 4 waves; wave q of block x walks the tiles
+// (it*gridDim.x + x)*4 + q.  LHP >= Lh frequencies are processed (zero table rows beyond Lh), NT output tiles of 32 rows
+// on the matrix pipe and, with REM1, the single extra row w = 32*NT as a dot product on the vector ALU.
+template <int LHP, int NT, bool REM1>
+__global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* __restrict__ T, const float* __restrict__ EO,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int M, int R, int B, int Ho, int Lh, long NBpad, int act,
+                                                            float slope, int iters) {
+    constexpr int NTT = NT + (REM1 ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    float* eo = sm_w;                                            // [LHP][NTT][64]
+    const int SWO = Ho | 1;                                      // odd row stride: conflict-free transposition
+    float* stg = eo + LHP * NTT * 64 + (threadIdx.x >> 6) * 32 * SWO;   // this wave's [32 columns][SWO]
+    for (int i = threadIdx.x; i < LHP * NTT * 64; i += 256) eo[i] = EO[i];
     __syncthreads();
-    float* wst = stg + wave * 32 * (DFT_WROWS + 1);
-    const int khalf = lane >> 5, j = lane & 31;
-    const long tiles_n = NBpad / 32;
-    const long ntiles = (long)M * tiles_n;
-    const long NB = (long)B * Ho;
-    const long plane = (long)M * Lh * 128;                        // offset of the imaginary rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, ri = lane >> 5;
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
     const int P = Ho * Ho;
-    const int nsteps = KO / 2;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const int m = (int)(tile / tiles_n);
-        const long n0 = (tile - (long)m * tiles_n) * 32;
-        f32x16 acc[2];
+    const float inv_ho = 1.0f / (float)Ho;
+    auto tile_ptr = [&](long tile, int& m, long& n0) -> const float* {
+        const long tl = tile < ntiles ? tile : ntiles - 1;       // past the end: reload the last tile (never stored)
+        m = (int)(tl / tiles_n);
+        n0 = (tl - (long)m * tiles_n) * 32;
+        return T + dft_t_off(n0 + j, ri * M + m, 2 * M, Lh);
+    };
+    auto load_tile = [&](const float* tp, float (&v)[LHP]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int fx = 0; fx < LHP; ++fx)      // LHP == 64: generic instance, padding rows meet zero weights; else LHP == Lh
+            v[fx] = tp[(LHP == 64 ? (fx < Lh ? fx : Lh - 1) : fx) * 128];
+    };
+    // one tile: 49 MFMAs on two alternating accumulators (no back-to-back dependence), then the transposing store
+    auto compute = [&](long tile, int m, long n0, const float (&v)[LHP]) {
+        f32x16 acc[NT][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        const float* tcol = T + dft_t_off(n0 + j, m, 2 * M, Lh);        // T is [n >> 7][ri*M + m][fx][n & 127]
-        // all 8*nsteps values of this lane's column first (independent loads in flight), then split + MFMA
-        constexpr int MAXS = 8;                         // nsteps <= 8 (2*KH <= 128)
-        float v[MAXS][8];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s)
+            for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
+        float racc = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = 16 * s + 8 * khalf + q;
-                const int ri = k / KH, fx = k - ri * KH;
-                v[s][q] = (s < nsteps && fx < Lh && ri < 2) ? tcol[fx * 128 + ri * plane] : 0.f;
-            }
+        for (int fx = 0; fx < LHP; ++fx) {
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            if (s < nsteps) {
-                Cell16 bf[3];
-                split3x8(v[s], bf[0], bf[1], bf[2]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Cell16 af[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) af[p].u = Es[(p * KO + 2 * s + khalf) * DFT_WROWS + i * 32 + j];
-                    mfma6(acc[i], af, bf);
-                }
-            }
+            for (int t = 0; t < NT; ++t)
+                acc[t][fx & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[(fx * NTT + t) * 64 + lane], v[fx], acc[t][fx & 1], 0, 0, 0);
+            if (REM1) racc = __fmaf_rn(eo[(fx * NTT + NT) * 64 + lane], v[fx], racc);
         }
-        // stage [col][w] through LDS, then contiguous runs
-        const int c = m / R, rr = m - c * R;
+        if (tile >= ntiles) return;
+        const int c = m / R, r_ = m - c * R;
         const float bv = bias ? bias[c] : 0.f;
+        auto fin = [&](float x) {
+            x += bv;
+            if (act == ACT_LRELU) x = x > 0.f ? x : x * slope;
+            else if (act == ACT_TANH) x = tanhf(x);
+            return x;
+        };
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int w = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = acc[i][r] + bv;
-                if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
-                else if (act == ACT_TANH) v = tanhf(v);
-                wst[j * (DFT_WROWS + 1) + w] = v;
+                const int w = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * ri;
+                if (32 * t + 31 < Ho || w < Ho) stg[j * SWO + w] = fin(acc[t][0][r] + acc[t][1][r]);
             }
-        // two columns per pass (lanes 0..31 / 32..63 take w = lane & 31 and, in a second sweep, w + 32)
-        const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
-        for (int t = khalf; t < 32; t += 2) {
-            int h = h0 + t, b = b0;
-            while (h >= Ho) { h -= Ho; ++b; }
-            if (n0 + t < NB) {
-                float* dst = out + (((long)c * B + b) * R + rr) * P + h * Ho;
-                for (int w = j; w < Ho; w += 32) dst[w] = wst[t * (DFT_WROWS + 1) + w];
-            }
+        if (REM1) {
+            const float tot = racc + __shfl_xor(racc, 32, 64);
+            if (ri == 0) stg[j * SWO + 32 * NT] = fin(tot);
         }
+        __builtin_amdgcn_wave_barrier();
+        // the 32 output rows of the tile are 32*Ho consecutive floats of out, plus (R-1)*P for every image
+        // boundary before the row (divisions through the float reciprocal: exact for these ranges)
+        const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+        float* obase = out + (((long)c * B + b0) * R + r_) * P + (long)h0 * Ho;
+        const int jump = (R - 1) * P;
+        const int tmax = (int)(NB - n0 < 32 ? NB - n0 : 32);
+        const int cnt = tmax * Ho;
+        for (int e = lane; e < cnt; e += 64) {
+            const int t = (int)(((float)e + 0.5f) * inv_ho), w = e - t * Ho;
+            const int k = (int)(((float)(h0 + t) + 0.5f) * inv_ho);
+            obase[e + k * jump] = stg[t * SWO + w];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // two register buffers, the loop walks two tiles per trip: the loads of one buffer are in flight while the other
+    // is on the matrix pipe (no register copies: a copy would wait for the loads it moves)
+    float va[LHP], vb[LHP];
+    int ma, mb;
+    long na, nb;
+    const long stride = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    load_tile(tile_ptr(tile, ma, na), va);
+    for (int it = 0; it < iters; it += 2) {
+        load_tile(tile_ptr(tile + stride, mb, nb), vb);
+        compute(tile, ma, na, va);
+        load_tile(tile_ptr(tile + 2 * stride, ma, na), va);
+        compute(tile + stride, mb, nb, vb);
+        tile += 2 * stride;
     }
 }
 
-// S'[fx][ri*M + m][n] = sum_w E'[ri*KH+fx][w] dY[(m,n)][w].  One wave per tile of 32 columns; dY rows are staged
-// through LDS (per wave [32 cols][pitch]) so that every lane finds its 8-value cells 16-byte aligned.
-__global__ __launch_bounds__(256) void dft_dy_mfma_kernel(const float* __restrict__ dY, const uint4* __restrict__ Ep3,
-                                                          float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
-                                                          int KH, int WOCT, long NBpad) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_o[];
-    uint4* Es = reinterpret_cast<uint4*>(sm_o);      // [part][octet < WOCT][128 rows]
-    const int pitch = 8 * WOCT + 4;                  // floats per staged column (16-byte multiple, odd multiple of 4)
-    float* stg = reinterpret_cast<float*>(sm_o + (size_t)3 * WOCT * 128 * 16);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * WOCT * 128; i += 256) Es[i] = Ep3[i];
+// S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]; dY is [c][b][r][h][w].  Same tile walk as above.  The 32 x Ho
+// values of a tile are (mostly) one contiguous run: coalesced loads into registers one tile ahead, transposed through
+// this wave's LDS patch to the B-operand layout (column n = lane & 31, w = 2s + (lane >> 5)).
+// LH2 = 2*Lh when known at compile time (row validity and store addresses fold), 0 = run-time check;
+// AREG: the constant operand (NS*NRT values per lane) lives in registers for the whole kernel, else it is read from LDS.
+template <int NS, int NRT, int LH2, bool AREG>
+__global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+                                                           float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
+                                                           long NBpad, int iters) {
+    constexpr int NL = NS;                                       // 64-element slices of the 32 x Ho tile: ceil(32*Ho/64) <= NS
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    float* ed = sm_w;                                            // [NS][NRT][64] (used when !AREG)
+    const int SWD = (2 * NS) | 1;                                // odd row stride >= 2*NS
+    float* stg = ed + NS * NRT * 64 + (threadIdx.x >> 6) * (32 * SWD + 64);   // + 64 dump slots per wave
+    if (!AREG)
+        for (int i = threadIdx.x; i < NS * NRT * 64; i += 256) ed[i] = ED[i];
+    for (int i = threadIdx.x; i < 4 * (32 * SWD + 64); i += 256) ed[NS * NRT * 64 + i] = 0.f;   // columns w >= Ho stay zero
     __syncthreads();
-    float* wst = stg + wave * 32 * pitch;
-    const int khalf = lane >> 5, j = lane & 31;
-    const long tiles_n = NBpad / 32;
-    const long ntiles = (long)M * tiles_n;
-    const long NB = (long)B * Ho;
-    const long plane = (long)M * Lh * 128;                        // offset of the imaginary rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
     const int P = Ho * Ho;
-    const int nsteps = (WOCT + 1) / 2;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const int m = (int)(tile / tiles_n);
-        const long n0 = (tile - (long)m * tiles_n) * 32;
-        const int c = m / R, rr = m - c * R;
-        // stage the 32 columns (zeros beyond Ho and beyond NB): lanes 0..31 / 32..63 take alternate columns and
-        // w = lane & 31 (+32); all loads of the tile are issued before the first LDS write
-        {
-            const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
-            float sv[16][2];
+    const float inv_ho = 1.0f / (float)Ho;
+    float areg[AREG ? NS : 1][AREG ? NRT : 1];
+    if (AREG) {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int t = 2 * it + khalf;
-                int h = h0 + t, b = b0;
-                while (h >= Ho) { h -= Ho; ++b; }
-                const bool ok = n0 + t < NB;
-                const float* src = dY + (((long)c * B + (ok ? b : 0)) * R + rr) * P + h * Ho;
+        for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int w = j + 32 * q;
-                    sv[it][q] = (ok && w < Ho) ? src[w] : 0.f;
-                }
-            }
+            for (int rt = 0; rt < NRT; ++rt) areg[AREG ? s_ : 0][AREG ? rt : 0] = ED[(s_ * NRT + rt) * 64 + lane];
+    }
+    // A tile is 32*Ho consecutive floats of dY, plus (R-1)*P for every image boundary before the column.  Element
+    // e = 64 i + lane is (column t = e / Ho, w = e % Ho) (exact through the float reciprocal for e < 4096).  All loads are
+    // unconditional: columns past the end of the batch re-read the last valid column (finite values; those columns
+    // of S' only ever meet the zero columns of A^T).
+    auto load_tile = [&](long tile, float (&v)[NL]) {
+        const long tl = tile < ntiles ? tile : ntiles - 1;
+        const int m = (int)(tl / tiles_n);
+        long n0 = (tl - (long)m * tiles_n) * 32;
+        if (n0 >= NB) n0 = 0;
+        const int c = m / R, r_ = m - c * R;
+        const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+        const float* base = dY + (((long)c * B + b0) * R + r_) * P + (long)h0 * Ho;
+        const int jump = (R - 1) * P;
+        const int tlast = (int)(NB - n0 < 32 ? NB - n0 : 32) - 1;
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int t = 2 * it + khalf;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int w = j + 32 * q;
-                    if (w < pitch) wst[t * pitch + w] = sv[it][q];
-                }
-            }
+        for (int i = 0; i < NL; ++i) {
+            const int e = i * 64 + lane;
+            const int t = (int)(((float)e + 0.5f) * inv_ho);
+            const int tc = t < tlast ? t : tlast;
+            const int k = (int)(((float)(h0 + tc) + 0.5f) * inv_ho);
+            v[i] = base[e + (tc - t) * Ho + k * jump];
         }
-        f32x16 acc[4];
+    };
+    float v[NL];
+    load_tile((long)blockIdx.x * 4 + wave, v);
+    for (int it = 0; it < iters; ++it) {
+        const long tile = ((long)it * gridDim.x + blockIdx.x) * 4 + wave;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        for (int s = 0; s < nsteps; ++s) {
-            const int o = 2 * s + khalf;
-            float v[8];
-            if (o < WOCT) {
-                const float4 a = *reinterpret_cast<const float4*>(wst + j * pitch + 8 * o);
-                const float4 bq = *reinterpret_cast<const float4*>(wst + j * pitch + 8 * o + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = 0.f;
-            }
-            Cell16 bf[3];
-            split3x8(v, bf[0], bf[1], bf[2]);
-            const int oa = o < WOCT ? o : 0;         // padding octet: B is zero, any valid A cell
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Cell16 af[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) af[p].u = Es[(p * WOCT + oa) * 128 + i * 32 + j];
-                mfma6(acc[i], af, bf);
-            }
+        for (int i = 0; i < NL; ++i) {
+            const int e = i * 64 + lane;
+            const int t = (int)(((float)e + 0.5f) * inv_ho);
+            stg[t < 32 ? t * SWD + (e - t * Ho) : 32 * SWD + lane] = v[i];
         }
-        // direct stores: row k = (ri, fx), 32 consecutive n per row
-        float* scol = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);             // S' is [n >> 7][ri*M + m][fx][n & 127]
+        __builtin_amdgcn_wave_barrier();
+        float bq[NS];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int s_ = 0; s_ < NS; ++s_) bq[s_] = stg[j * SWD + 2 * s_ + kh];
+        __builtin_amdgcn_wave_barrier();
+        load_tile(tile + (long)gridDim.x * 4, v);                // next tile: in flight during the MFMAs below
+        f32x16 acc[NRT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int ri = k / KH, fx = k - ri * KH;
-                if (ri < 2 && fx < Lh) scol[fx * 128 + ri * plane] = acc[i][r];
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const float av = AREG ? areg[AREG ? s_ : 0][AREG ? rt : 0] : ed[(s_ * NRT + rt) * 64 + lane];
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[s_], acc[rt], 0, 0, 0);
             }
+        if (tile < ntiles) {
+            const int m = (int)(tile / tiles_n);
+            const long n0 = (tile - (long)m * tiles_n) * 32;
+            // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh: ri is a compile-time property of (rt, r)
+            float* p0 = Sp + dft_t_off(n0 + j, m, 2 * M, Lh) + 2 * kh * 128;          // real rows, fx = fx0 + 2 kh
+            float* p1 = Sp + dft_t_off(n0 + j, M + m, 2 * M, Lh) + 2 * kh * 128;      // imaginary rows
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);                 // kh = 0; kh = 1 adds 4
+                    float* p = (kk0 & 1) ? p1 : p0;
+                    const int fx0 = kk0 >> 1;
+                    if (LH2 > 0) {
+                        if (kk0 + 4 < LH2) p[fx0 * 128] = acc[rt][r];
+                        else if (kk0 < LH2) { if (kh == 0) p[fx0 * 128] = acc[rt][r]; }
+                    } else {
+                        if (fx0 + 2 * kh < Lh) p[fx0 * 128] = acc[rt][r];
+                    }
+                }
+        }
     }
 }
 

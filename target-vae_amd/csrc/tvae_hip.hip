@@ -131,7 +131,8 @@ static long tvae_dense_x6_bytes_impl(int rows, int K) {
 constexpr int DFT_WG_SPLITS = 8;
 struct DftPlan {
     int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
-    int KH, KO, WOCT;          // padded half spectrum, its octets (x2 planes), octets of an output row
+    int LHP, NT, REM1;         // forward w-transform instance: frequencies processed, 32-row output tiles, extra row
+    int NS, NRT;               // backward w-transform instance: k2-steps (pairs of w), 32-row tiles of (fx, ri)
     int Mb;                    // rows per fx in the stacked spectral weight (2M rounded up to the 512-row tile)
     long NB, NBpad;            // (image, output row) columns
     long at_floats;            // A^T [Lh][2L][NBpad]
@@ -156,14 +157,17 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.w_floats = (long)q.Lh * q.Mb * q.K2;
     q.w3_floats = tvae_dense_x6_bytes_impl(q.Lh * q.Mb, q.K2) / 4;
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
-    q.KH = (q.Lh + 7) / 8 * 8;
-    q.KO = 2 * q.KH / 8;
-    q.WOCT = (q.Ho + 7) / 8;
-    q.tab_floats = 4L * (3L * q.KO * DFT_WROWS + 3L * q.WOCT * 128) + 4L * q.Lh * DFT_WMAX;   // E, E' cells + ALU tables
+    q.LHP = q.Lh == 23 ? 23 : (q.Lh == 49 ? 49 : 64);          // exact instances of the two reference frames, else generic
+    q.NT = q.Ho <= 33 ? 1 : 2;
+    q.REM1 = q.Ho == 33 ? 1 : 0;
+    if (q.Ho <= 18 && q.Lh <= 32) { q.NS = 9; q.NRT = 2; }
+    else if (q.Ho <= 34) { q.NS = 17; q.NRT = 4; }
+    else { q.NS = 32; q.NRT = 4; }
+    q.tab_floats = 64L * 2 * 64 + 32L * 4 * 64 + 4L * q.Lh * DFT_WMAX;       // EO + ED (largest instances) + ALU tables
     q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && 2 * q.KH <= 128 && lds_img <= 150 * 1024 &&
+    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && q.Lh <= 64 && lds_img <= 150 * 1024 &&
            lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
     return q;
 }
@@ -431,10 +435,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         hipError_t e = hipMemsetAsync(at, 0, (size_t)q.at_floats * 4, st);
         if (e != hipSuccess) return (int)e;
     }
-    uint4* E3 = reinterpret_cast<uint4*>(tab);
-    uint4* Ep3 = E3 + 3L * q.KO * DFT_WROWS;
-    hipLaunchKernelGGL(dft_etab_kernel, dim3(16), dim3(256), 0, st, E3, Ep3, q.L, q.Lh, q.KH, q.Ho, q.WOCT);
-    TVAE_CHECK_LAUNCH();
+    float* EO = tab;
+    float* ED = EO + 64L * 2 * 64;
+    float* vtab = ED + 32L * 4 * 64;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     hipError_t e = allow_big_lds(dft_image_kernel, lds_img);
     if (e != hipSuccess) return (int)e;
@@ -468,19 +471,35 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
                            VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f});
         TVAE_CHECK_LAUNCH();
     }
-    static const bool out_mfma = [] { const char* e_ = getenv("TVAE_DFT_OUT_MFMA"); return e_ && e_[0] == '1'; }();
-    if (out_mfma || q.Ho > DFT_WMAX) {
-        const size_t lds_o = (size_t)3 * q.KO * DFT_WROWS * 16 + (size_t)4 * 32 * (DFT_WROWS + 1) * 4;
-        e = allow_big_lds(dft_out_mfma_kernel, lds_o);
-        if (e != hipSuccess) return (int)e;
+    // TVAE_DFT_W_VALU = 1 | out | dy selects the vector-ALU transform(s) along w instead of the matrix-pipe ones
+    static const bool w_valu = [] { const char* e_ = getenv("TVAE_DFT_W_VALU"); return e_ && (e_[0] == '1' || e_[0] == 'o'); }();
+    if (!(w_valu && q.Ho <= DFT_WMAX)) {
+        // contraction over fx on the fp32 matrix pipe (dft_out_mf_kernel)
+        const int NTT = q.NT + q.REM1;
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT, NTT, q.NS,
+                           q.NRT);
+        TVAE_CHECK_LAUNCH();
+        const size_t lds_o = ((size_t)q.LHP * NTT * 64 + (size_t)4 * 32 * (q.Ho | 1)) * 4;
         const long ntiles = (long)q.M * (q.NBpad / 32);
-        const int grid = (int)(ntiles / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
-        hipLaunchKernelGGL(dft_out_mfma_kernel, dim3(grid), dim3(256), lds_o, st, (const float*)T, (const uint4*)E3, bias,
-                           out, q.M, R, B, q.Ho, q.Lh, q.KH, q.NBpad, act, slope);
+        const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
+        const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
+#define TVAE_OUT_MF(L_, N_, R_)                                                                                     \
+    do {                                                                                                            \
+        e = allow_big_lds(dft_out_mf_kernel<L_, N_, R_>, lds_o);                                                    \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((dft_out_mf_kernel<L_, N_, R_>), dim3(grid), dim3(256), lds_o, st, (const float*)T,      \
+                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters);        \
+    } while (0)
+#define TVAE_OUT_MF_L(L_)                                                                                           \
+    do {                                                                                                            \
+        if (q.REM1) TVAE_OUT_MF(L_, 1, true); else if (q.NT == 1) TVAE_OUT_MF(L_, 1, false); else TVAE_OUT_MF(L_, 2, false); \
+    } while (0)
+        if (q.LHP == 23) TVAE_OUT_MF_L(23); else if (q.LHP == 49) TVAE_OUT_MF_L(49); else TVAE_OUT_MF_L(64);
+#undef TVAE_OUT_MF_L
+#undef TVAE_OUT_MF
         TVAE_CHECK_LAUNCH();
     } else {
-        // vector-ALU contraction over fx (measured faster than the MFMA variant for Ho <= 40: 2.2 vs 3.3 ms)
-        float* vtab = reinterpret_cast<float*>(Ep3 + 3L * q.WOCT * 128);
+        // vector-ALU contraction over fx (opt-in: TVAE_DFT_W_VALU=1)
         hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, vtab, q.L, q.Lh);
         TVAE_CHECK_LAUNCH();
         const dim3 og((unsigned)((q.NB + 255) / 256), q.M);
@@ -508,22 +527,32 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
     float* G = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
     float* tab = G + ((q.g_floats + 3) & ~3L);
-    uint4* E3 = reinterpret_cast<uint4*>(tab);
-    uint4* Ep3 = E3 + 3L * q.KO * DFT_WROWS;
-    hipLaunchKernelGGL(dft_etab_kernel, dim3(16), dim3(256), 0, st, E3, Ep3, q.L, q.Lh, q.KH, q.Ho, q.WOCT);
-    TVAE_CHECK_LAUNCH();
-    static const bool dy_mfma = [] { const char* e_ = getenv("TVAE_DFT_DY_MFMA"); return e_ && e_[0] == '1'; }();
-    if (dy_mfma || q.Ho > DFT_WMAX) {
-        const size_t lds_d = (size_t)3 * q.WOCT * 128 * 16 + (size_t)4 * 32 * (8 * q.WOCT + 4) * 4;
-        hipError_t e0 = allow_big_lds(dft_dy_mfma_kernel, lds_d);
-        if (e0 != hipSuccess) return (int)e0;
+    float* EO = tab;
+    float* ED = EO + 64L * 2 * 64;
+    float* vtab = ED + 32L * 4 * 64;
+    static const bool w_valu = [] { const char* e_ = getenv("TVAE_DFT_W_VALU"); return e_ && (e_[0] == '1' || e_[0] == 'd'); }();
+    if (!(w_valu && q.Ho <= DFT_WMAX)) {
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT,
+                           q.NT + q.REM1, q.NS, q.NRT);
+        TVAE_CHECK_LAUNCH();
+        const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
         const long ntiles = (long)q.M * (q.NBpad / 32);
-        const int grid = (int)(ntiles / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
-        hipLaunchKernelGGL(dft_dy_mfma_kernel, dim3(grid), dim3(256), lds_d, st, dpre, (const uint4*)Ep3, Sp, q.M, R, B,
-                           q.Ho, q.Lh, q.KH, q.WOCT, q.NBpad);
+        const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
+        const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
+        hipError_t e0 = hipSuccess;
+#define TVAE_DY_MF(S_, T_, L2_, A_)                                                                                 \
+    do {                                                                                                            \
+        e0 = allow_big_lds(dft_dy_mf_kernel<S_, T_, L2_, A_>, lds_d);                                               \
+        if (e0 != hipSuccess) return (int)e0;                                                                       \
+        hipLaunchKernelGGL((dft_dy_mf_kernel<S_, T_, L2_, A_>), dim3(grid), dim3(256), lds_d, st, dpre,             \
+                           (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, iters);                            \
+    } while (0)
+        if (q.NS == 9) { if (q.Lh == 23) TVAE_DY_MF(9, 2, 46, true); else TVAE_DY_MF(9, 2, 0, true); }
+        else if (q.NS == 17) { if (q.Lh == 49) TVAE_DY_MF(17, 4, 98, true); else TVAE_DY_MF(17, 4, 0, true); }
+        else TVAE_DY_MF(32, 4, 0, false);
+#undef TVAE_DY_MF
         TVAE_CHECK_LAUNCH();
     } else {
-        float* vtab = reinterpret_cast<float*>(Ep3 + 3L * q.WOCT * 128);
         hipLaunchKernelGGL(dft_tables_kernel, dim3(8), dim3(256), 0, st, vtab, q.L, q.Lh);
         TVAE_CHECK_LAUNCH();
         const dim3 dg((unsigned)((q.NBpad + 255) / 256), q.M);
