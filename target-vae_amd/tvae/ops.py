@@ -481,9 +481,13 @@ class DecoderFn(torch.autograd.Function):
         _expect(Wl is None or (z is not None and tuple(z.shape) == (B, Wl.shape[1])), 'latent z does not match latent_linear')
         dev = xr.device
         LB = None
+        # Fourier-feature first layer on the split pipe: the per-image latent term joins the reduction (rows z[img(n)] under
+        # the features, weights [Wc | Wl]) instead of being a per-image bias
+        four_x6 = Wf is not None and _dense_x6_ok(F_, Nt)
         if Wl is not None:
-            zd = Wl.shape[1]
             z = z.contiguous()
+        if Wl is not None and not four_x6:
+            zd = Wl.shape[1]
             LB = torch.empty(B, F_, dtype=torch.float32, device=dev)
             call('tvae_latent_bias', Wl.contiguous(), z, LB, B, F_, zd)
         feat = None
@@ -498,9 +502,19 @@ class DecoderFn(torch.autograd.Function):
             pass
         elif Wf is not None:
             Ff = Wf.shape[0]
-            feat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
+            zx = Wl.shape[1] if (four_x6 and Wl is not None) else 0
+            feat_all = torch.empty(Ff + zx, Nt, dtype=torch.float32, device=dev)
+            feat = feat_all[:Ff]
             call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, Nt, Ff, Nt)
-            call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
+            if four_x6:
+                if zx:
+                    feat_all[Ff:].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
+                w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
+                with _timed('tvae_linear_fwd_x6'):
+                    call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
+                         None, None, None, None, None, None, None, 0)
+            else:
+                call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
         else:
             call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
         hs = [h]
@@ -619,7 +633,13 @@ class DecoderFn(torch.autograd.Function):
             Ff = Wf.shape[0]
             dWc = _wgrad(d, feat, F_, Nt, Ff)
             dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
-            call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
+            if _dense_x6_ok(Ff, Nt):
+                w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
+                with _timed('tvae_linear_dgrad_x6'):
+                    call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
+                         None, None, None, None, 0, None, None, None, None, 0)
+            else:
+                call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
         out = [gxr, dz, None, None, None, None, dWc, dbc, dWl]
         for (dW, db) in grads_hidden:
