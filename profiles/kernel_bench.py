@@ -17,7 +17,7 @@ only = os.environ.get('ONLY', '')
 
 
 def timeit(name, flops, fn):
-    if only and only not in name:
+    if only and not any(tok in name for tok in only.split(',')):
         return
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -115,4 +115,13 @@ if only and 'tail' in only:
     timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, 0))
     timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, 0))
     timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0))
+    Np_ = n * n
+    bc2 = torch.randn(F_, device=dev); lb2 = torch.randn(B, F_, device=dev)
+    va = (xr2, wc2, bc2, lb2, Np_)
+    # the step's actual launches: forward with the recomputed first layer (+ fused output column), data gradient with the
+    # implicit gradient + fused first-layer backward + recomputed mask, weight gradient with both implicit operands
+    cy = torch.empty(Nt, device=dev)
+    timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va))
+    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, bc2, lb2, Np_))
+    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va))
     timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0))

@@ -16,8 +16,14 @@ from collections import defaultdict
 
 ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tvae_conv1_wgrad',
          'conv1_fwd_x6_kernel': 'tvae_conv1_fwd_x6', 'conv1_wgrad_x6_kernel': 'tvae_conv1_wgrad_x6',
-         'dy_split3_kernel': 'tvae_dy_split3', 'dense_x6_kernel': 'tvae_linear_fwd_x6',
-         'dense_wgrad_x6_kernel': 'tvae_linear_wgrad_x6', 'dft_out_kernel': 'tvae_dft_out', 'dft_dy_mfma_kernel': 'tvae_dft_dy',
+         'dy_split3_kernel': 'tvae_dy_split3',
+         # dense_x6_kernel<XV>: 0 = operand from memory (spectral GEMM of the convolution, decoder layers without the
+         # recomputed first layer), 2 = forward with the recomputed first-layer operand, 1 = data gradient with the implicit
+         # gradient operand; the bench line looks its launch up by grid size
+         'dense_x6_kernel<0>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2>': 'tvae_linear_fwd_x6',
+         'dense_x6_kernel<1>': 'tvae_linear_dgrad_x6',
+         'dense_wgrad_x6_kernel': 'tvae_linear_wgrad_x6', 'dft_out_kernel': 'tvae_dft_out',
+         'dft_out_mf_kernel': 'tvae_dft_out', 'dft_dy_kernel': 'tvae_dft_dy', 'dft_dy_mf_kernel': 'tvae_dft_dy',
          'outer_mask_kernel<1>': 'calibration_outer_mask', 'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
