@@ -15,6 +15,7 @@
 //     bias, residual, activation, activation-derivative mask.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "conv_x6_kernels.hpp"
 #include "small_kernels.hpp"
 
@@ -569,6 +570,248 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
         __syncthreads();
     }
     // slab partial: ws[split][M][Kf]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+            float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = acc[i][j][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense_wgrad_x6_kernel with EVERY streamed operand of the loop brought in by global_load_lds DMAs three steps deep
+// instead of per-lane loads one step ahead.  A debug build that skipped the A loads ran 1.1-1.4 ms faster per launch
+// (4.1 -> 2.8 ms): the per-lane loads were each wave's critical path (flight time of about half a step, 32 partially
+// used cache lines per instruction).  Here
+//   * every wave owns a ring of three slots; a slot holds what THIS wave needs for one step: its 64 rows x 16 n of the
+//     A operand (4 KB, four DMA instructions: instruction g moves rows 16g..16g+15, four lanes per row = one full
+//     64-byte line per row), the 16 x 16 n of the X operand its own threads split (1 KB: every lane DMAs exactly the
+//     16 bytes it later reads back) -- or, for the recomputed first-layer operand, the 32 coordinates and this
+//     thread's latent term -- and the 16 gy values of the implicit gradient;
+//   * the 16-byte piece of A a lane fetches is XOR-swizzled with (row >> 2) & 3, so that the per-lane fragment reads
+//     (row = lane & 31 (+32), two pieces) are conflict-free ds_read_b128 although the DMA destination is lane-linear;
+//   * the DMAs are issued from inline asm and waited for with hand-written s_waitcnt (the compiler would put vmcnt(0)
+//     in front of every LDS read behind a DMA).  There is NO ordinary vector-memory load in the loop: DMAs complete in
+//     order among themselves, but a first version that mixed them with register loads and counted both in one vmcnt
+//     read slots (and let late register loads land in reallocated registers) before they were complete.
+//     Per step: [s_waitcnt vmcnt(NDMA): only the previous step's DMAs may be in flight] -> [DMAs of step t+3].
+// Same tile, B stage, MFMA schedule and slab output as dense_wgrad_x6_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int WG_SLOT_BYTES = 4096 + 1024 + 256;      // A | X (or coordinates 256 + latent term 256) | gy
+constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
+
+template <bool VIRT, bool XVA>
+__global__ __launch_bounds__(DX6_THREADS, 2)
+void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
+                               int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
+                               VirtAct va, ATile atile) {
+    constexpr int NDMA = 4 + (XVA ? 2 : 1) + (VIRT ? 1 : 0);              // DMA instructions per wave and step
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_ring[];   // [wave][slot < 3][WG_SLOT_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_k, split;
+    if (!tm.decode(blockIdx.x, tile_m, tile_k, split)) return;
+    int batch = 0, nbatch = 1;
+    if (bt.tiles_per_batch > 0) {
+        batch = tile_m / bt.tiles_per_batch;
+        nbatch = tm.tilesM / bt.tiles_per_batch;
+        tile_m -= batch * bt.tiles_per_batch;
+        dY += batch * dy_stride;
+        X += batch * bt.x_stride;
+    }
+    const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
+    const int nbeg = split * nchunk;
+    const int nend = min(N, nbeg + nchunk);
+    const int nk = (nend - nbeg) >> 4;
+    const int khalf = lane >> 5;
+    if (nk <= 0) {                                      // empty reduction slice: zero partial
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m >= M) continue;
+                float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = 0.f;
+            }
+        return;
+    }
+
+    // ---- DMA sources
+    const float* d_ptr[4];                               // A: instruction g, row 16g + lane/4 of this wave, swizzled piece
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = m0 + 64 * wave + 16 * g + (lane >> 2);
+        d_ptr[g] = dY + (long)min(row, M - 1) * ldd + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+    }
+    const int kr = tid >> 2, q4 = tid & 3;               // B build role: feature row kr, n-quad q4
+    const int kx = min(k0 + kr, Kf - 1);
+    const float b_ok = (k0 + kr) < Kf ? 1.f : 0.f;
+    // X: this thread's own 16 bytes (4 consecutive n of its row); XVA: dword lane & 31 of the step's 32 coordinates
+    const float* x_src = XVA ? va.xr + 2 * (long)nbeg + (lane & 31) : X + (long)kx * ldx + nbeg + 4 * q4;
+    const float* lb_src = XVA ? (va.lb ? va.lb + kx : va.bc + kx) : nullptr;   // no latent term: a valid dummy, scaled by 0
+    const float lb_on = (XVA && va.lb) ? 1.f : 0.f;
+    const float* g_src = VIRT ? vg.gy + nbeg + (lane & 15) : nullptr;
+    const float va_w0 = XVA ? va.wc[2 * kx] : 0.f, va_w1 = XVA ? va.wc[2 * kx + 1] : 0.f, va_bc = XVA ? va.bc[kx] : 0.f;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)wg_ring +
+                              (unsigned)(wave * 3 * WG_SLOT_BYTES);
+    const unsigned char* ring = wg_ring + wave * 3 * WG_SLOT_BYTES;
+    auto dma_step = [&](int slot, int t) {
+        const int na = nbeg + 16 * t;                    // wave-uniform; a 16-wide step never straddles a column tile
+        const long off = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
+        const unsigned sl = ring_lds + (unsigned)(slot * WG_SLOT_BYTES);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* src = d_ptr[g] + off;
+            const unsigned dst = sl + (unsigned)(g * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+        }
+        if (XVA) {
+            const float* sx = x_src + 32 * t;
+            const unsigned dx = sl + 4096u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dx), "v"(sx) : "memory");
+            const float* slb = lb_src + (long)(lb_on != 0.f ? na / va.Np : 0) * Kf;
+            const unsigned dl = sl + 4096u + 256u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dl), "v"(slb) : "memory");
+        } else {
+            const float* sx = x_src + 16 * t;
+            const unsigned dx = sl + 4096u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dx), "v"(sx) : "memory");
+        }
+        if (VIRT) {
+            const float* sg = g_src + 16 * t;
+            const unsigned dg = sl + 4096u + 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dg), "v"(sg) : "memory");
+        }
+    };
+    // ---- reads from a landed slot
+    int a_at[2][2];                                      // byte offsets of this lane's two pieces of fragment i
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            a_at[i][h] = (2 * i + ((lane >> 4) & 1)) * 1024 + (lane & 15) * 64 + (((2 * khalf + h) ^ ((lane >> 2) & 3)) * 16);
+    auto read_a = [&](int slot, float4 (&r)[2][2], float4 (&gq)[2]) {
+        const unsigned char* sl = ring + slot * WG_SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) r[i][h] = *reinterpret_cast<const float4*>(sl + a_at[i][h]);
+        if (VIRT) {
+            gq[0] = *reinterpret_cast<const float4*>(sl + 4096 + 1024 + 32 * khalf);
+            gq[1] = *reinterpret_cast<const float4*>(sl + 4096 + 1024 + 32 * khalf + 16);
+        }
+    };
+    auto read_x = [&](int slot) -> float4 {
+        const unsigned char* sl = ring + slot * WG_SLOT_BYTES + 4096;
+        if (XVA) {
+            const float4 c0 = *reinterpret_cast<const float4*>(sl + 32 * q4);
+            const float4 c1 = *reinterpret_cast<const float4*>(sl + 32 * q4 + 16);
+            const float lbv = *reinterpret_cast<const float*>(sl + 256 + 4 * lane) * lb_on;
+            return make_float4(act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), va.act, va.slope),
+                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.z, c1.w), va.act, va.slope));
+        }
+        return *reinterpret_cast<const float4*>(sl + 16 * lane);
+    };
+    float a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 64 * wave + 32 * i + (lane & 31);
+        a_ok[i] = m < M ? (VIRT ? vg.wo[m] : 1.f) : 0.f;
+    }
+    auto virt_a = [&](float4 (&r)[2][2], const float4 (&gq)[2]) {
+        if (VIRT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    r[i][h] = make_float4(virt_value(vg, r[i][h].x, 1.f, gq[h].x), virt_value(vg, r[i][h].y, 1.f, gq[h].y),
+                                          virt_value(vg, r[i][h].z, 1.f, gq[h].z), virt_value(vg, r[i][h].w, 1.f, gq[h].w));
+        }
+    };
+    auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
+                                r[i][1].x * a_ok[i], r[i][1].y * a_ok[i], r[i][1].z * a_ok[i], r[i][1].w * a_ok[i]};
+            split3x8(v, a[i][0], a[i][1], a[i][2]);
+        }
+    };
+    auto store_b = [&](int stage, const float4& x) {
+        unsigned hw[2], mw[2], lw[2];
+        const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
+        dst[0] = make_uint2(hw[0], hw[1]);
+        dst[2 * 256] = make_uint2(mw[0], mw[1]);
+        dst[2 * 512] = make_uint2(lw[0], lw[1]);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Cell16 af[2][3];
+    const int tl = nk - 1;
+    {   // prologue: three steps in flight, step 0 split as soon as its slot has landed
+        dma_step(0, 0);
+        dma_step(1, min(1, tl));
+        dma_step(2, min(2, tl));
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+        float4 ar[2][2], g0[2];
+        read_a(0, ar, g0);
+        virt_a(ar, g0);
+        split_a(ar, af);
+        store_b(0, read_x(0));
+    }
+    __syncthreads();
+    int s_next = 1, s_dma = 0;                           // slot of step t+1, slot the DMAs of step t+3 go to (= t % 3)
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");      // slot of step t+1 has landed
+        dma_step(s_dma, min(t + 3, tl));                 // unconditional (clamped): uniform vmcnt bookkeeping
+        Cell16 an[2][3];
+        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Cell16 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
+            mfma6(acc[0][j], af[0], bf);
+            mfma6(acc[1][j], af[1], bf);
+            if (j == 0) {                                // A cells of step t+1 from the ring
+                float4 ar[2][2], gn[2];
+                read_a(s_next, ar, gn);
+                virt_a(ar, gn);
+                split_a(ar, an);
+            }
+            if (j == 1) store_b(cur ^ 1, read_x(s_next));   // B cells of step t+1
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
+        s_next = s_next == 2 ? 0 : s_next + 1;
+        s_dma = s_dma == 2 ? 0 : s_dma + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's ring
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -127,6 +127,12 @@ static long tvae_dense_x6_bytes_impl(int rows, int K) {
     return 3 * K8pad * Rpad * 16;
 }
 
+// TVAE_WGRAD_DMA=0: weight-gradient GEMM with per-lane A loads instead of the LDS-DMA ring (dense_x6_kernels.hpp)
+static bool wgrad_dma() {
+    static const bool on = [] { const char* e_ = getenv("TVAE_WGRAD_DMA"); return !(e_ && e_[0] == '0'); }();
+    return on;
+}
+
 // Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
 constexpr int DFT_WG_SPLITS = 8;
 struct DftPlan {
@@ -389,8 +395,18 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
 #define TVAE_WG_LAUNCH(V_, X_)                                                                                        \
-    hipLaunchKernelGGL((dense_wgrad_x6_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, ldd, X, \
-                       ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN)
+    do {                                                                                                              \
+        if (wgrad_dma() && (!va_xr || va_np % 16 == 0)) {                                                             \
+            hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_>, WG_RING_BYTES);                          \
+            if (e_ != hipSuccess) return (int)e_;                                                                     \
+            hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), WG_RING_BYTES, \
+                               S(stream), dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, \
+                               ATILE_PLAIN);                                                                          \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((dense_wgrad_x6_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, \
+                               ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN); \
+        }                                                                                                             \
+    } while (0)
     if (vg_wo) { if (va_xr) TVAE_WG_LAUNCH(true, true); else TVAE_WG_LAUNCH(true, false); }
     else { if (va_xr) TVAE_WG_LAUNCH(false, true); else TVAE_WG_LAUNCH(false, false); }
 #undef TVAE_WG_LAUNCH
@@ -579,10 +595,19 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
-        hipLaunchKernelGGL((dense_wgrad_x6_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, st, (const float*)Sp,
-                           (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt, 128L,
-                           VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f},
-                           ATile{7, 127, (long)M2 * q.Lh * 128});
+        if (wgrad_dma()) {
+            hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<false, false>, WG_RING_BYTES);
+            if (e_ != hipSuccess) return (int)e_;
+            hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), WG_RING_BYTES,
+                               st, (const float*)Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk,
+                               tmk, bt, 128L, VirtGrad{nullptr, nullptr, 0, 0.f},
+                               VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, ATile{7, 127, (long)M2 * q.Lh * 128});
+        } else {
+            hipLaunchKernelGGL((dense_wgrad_x6_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, st,
+                               (const float*)Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk,
+                               bt, 128L, VirtGrad{nullptr, nullptr, 0, 0.f},
+                               VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, ATile{7, 127, (long)M2 * q.Lh * 128});
+        }
         TVAE_CHECK_LAUNCH();
         Epilogue ep;
         ep.C = G; ep.ldc = q.K2;
