@@ -127,6 +127,11 @@ static long tvae_dense_x6_bytes_impl(int rows, int K) {
     return 3 * K8pad * Rpad * 16;
 }
 
+// TVAE_DENSE_DMA=1: forward / data-gradient GEMM with LDS-DMA rings for its streamed operands (dense_x6_dma_kernel)
+static bool dense_dma() {
+    static const bool on = [] { const char* e_ = getenv("TVAE_DENSE_DMA"); return e_ && e_[0] == '1'; }();
+    return on;
+}
 // TVAE_WGRAD_DMA=0: weight-gradient GEMM with per-lane A loads instead of the LDS-DMA ring (dense_x6_kernels.hpp)
 static bool wgrad_dma() {
     static const bool on = [] { const char* e_ = getenv("TVAE_WGRAD_DMA"); return !(e_ && e_[0] == '0'); }();
@@ -317,7 +322,18 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
     if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
         return (int)hipErrorInvalidValue;
-    if (va.xr)
+    if (dense_dma() && (!vg.wo || K <= 512)) {
+#define TVAE_DX_DMA(V_)                                                                                               \
+    do {                                                                                                              \
+        const size_t rb_ = (V_) == 2 ? (size_t)8 * 2 * DX_A_SLOT : (size_t)DX_RING_BYTES;   /* no X ring when recomputed */ \
+        hipError_t e_ = allow_big_lds(dense_x6_dma_kernel<V_>, rb_);                                                  \
+        if (e_ != hipSuccess) return (int)e_;                                                                         \
+        hipLaunchKernelGGL(dense_x6_dma_kernel<V_>, dim3(tm.grid()), dim3(DX6_THREADS), rb_, st,                       \
+                           (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg, va); \
+    } while (0)
+        if (va.xr) TVAE_DX_DMA(2); else if (vg.wo) TVAE_DX_DMA(1); else TVAE_DX_DMA(0);
+#undef TVAE_DX_DMA
+    } else if (va.xr)
         hipLaunchKernelGGL(dense_x6_kernel<2>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)a3, X, ldx, ep,
                            rows, Rpad, N, K, K8pad, tm, DenseBatch{0, 0, 0}, cd, it, vg, va);
     else if (vg.wo)
@@ -481,6 +497,14 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, 128};
+        if (dense_dma()) {
+            hipError_t e_ = allow_big_lds(dense_x6_dma_kernel<0>, DX_RING_BYTES);
+            if (e_ != hipSuccess) return (int)e_;
+            hipLaunchKernelGGL(dense_x6_dma_kernel<0>, dim3(tm.grid()), dim3(DX6_THREADS), DX_RING_BYTES, st, (const uint4*)W3,
+                               (const float*)at, q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt,
+                               ColDot{nullptr, nullptr, nullptr}, InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
+                               VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f});
+        } else
         hipLaunchKernelGGL(dense_x6_kernel<0>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, (const uint4*)W3, (const float*)at,
                            q.NBpad, ep, 2 * q.M, Rpad, (int)q.NBpad, q.K2, K8pad, tm, bt, ColDot{nullptr, nullptr, nullptr},
                            InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
