@@ -865,7 +865,11 @@ void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* 
 constexpr int WG_SLOT_BYTES = 4096 + 1024 + 256;      // A | X (or coordinates 256 + latent term 256) | gy
 constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 
-template <bool VIRT, bool XVA>
+// LRF (implicit LeakyReLU gradient only): the implicit operand wo[m] * gy[n] * act'(H[m][n]) is factored -- gy[n] goes
+// into the X values before they are split, wo[m] onto the finished accumulator rows -- and what is left of the A operand
+// takes only the two values {1, slope}, whose three bf16 parts are constants: an A cell is two compares and three
+// selects per pair of elements instead of the 17 vector instructions of forming and splitting the product.
+template <bool VIRT, bool XVA, bool LRF>
 __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
@@ -965,7 +969,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) r[i][h] = *reinterpret_cast<const float4*>(sl + a_at[i][h]);
-        if (VIRT) {
+        if (VIRT && !LRF) {
             gq[0] = *reinterpret_cast<const float4*>(sl + 4096 + 1024 + 32 * khalf);
             gq[1] = *reinterpret_cast<const float4*>(sl + 4096 + 1024 + 32 * khalf + 16);
         }
@@ -987,10 +991,17 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + 64 * wave + 32 * i + (lane & 31);
-        a_ok[i] = m < M ? (VIRT ? vg.wo[m] : 1.f) : 0.f;
+        a_ok[i] = m < M ? ((VIRT && !LRF) ? vg.wo[m] : 1.f) : 0.f;
+    }
+    unsigned lr_lo[3] = {0, 0, 0}, lr_hi[3] = {0, 0, 0};  // bf16 parts of the slope, in the low / high half of a word
+    if (LRF) {
+        unsigned hw, mw, lw;
+        split3_pair(vg.slope, vg.slope, hw, mw, lw);
+        lr_lo[0] = hw & 0xffffu; lr_lo[1] = mw & 0xffffu; lr_lo[2] = lw & 0xffffu;
+        lr_hi[0] = hw & 0xffff0000u; lr_hi[1] = mw & 0xffff0000u; lr_hi[2] = lw & 0xffff0000u;
     }
     auto virt_a = [&](float4 (&r)[2][2], const float4 (&gq)[2]) {
-        if (VIRT) {
+        if (VIRT && !LRF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1000,6 +1011,20 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
     };
     auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
+        if (LRF) {                                       // cells of act'(H) in {1, slope}: 1 = (0x3f80, 0, 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float v[8] = {r[i][0].x, r[i][0].y, r[i][0].z, r[i][0].w, r[i][1].x, r[i][1].y, r[i][1].z, r[i][1].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool c0 = v[2 * q] > 0.f, c1 = v[2 * q + 1] > 0.f;
+                    a[i][0].w[q] = (c0 ? 0x3f80u : lr_lo[0]) | (c1 ? 0x3f800000u : lr_hi[0]);
+                    a[i][1].w[q] = (c0 ? 0u : lr_lo[1]) | (c1 ? 0u : lr_hi[1]);
+                    a[i][2].w[q] = (c0 ? 0u : lr_lo[2]) | (c1 ? 0u : lr_hi[2]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
@@ -1007,9 +1032,14 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             split3x8(v, a[i][0], a[i][1], a[i][2]);
         }
     };
-    auto store_b = [&](int stage, const float4& x) {
+    auto store_b = [&](int stage, const float4& x, int slot) {
         unsigned hw[2], mw[2], lw[2];
-        const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};
+        float4 gm = make_float4(b_ok, b_ok, b_ok, b_ok);
+        if (LRF) {                                       // gy of this thread's four columns joins the X values
+            const float4 g4 = *reinterpret_cast<const float4*>(ring + slot * WG_SLOT_BYTES + 4096 + 1024 + 16 * q4);
+            gm = make_float4(g4.x * b_ok, g4.y * b_ok, g4.z * b_ok, g4.w * b_ok);
+        }
+        const float v[4] = {x.x * gm.x, x.y * gm.y, x.z * gm.z, x.w * gm.w};
 #pragma unroll
         for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
@@ -1037,7 +1067,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         read_a(0, ar, g0);
         virt_a(ar, g0);
         split_a(ar, af);
-        store_b(0, read_x(0));
+        store_b(0, read_x(0), 0);
     }
     __syncthreads();
     int s_next = 1, s_dma = 0;                           // slot of step t+1, slot the DMAs of step t+3 go to (= t % 3)
@@ -1060,7 +1090,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
                 virt_a(ar, gn);
                 split_a(ar, an);
             }
-            if (j == 1) store_b(cur ^ 1, read_x(s_next));   // B cells of step t+1
+            if (j == 1) store_b(cur ^ 1, read_x(s_next), s_next);   // B cells of step t+1
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1078,10 +1108,11 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= M) continue;
+            const float wm = LRF ? vg.wo[m] : 1.f;       // the row factor of the factored implicit gradient
             float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = acc[i][j][r];
+                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = LRF ? acc[i][j][r] * wm : acc[i][j][r];
         }
 }
 

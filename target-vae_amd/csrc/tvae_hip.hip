@@ -132,6 +132,11 @@ static bool dense_dma() {
     static const bool on = [] { const char* e_ = getenv("TVAE_DENSE_DMA"); return e_ && e_[0] == '1'; }();
     return on;
 }
+// TVAE_WGRAD_LRF=0: implicit LeakyReLU gradient formed and split per element instead of the factored two-valued form
+static bool wgrad_lrf() {
+    static const bool on = [] { const char* e_ = getenv("TVAE_WGRAD_LRF"); return !(e_ && e_[0] == '0'); }();
+    return on;
+}
 // TVAE_WGRAD_DMA=0: weight-gradient GEMM with per-lane A loads instead of the LDS-DMA ring (dense_x6_kernels.hpp)
 static bool wgrad_dma() {
     static const bool on = [] { const char* e_ = getenv("TVAE_WGRAD_DMA"); return !(e_ && e_[0] == '0'); }();
@@ -413,11 +418,19 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
 #define TVAE_WG_LAUNCH(V_, X_)                                                                                        \
     do {                                                                                                              \
         if (wgrad_dma() && (!va_xr || va_np % 16 == 0)) {                                                             \
-            hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_>, WG_RING_BYTES);                          \
-            if (e_ != hipSuccess) return (int)e_;                                                                     \
-            hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), WG_RING_BYTES, \
-                               S(stream), dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, \
-                               ATILE_PLAIN);                                                                          \
+            if ((V_) && vg_act == ACT_LRELU && wgrad_lrf()) {                                                         \
+                hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, V_>, WG_RING_BYTES);                  \
+                if (e_ != hipSuccess) return (int)e_;                                                                 \
+                hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_, V_>), dim3(tmk.grid()), dim3(DX6_THREADS),       \
+                                   WG_RING_BYTES, S(stream), dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk,             \
+                                   DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN);                                   \
+            } else {                                                                                                  \
+                hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, false>, WG_RING_BYTES);               \
+                if (e_ != hipSuccess) return (int)e_;                                                                 \
+                hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_, false>), dim3(tmk.grid()), dim3(DX6_THREADS),    \
+                                   WG_RING_BYTES, S(stream), dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk,             \
+                                   DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN);                                   \
+            }                                                                                                         \
         } else {                                                                                                      \
             hipLaunchKernelGGL((dense_wgrad_x6_kernel<V_, X_>), dim3(tmk.grid()), dim3(DX6_THREADS), 0, S(stream), dpre, \
                                ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN); \
@@ -620,9 +633,9 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         if (wgrad_dma()) {
-            hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<false, false>, WG_RING_BYTES);
+            hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<false, false, false>, WG_RING_BYTES);
             if (e_ != hipSuccess) return (int)e_;
-            hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), WG_RING_BYTES,
+            hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<false, false, false>), dim3(tmk.grid()), dim3(DX6_THREADS), WG_RING_BYTES,
                                st, (const float*)Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk,
                                tmk, bt, 128L, VirtGrad{nullptr, nullptr, 0, 0.f},
                                VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, ATile{7, 127, (long)M2 * q.Lh * 128});
