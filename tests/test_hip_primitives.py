@@ -659,7 +659,8 @@ print('ERRS', e1, e2, e3)
 '''
 
 
-@pytest.mark.parametrize('env', [{}, {'TVAE_WGRAD_DMA': '0'}, {'TVAE_DFT_W_VALU': '1'}, {'TVAE_DENSE_DMA': '1'}])
+@pytest.mark.parametrize('env', [{}, {'TVAE_WGRAD_DMA': '0'}, {'TVAE_DFT_W_VALU': '1'}, {'TVAE_DENSE_DMA': '1'},
+                                 {'TVAE_WGRAD_LRF': '0'}])
 def test_alternative_kernel_paths(env):
     """The kernels behind the environment switches (per-lane-load weight gradient, vector-ALU transforms along w) stay
     correct: the same fp64 comparison in a fresh process per setting (the switches are read once per process)."""
