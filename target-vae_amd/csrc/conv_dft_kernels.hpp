@@ -14,8 +14,9 @@
 // followed by a small inverse DFT per filter.  Everything else here is small streaming work:
 //   dft_image_kernel   y -> A^T[fx][(re/im, fy)][(b,h)]           (one workgroup per image, DFT by direct sums in LDS)
 //   dft_bank_kernel    bank -> W[fx][m | M+m][(re/im, fy)]         (one workgroup per filter)
-//   dft_out_kernel     T -> out (+bias, activation)                (contraction over fx on the vector ALU)
-//   dft_dy_kernel      dY -> S'[fx][m | M+m][(b,h)]
+//   dft_out_mf_kernel  T -> out (+bias, activation)                (contraction over fx: fp32 MFMA, constant operand in LDS)
+//   dft_dy_mf_kernel   dY -> S'[m | M+m][fx][(b,h)]                (DFT over w: fp32 MFMA, constant operand in registers)
+//   dft_out_kernel / dft_dy_kernel                                  (the same two on the vector ALU: TVAE_DFT_W_VALU)
 //   dft_dbank_kernel   G[fx][m | M+m][(re/im, fy)] -> dbank        (inverse DFT per filter, cropped to ksz x ksz)
 // Single input channel (Cin = 1: MNIST / particle configurations).  Twiddles: sincospi of exactly reduced angles.
 #pragma once
