@@ -130,6 +130,30 @@ def cpu_baseline(batch=32, steps=4):
                        f'min; torch {torch.__version__} CPU, {cores} threads')
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: this parent never touches the GPU (device_count does
+    not initialise HIP); it starts one child per GPU with the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), lets rank 0 print the JSON line and returns the worst exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) are visible', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -142,6 +166,8 @@ def main():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='S64',
                     help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     from tvae import dp, ops, optim, step
     from tvae import _lib
@@ -160,8 +186,9 @@ def main():
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
     opt = optim.FlatAdam(params, lr=2e-4, reducer=reducer)
-    if world > 1:                                   # identical replicas: broadcast rank 0's flat parameters
+    if world > 1:                                   # identical replicas: rank 0's flat parameters and every buffer
         dist.broadcast(opt.flat_p, src=0)
+        dp.broadcast_buffers(gen, enc)
 
     B, c = args.batch, wl
     total_steps = args.steps + args.warmup

@@ -29,6 +29,16 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def broadcast_buffers(*modules, src: int = 0, group=None):
+    """Replicas must agree on every BUFFER too: RandomFourierEmbedding2d.weight / .bias are random buffers
+    (src/models.py:37-39 of the reference), not parameters, so the flat-parameter broadcast does not cover them."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for m in modules:
+        for b in m.buffers():
+            dist.broadcast(b, src=src, group=group)
+
+
 class GradReducer:
     """Sum all-reduce of the flat gradient buffer; returns the scale Adam applies (1/world for equal shards).
 
@@ -75,8 +85,9 @@ def epoch_permutation(n_items: int, seed: int, epoch: int, shuffle: bool = True)
 
 class ShardedBatches:
     """Iterator of (y,) minibatch shards over a device-resident dataset tensor (the reference keeps the whole
-    dataset on the device, train_mnist.py:495).  Empty shards (ragged tail smaller than world) are skipped by
-    the reducer weight being 0 -- they still take part in the collective."""
+    dataset on the device, train_mnist.py:495).  A ragged tail smaller than the number of ranks gives some ranks an
+    EMPTY shard (b = 0): the iterator still yields it (reducer weight 0) and tvae.step.train_epoch / eval_model skip
+    the forward/backward for it while still joining the gradient all-reduce and the Adam step."""
 
     def __init__(self, data, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
                  seed: int = 0, reducer: GradReducer = None):

@@ -27,7 +27,7 @@ DEFAULTS = {
     'mnist':    (28,    8,   1,    50,       2,         9,       0.0),
     'particles': (64,   16,  1,    None,     2,         9,       1e-6),
     'galaxy':   (64,    32,  3,    64,       4,         10,      0.0),
-    'dsprites': (64,    32,  1,    64,       2,         9,       0.0),
+    'dsprites': (64,    32,  1,    64,       2,         9,       1e-6),     # train_dsprites.py:537
 }
 
 
@@ -86,14 +86,16 @@ def build_parser(kind: str) -> argparse.ArgumentParser:
 
 
 def _load_arrays(kind, args):
-    """Returns (train, test) float tensors shaped (N, Cin, n, n) and the dataset name used in the log dir."""
+    """Returns (train, test) float tensors shaped (N, Cin, n, n), the dataset name used in the log dir and the image
+    side BEFORE --crop (the particles CTF kernels are sized from it, train_particles.py:540-577)."""
     if args.synthetic > 0:
-        n = getattr(args, 'image_dim', None) or 64
+        n = getattr(args, 'image_dim', None) or getattr(args, 'crop', 0) or 64    # particles: --crop sets the side
         cin = args.in_channels
         g = torch.Generator().manual_seed(0)
         mk = (lambda m: torch.randn(m, cin, n, n, generator=g)) if kind == 'particles' else \
             (lambda m: torch.rand(m, cin, n, n, generator=g))
-        return mk(args.synthetic), mk(max(args.synthetic // 10, 1)), getattr(args, 'dataset', kind)
+        name = getattr(args, 'dataset', None) or ('synthetic' if kind == 'particles' else kind)
+        return mk(args.synthetic), mk(max(args.synthetic // 10, 1)), name, n
     if kind == 'mnist':
         if args.dataset == 'mnist':
             try:
@@ -111,17 +113,17 @@ def _load_arrays(kind, args):
             a, b = np.load(f'data/{sub}/images_train.npy'), np.load(f'data/{sub}/images_test.npy')
         tr, te = torch.from_numpy(a).float() / 255, torch.from_numpy(b).float() / 255
         n = args.image_dim
-        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), args.dataset
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), args.dataset, n
     if kind == 'galaxy':
         tr = torch.from_numpy(np.load(args.train_path)).float() / 255
         te = torch.from_numpy(np.load(args.test_path)).float() / 255
         n = args.image_dim                              # raw reinterpretation like the reference (train_galaxy.py:454)
-        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'galaxy'
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'galaxy', n
     if kind == 'dsprites':
         tr = torch.from_numpy(np.load(args.train_path)[:1000]).float()      # reference truncation, train_dsprites.py:436
         te = torch.from_numpy(np.load(args.test_path)[:100]).float()
         n = args.image_dim
-        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'dsprites'
+        return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'dsprites', n
     # particles: .npy stacks or MRC/MRCS stacks (train_particles.py:454-461)
     def load(path):
         if path.endswith('.npy'):
@@ -137,6 +139,7 @@ def _load_arrays(kind, args):
         allim = load(args.train_path)
         k = int(allim.shape[0] * args.train_portion)
         a, b = allim[:k], allim[k:]
+    n_raw = a.shape[-1]
     if args.crop > 0:
         def crop(s, m):
             n0 = s.shape[-1]
@@ -150,11 +153,14 @@ def _load_arrays(kind, args):
         a, b = norm(a), norm(b)
     n = a.shape[-1]
     tr, te = torch.from_numpy(a).float(), torch.from_numpy(b).float()
-    return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'particles'
+    # log directory name: the training path with '/' -> '-' (train_particles.py:729-731)
+    return (tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n),
+            args.train_path.replace('/', '-'), n_raw)
 
 
 def _load_ctf(args, n_train, n_test, n):
-    """Real-space CTF kernels per image (train_particles.py:540-577): odd size n-1 for even images."""
+    """Real-space CTF kernels per image (train_particles.py:540-577): odd size n-1 for even images, where n is the
+    side of the stack as loaded, BEFORE --crop (the reference sizes the kernels first and crops afterwards)."""
     if not getattr(args, 'ctf_train', None):
         return None, None
     from src import ctf as C
@@ -179,7 +185,7 @@ def run(kind: str, argv=None):
     digits = int(np.log10(num_epochs)) + 1
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    y_train, y_test, dataset_name = _load_arrays(kind, args)
+    y_train, y_test, dataset_name, n_raw = _load_arrays(kind, args)
     image_dim = y_train.shape[-1]
     in_channels = y_train.shape[1]
     if not torch.cuda.is_available() or args.device == -1:
@@ -191,7 +197,7 @@ def run(kind: str, argv=None):
         print('# using device:', device, f'(rank {rank}/{world})', file=sys.stderr)
     ctf_train = ctf_test = None
     if kind == 'particles' and not args.synthetic:
-        ctf_train, ctf_test = _load_ctf(args, len(y_train), len(y_test), image_dim)
+        ctf_train, ctf_test = _load_ctf(args, len(y_train), len(y_test), n_raw)
     y_train, y_test = y_train.to(device), y_test.to(device)        # whole dataset resident (train_mnist.py:495)
     if ctf_train is not None:
         ctf_train, ctf_test = ctf_train.to(device), ctf_test.to(device)
@@ -210,6 +216,10 @@ def run(kind: str, argv=None):
     t_inf, r_inf, group_conv = args.t_inf, args.r_inf, args.groupconv
     if kind == 'mnist' and args.dataset == 'mnist-N':
         theta_prior, normal_prior_over_r = np.pi / 4, True          # train_mnist.py:538-543
+    elif kind == 'dsprites':
+        # train_dsprites.py:509-523 sets normal_prior_over_r = False but never passes it to the encoder, so the
+        # constructor default (True) applies: p(r) = Normal(0, pi) over the offsets
+        theta_prior, normal_prior_over_r = np.pi, True
     else:
         theta_prior, normal_prior_over_r = np.pi, False
     if t_inf == 'unimodal' and r_inf == 'unimodal':                 # secondary encoders (train_mnist.py:546-557)
@@ -243,7 +253,15 @@ def run(kind: str, argv=None):
     reducer = dp.GradReducer() if world > 1 else None
     optimizer = optim.FlatAdam(params, lr=args.learning_rate, reducer=reducer)
     if world > 1:
-        torch.distributed.broadcast(optimizer.flat_p, src=0)       # identical replicas
+        torch.distributed.broadcast(optimizer.flat_p, src=0)       # identical replicas: parameters ...
+        dp.broadcast_buffers(generator_model, encoder_model)       # ... and the random Fourier buffers
+    # the shared seed covers init and the epoch permutation; the per-step noise (Exp(1), N(0,1)) comes from a
+    # per-rank stream so that the shards of one global minibatch see independent draws
+    if world > 1 or args.seed is not None:
+        noise_gen = torch.Generator(device=device)
+        noise_gen.manual_seed((args.seed if args.seed is not None else int(torch.initial_seed() % (1 << 31))) * world
+                              + rank + 1)
+        step.set_noise_generator(device, noise_gen)
     patience, min_lr = DEFAULTS[kind][5], DEFAULTS[kind][6]
     scheduler = ReduceLROnPlateau(optimizer, mode='max', factor=0.5, patience=patience, threshold=1e-4,
                                   threshold_mode='abs', cooldown=0, min_lr=min_lr, eps=1e-08)
@@ -269,6 +287,11 @@ def run(kind: str, argv=None):
                          'translation', t_inf, 'rotation', r_inf])
         if group_conv > 0:
             desc += '_groupconv' + str(group_conv)
+        if kind == 'particles':                                     # train_particles.py:734-737
+            if getattr(args, 'ctf_train', None):
+                desc += '_ctf'
+            if args.fourier_expansion:
+                desc += '_Fr_sigma' + str(fourier_sigma)
         path_prefix = os.path.join(args.log_root, desc, '')
         os.makedirs(path_prefix, exist_ok=True)
         print('# learning-rate is {}'.format(args.learning_rate))

@@ -64,6 +64,14 @@ class _timed:
         return False
 
 
+PATH_LOG = None          # set to a set() to record which fused branches a step actually took (tests assert on it)
+
+
+def _note(name: str) -> None:
+    if PATH_LOG is not None:
+        PATH_LOG.add(name)
+
+
 def kernel_event_ms():
     """Mean milliseconds per launch for every recorded entry point (call after torch.cuda.synchronize())."""
     out = {}
@@ -216,6 +224,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
         at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), dtype=torch.float32,
                          device=y.device)
         ws = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
+        _note('conv1.dft')
         with _timed('tvae_conv1_fwd'):
             call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,
                  LRELU_SLOPE)
@@ -225,9 +234,11 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
     if _use_x6(Cin, n, k, pad):
         a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
         call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k)
+        _note('conv1.x6')
         with _timed('tvae_conv1_fwd'):
             call('tvae_conv1_fwd_x6', y, a3, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
         return out
+    _note('conv1.f32')
     with _timed('tvae_conv1_fwd'):
         call('tvae_conv1_fwd', y, bank, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
     return out
@@ -499,7 +510,7 @@ class DecoderFn(torch.autograd.Function):
         va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if virt_act else None
         h = None if virt_act else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
         if virt_act:
-            pass
+            _note('dec.virt_act')
         elif Wf is not None:
             Ff = Wf.shape[0]
             zx = Wl.shape[1] if (four_x6 and Wl is not None) else 0
@@ -507,6 +518,7 @@ class DecoderFn(torch.autograd.Function):
             feat = feat_all[:Ff]
             call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, Nt, Ff, Nt)
             if four_x6:
+                _note('dec.four_x6')
                 if zx:
                     feat_all[Ff:].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
                 w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
@@ -531,6 +543,7 @@ class DecoderFn(torch.autograd.Function):
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)))
                 fused_out = fuse
+                _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
                      Nt, Nt, act, LRELU_SLOPE)
@@ -572,6 +585,8 @@ class DecoderFn(torch.autograd.Function):
         call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
              part.numel(), tot)
         vg = (Wo.contiguous().view(-1), gy.view(-1), act) if virt else None
+        if virt:
+            _note('dec.virt_grad')
         dWo, drow = tot[1:], tot[0]
         grads_hidden = []
         fused_in = False
@@ -601,6 +616,8 @@ class DecoderFn(torch.autograd.Function):
                          vg[0] if use_vg else None, vg[1] if use_vg else None,
                          bc if va else None, LB if va else None, Np if va else 0)
                 fused_in = fuse_in
+                if fuse_in:
+                    _note('dec.fuse_in')
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
                      act, LRELU_SLOPE)

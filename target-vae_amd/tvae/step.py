@@ -28,9 +28,22 @@ def pixel_spacing(x_coord: torch.Tensor) -> float:
     return v
 
 
+_NOISE_GEN = {}
+
+
+def set_noise_generator(device, generator: Optional[torch.Generator]) -> None:
+    """Generator the per-step draws of `elbo_terms` use on `device` (None = torch's default device generator).
+    Data-parallel runs give every rank its own stream so that the noise of a global minibatch is independent across
+    its shards, as it is in a single-process run (tvae/driver.py)."""
+    _NOISE_GEN[(torch.device(device).type, torch.device(device).index)] = generator
+
+
 def draw_noise(B: int, RP: int, zd: int, device, generator: Optional[torch.Generator] = None):
     """The three per-step draws of the reference, in its order: Exp(1) for the Gumbel-softmax
     (models.py:387), N(0,1) for z (train_mnist.py:206) and for theta (train_mnist.py:230)."""
+    if generator is None and _NOISE_GEN:
+        d = torch.device(device)
+        generator = _NOISE_GEN.get((d.type, d.index))
     E = torch.empty(B, RP, dtype=torch.float32, device=device).exponential_(generator=generator)
     eps_z = torch.randn(B, zd, dtype=torch.float32, device=device, generator=generator)
     eps_t = torch.randn(B, dtype=torch.float32, device=device, generator=generator)
@@ -130,6 +143,12 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
         y = mb[0]
         b = y.size(0)
         noise = next(noise_iter) if noise_iter is not None else None
+        if b == 0:
+            # ragged tail smaller than the number of ranks: this rank has no image of the global minibatch, but it
+            # still joins the gradient all-reduce (zero gradient, reducer weight 0) and takes the same Adam step
+            optim.step()
+            optim.zero_grad()
+            continue
         if mask_radius is not None:
             elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None, generator_model,
                                                        encoder_model, t_inf, r_inf, epoch, device, theta_prior,
@@ -156,7 +175,7 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
 
 
 def eval_model(iterator, x_coord, generator_model, encoder_model, t_inf, r_inf, epoch, device, theta_prior,
-               groupconv, image_dim, likelihood='bce', mask_radius=None):
+               groupconv, image_dim, likelihood='bce', mask_radius=None, noise_iter=None):
     """Reference train_mnist.py:352-387 (noise is still drawn in eval); particles variant
     (train_particles.py:413-470) when `mask_radius` is not None."""
     generator_model.eval()
@@ -167,13 +186,16 @@ def eval_model(iterator, x_coord, generator_model, encoder_model, t_inf, r_inf, 
         for mb in iterator:
             y = mb[0]
             b = y.size(0)
+            noise = next(noise_iter) if noise_iter is not None else None
+            if b == 0:
+                continue                     # empty shard of a ragged tail: nothing to evaluate on this rank
             if mask_radius is not None:
                 elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None,
                                                            generator_model, encoder_model, t_inf, r_inf, epoch, device,
-                                                           theta_prior, groupconv, image_dim, mask_radius)
+                                                           theta_prior, groupconv, image_dim, mask_radius, noise)
             else:
                 elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch,
-                                                 device, theta_prior, groupconv, image_dim, likelihood)
+                                                 device, theta_prior, groupconv, image_dim, likelihood, noise)
             stats = torch.stack([elbo.double(), log_p.double(), kl.double()]).tolist()
             c += b
             gen_loss_accum += b * (-stats[1] - gen_loss_accum) / c

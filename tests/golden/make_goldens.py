@@ -452,6 +452,67 @@ def gen_epoch():
     print('    epoch', elbo, err, kl)
 
 
+def param_digest(t):
+    """(sum, abs-sum, first, last) in float64: enough to detect any difference in seeded construction."""
+    t = t.detach().double().reshape(-1)
+    return np.array([float(t.sum()), float(t.abs().sum()), float(t[0]), float(t[-1])])
+
+
+def gen_hotpath():
+    """Full-WIDTH steps that reach the fused split-pipe decoder branches bench.py times (ops._dense_x6_ok + virt_act +
+    virt + fuse_in; the Fourier [Wc | Wl] first layer): S64 widths (n=64 -> 4096 pixels per image, hidden 512, C=128,
+    B=2) and S28F (n=28, P16, Fourier 1024 -> 512 -> 512 -> 1, B=8: 6272 pixels = 49 x 128).  The parameters are the
+    reference's default init under a seed (generator first, then encoder, head weights scaled so that attention is
+    peaked); the fixture stores the SEED and a digest of every state_dict entry instead of 3-4 MB of parameter arrays,
+    plus the inputs, the injected noise, the three ELBO terms and EVERY parameter gradient from the real
+    train_particles / train_mnist eval_minibatch."""
+    cases = [
+        ('hot_S64_B2', train_particles, dict(n=64, cin=1, zd=2, C=128, k=64, p=16, R=8, hidden=512, layers=2, n_out=1,
+                                             fourier=False), 2, 'randn', 10.0, True, 31),
+        ('hot_S28F_B8', train_mnist, dict(n=28, cin=1, zd=2, C=128, k=28, p=8, R=16, hidden=512, layers=2, n_out=1,
+                                          fourier=True), 8, 'rand', 10.0, False, 32),
+    ]
+    for name, tm, c, B, data, scale, particles, seed in cases:
+        n, R, zd, p = c['n'], c['R'], c['zd'], c['p']
+        sigma = 2.0 / (n - 1)
+        torch.manual_seed(seed)
+        gen = models.SpatialGenerator(zd, c['hidden'], n_out=c['n_out'], num_layers=c['layers'], resid=False,
+                                      fourier_expansion=c['fourier'], sigma=sigma)
+        enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+            n, c['cin'], zd, kernels_num=c['C'], kernels_size=c['k'], padding=p, groupconv=R, rot_refinement=True,
+            theta_prior=np.pi, normal_prior_over_r=False)
+        with torch.no_grad():
+            for nm in ('conv_a', 'conv_r', 'conv_z'):
+                getattr(enc, nm).weight.mul_(scale)
+        torch.manual_seed(seed + 1000)
+        y = torch.rand(B, c['cin'], n, n) if data == 'rand' else torch.randn(B, c['cin'], n, n)
+        Ho = n + 2 * p - c['k'] + 1
+        E, eps_z, eps_t = draw_noise(123, B, R * Ho * Ho, zd)
+        torch.manual_seed(123)
+        if particles:
+            elbo, logp, kl = tm.eval_minibatch(coords(n), y, None, gen, enc, 'attention', 'attention+offsets', 0,
+                                               'cpu', np.pi, R, p, 0)
+        else:
+            elbo, logp, kl = tm.eval_minibatch(coords(n), y, gen, enc, 'attention', 'attention+offsets', 0, 'cpu',
+                                               np.pi, R, n)
+        (-elbo).backward()
+        out = dict(y=y, E=E, eps_z=eps_z, eps_theta=eps_t, elbo=elbo, log_p=logp, kl=kl,
+                   cfg=np.array([n, c['cin'], zd, c['C'], c['k'], p, R, 1, 0, c['hidden'], c['layers'], c['n_out'],
+                                 int(c['fourier']), 0]),
+                   theta_prior=np.float64(np.pi), sigma=np.float64(sigma), seed=np.int64(seed),
+                   scale_heads=np.float64(scale))
+        for k_, v in enc.state_dict().items():
+            out['se.' + k_] = param_digest(v)
+        for k_, v in gen.state_dict().items():
+            out['sd.' + k_] = param_digest(v)
+        for k_, v in enc.named_parameters():
+            out['ge.' + k_] = v.grad
+        for k_, v in gen.named_parameters():
+            out['gd.' + k_] = v.grad
+        save(name, **out)
+        print('   ', name, 'elbo', float(elbo), 'log_p', float(logp), 'kl', float(kl))
+
+
 def gen_cli():
     """argparse surface of the four reference scripts (flags, defaults, choices) -> cli_flags.json."""
     import argparse
@@ -491,7 +552,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc', 'secondary']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc', 'secondary', 'hotpath']
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc, 'secondary': gen_secondary}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc, 'secondary': gen_secondary, 'hotpath': gen_hotpath}[w]()

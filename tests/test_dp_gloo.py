@@ -112,3 +112,94 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert rel_err(r0['flat'][k_], flat1[k_]) < 2e-4, k_          # == the single-process global-batch run
     assert r0['stats'][1] == stats1[1] == 2 * N_IMG
     assert abs(r0['stats'][0] - stats1[0]) / abs(stats1[0]) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ragged tail smaller than the number of ranks (empty shard) + random Fourier BUFFERS that differ per rank at
+# construction: the product's train_epoch / eval_model / broadcast_buffers must keep the replicas identical and equal to
+# the single-process run
+N2, GB2 = 13, 6          # global minibatches of 6, 6, 1 -> rank 1 holds no image of the last one
+
+
+def _train_epoch_product(rank, world):
+    from oracle import tvae_oracle as O
+    from tvae import dp, optim, step
+    import src.models as M
+    torch.manual_seed(3 + 17 * rank)            # replicas start DIFFERENT (unseeded construction in the driver)
+    gen = M.SpatialGenerator(ZD, 8, num_layers=2, fourier_expansion=True, sigma=2.0 / (NPIX - 1))
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        NPIX, 1, ZD, kernels_num=4, kernels_size=12, padding=2, groupconv=4, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False)
+    params = list(gen.parameters()) + list(enc.parameters())
+    reducer = dp.GradReducer() if world > 1 else None
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    if world > 1:
+        dist.broadcast(opt.flat_p, src=0)
+        dp.broadcast_buffers(gen, enc)
+    g = torch.Generator().manual_seed(11)
+    data = torch.rand(N2, 1, NPIX, NPIX, generator=g)
+    E = torch.empty(N2, 4 * HO * HO).exponential_(generator=g)
+    ez, et = torch.randn(N2, ZD, generator=g), torch.randn(N2, generator=g)
+    x = O.image_coords(NPIX)
+    cfg = dict(CFG, fourier_sigma=2.0 / (NPIX - 1))
+
+    def oracle_minibatch(xc, y, gm, em, t_inf, r_inf, epoch, device, theta_prior, groupconv, image_dim, likelihood='bce',
+                         noise=None):
+        gsd = dict(gm.named_parameters())
+        gsd.update(dict(gm.named_buffers()))
+        return O.elbo_step(xc, y, dict(em.named_parameters()), gsd, likelihood='bce', E=noise[0], eps_z=noise[1],
+                           eps_theta=noise[2], **cfg)
+
+    step.eval_minibatch = oracle_minibatch       # the HIP kernels need a GPU; the host logic under test is the loop
+    batches = dp.ShardedBatches(data, GB2, rank, world, shuffle=True, seed=5, reducer=reducer)
+    perm = dp.epoch_permutation(N2, 5, 0)
+    noise = [(E[perm[lo:hi]], ez[perm[lo:hi]], et[perm[lo:hi]]) for lo, hi, _ in dp.shard_slices(N2, GB2, rank, world)]
+    sizes = [hi - lo for lo, hi, _ in dp.shard_slices(N2, GB2, rank, world)]
+    tr = step.train_epoch(batches, x, gen, enc, opt, 'attention', 'attention+offsets', 0, 1, max(sum(sizes), 1), 'cpu',
+                          params, np.pi, 4, NPIX, progress=False, noise_iter=iter(noise))
+    test_it = dp.ShardedBatches(data, GB2, rank, world, shuffle=False, seed=5)
+    noise_t = [(E[lo:hi], ez[lo:hi], et[lo:hi]) for lo, hi, _ in dp.shard_slices(N2, GB2, rank, world)]
+    ev = step.eval_model(test_it, x, gen, enc, 'attention', 'attention+offsets', 0, 'cpu', np.pi, 4, NPIX,
+                         noise_iter=iter(noise_t))
+    tot = dp.allreduce_stats([tr[0] * sum(sizes), ev[0] * sum(sizes), float(sum(sizes))], torch.device('cpu'))
+    named = {'d.' + k_: v.detach().clone() for k_, v in gen.state_dict().items()}
+    named.update({'e.' + k_: v.detach().clone() for k_, v in enc.state_dict().items()})
+    return named, tot, sizes
+
+
+def _worker2(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tvae import dp
+    dp.init_from_env(backend='gloo')
+    named, tot, sizes = _train_epoch_product(rank, world)
+    torch.save(dict(named=named, tot=tot, sizes=sizes), os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_empty_shard_and_fourier_buffers(tmp_path):
+    torch.set_num_threads(4)
+    from tvae import step
+    keep = step.eval_minibatch
+    try:
+        one, tot1, _ = _train_epoch_product(0, 1)
+    finally:
+        step.eval_minibatch = keep
+    mp.spawn(_worker2, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    assert r0['sizes'] == [3, 3, 1] and r1['sizes'] == [3, 3, 0]                 # rank 1's last shard is empty
+    for k_ in one:
+        assert torch.isfinite(r1['named'][k_]).all(), k_                          # no NaN from an empty mean
+        assert torch.equal(r0['named'][k_], r1['named'][k_]), k_                  # replicas identical, buffers included
+        if k_ == 'e.conv_a.bias':
+            continue
+        assert rel_err(r0['named'][k_], one[k_]) < 2e-4, k_                       # == single process, global batches
+    assert r0['tot'][2] == tot1[2] == N2
+    for i in (0, 1):
+        assert abs(r0['tot'][i] - tot1[i]) / abs(tot1[i]) < 1e-5

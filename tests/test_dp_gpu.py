@@ -31,9 +31,10 @@ def _models(dev):
     return gen.to(dev), enc.to(dev)
 
 
-def _train(rank, world):
+def _train(rank, world, dev_index=0):
     from tvae import dp, optim, step, tables
-    dev = torch.device('cuda:0')
+    dev = torch.device('cuda', dev_index)
+    torch.cuda.set_device(dev)
     gen, enc = _models(dev)
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
@@ -94,3 +95,51 @@ def test_two_ranks_on_gpu_match_single_process(tmp_path):
         assert rel_err(r0['named'][k_], named1[k_]) < 2e-4, k_
     assert r0['tot'][1] == tot1[1] == 2 * N_IMG
     assert abs(r0['tot'][0] - tot1[0]) / abs(tot1[0]) < 1e-5
+
+
+def _worker_rccl(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from tvae import dp
+    r, w, local = dp.init_from_env(backend='nccl')          # "nccl" IS RCCL on ROCm; one process per GPU
+    assert dist.get_backend() == 'nccl' and local == rank
+    named, tot = _train(rank, world, dev_index=local)
+    torch.save(dict(named=named, tot=tot), os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL parity needs 2 GPUs (one process per GPU)')
+def test_two_ranks_rccl_match_single_process(tmp_path):
+    """The same comparison over RCCL: one process per GPU, flat-gradient all-reduce on the nccl backend."""
+    named1, tot1 = _train(0, 1)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.start_processes(_worker_rccl, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    for k_ in named1:
+        assert torch.equal(r0['named'][k_], r1['named'][k_]), k_
+        if k_ == 'e.conv_a.bias':
+            continue
+        assert rel_err(r0['named'][k_], named1[k_]) < 2e-4, k_
+    assert r0['tot'][1] == tot1[1] == 2 * N_IMG
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs 2 GPUs')
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun): the parent starts one RCCL rank per GPU and rank 0 prints n_gpus = 2."""
+    import json
+    import subprocess
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--workload', 'S28', '--no-cpu-baseline'], capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 512 and line['value'] > 0

@@ -1,0 +1,120 @@
+"""The four command-line drivers and eval_model on the GPU.
+
+Reference behaviour pinned here: stdout TSV `Epoch Split ELBO Error KL` with one train and one test line per epoch
+(train_mnist.py:590,640-664), the `training_logs/<timestamp>_<dataset>_zDim_<z>_translation_<t>_rotation_<r>[_groupconvR]`
+directory with train_log.txt, generator.sav / inference.sav (best test ELBO, src/utils.py:37-48) and
+generator_epochNNN.sav / inference_epochNNN.sav every --save-interval epochs (train_mnist.py:672-681), all of them
+whole-module pickles that reload as src.models.* classes."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, load_golden, tdict
+from oracle import tvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ['--minibatch-size', '8', '--num-epochs', '2', '--save-interval', '1', '--encoder-kernel-number', '8',
+         '--generator-hidden-dim', '32', '--encoder-kernel-size', '20', '--encoder-padding', '4', '--seed', '3',
+         '--synthetic', '20']
+CASES = {
+    'train_mnist': (['--dataset', 'mnist-U', '--image-dim', '20', '-z', '2'], r'mnist-U_zDim_2'),
+    'train_particles': (['--crop', '20', '-z', '2', '--mask-radius', '7', '--fourier-expansion'],
+                        r'synthetic_zDim_2'),
+    'train_galaxy': (['--image-dim', '20', '-z', '5', '--groupconv', '4'], r'galaxy_zDim_5'),
+    'train_dsprites': (['--image-dim', '20', '-z', '2', '--r-inf', 'attention'], r'dsprites_zDim_2'),
+}
+
+
+@pytest.mark.parametrize('script', sorted(CASES))
+def test_cli_two_epochs(script, tmp_path):
+    extra, stem = CASES[script]
+    cmd = [sys.executable, os.path.join(PKG, script + '.py')] + SMALL + extra + ['--log-root', str(tmp_path / 'logs')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [ln.split('\t') for ln in r.stdout.splitlines() if '\t' in ln]
+    assert rows[0] == ['Epoch', 'Split', 'ELBO', 'Error', 'KL']
+    body = rows[1:]
+    assert [(b[0], b[1]) for b in body] == [('1', 'train'), ('1', 'test'), ('2', 'train'), ('2', 'test')]
+    vals = np.array([[float(v) for v in b[2:]] for b in body])
+    assert np.isfinite(vals).all()
+    assert np.allclose(vals[:, 0], -vals[:, 1] - vals[:, 2], rtol=1e-6)           # ELBO = -(Error) - KL
+    assert '#ELBO increased' in r.stdout                                            # src/utils.py:40 message
+    dirs = glob.glob(str(tmp_path / 'logs' / '*'))
+    assert len(dirs) == 1
+    name = os.path.basename(dirs[0])
+    gc = '4' if script == 'train_galaxy' else '8'
+    r_inf = 'attention' if script == 'train_dsprites' else 'attention\\+offsets'
+    pat = r'^\d{4}-\d{2}-\d{2}-\d{2}-\d{2}_' + stem + '_translation_attention_rotation_' + r_inf + '_groupconv' + gc
+    if script == 'train_particles':
+        pat += r'_Fr_sigma' + re.escape(str(2.0 / 19))                              # train_particles.py:736-737
+    assert re.match(pat + '$', name), name
+    files = sorted(os.listdir(dirs[0]))
+    assert files == ['generator.sav', 'generator_epoch1.sav', 'generator_epoch2.sav', 'inference.sav',
+                     'inference_epoch1.sav', 'inference_epoch2.sav', 'train_log.txt'], files
+    log = open(os.path.join(dirs[0], 'train_log.txt')).read()
+    assert log.startswith(name) and 'Epoch\tSplit\tELBO\tError\tKL' in log and '2\ttest\t' in log
+    # whole-module pickles reload as the drop-in classes and evaluate on the device
+    sys.path.insert(0, PKG)
+    import src.models as M
+    from tvae import step, tables
+    gen = torch.load(os.path.join(dirs[0], 'generator.sav'), weights_only=False)
+    enc = torch.load(os.path.join(dirs[0], 'inference.sav'), weights_only=False)
+    assert type(gen) is M.SpatialGenerator and type(enc) is M.InferenceNetwork_AttentionTranslation_AttentionRotation
+    assert not gen.training and not enc.training and next(gen.parameters()).device.type == 'cpu'
+    dev = torch.device('cuda:0')
+    gen, enc = gen.to(dev), enc.to(dev)
+    cin = 3 if script == 'train_galaxy' else 1
+    y = torch.rand(6, cin, 20, 20, device=dev)
+    x = torch.from_numpy(tables.image_coords(20)).to(dev)
+    lik = {'train_galaxy': 'bce3', 'train_particles': 'gauss'}.get(script, 'bce')
+    kw = dict(mask_radius=7) if script == 'train_particles' else {}
+    e, err, kl = step.eval_model([(y[:4],), (y[4:],)], x, gen, enc, 'attention',
+                                 'attention' if script == 'train_dsprites' else 'attention+offsets', 0, dev, np.pi,
+                                 int(gc), 4 if script == 'train_particles' else 20, likelihood=lik, **kw)
+    assert np.isfinite([e, err, kl]).all() and abs(e + err + kl) < 1e-6 * abs(e)
+
+
+def test_eval_model_matches_oracle():
+    """eval_model (train_mnist.py:352-387): no-grad twin of train_epoch -- batch-weighted running means of the three
+    ELBO terms over a ragged pair of minibatches, against the oracle with the same injected noise; parameters and
+    gradients untouched, modules left in eval mode."""
+    from tvae import step
+    import src.models as M
+    fx = load_golden('epoch_2steps')
+    n, cin, zd, C, k, p, R, refine, normal, hid, L, n_out, fourier, resid = [int(v) for v in fx['cfg']]
+    dev = torch.device('cuda:0')
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, cin, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R, rot_refinement=True,
+        theta_prior=float(fx['theta_prior']), normal_prior_over_r=False)
+    gen = M.SpatialGenerator(zd, hid, n_out=n_out, num_layers=L)
+    enc.load_state_dict(tdict(fx, 'e.'))
+    gen.load_state_dict(tdict(fx, 'd.'))
+    data = torch.from_numpy(fx['data'])
+    sizes = [(0, 4), (4, 7)]                     # ragged: 4 + 3 images
+    noises = [tuple(torch.from_numpy(fx[f'{k_}{i}'])[:hi - lo] for k_ in ('E', 'eps_z', 'eps_theta'))
+              for i, (lo, hi) in enumerate(sizes)]
+    want = np.zeros(3)
+    c = 0
+    for (lo, hi), (E, ez, et) in zip(sizes, noises):
+        with torch.no_grad():
+            e, lp, kl = O.elbo_step(O.image_coords(n), data[lo:hi], enc.state_dict(), gen.state_dict(), R=R, padding=p,
+                                    rot_refinement=True, theta_prior=float(fx['theta_prior']), normal_prior_over_r=False,
+                                    num_layers=L, likelihood='bce', E=E, eps_z=ez, eps_theta=et)
+        c += hi - lo
+        want += (hi - lo) * (np.array([float(e), -float(lp), float(kl)]) - want) / c
+    enc, gen = enc.to(dev), gen.to(dev)
+    before = [t.detach().clone() for t in list(enc.parameters()) + list(gen.parameters())]
+    it = [(data[lo:hi].to(dev),) for lo, hi in sizes]
+    got = step.eval_model(it, O.image_coords(n).to(dev), gen, enc, 'attention', 'attention+offsets', 0, dev, np.pi, R,
+                          n, noise_iter=iter([tuple(t.to(dev) for t in nz) for nz in noises]))
+    assert np.allclose(got, want, rtol=1e-4), (got, want)
+    assert not enc.training and not gen.training
+    for t, b in zip(list(enc.parameters()) + list(gen.parameters()), before):
+        assert t.grad is None and torch.equal(t.detach(), b)

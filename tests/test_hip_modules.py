@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, assert_grad_close, load_golden, rel_err, tdict
+from conftest import GOLDEN, assert_grad_close, load_golden, rel_err, seeded_models, tdict
 from oracle import tvae_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -178,6 +178,70 @@ def test_step_golden(name):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
 
 
+HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.fuse_in'}),
+       'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad'})}
+
+
+@pytest.mark.parametrize('name', sorted(HOT))
+def test_step_hot_widths_golden(name, gemm_mode):
+    """The branches bench.py times, against the real reference at FULL widths (hidden 512, C = 128): S64 (64x64, P8:
+    recomputed first layer, fused output dot, implicit last-layer gradient, fused first-layer backward, frequency-domain
+    convolution) and S28F (P16, Fourier first layer with [Wc | Wl] on the split pipe).  ELBO terms within 1e-4 and every
+    parameter gradient within 1e-3 of max-norm; in the default arithmetic the test also asserts that those fused branches
+    and the split-pipe GEMM entry points were the ones that ran."""
+    from tvae import ops, step
+    if gemm_mode == 'bf16x3':
+        pytest.skip('opt-in mode: covered by the small fixtures')
+    fx = load_golden(name)
+    lik, want = HOT[name]
+    enc, gen, n = seeded_models(fx)
+    enc, gen = enc.to(dev()), gen.to(dev())
+    x = O.image_coords(n).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    ops.PATH_LOG, ops.KERNEL_EVENTS = set(), {}
+    try:
+        elbo, logp, kl = step.elbo_terms(x, torch.from_numpy(fx['y']).to(dev()), gen, enc, lik, noise)
+        (-elbo).backward()
+        torch.cuda.synchronize()
+        took, events = set(ops.PATH_LOG), set(ops.KERNEL_EVENTS)
+    finally:
+        ops.PATH_LOG, ops.KERNEL_EVENTS = None, None
+    if gemm_mode == 'x6':
+        assert want <= took, (want - took, took)
+        assert {'tvae_linear_fwd_x6', 'tvae_linear_dgrad_x6', 'tvae_linear_wgrad_x6', 'tvae_conv1_fwd',
+                'tvae_conv1_wgrad'} <= events, events
+    assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
+    assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
+    for k_, t in enc.named_parameters():
+        assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
+
+
+def test_step_hot_widths_intermediates_vs_oracle():
+    """Reconstruction, latent sample, theta, dx of the S64-width step against the pinned oracle (default arithmetic)."""
+    from tvae import step
+    fx = load_golden('hot_S64_B2')
+    enc, gen, n = seeded_models(fx)
+    cfgv = [int(v) for v in fx['cfg']]
+    noise_c = dict(E=torch.from_numpy(fx['E']), eps_z=torch.from_numpy(fx['eps_z']),
+                   eps_theta=torch.from_numpy(fx['eps_theta']))
+    with torch.no_grad():
+        _, _, _, aux = O.elbo_step(O.image_coords(n), torch.from_numpy(fx['y']), enc.state_dict(), gen.state_dict(),
+                                   R=cfgv[6], padding=cfgv[5], rot_refinement=True, theta_prior=float(fx['theta_prior']),
+                                   normal_prior_over_r=False, num_layers=cfgv[10], resid=False, fourier_sigma=None,
+                                   likelihood='gauss', return_aux=True, **noise_c)
+    enc, gen = enc.to(dev()), gen.to(dev())
+    noise = tuple(t.to(dev()) for t in noise_c.values())
+    with torch.no_grad():
+        _, _, _, got = step.elbo_terms(O.image_coords(n).to(dev()), torch.from_numpy(fx['y']).to(dev()), gen, enc,
+                                       'gauss', noise, return_aux=True)
+    for k_ in ('z', 'theta', 'dx', 'x_rot', 'y_hat', 'kl_per_image', 'a_sampled', 'q_t_r'):
+        assert rel_err(got[k_].reshape(-1), aux[k_].reshape(-1)) < OUT_TOL, k_
+
+
 def test_step_intermediates_vs_oracle():
     """Latent sample z, theta, dx, reconstruction y_hat against the oracle on the peaked fixture (SURVEY 8d gate)."""
     from tvae import step
@@ -262,8 +326,8 @@ def test_galaxy_full_size_runs(gemm_mode):
     """BASELINE configs[4] at full size (128x128x3, k=64 p=32, P16, z=50, Fourier, 4 decoder layers, n_out=3), B=2:
     the padded image does not fit LDS, so conv1 takes the generic implicit-GEMM path.  Size-independent properties:
     finite ELBO, exp(q) and the Gumbel sample sum to 1, determinism, finite gradients for every parameter."""
-    if gemm_mode != 'f32':
-        pytest.skip('one arithmetic mode is enough at this size')
+    if gemm_mode == 'bf16x3':
+        pytest.skip('the exact-fp32 mode and the default split-pipe mode cover this size')
     import src.models as M
     from tvae import step
     torch.manual_seed(0)
