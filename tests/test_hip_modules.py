@@ -213,11 +213,15 @@ def test_step_hot_widths_golden(name, gemm_mode):
     assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
     assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
     assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    # gradient gate: 1e-3 of max-norm, or twice the fixture's own kink conditioning where that is larger -- `ke.*` /
+    # `kd.*` is how far the REFERENCE's gradient moves under a 1e-5 relative input perturbation (a few LeakyReLU
+    # pre-activations out of 3-6 M cross 0; make_goldens.py:gen_hotpath); no free outlier for single-row tensors
     floor = 1e-3 * max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith('ge.'))
     for k_, t in enc.named_parameters():
-        assert_grad_close(t.grad, fx['ge.' + k_], tol=GRAD_TOL, floor=floor, name='enc.' + k_)
+        assert_grad_close(t.grad, fx['ge.' + k_], tol=max(GRAD_TOL, 2 * float(fx['ke.' + k_])) if k_ != 'conv_a.bias'
+                          else GRAD_TOL, floor=floor, name='enc.' + k_)
     for k_, t in gen.named_parameters():
-        assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
+        assert_grad_close(t.grad, fx['gd.' + k_], tol=max(GRAD_TOL, 2 * float(fx['kd.' + k_])), name='gen.' + k_)
 
 
 def test_step_hot_widths_intermediates_vs_oracle():
