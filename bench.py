@@ -216,8 +216,6 @@ def main():
         torch.cuda.synchronize()
 
     mode = _lib.get_gemm_mode()
-    if mode not in MODE_INFO:
-        mode = 'f32' if mode == 'bf16x3' else mode
     for i in range(args.warmup):
         one_step(i)
     barrier()

@@ -20,11 +20,10 @@ typedef void* tvae_stream_t;
 
 int tvae_abi_version(void);
 
-/* GEMM arithmetic of every MFMA entry point below (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
- * 1 = split-bf16 x3 (x = hi + lo in bf16, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; ~1e-5 relative
- * tensor error, inside the 1e-4 parity gate).  Returns 0 or hipErrorInvalidValue. */
-int tvae_set_gemm_mode(int mode);
-int tvae_get_gemm_mode(void);
+/* The library keeps NO process-wide state.  The arithmetic of a matrix product is chosen per call by the entry point:
+ * tvae_conv1_fwd / tvae_conv1_wgrad / tvae_linear_* compute exact fp32 products (v_mfma_f32_32x32x2_f32); the *_x6 and
+ * *_dft entry points compute in the "x6" arithmetic (every fp32 operand split EXACTLY into three bf16 numbers, six
+ * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results).  tvae_abi_version() == 2. */
 
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed

@@ -1,0 +1,213 @@
+// libtvae_hip.so, lifting convolution through the frequency domain (conv_dft_kernels.hpp): image / bank
+// spectra, the spectral contraction as batched launches of the split-pipe dense GEMMs (units 5 and 6), the transforms
+// along w on the fp32 matrix pipe, inverse transform of the weight gradient.
+#include "abi_dense_x6.hpp"
+#include "conv_dft_kernels.hpp"
+
+using namespace tvae;
+
+// Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
+constexpr int DFT_WG_SPLITS = 8;
+struct DftPlan {
+    int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
+    int LHP, NT, REM1;         // forward w-transform instance: frequencies processed, 32-row output tiles, extra row
+    int NS, NRT;               // backward w-transform instance: k2-steps (pairs of w), 32-row tiles of (fx, ri)
+    int Mb;                    // rows per fx in the stacked spectral weight (2M rounded up to the 512-row tile)
+    long NB, NBpad;            // (image, output row) columns
+    long at_floats;            // A^T [Lh][2L][NBpad]
+    long w_floats;             // W   [Lh][2M][2L]
+    long w3_floats;            // split cells of W
+    long t_floats;             // T / S' [Lh][2M][NBpad]
+    long tab_floats;
+    long g_floats;             // G [Lh][2M][2L] (finalised spectral weight gradient)
+    bool ok;
+};
+static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    DftPlan q;
+    q.L = n + 2 * pad;
+    q.Lh = q.L / 2 + 1;
+    q.Ho = q.L - ksz + 1;
+    q.M = C * R;
+    q.K2 = 2 * q.L;
+    q.NB = (long)B * q.Ho;
+    q.NBpad = (q.NB + 127) / 128 * 128;
+    q.Mb = x6_round_up(2 * q.M, DX6_ROWS);
+    q.at_floats = (long)q.Lh * q.K2 * q.NBpad;
+    q.w_floats = (long)q.Lh * q.Mb * q.K2;
+    q.w3_floats = dense_x6_bytes(q.Lh * q.Mb, q.K2) / 4;
+    q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
+    q.LHP = q.Lh == 23 ? 23 : (q.Lh == 49 ? 49 : 64);          // exact instances of the two reference frames, else generic
+    q.NT = q.Ho <= 33 ? 1 : 2;
+    q.REM1 = q.Ho == 33 ? 1 : 0;
+    if (q.Ho <= 18 && q.Lh <= 32) { q.NS = 9; q.NRT = 2; }
+    else if (q.Ho <= 34) { q.NS = 17; q.NRT = 4; }
+    else { q.NS = 32; q.NRT = 4; }
+    q.tab_floats = 64L * 2 * 64 + 32L * 4 * 64;                // EO + ED (largest instances)
+    q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
+    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && q.Lh <= 64 && lds_img <= 150 * 1024 &&
+           lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
+    return q;
+}
+
+extern "C" {
+
+// ---- lifting convolution through the frequency domain (conv_dft_kernels.hpp) -------------------------------------
+int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
+}
+long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    return dft_plan(B, Cin, n, ksz, pad, C, R).at_floats;
+}
+long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    // forward: W + W3 + T + tables; backward: S' (= T) + slabs (2 x G) + G + tables
+    const long fwd = q.w_floats + q.w3_floats + q.t_floats + q.tab_floats + 64;
+    const long bwd = q.t_floats + (DFT_WG_SPLITS + 1) * q.g_floats + q.tab_floats + 64;
+    return fwd > bwd ? fwd : bwd;
+}
+
+int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
+                       long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
+                       tvae_stream_t stream) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = S(stream);
+    float* W = ws;
+    float* W3 = W + ((q.w_floats + 3) & ~3L);
+    float* T = W3 + ((q.w3_floats + 3) & ~3L);
+    float* tab = T + ((q.t_floats + 3) & ~3L);
+    if (q.NBpad != q.NB) {
+        hipError_t e = hipMemsetAsync(at, 0, (size_t)q.at_floats * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    float* EO = tab;
+    float* ED = EO + 64L * 2 * 64;
+    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    hipError_t e = allow_big_lds(dft_image_kernel, lds_img);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_image_kernel, dim3(B), dim3(256), lds_img, st, y, at, n, pad, q.L, q.Lh, q.Ho, q.NBpad);
+    TVAE_CHECK_LAUNCH();
+    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
+    e = allow_big_lds(dft_bank_kernel, lds_bank);
+    if (e != hipSuccess) return (int)e;
+    if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
+        e = hipMemsetAsync(W, 0, (size_t)q.w_floats * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dft_bank_kernel, dim3(q.M), dim3(256), lds_bank, st, bank, W, ksz, q.L, q.Lh, q.M, q.Mb);
+    TVAE_CHECK_LAUNCH();
+    // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
+    const int rows = q.Lh * q.Mb;
+    int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, stream);
+    if (rc) return rc;
+    {
+        Epilogue ep;
+        ep.C = T; ep.ldc = (long)q.Lh * 128;              // T is [n >> 7][m'][fx][n & 127] (dft_t_off)
+        ep.ctile = (long)2 * q.M * q.Lh * 128;
+        const int Rpad = x6_round_up(rows, DX6_ROWS);
+        TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
+        tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
+        tm.nch = 4;
+        const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, 128};
+        rc = dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, st);
+        if (rc) return rc;
+    }
+    {
+        // contraction over fx on the fp32 matrix pipe (dft_out_mf_kernel)
+        const int NTT = q.NT + q.REM1;
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT, NTT, q.NS,
+                           q.NRT);
+        TVAE_CHECK_LAUNCH();
+        const size_t lds_o = ((size_t)q.LHP * NTT * 64 + (size_t)4 * 32 * (q.Ho | 1)) * 4;
+        const long ntiles = (long)q.M * (q.NBpad / 32);
+        const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
+        const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
+#define TVAE_OUT_MF(L_, N_, R_)                                                                                     \
+    do {                                                                                                            \
+        e = allow_big_lds(dft_out_mf_kernel<L_, N_, R_>, lds_o);                                                    \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((dft_out_mf_kernel<L_, N_, R_>), dim3(grid), dim3(256), lds_o, st, (const float*)T,      \
+                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters);        \
+    } while (0)
+#define TVAE_OUT_MF_L(L_)                                                                                           \
+    do {                                                                                                            \
+        if (q.REM1) TVAE_OUT_MF(L_, 1, true); else if (q.NT == 1) TVAE_OUT_MF(L_, 1, false); else TVAE_OUT_MF(L_, 2, false); \
+    } while (0)
+        if (q.LHP == 23) TVAE_OUT_MF_L(23); else if (q.LHP == 49) TVAE_OUT_MF_L(49); else TVAE_OUT_MF_L(64);
+#undef TVAE_OUT_MF_L
+#undef TVAE_OUT_MF
+        TVAE_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* dbias, float* ws, long ws_floats, int B,
+                         int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = S(stream);
+    float* Sp = ws;
+    float* slabs = Sp + ((q.t_floats + 3) & ~3L);
+    float* G = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
+    float* tab = G + ((q.g_floats + 3) & ~3L);
+    float* EO = tab;
+    float* ED = EO + 64L * 2 * 64;
+    {
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT,
+                           q.NT + q.REM1, q.NS, q.NRT);
+        TVAE_CHECK_LAUNCH();
+        const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
+        const long ntiles = (long)q.M * (q.NBpad / 32);
+        const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
+        const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
+        hipError_t e0 = hipSuccess;
+#define TVAE_DY_MF(S_, T_, L2_, A_)                                                                                 \
+    do {                                                                                                            \
+        e0 = allow_big_lds(dft_dy_mf_kernel<S_, T_, L2_, A_>, lds_d);                                               \
+        if (e0 != hipSuccess) return (int)e0;                                                                       \
+        hipLaunchKernelGGL((dft_dy_mf_kernel<S_, T_, L2_, A_>), dim3(grid), dim3(256), lds_d, st, dpre,             \
+                           (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, iters);                            \
+    } while (0)
+        if (q.NS == 9) { if (q.Lh == 23) TVAE_DY_MF(9, 2, 46, true); else TVAE_DY_MF(9, 2, 0, true); }
+        else if (q.NS == 17) { if (q.Lh == 49) TVAE_DY_MF(17, 4, 98, true); else TVAE_DY_MF(17, 4, 0, true); }
+        else TVAE_DY_MF(32, 4, 0, false);
+#undef TVAE_DY_MF
+        TVAE_CHECK_LAUNCH();
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(dft_dbias_kernel, dim3(C), dim3(256), 0, st, (const float*)Sp, dbias, R, q.Lh, q.NB, q.M);
+        TVAE_CHECK_LAUNCH();
+    }
+    // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
+    {
+        const int M2 = 2 * q.M, tiles_b = q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
+        // 8 reduction slices: TileMap deals the slices round-robin to the 8 XCDs, fewer would leave XCDs idle
+        const int splits = DFT_WG_SPLITS;
+        const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
+        const TileMap tmk{tilesM, tilesK, splits};
+        const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
+        int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
+                                        128L, ATile{7, 127, (long)M2 * q.Lh * 128}, st);
+        if (rc) return rc;
+        Epilogue ep;
+        ep.C = G; ep.ldc = q.K2;
+        const long per = (long)q.Lh * M2 * q.K2;
+        int blocks = cdiv(per, 64);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, splits,
+                           q.Lh * M2, q.K2, ep);
+        TVAE_CHECK_LAUNCH();
+    }
+    const size_t lds_db = (size_t)q.L * q.Lh * 8 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * 8;
+    hipError_t e = allow_big_lds(dft_dbank_kernel, lds_db);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M), dim3(256), lds_db, st, (const float*)G, dbank, ksz, q.L, q.Lh, q.M);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

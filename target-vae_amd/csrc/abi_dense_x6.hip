@@ -1,0 +1,88 @@
+// libtvae_hip.so: forward / data-gradient GEMM of the wide dense layers on the bf16 matrix pipe with exactly split
+// operands (dense_x6_kernels.hpp: dense_x6_kernel; its three operand variants are compiled in abi_dense_x6_v{0,1,2}.hip),
+// plus the weight pre-pass.
+#include "abi_dense_x6.hpp"
+
+using namespace tvae;
+
+namespace tvae {
+int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
+                     int N, int K, const TileMap& tm, const DenseBatch& bt, hipStream_t st) {
+    const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    if (N % 128 != 0 || !aligned16(w3)) return (int)hipErrorInvalidValue;
+    return dense_x6_launch_v0((const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
+                              ColDot{nullptr, nullptr, nullptr},
+                              InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
+                              VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st);
+}
+}  // namespace tvae
+
+extern "C" {
+
+// ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
+long tvae_dense_x6_bytes(int rows, int K) { return dense_x6_bytes(rows, K); }
+int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                      tvae_stream_t stream) {
+    if (rows <= 0 || K <= 0) return 0;
+    if (a3_bytes < tvae_dense_x6_bytes(rows, K) || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const long total = (long)K8pad * Rpad;
+    hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
+                       Rpad, K, K8pad, transpose);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
+                           hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
+                           InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
+                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
+    if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
+    if (rows <= 0 || N <= 0) return 0;
+    if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
+    // the recomputed operands need tiles inside one image and tables of <= 512 entries
+    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
+        return (int)hipErrorInvalidValue;
+    const DenseBatch nb{0, 0, 0};
+    if (va.xr) return dense_x6_launch_v2((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    if (vg.wo) return dense_x6_launch_v1((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    return dense_x6_launch_v0((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+}
+int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
+                       int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
+                       float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
+                       int va_np, tvae_stream_t stream) {
+    Epilogue ep;
+    ep.C = Y; ep.ldc = ldy;
+    ep.bias = bias;
+    ep.res = res; ep.ldres = ldy;
+    ep.act = act; ep.slope = slope;
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y},
+                           InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
+}
+int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
+                         int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
+                         const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
+                         const float* vg_gy, const float* in_bc, const float* in_lb, int in_np, tvae_stream_t stream) {
+    // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
+    Epilogue ep;
+    ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
+    ep.res = add; ep.ldres = ldx;
+    ep.aux = aux; ep.ldaux = ldx;
+    ep.mask = (aux || in_bc) ? mask : ACT_NONE; ep.slope = slope;
+    if (in_bc && !in_xr) return (int)hipErrorInvalidValue;               // the recomputed mask needs the coordinates
+    if (in_xr) {
+        if (!in_wc || !in_gxr || !in_part || in_part_floats < (long)(N / 128) * K * 3) return (int)hipErrorInvalidValue;
+    } else if (!dX) {
+        return (int)hipErrorInvalidValue;
+    }
+    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
+                           InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
+                           VirtGrad{vg_wo, vg_gy, mask, slope});
+}
+
+
+}  // extern "C"

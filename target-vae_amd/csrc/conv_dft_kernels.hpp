@@ -16,7 +16,6 @@
 //   dft_bank_kernel    bank -> W[fx][m | M+m][(re/im, fy)]         (one workgroup per filter)
 //   dft_out_mf_kernel  T -> out (+bias, activation)                (contraction over fx: fp32 MFMA, constant operand in LDS)
 //   dft_dy_mf_kernel   dY -> S'[m | M+m][fx][(b,h)]                (DFT over w: fp32 MFMA, constant operand in registers)
-//   dft_out_kernel / dft_dy_kernel                                  (the same two on the vector ALU: TVAE_DFT_W_VALU)
 //   dft_dbank_kernel   G[fx][m | M+m][(re/im, fy)] -> dbank        (inverse DFT per filter, cropped to ksz x ksz)
 // Single input channel (Cin = 1: MNIST / particle configurations).  Twiddles: sincospi of exactly reduced angles.
 #pragma once
@@ -25,8 +24,6 @@
 #include "conv_x6_kernels.hpp"
 
 namespace tvae {
-
-constexpr int DFT_WMAX = 40;           // output width / height handled by the register accumulators
 
 // T / S' layout: [n >> 7][row m' < 2M][fx < Lh][n & 127] -- the 2*Lh frequency rows of one (m, 128 columns) are one
 // contiguous run for the transforms along w, and a GEMM tile (512 rows x 128 columns of one fx) touches 512-byte runs
@@ -51,7 +48,7 @@ __device__ __forceinline__ void fill_twiddles(float2* tw, int L) {
 // AT[fx][fy][b*Ho + h] = Re(Yh[fy][fx] e^{+2 pi i fy h / L}),  AT[fx][L + fy][..] = Im(..).
 // LDS: image n*n floats, R n*Lh complex, Yh L*Lh complex, tw L complex.
 // ------------------------------------------------------------------------------------------
-__global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict__ AT, int n, int pad, int L, int Lh,
+static __global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict__ AT, int n, int pad, int L, int Lh,
                                  int Ho, long NBpad) {
     extern __shared__ float sm_dft[];
     float* img = sm_dft;
@@ -112,7 +109,7 @@ __global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict_
 // One workgroup per filter m:  Kh = DFT2(filter at the origin of the L x L frame), fx < Lh, then the real operand
 // rows of the spectral GEMM:  W[fx][m][fy] = Kr, W[fx][m][L+fy] = Ki;  W[fx][M+m][fy] = -Ki, W[fx][M+m][L+fy] = Kr.
 // ------------------------------------------------------------------------------------------
-__global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M,
+static __global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M,
                                 int Mb) {
     extern __shared__ float sm_dft[];
     float* ker = sm_dft;
@@ -164,138 +161,13 @@ __global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restric
     }
 }
 
-// tables for the contraction over fx: cs[fx][w] = c_fx/L^2 cos(2 pi fx w / L), sn likewise (scaled: forward), and the
-// unscaled pair cw / sw (backward);  4 * Lh * DFT_WMAX floats:  [cs | sn | cw | sw]
-__global__ void dft_tables_kernel(float* __restrict__ tab, int L, int Lh) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Lh * DFT_WMAX; i += gridDim.x * blockDim.x) {
-        const int fx = i / DFT_WMAX, w = i - fx * DFT_WMAX;
-        float s, c;
-        sincospif(2.0f * (float)((fx * w) % L) / (float)L, &s, &c);
-        const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
-        const float sc = cf / ((float)L * (float)L);
-        tab[i] = c * sc;
-        tab[Lh * DFT_WMAX + i] = s * sc;
-        tab[2 * Lh * DFT_WMAX + 2 * i] = c;           // (cos, -sin) pairs for the dY transform
-        tab[2 * Lh * DFT_WMAX + 2 * i + 1] = -s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// out[c][b][r][h][w] = act( bias[c] + sum_fx ( Tr[fx][m][n] cs[fx][w] - Ti[fx][m][n] sn[fx][w] ) ),  m = c*R + r,
-// n = b*Ho + h.  One thread per (m, n); the 2*Lh values of T are coalesced along n, the tables are wave-uniform
-// (scalar loads); results go through LDS so that the stores are contiguous runs.
-// grid (ceil(NB/256), M), block 256.
-// ------------------------------------------------------------------------------------------
-typedef float f32x2p __attribute__((ext_vector_type(2)));
-
-// WT = compile-time output width (33 and 17 are the reference configurations; DFT_WMAX is the generic instance):
-// the 2*Lh*WT multiply-adds per (m, n) run as packed v_pk_fma_f32 on pairs of outputs.
-template <int WT>
-__global__ __launch_bounds__(256) void dft_out_kernel(const float* __restrict__ T, const float* __restrict__ tab,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int M,
-                                                      int R, int B, int Ho, int Lh, long NBpad, int act, float slope) {
-    constexpr int W2 = (WT + 1) / 2;
-    __shared__ float st[256 * (2 * W2 + 1)];
-    const int m = blockIdx.y;
-    const long n0 = (long)blockIdx.x * 256;
-    const long n = n0 + threadIdx.x;
-    const long NB = (long)B * Ho;
-    const f32x2p* cs = reinterpret_cast<const f32x2p*>(tab);                       // [Lh][DFT_WMAX/2] pairs
-    const f32x2p* sn = reinterpret_cast<const f32x2p*>(tab + Lh * DFT_WMAX);
-    f32x2p acc[W2];
-#pragma unroll
-    for (int q = 0; q < W2; ++q) acc[q] = (f32x2p){0.f, 0.f};
-    const long col = n < NBpad ? n : NBpad - 1;
-    const float* tr_p = T + dft_t_off(col, m, 2 * M, Lh);
-    const float* ti_p = T + dft_t_off(col, M + m, 2 * M, Lh);
-#pragma unroll 2
-    for (int fx = 0; fx < Lh; ++fx) {
-        const float tr = tr_p[fx * 128];
-        const float ti = ti_p[fx * 128];
-        const f32x2p tr2 = {tr, tr}, ti2 = {-ti, -ti};
-#pragma unroll
-        for (int q = 0; q < W2; ++q) {
-            acc[q] = __builtin_elementwise_fma(tr2, cs[fx * (DFT_WMAX / 2) + q], acc[q]);
-            acc[q] = __builtin_elementwise_fma(ti2, sn[fx * (DFT_WMAX / 2) + q], acc[q]);
-        }
-    }
-    const int c = m / R, r = m - c * R;
-    const float bv = bias ? bias[c] : 0.f;
-#pragma unroll
-    for (int q = 0; q < W2; ++q)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v = acc[q][e] + bv;
-            if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
-            else if (act == ACT_TANH) v = tanhf(v);
-            st[threadIdx.x * (2 * W2 + 1) + 2 * q + e] = v;
-        }
-    __syncthreads();
-    const int P = Ho * Ho;
-    const int cnt = 256 * Ho;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int t = e / Ho, w = e - t * Ho;
-        const long nn = n0 + t;
-        if (nn < NB) {
-            const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
-            out[(((long)c * B + b) * R + r) * P + h * Ho + w] = st[t * (2 * W2 + 1) + w];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// S'[fx][m][n] = sum_w dY[m][n][w] cos(2 pi fx w / L),   S'[fx][M+m][n] = - sum_w dY[m][n][w] sin(2 pi fx w / L)
-// (S = DFT over w of the output gradient).  dY is [c][b][r][h][w]; one thread per (m, n).
-// grid (ceil(NBpad/256), M), block 256: columns n >= NB are written as zeros.
-// ------------------------------------------------------------------------------------------
-template <int WT>
-__global__ __launch_bounds__(256) void dft_dy_kernel(const float* __restrict__ dY, const float* __restrict__ tab,
-                                                     float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
-                                                     long NBpad) {
-    __shared__ float st[256 * (WT + 1)];
-    const int m = blockIdx.y;
-    const long n0 = (long)blockIdx.x * 256;
-    const long NB = (long)B * Ho;
-    const int c = m / R, r = m - c * R;
-    const int P = Ho * Ho;
-    const int cnt = 256 * Ho;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int t = e / Ho, w = e - t * Ho;
-        const long nn = n0 + t;
-        float v = 0.f;
-        if (nn < NB) {
-            const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
-            v = dY[(((long)c * B + b) * R + r) * P + h * Ho + w];
-        }
-        st[t * (WT + 1) + w] = v;
-    }
-    __syncthreads();
-    float d[WT];
-#pragma unroll
-    for (int w = 0; w < WT; ++w) d[w] = w < Ho ? st[threadIdx.x * (WT + 1) + w] : 0.f;
-    // (cos, -sin) pairs: S = sum_w d[w] e^{-2 pi i fx w / L} as ONE packed FMA per w
-    const f32x2p* cm = reinterpret_cast<const f32x2p*>(tab + 2 * Lh * DFT_WMAX);   // [Lh][DFT_WMAX] pairs
-    const long n = n0 + threadIdx.x;
-    if (n >= NBpad) return;
-    float* sr_p = Sp + dft_t_off(n, m, 2 * M, Lh);
-    float* si_p = Sp + dft_t_off(n, M + m, 2 * M, Lh);
-#pragma unroll 2
-    for (int fx = 0; fx < Lh; ++fx) {
-        f32x2p s2 = {0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < WT; ++w) s2 = __builtin_elementwise_fma((f32x2p){d[w], d[w]}, cm[fx * DFT_WMAX + w], s2);
-        sr_p[fx * 128] = s2[0];
-        si_p[fx * 128] = s2[1];
-    }
-}
-
 // ==========================================================================================
 // The two transforms along w on the matrix pipe, in plain fp32 (v_mfma_f32_32x32x2_f32: exact products, fp32
 // accumulate -- no operand splitting, so the vector ALU only moves data).  They are small GEMMs with a constant operand,
 //     out[w][(m,n)] = sum_{(fx,ri)} E[w][(fx,ri)] T[(fx,ri)][(m,n)]      (K = 2*Lh, 32 output rows per MFMA tile)
 //     S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]              (K = Ho)
-// and one wave owns a tile of 32 consecutive columns n of one filter row m.  The vector-ALU versions above issue
-// 3 234 FMAs per (m,n) with one scalar table load per FMA pair and wait on the scalar cache 60 % of the time; here a
+// and one wave owns a tile of 32 consecutive columns n of one filter row m.  A vector-ALU version issued
+// 3 234 FMAs per (m,n) with one scalar table load per FMA pair and waited on the scalar cache 60 % of the time; here a
 // tile costs 49 (resp. 68) MFMAs and the constant operand comes from LDS (one ds_read_b32 per 64-cycle MFMA).
 // The values of the NEXT tile are loaded into registers while the current one is on the matrix pipe.
 // ==========================================================================================
@@ -305,7 +177,7 @@ constexpr int DFT_WROWS = 64;          // largest output width of the matrix-pip
 //                              t == NT (REM1 only): the same for the single extra row w = 32*NT, identical in all 32 lanes
 // ED[s < NS][rt < NRT][lane]:  E'[kk = 32 rt + (lane & 31)][w = 2s + (lane >> 5)], kk = 2 fx + ri: ri ? -sin : cos
 // Entries outside fx < Lh, w < Ho are zero (they pad the loops of the kernels).
-__global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict__ ED, int L, int Lh, int Ho, int LHP, int NT,
+static __global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict__ ED, int L, int Lh, int Ho, int LHP, int NT,
                                 int NTT, int NS, int NRT) {
     const int nEO = LHP * NTT * 64, nED = NS * NRT * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nEO + nED; i += gridDim.x * blockDim.x) {
@@ -340,7 +212,7 @@ __global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict__ ED, 
 // (it*gridDim.x + x)*4 + q.  LHP >= Lh frequencies are processed (zero table rows beyond Lh), NT output tiles of 32 rows
 // on the matrix pipe and, with REM1, the single extra row w = 32*NT as a dot product on the vector ALU.
 template <int LHP, int NT, bool REM1>
-__global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* __restrict__ T, const float* __restrict__ EO,
+static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int M, int R, int B, int Ho, int Lh, long NBpad, int act,
                                                             float slope, int iters) {
@@ -439,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* __restr
 // LH2 = 2*Lh when known at compile time (row validity and store addresses fold), 0 = run-time check;
 // AREG: the constant operand (NS*NRT values per lane) lives in registers for the whole kernel, else it is read from LDS.
 template <int NS, int NRT, int LH2, bool AREG>
-__global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                            float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
                                                            long NBpad, int iters) {
     constexpr int NL = NS;                                       // 64-element slices of the 32 x Ho tile: ceil(32*Ho/64) <= NS
@@ -539,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restri
 
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
 // db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  One workgroup per channel.
-__global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, int M) {
+static __global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, int M) {
     __shared__ float sm[16];
     const int c = blockIdx.x;
     float acc[1] = {0.f};
@@ -554,7 +426,7 @@ __global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict
 //   Re = G[m][fy] + G[M+m][L+fy],  Im = G[m][L+fy] - G[M+m][fy]
 // then dbank[m][u][v] = 1/L^2 sum_fx c_fx Re( e^{2 pi i fx v/L} sum_fy dKh'[fy][fx] e^{2 pi i fy u/L} ),  u, v < ksz.
 // ------------------------------------------------------------------------------------------
-__global__ void dft_dbank_kernel(const float* __restrict__ G, float* __restrict__ dbank, int ksz, int L, int Lh, int M) {
+static __global__ void dft_dbank_kernel(const float* __restrict__ G, float* __restrict__ dbank, int ksz, int L, int Lh, int M) {
     extern __shared__ float sm_dft[];
     float2* Kh = reinterpret_cast<float2*>(sm_dft);
     float2* Z = Kh + L * Lh;

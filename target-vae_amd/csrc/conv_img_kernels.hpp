@@ -62,7 +62,7 @@ __device__ __forceinline__ void load_padded_image(float* img, const float* __res
 // in L2).  VEC: K % 16 == 0 and M % 128 == 0 -> unguarded float4 loads of the bank with incremented pointers.
 // ------------------------------------------------------------------------------------------
 template <bool VEC, int MH>
-__global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
+static __global__ __launch_bounds__(GEMM_THREADS, (MH == 1 ? 3 : 2))
 void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
                           int K, int tilesPerImg, int rows) {
     // MH = number of 128-row halves per workgroup tile: 1 -> 128 x 128 (wave 64 x 64), 2 -> 256 x 128 (wave 128 x 64:
@@ -243,7 +243,7 @@ void conv1_fwd_img_kernel(const float* __restrict__ bank, const float* __restric
 // grid.x = tilesM * tilesN (n fastest), grid.y = split over images.  dY is feature-major [c][img][r][p] (ld = lddy).
 // ------------------------------------------------------------------------------------------
 template <int MH, int KB, int NH>
-__global__ __launch_bounds__(GEMM_THREADS, ((MH == 1 && NH == 1) ? 3 : 2))
+static __global__ __launch_bounds__(GEMM_THREADS, ((MH == 1 && NH == 1) ? 3 : 2))
 void conv1_wgrad_img_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, ConvGeom g,
                             Epilogue ep, int M, int N, int imgs_per_split, float* ws, int tilesN, int rows, int nsplits,
                             int ngroups) {

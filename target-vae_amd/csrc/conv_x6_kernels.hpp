@@ -22,10 +22,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_f32_mfma.hpp"
-#include "gemm_bf16x3.hpp"
 #include "conv_img_kernels.hpp"
 
 namespace tvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union Cell16 {                 // one fragment cell: 8 consecutive-k bf16 of one row (an MFMA operand register quad)
+    uint4 u;
+    bf16x8 v;
+    unsigned w[4];
+};
 
 constexpr int X6_STAGE_CELLS_FWD = 3 * 2 * 256;      // [part][octet half][256 rows]
 constexpr int X6_STAGE_CELLS_WG = 3 * 2 * 128;       // [part][octet half][128 rows]
@@ -83,7 +89,7 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const Cell16 (&a)[3], const C
 // Pre-pass 1: filter bank fp32 [M][Cin*ksz*ksz] -> cells [part][octet o = (ci*ksz + u)*opr + vo][row m < Mpad]
 // (v = 8*vo + j; zero beyond ksz, beyond M and in the octets o >= Cin*ksz*opr that pad the count to K8pad).
 // ------------------------------------------------------------------------------------------
-__global__ void bank_split3_kernel(const float* __restrict__ bank, uint4* __restrict__ A3, int M, int Mpad, int Cin,
+static __global__ void bank_split3_kernel(const float* __restrict__ bank, uint4* __restrict__ A3, int M, int Mpad, int Cin,
                                    int ksz, int opr, int K8pad) {
     const long total = (long)K8pad * Mpad;
     const int K = Cin * ksz * ksz;
@@ -113,7 +119,7 @@ __global__ void bank_split3_kernel(const float* __restrict__ bank, uint4* __rest
 //   q >= cells     : zero (pads the count to an even number)
 // Zero for h >= Ho, m >= M.  One workgroup per (img, c): coalesced reads of R*P floats, 16*R-byte write runs.
 // ------------------------------------------------------------------------------------------
-__global__ void dy_split3_kernel(const float* __restrict__ dy, long lddy, uint4* __restrict__ D3, int B, int C, int R,
+static __global__ void dy_split3_kernel(const float* __restrict__ dy, long lddy, uint4* __restrict__ D3, int B, int C, int R,
                                  int Ho, int opwf, int opc, int row_cells, int ncells, int QP, int Mpad) {
     // the R*P floats of (c, img) are contiguous: stage them through LDS with coalesced loads, gather cells from LDS
     extern __shared__ float tile[];
@@ -257,7 +263,7 @@ constexpr int X6_FWD_SLOT_CELLS = 3 * 2 * 64;        // one wave's stage: [part]
 constexpr int X6_FWD_RING_BYTES = 4 * 3 * X6_FWD_SLOT_CELLS * 16;
 constexpr int X6_FWD_BIAS_BYTES = 1024;
 
-__global__ __launch_bounds__(GEMM_THREADS, 1)
+static __global__ __launch_bounds__(GEMM_THREADS, 1)
 void conv1_fwd_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ y, ConvGeom g, Epilogue ep, int M,
                          int Mpad, int K8pad, int opr, int tilesPerImg, int rows, int Wp, int arr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -465,7 +471,7 @@ static inline X6WgK x6_wg_k(int Ho) {
 }
 constexpr int X6_WG_TAB_INTS = 2 * 256;            // (cell id, packed offset) per octet of the tile's k range, <= 256
 
-__global__ __launch_bounds__(GEMM_THREADS, 1)
+static __global__ __launch_bounds__(GEMM_THREADS, 1)
 void conv1_wgrad_x6_kernel(const uint4* __restrict__ D3, const float* __restrict__ y, ConvGeom g, int M, int Mpad,
                            int N, X6WgK kk, int imgs_per_split, float* ws, int tilesN, int rows, int Wp, int arr,
                            int PT, int arrT, int nsplits, int ngroups) {

@@ -25,7 +25,7 @@ namespace tvae {
 //   transpose == 0: A(row, k) = W[row*ldw + k]        (forward: rows = out features, k = in features)
 //   transpose == 1: A(row, k) = W[k*ldw + row]        (data gradient: rows = in features, k = out features)
 // Rows >= Rrows and k >= K are zero; K8pad octets (even).
-__global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
+static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
                                     int K, int K8pad, int transpose) {
     const long total = (long)K8pad * Rpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -193,7 +193,7 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 
 // XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct)
 template <int XV>
-__global__ __launch_bounds__(DX6_THREADS, 2)
+static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                      int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
     constexpr bool VIRT = XV == 1;
@@ -402,266 +402,6 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     }
 }
 
-// dense_x6_kernel with its two streamed operands brought in by global_load_lds DMAs (see dense_wgrad_x6_dma_kernel for
-// the rules: inline asm, hand-counted waits, no ordinary vector-memory load inside the loop).  Every wave owns a ring
-// of TWO 6 KB slots for its weight cells (a lane reads back exactly the 16 bytes it fetched; 48 KB per step and
-// workgroup rule out a third slot) and a ring of THREE 1 KB slots for the four k-rows x 64 columns of X its threads
-// split.  Issue order per step: [cells of step t+2] [X of step t+3]; the X values of step t+1 are needed first (20
-// younger DMAs), the cells of step t+1 near the end of the step (14 younger DMAs): both get about two steps of flight.
-constexpr int DX_A_SLOT = 6 * 1024, DX_X_SLOT = 1024;
-constexpr int DX_RING_BYTES = 8 * 2 * DX_A_SLOT + 8 * 3 * DX_X_SLOT;
-template <int XV>
-__global__ __launch_bounds__(DX6_THREADS, 2)
-void dense_x6_dma_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
-    constexpr bool VIRT = XV == 1;
-    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
-    __shared__ float bsm[DX6_ROWS];
-    __shared__ float wsm_[2 * DX6_ROWS];
-    __shared__ float vwo_[XV == 1 ? 512 : (XV == 2 ? 2048 : 1)];   // tables of the implicit operand (K <= 512)
-    __shared__ float cbm_[2 * DX6_ROWS];                 // (bc, lb) rows of the recomputed mask operand (InTail.bc)
-    extern __shared__ __attribute__((aligned(16))) unsigned char dx_ring[];   // [wave][2][6 KB] cells | [wave][3][1 KB] X
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_m, tile_n, split_unused;
-    if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
-    // batched: the rows of all problems are stacked in A3 (Mpad = total padded rows, M = rows per problem)
-    int batch = 0;
-    if (bt.tiles_per_batch > 0) {
-        batch = tile_m / bt.tiles_per_batch;
-        X += batch * bt.x_stride;
-        ep.C += batch * bt.c_stride;
-        if (ep.aux) ep.aux += batch * bt.c_stride;
-        if (ep.res) ep.res += batch * bt.c_stride;
-    }
-    const int m0g = tile_m * DX6_ROWS;                                   // row offset inside A3
-    const int m0 = m0g - batch * bt.tiles_per_batch * DX6_ROWS, n0 = tile_n * 128;   // row offset inside the problem
-    const int khalf = lane >> 5;
-    const int nk = K8pad >> 1;
-    bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
-    if (it.xr) {
-        wsm_[2 * tid] = (m0 + tid) < M ? it.wc[2 * (m0 + tid)] : 0.f;
-        wsm_[2 * tid + 1] = (m0 + tid) < M ? it.wc[2 * (m0 + tid) + 1] : 0.f;
-    } else {
-        wsm_[tid] = (cd.w && (m0 + tid) < M) ? cd.w[m0 + tid] : 0.f;
-    }
-    const float* wsm = (cd.w && !it.xr) ? wsm_ : nullptr;
-    if (it.bc) {
-        const int img_ = n0 / it.Np;
-        cbm_[tid] = (m0 + tid) < M ? it.bc[m0 + tid] : 0.f;
-        cbm_[DX6_ROWS + tid] = (it.lb && (m0 + tid) < M) ? it.lb[(long)img_ * M + m0 + tid] : 0.f;
-    }
-
-    // A cells of this lane: fragment i (rows 64*wave + 32*i + lane&31), part p, octet 2t + khalf
-    const long part_cells = (long)K8pad * Mpad;
-    const uint4* a_ptr = A3 + (long)khalf * Mpad + m0g + 64 * wave + (lane & 31);
-    const unsigned ring_a = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dx_ring +
-                            (unsigned)(wave * 2 * DX_A_SLOT);
-    const unsigned ring_x = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dx_ring +
-                            (unsigned)(8 * 2 * DX_A_SLOT + wave * 3 * DX_X_SLOT);
-    const unsigned char* ra = dx_ring + wave * 2 * DX_A_SLOT;
-    const unsigned char* rx = dx_ring + 8 * 2 * DX_A_SLOT + wave * 3 * DX_X_SLOT;
-    auto dma_a = [&](int slot, int t) {
-        const uint4* q = a_ptr + (long)(2 * t) * Mpad;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const uint4* src = q + p * part_cells + i * 32;
-                const unsigned dst = ring_a + (unsigned)(slot * DX_A_SLOT + (i * 3 + p) * 1024);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
-            }
-    };
-    auto read_a = [&](int slot, Cell16 (&a)[2][3]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[i][p].u = *reinterpret_cast<const uint4*>(ra + slot * DX_A_SLOT + (i * 3 + p) * 1024 + lane * 16);
-    };
-    // B build role: k-quad kq (4 consecutive k = half a cell), column nb
-    const int kq = tid >> 7, nb = tid & 127;
-    // VIRT (compile time, so that the plain instance keeps its straight-line load stream): the operand is the saved
-    // activation and the gradient wo[k] * gy[n] * act'(h) is formed when the cells are built (store_b)
-    const float vg_g = VIRT ? vg.gy[n0 + nb] : 0.f;
-    if (VIRT) {
-        if (tid < K && tid < 512) vwo_[tid] = vg.wo[tid];
-    }
-    float va_x0 = 0.f, va_x1 = 0.f;
-    if (XV == 2) {                                       // tables (w0, w1, bc, lb) of the recomputed activation, K <= 512
-        const int img_ = n0 / va.Np;
-        if (tid < K) {
-            vwo_[tid] = va.wc[2 * tid];
-            vwo_[512 + tid] = va.wc[2 * tid + 1];
-            vwo_[1024 + tid] = va.bc[tid];
-            vwo_[1536 + tid] = va.lb ? va.lb[(long)img_ * K + tid] : 0.f;
-        }
-        va_x0 = va.xr[2 * (long)(n0 + nb)];
-        va_x1 = va.xr[2 * (long)(n0 + nb) + 1];
-    }
-    // nothing ordinary may be in flight when the DMAs start (one vmcnt counts both kinds, completion order between them
-    // is not guaranteed): the table / per-thread loads above are waited for here, the per-thread values pinned to it
-    float vgg = vg_g, vx0 = va_x0, vx1 = va_x1;
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(vgg), "+v"(vx0), "+v"(vx1) :: "memory");
-    auto dma_x = [&](int slot, int t) {
-        if (XV == 2) return;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kk = min(16 * t + 4 * kq + j, K - 1);          // rows beyond K: any valid row, zeroed when read
-            const float* src = X + (long)kk * ldx + n0 + nb;
-            const unsigned dst = ring_x + (unsigned)(slot * DX_X_SLOT + j * 256);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dst), "v"(src) : "memory");
-        }
-    };
-    auto load_x = [&](int slot, int t, float (&x)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            x[j] = (XV != 2 && 16 * t + 4 * kq + j < K)
-                       ? *reinterpret_cast<const float*>(rx + slot * DX_X_SLOT + j * 256 + lane * 4) : 0.f;
-    };
-    auto virt_x = [&](int t, float (&x)[4]) {
-        if (VIRT) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 16 * t + 4 * kq + j;
-                x[j] = (k < K) ? virt_value(vg, x[j], vwo_[k & 511], vgg) : 0.f;
-            }
-        }
-        if (XV == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = (16 * t + 4 * kq + j) & 511;
-                const float pre = dec_l0_pre(vwo_[k], vwo_[512 + k], vwo_[1024 + k], vwo_[1536 + k], vx0, vx1);
-                x[j] = (16 * t + 4 * kq + j < K) ? act_apply(pre, va.act, va.slope) : 0.f;
-            }
-        }
-    };
-    auto store_b = [&](int stage, const float (&x)[4]) {
-        unsigned hw[2], mw[2], lw[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) split3_pair(x[2 * q], x[2 * q + 1], hw[q], mw[q], lw[q]);
-        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
-        dst[0] = make_uint2(hw[0], hw[1]);
-        dst[2 * 256] = make_uint2(mw[0], mw[1]);
-        dst[2 * 512] = make_uint2(lw[0], lw[1]);
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    constexpr int NX = XV == 2 ? 0 : 4;                  // X DMAs per step
-    Cell16 af[2][3];
-    const int tl = nk - 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                     // tables (vwo_, bsm, wsm_, cbm_) visible
-    {
-        dma_x(0, 0);                                     // same interleaving as the loop: ... [cells s] [X s+1] ...
-        dma_a(0, 0);
-        dma_x(1, min(1, tl));
-        dma_a(1, min(1, tl));
-        dma_x(2, min(2, tl));
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 + 2 * NX) : "memory");
-        float x0[4];
-        read_a(0, af);
-        load_x(0, 0, x0);
-        virt_x(0, x0);
-        store_b(0, x0);
-    }
-    __syncthreads();
-    int sx_next = 1, sx_dma = 0;                         // X slot of step t+1; X slot of step t+3 (= t % 3)
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        dma_a(cur, min(t + 2, tl));                      // slot of step t: its cells are in af since the last step
-        dma_x(sx_dma, min(t + 3, tl));
-        Cell16 an[2][3];
-        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Cell16 bf[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-            mfma6(acc[0][j], af[0], bf);
-            mfma6(acc[1][j], af[1], bf);
-            if (j == 1) {                                // cells of step t+1
-                float x1[4];
-                if (XV != 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 2 * NX) : "memory");   // X of step t+1 landed
-                load_x(sx_next, t + 1 < nk ? t + 1 : t, x1);
-                virt_x(t + 1 < nk ? t + 1 : t, x1);
-                store_b(cur ^ 1, x1);
-            }
-            if (j == 2) {                                // weight cells of step t+1
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 + 2 * NX) : "memory");
-                read_a(cur ^ 1, an);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
-        sx_next = sx_next == 2 ? 0 : sx_next + 1;
-        sx_dma = sx_dma == 2 ? 0 : sx_dma + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's rings
-    // epilogue specialised on (activation, mask, residual): no per-element branches
-    const bool res = ep.res != nullptr;
-    float ysum[4] = {0.f, 0.f, 0.f, 0.f};
-    float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#define TVAE_DX6_EPI(A_, M_, R_, V_) \
-    dense_x6_epilogue<A_, M_, R_, V_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_)
-#define TVAE_DX6_EPI_R(A_, M_, V_) \
-    do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
-    if (ep.mask == ACT_NONE) {
-        if (ep.act == ACT_LRELU) TVAE_DX6_EPI_R(ACT_LRELU, ACT_NONE, false);
-        else if (ep.act == ACT_TANH) TVAE_DX6_EPI_R(ACT_TANH, ACT_NONE, false);
-        else TVAE_DX6_EPI_R(ACT_NONE, ACT_NONE, false);
-    } else if (ep.mask == ACT_LRELU) {
-        if (it.bc) TVAE_DX6_EPI_R(ACT_NONE, ACT_LRELU, true); else TVAE_DX6_EPI_R(ACT_NONE, ACT_LRELU, false);
-    } else {
-        if (it.bc) TVAE_DX6_EPI_R(ACT_NONE, ACT_TANH, true); else TVAE_DX6_EPI_R(ACT_NONE, ACT_TANH, false);
-    }
-#undef TVAE_DX6_EPI_R
-#undef TVAE_DX6_EPI
-    if (it.xr) {
-        float* cds = reinterpret_cast<float*>(Bs);          // [wave][128][2]
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float v = gsum[j][k] + __shfl_xor(gsum[j][k], 32, 64);
-                if (lane < 32) cds[(wave * 128 + j * 32 + lane) * 2 + k] = v;
-            }
-        __syncthreads();
-        if (tid < 256) {
-            float g = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) g += cds[w * 256 + tid];
-            it.gxr[2 * (long)n0 + tid] = g;
-        }
-    } else if (cd.w) {
-        // the eight waves hold disjoint rows of the same 128 columns: lane halves first, then waves through LDS
-        float* cds = reinterpret_cast<float*>(Bs);          // the B stages are free after the k-loop
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = ysum[j] + __shfl_xor(ysum[j], 32, 64);
-            if (lane < 32) cds[wave * 128 + j * 32 + lane] = v;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            float y = cd.b ? cd.b[0] : 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) y += cds[w * 128 + tid];
-            cd.y[n0 + tid] = y;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Weight gradient of a dense layer in the same arithmetic:  dW[m][k] = sum_n dY[m][n] X[k][n].
 // Both operands are row-major with the reduction index n contiguous, so a fragment cell (8 consecutive n of one row)
@@ -681,167 +421,6 @@ struct ATile {             // column addressing of the streamed A operand: eleme
     long ts;               // frequency-domain convolution (conv_dft_kernels.hpp): {7, 127, tile stride}
 };
 constexpr ATile ATILE_PLAIN = {30, 0x3fffffff, 0};
-
-template <bool VIRT, bool XVA>
-__global__ __launch_bounds__(DX6_THREADS, 2)
-void dense_wgrad_x6_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
-                           int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
-                           VirtAct va, ATile atile) {
-    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_m, tile_k, split;
-    if (!tm.decode(blockIdx.x, tile_m, tile_k, split)) return;
-    // batched: row tile t belongs to problem t / tiles_per_batch; slabs are [split][batch][M][Kf]
-    int batch = 0, nbatch = 1;
-    if (bt.tiles_per_batch > 0) {
-        batch = tile_m / bt.tiles_per_batch;
-        nbatch = tm.tilesM / bt.tiles_per_batch;
-        tile_m -= batch * bt.tiles_per_batch;
-        dY += batch * dy_stride;
-        X += batch * bt.x_stride;
-    }
-    const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
-    const int nbeg = split * nchunk;
-    const int nend = min(N, nbeg + nchunk);
-    const int nk = (nend - nbeg) >> 4;
-    const int khalf = lane >> 5;
-
-    // A: this lane's two fragment rows
-    const float* a_ptr[2];
-    float a_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 64 * wave + 32 * i + (lane & 31);
-        a_ok[i] = m < M ? (VIRT ? vg.wo[m] : 1.f) : 0.f;          // row validity (and the row's output weight)
-        a_ptr[i] = dY + (long)min(m, M - 1) * ldd;
-    }
-    const float* g_ptr = VIRT ? vg.gy + nbeg + 8 * khalf : nullptr;
-    float4 gq[2];                                      // gy of the cell being split (VIRT), loaded with the A values
-    auto load_a = [&](int t, float4 (&r)[2][2]) {
-        if (VIRT) {
-            gq[0] = *reinterpret_cast<const float4*>(g_ptr + 16 * t);
-            gq[1] = *reinterpret_cast<const float4*>(g_ptr + 16 * t + 4);
-        }
-        const int na = nbeg + 8 * khalf + 16 * t;        // the 8 values of a cell never straddle a column tile
-        const long aoff = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float4* q = reinterpret_cast<const float4*>(a_ptr[i] + aoff);
-            r[i][0] = q[0];
-            r[i][1] = q[1];
-        }
-    };
-    auto virt_a = [&](float4 (&r)[2][2]) {
-        if (VIRT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                r[i][0] = make_float4(virt_value(vg, r[i][0].x, 1.f, gq[0].x), virt_value(vg, r[i][0].y, 1.f, gq[0].y),
-                                      virt_value(vg, r[i][0].z, 1.f, gq[0].z), virt_value(vg, r[i][0].w, 1.f, gq[0].w));
-                r[i][1] = make_float4(virt_value(vg, r[i][1].x, 1.f, gq[1].x), virt_value(vg, r[i][1].y, 1.f, gq[1].y),
-                                      virt_value(vg, r[i][1].z, 1.f, gq[1].z), virt_value(vg, r[i][1].w, 1.f, gq[1].w));
-            }
-        }
-    };
-    auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
-                                r[i][1].x * a_ok[i], r[i][1].y * a_ok[i], r[i][1].z * a_ok[i], r[i][1].w * a_ok[i]};
-            split3x8(v, a[i][0], a[i][1], a[i][2]);
-        }
-    };
-    // B build role: row kr (of the 128 feature rows), n-quad q (4 consecutive n = half a cell)
-    const int kr = tid >> 2, q4 = tid & 3;
-    const float b_ok = (k0 + kr) < Kf ? 1.f : 0.f;
-    const float* x_ptr = XVA ? nullptr : X + (long)min(k0 + kr, Kf - 1) * ldx + nbeg + 4 * q4;
-    const int kx = min(k0 + kr, Kf - 1);
-    const float va_w0 = XVA ? va.wc[2 * kx] : 0.f, va_w1 = XVA ? va.wc[2 * kx + 1] : 0.f, va_bc = XVA ? va.bc[kx] : 0.f;
-    auto load_x = [&](int t) -> float4 {
-        if (XVA) {
-            // recompute h0[kx][n .. n+3] from the coordinates (8 contiguous floats) and the per-image latent bias
-            const long n = (long)nbeg + 16 * t + 4 * q4;
-            const float4 c0 = *reinterpret_cast<const float4*>(va.xr + 2 * n);
-            const float4 c1 = *reinterpret_cast<const float4*>(va.xr + 2 * n + 4);
-            const float lbv = va.lb ? va.lb[(n / va.Np) * Kf + kx] : 0.f;
-            return make_float4(act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), va.act, va.slope),
-                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w), va.act, va.slope),
-                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), va.act, va.slope),
-                               act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.z, c1.w), va.act, va.slope));
-        }
-        return *reinterpret_cast<const float4*>(x_ptr + 16 * t);
-    };
-    auto store_b = [&](int stage, const float4& x) {
-        unsigned hw[2], mw[2], lw[2];
-        const float v[4] = {x.x * b_ok, x.y * b_ok, x.z * b_ok, x.w * b_ok};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
-        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
-        dst[0] = make_uint2(hw[0], hw[1]);
-        dst[2 * 256] = make_uint2(mw[0], mw[1]);
-        dst[2 * 512] = make_uint2(lw[0], lw[1]);
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    Cell16 af[2][3];
-    float4 ar[2][2], x1;
-    if (nk > 0) {
-        load_a(0, ar);
-        const float4 x0 = load_x(0);
-        x1 = load_x(nk > 1 ? 1 : 0);
-        virt_a(ar);
-        split_a(ar, af);
-        load_a(nk > 1 ? 1 : 0, ar);
-        store_b(0, x0);
-    }
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        const float4 x2 = load_x(t + 2 < nk ? t + 2 : t);   // X values two steps ahead
-        Cell16 an[2][3];
-        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Cell16 bf[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-            mfma6(acc[0][j], af[0], bf);
-            mfma6(acc[1][j], af[1], bf);
-            if (j == 0) {                                // A cells of step t+1 (loaded during step t-1)
-                virt_a(ar);
-                split_a(ar, an);
-            }
-            if (j == 1) store_b(cur ^ 1, x1);            // B cells of step t+1
-            if (j == 2) load_a(t + 2 < nk ? t + 2 : t, ar);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
-        x1 = x2;
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-    // slab partial: ws[split][M][Kf]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m >= M) continue;
-            float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = acc[i][j][r];
-        }
-}
 
 // ------------------------------------------------------------------------------------------
 // dense_wgrad_x6_kernel with EVERY streamed operand of the loop brought in by global_load_lds DMAs three steps deep
@@ -870,7 +449,7 @@ constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 // takes only the two values {1, slope}, whose three bf16 parts are constants: an A cell is two compares and three
 // selects per pair of elements instead of the 17 vector instructions of forming and splitting the product.
 template <bool VIRT, bool XVA, bool LRF>
-__global__ __launch_bounds__(DX6_THREADS, 2)
+static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
                                VirtAct va, ATile atile) {

@@ -37,7 +37,7 @@ __device__ __forceinline__ void store4(float* __restrict__ row, long col, long c
 __device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // out[v*M + m] = sum_panel part[(panel*M + m)*NV + v]      (one workgroup per row m)
-__global__ void part_total_kernel(const float* __restrict__ part, int npanels, int M, int NV, float* __restrict__ out) {
+static __global__ void part_total_kernel(const float* __restrict__ part, int npanels, int M, int NV, float* __restrict__ out) {
     __shared__ float sm[16];
     const int m = blockIdx.x;
     for (int v = 0; v < NV; ++v) {
@@ -55,7 +55,7 @@ __global__ void part_total_kernel(const float* __restrict__ part, int npanels, i
 //   part[p][f][1+o] = sum_{n in panel p} H[f][n] * gy[n*NO + o]                -> dWo[o][f]
 // ------------------------------------------------------------------------------------------
 template <int NO>
-__global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ Wo,
+static __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ Wo,
                                                           const float* __restrict__ H, long ldh, float* __restrict__ D,
                                                           long ldd, int F, long N, int act, float slope,
                                                           float* __restrict__ part, int vec) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
 //   part[p][f][0..2]   = sum_{n in panel p} d[f][n] * (1, x'_0[n], x'_1[n])      -> per-image sums (latent path),
 //                                                                                   bias and coordinate-weight grads
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_in_bwd_kernel(const float* __restrict__ d, long ldd,
+static __global__ __launch_bounds__(256) void dec_in_bwd_kernel(const float* __restrict__ d, long ldd,
                                                          const float* __restrict__ xr, const float* __restrict__ Wc,
                                                          int F, int Np, int cpi, float* __restrict__ gxr,
                                                          float* __restrict__ part, int vec) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void dec_in_bwd_kernel(const float* __restrict
 }
 
 // Simg[b][f] = sum_c part[b*cpi + c][f][0];  dbc[f] = sum_b Simg[b][f];  dWc[f][j] = sum_{b,c} part[..][f][1+j]
-__global__ void dec_in_total_kernel(const float* __restrict__ part, int B, int cpi, int F, float* __restrict__ Simg,
+static __global__ void dec_in_total_kernel(const float* __restrict__ part, int B, int cpi, int F, float* __restrict__ Simg,
                                     float* __restrict__ dbc, float* __restrict__ dWc) {
     __shared__ float sm[3 * 16];
     const int f = blockIdx.x;
@@ -206,7 +206,7 @@ __global__ void dec_in_total_kernel(const float* __restrict__ part, int B, int c
 //   Y[j][n] = b[j] + sum_c W[j*C + c] * X[c][n]            thread = 4 columns, all C rows
 // ------------------------------------------------------------------------------------------
 template <int NO>
-__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ W, const float* __restrict__ X,
+static __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ W, const float* __restrict__ X,
                                                         long ldx, const float* __restrict__ bias,
                                                         float* __restrict__ Y, long ldy, int C, long N, int vec) {
     const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 //   part[p][c][j]   = sum_{n in panel p} dY[j][n] * X[c][n]        -> dW[j][c]
 //   part[p][c][NO]  = sum_{n in panel p} dX[c][n]                  -> bias gradient of the layer producing X
 template <int NO>
-__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ W, const float* __restrict__ dY,
+static __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ W, const float* __restrict__ dY,
                                                         long ldy, const float* __restrict__ X, long ldx,
                                                         float* __restrict__ dX, long lddx, int C, long N, int act,
                                                         float slope, float* __restrict__ part, int vec) {

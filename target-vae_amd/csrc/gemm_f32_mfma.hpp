@@ -473,7 +473,7 @@ struct TileMap {
 // splitk_finalize_kernel (deterministic reduction order).
 // ------------------------------------------------------------------------------------------
 template <class AL, class BL>
-__global__ __launch_bounds__(GEMM_THREADS, 3)
+static __global__ __launch_bounds__(GEMM_THREADS, 3)
 void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk, float* ws, TileMap tm) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDS_LD];   // [buf][A|B][BK][LDS_LD]
     const int tid = threadIdx.x;
@@ -551,7 +551,7 @@ void gemm_f32_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int kchunk,
 // The A operand keeps the register-staged loader (weights are k-contiguous and must be transposed on the way in).
 // ------------------------------------------------------------------------------------------
 template <class AL>
-__global__ __launch_bounds__(GEMM_THREADS, 4)
+static __global__ __launch_bounds__(GEMM_THREADS, 4)
 void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue ep, int M, int N, int K, TileMap tm,
                           int vec_ep) {
     constexpr int AT = BK * LDS_LD, BT = BK * BN;
@@ -631,7 +631,7 @@ void gemm_f32_glds_kernel(AL al, const float* __restrict__ X, long ldx, Epilogue
 // Both operands by LDS-DMA: A(row x, red k) at At[k*lda + x] (x contiguous: W^T for forward, W itself for dgrad),
 // B(k, n) at X[k*ldx + n].  No register staging at all: per k-step a wave issues 4 DMA instructions, reads 32
 // fragments and issues 32 MFMAs.  Both LDS tiles are unpadded [BK][128].
-__global__ __launch_bounds__(GEMM_THREADS, 4)
+static __global__ __launch_bounds__(GEMM_THREADS, 4)
 void gemm_f32_glds2_kernel(const float* __restrict__ At, long lda, const float* __restrict__ X, long ldx, Epilogue ep,
                            int M, int N, int K, TileMap tm, int vec_ep) {
     constexpr int TT = BK * BN;                      // one operand tile (floats)
@@ -701,7 +701,7 @@ void gemm_f32_glds2_kernel(const float* __restrict__ At, long lda, const float* 
 }
 
 // out[c][r] = in[r][c]   (small weight transposes feeding the DMA forward GEMM)
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+static __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -718,7 +718,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 // Deterministic reduction of the split-K slabs: a workgroup owns 64 consecutive outputs, its four thread rows sum
 // every fourth slab (independent loads in flight, 256-byte coalesced rows) and the four partial sums are added in a
 // fixed order.  (A thread per output walking all slabs is latency bound when there are hundreds of small slabs.)
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
+static __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* ws, int splits, int M, int N, Epilogue ep) {
     __shared__ float part[4][64];
     const long total = (long)M * N;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;

@@ -70,7 +70,7 @@ __device__ __forceinline__ float act_deriv_from_out(float y, int act, float slop
 // The R fixed rotations are a constant sparse interpolation operator: 4 taps per output pixel.
 // bank[(c*R + r)][ci*k2 + d] = sum_t w[r][d][t] * weight[(c*Cin + ci)*k2 + idx[r][d][t]]
 // ------------------------------------------------------------------------------------------
-__global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const int* __restrict__ tap_idx,
+static __global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const int* __restrict__ tap_idx,
                                        const float* __restrict__ tap_w, float* __restrict__ bank, int C, int Cin,
                                        int k2, int R) {
     const long total = (long)C * R * Cin * k2;
@@ -95,7 +95,7 @@ __global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const i
 
 // Transposed operator in gather (CSR) form: deterministic, no atomics.
 // dweight[(c*Cin+ci)*k2 + s] = sum_{e in [ptr[s],ptr[s+1])} w[e] * dbank[(c*R + r[e])][ci*k2 + dst[e]]
-__global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const int* __restrict__ csr_ptr,
+static __global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const int* __restrict__ csr_ptr,
                                        const int* __restrict__ csr_r, const int* __restrict__ csr_dst,
                                        const float* __restrict__ csr_w, float* __restrict__ dweight, int C, int Cin,
                                        int k2, int R, int accumulate) {
@@ -118,7 +118,7 @@ __global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const in
 // grid (M, nseg), block 256.  Used for bias grads, per-image sums, coordinate-layer weight grads.
 // ------------------------------------------------------------------------------------------
 template <int NO>
-__global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ V, int N,
+static __global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ V, int N,
                                   int seglen, float* __restrict__ out, int M) {
     __shared__ float sm[NO * 16];
     const int m = blockIdx.x, seg = blockIdx.y;
@@ -145,7 +145,7 @@ __global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, const f
 }
 
 // out[i] (+)= scale * sum_s in[s*L + i]
-__global__ void seg_sum_kernel(const float* __restrict__ in, int S, long L, float* __restrict__ out, float scale,
+static __global__ void seg_sum_kernel(const float* __restrict__ in, int S, long L, float* __restrict__ out, float scale,
                                int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -158,7 +158,7 @@ __global__ void seg_sum_kernel(const float* __restrict__ in, int S, long L, floa
 // Column "dot" with a skinny matrix: out[n*NO + o] = b[o] + sum_m W[m*wsm + o*wso] * X[m*ldx + n]
 // (last decoder layer n_out <= 4; coordinate gradient dx'[pix][2]).  Lanes run along n.
 template <int NO>
-__global__ void coldot_kernel(const float* __restrict__ X, long ldx, int M, int N, const float* __restrict__ W,
+static __global__ void coldot_kernel(const float* __restrict__ X, long ldx, int M, int N, const float* __restrict__ W,
                               int wsm, int wso, const float* __restrict__ bias, float* __restrict__ out) {
     extern __shared__ float wsh[];   // [M][NO]
     for (int i = threadIdx.x; i < M * NO; i += blockDim.x) {
@@ -182,7 +182,7 @@ __global__ void coldot_kernel(const float* __restrict__ X, long ldx, int M, int 
 
 // D[m][n] = (sum_o W[m*wsm + o*wso] * dy[n*NO + o]) * act'(H[m][n])      (backward of the last decoder layer)
 template <int NO>
-__global__ void outer_mask_kernel(const float* __restrict__ dy, const float* __restrict__ W, int wsm, int wso,
+static __global__ void outer_mask_kernel(const float* __restrict__ dy, const float* __restrict__ W, int wsm, int wso,
                                   const float* __restrict__ H, long ldh, float* __restrict__ D, long ldd, int M, int N,
                                   int act, float slope) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +202,7 @@ __global__ void outer_mask_kernel(const float* __restrict__ dy, const float* __r
 }
 
 // dpre = dY * act'(Y) elementwise
-__global__ void act_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dpre,
+static __global__ void act_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dpre,
                                long n, int act, float slope) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         dpre[i] = dY[i] * act_deriv_from_out(Y[i], act, slope);
@@ -211,7 +211,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dY, const float* __rest
 // ------------------------------------------------------------------------------------------
 // Coordinate transform (reference train_mnist.py:222,234-239):  x' = (x - dx) * [[c, s], [-s, c]]
 // ------------------------------------------------------------------------------------------
-__global__ void coord_fwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
+static __global__ void coord_fwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
                                  const float* __restrict__ theta, float* __restrict__ xr, int B, int Np) {
     const long total = (long)B * Np;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -223,7 +223,7 @@ __global__ void coord_fwd_kernel(const float* __restrict__ xc, const float* __re
     }
 }
 // one workgroup per image: d_theta[b], d_dx[b][2] from gxr[b][p][2]
-__global__ void coord_bwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
+static __global__ void coord_bwd_kernel(const float* __restrict__ xc, const float* __restrict__ dx,
                                  const float* __restrict__ theta, const float* __restrict__ gxr,
                                  float* __restrict__ gdx, float* __restrict__ gtheta, int Np) {
     __shared__ float sm[3 * 16];
@@ -252,7 +252,7 @@ __global__ void coord_bwd_kernel(const float* __restrict__ xc, const float* __re
 __device__ __forceinline__ float dec_l0_pre(float w0, float w1, float bc, float lb, float x0, float x1) {
     return __fmaf_rn(w1, x1, __fmaf_rn(w0, x0, bc)) + lb;
 }
-__global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wc,
+static __global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wc,
                                   const float* __restrict__ bc, const float* __restrict__ LB, float* __restrict__ h,
                                   long ldh, int F, long Ntot, int Np, int act, float slope) {
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,7 +266,7 @@ __global__ void dec_l0_fwd_kernel(const float* __restrict__ xr, const float* __r
     }
 }
 // LB[img][f] = sum_d Wl[f][d] * z[img][d]     (latent_linear, no bias; models.py:111-116)
-__global__ void latent_bias_kernel(const float* __restrict__ Wl, const float* __restrict__ z, float* __restrict__ LB,
+static __global__ void latent_bias_kernel(const float* __restrict__ Wl, const float* __restrict__ z, float* __restrict__ LB,
                                    int B, int F, int zd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * F) return;
@@ -276,7 +276,7 @@ __global__ void latent_bias_kernel(const float* __restrict__ Wl, const float* __
     LB[i] = s;
 }
 // From S[img][f] = sum_{pix in img} dpre0[f][pix]:  dWl[f][d] = sum_img S*z,  dz[img][d] = sum_f Wl[f][d]*S
-__global__ void latent_bwd_kernel(const float* __restrict__ S, const float* __restrict__ Wl,
+static __global__ void latent_bwd_kernel(const float* __restrict__ S, const float* __restrict__ Wl,
                                   const float* __restrict__ z, float* __restrict__ dWl, float* __restrict__ dz, int B,
                                   int F, int zd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,7 +296,7 @@ __global__ void latent_bwd_kernel(const float* __restrict__ S, const float* __re
 
 // Random Fourier features (reference RandomFourierEmbedding2d.forward, models.py:53-58):
 //   feat[f][pix] = cos( (Wf[f][0]/sigma)*x0 + (Wf[f][1]/sigma)*x1 + bf[f] )
-__global__ void fourier_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
+static __global__ void fourier_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
                                    const float* __restrict__ bf, float sigma, float* __restrict__ feat, long ld, int F,
                                    long Ntot) {
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,7 +309,7 @@ __global__ void fourier_fwd_kernel(const float* __restrict__ xr, const float* __
     }
 }
 // gxr[pix][j] = sum_f -sin(arg_f) * (Wf[f][j]/sigma) * dfeat[f][pix]
-__global__ void fourier_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
+static __global__ void fourier_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
                                    const float* __restrict__ bf, float sigma, const float* __restrict__ dfeat, long ld,
                                    int F, long Ntot, float* __restrict__ gxr) {
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,7 +332,7 @@ __global__ void fourier_bwd_kernel(const float* __restrict__ xr, const float* __
 // train_particles.py:284-296,336-338).  kind: 0 BCE-with-logits, 1 Gaussian, 2 Gaussian with learned log-variance
 // (mu = yh[i], logvar = yh[L+i], i < L).
 // ------------------------------------------------------------------------------------------
-__global__ void loglik_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y, float* __restrict__ lp,
+static __global__ void loglik_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y, float* __restrict__ lp,
                                   int L, int kind) {
     __shared__ float sm[16];
     const int b = blockIdx.x;
@@ -349,7 +349,7 @@ __global__ void loglik_fwd_kernel(const float* __restrict__ yh, const float* __r
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) lp[b] = acc[0];
 }
-__global__ void loglik_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+static __global__ void loglik_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
                                   const float* __restrict__ glp, float* __restrict__ gyh, int B, int L, int kind) {
     const long total = (long)B * L;
     const long ldy = kind == 2 ? 2L * L : L;
@@ -378,7 +378,7 @@ __global__ void loglik_bwd_kernel(const float* __restrict__ yh, const float* __r
 //     (dx0/s - gx_j)^2 + (dx1/s - gy_i)^2 < radius^2 with gx_j = -ceil(n/2) + j, gy_i = floor(n/2) - i; masked pixels
 //     contribute nothing to the Gaussian log-likelihood and get no gradient (the mask itself carries no gradient).
 // ------------------------------------------------------------------------------------------
-__global__ void ctf_corr_kernel(const float* __restrict__ in, const float* __restrict__ ctf, float* __restrict__ out,
+static __global__ void ctf_corr_kernel(const float* __restrict__ in, const float* __restrict__ ctf, float* __restrict__ out,
                                 int n, int kc, int flip) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,7 +408,7 @@ __device__ __forceinline__ bool mask_keep(int i, int j, int n, float cx, float c
     return ddx * ddx + ddy * ddy < r2;
 }
 // Gaussian log-likelihood with optional circular mask: lp[b] = -0.5 * sum_{kept pixels} (yh - y)^2
-__global__ void loglik_masked_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+static __global__ void loglik_masked_fwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
                                          const float* __restrict__ dx, float inv_spacing, float radius, int n,
                                          float* __restrict__ lp) {
     __shared__ float sm[16];
@@ -426,7 +426,7 @@ __global__ void loglik_masked_fwd_kernel(const float* __restrict__ yh, const flo
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) lp[b] = acc[0];
 }
-__global__ void loglik_masked_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
+static __global__ void loglik_masked_bwd_kernel(const float* __restrict__ yh, const float* __restrict__ y,
                                          const float* __restrict__ dx, float inv_spacing, float radius, int n,
                                          const float* __restrict__ glp, float* __restrict__ gyh, int B) {
     const long L = (long)n * n, total = (long)B * L;
@@ -458,7 +458,7 @@ struct HeadParams {
     float theta_off_scale; // 1 if offsets are added to theta_mu (rot_refinement), else 0
 };
 
-__global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, float* __restrict__ q,
+static __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, float* __restrict__ q,
                                      float* __restrict__ a, float* __restrict__ zs, float* __restrict__ th,
                                      float* __restrict__ dxo, float* __restrict__ kl) {
     __shared__ float sm[4 * 16];
@@ -540,7 +540,7 @@ __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, fl
 
 // Backward of the head.  Upstream: gz[B][zd], gth[B], gdx[B][2], gkl[B] and (optional, may be null)
 // g_attn, g_q, g_a [B][RP] for the module-level 7-tuple API.  Output dheads[ch][img*RP + j].
-__global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q, const float* __restrict__ a,
+static __global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q, const float* __restrict__ a,
                                      const float* __restrict__ gz, const float* __restrict__ gth,
                                      const float* __restrict__ gdx, const float* __restrict__ gkl,
                                      const float* __restrict__ g_attn, const float* __restrict__ g_q,
@@ -627,7 +627,7 @@ __global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q,
 // attn = logit + log p(r); content vector (z_mu, exp(z_logstd)) and theta_mu gathered there; translation = expected
 // grid position under softmax(attn) summed over rotations.  One workgroup per image; first index wins ties.
 // ------------------------------------------------------------------------------------------
-__global__ void get_latent_kernel(HeadParams hp, float* __restrict__ zc, float* __restrict__ th,
+static __global__ void get_latent_kernel(HeadParams hp, float* __restrict__ zc, float* __restrict__ th,
                                   float* __restrict__ dxo) {
     __shared__ float smv[16];
     __shared__ int smi[16];
@@ -678,7 +678,7 @@ __global__ void get_latent_kernel(HeadParams hp, float* __restrict__ zc, float* 
 // Fused Adam over the flat parameter buffer (torch.optim.Adam defaults, reference train_mnist.py:579).
 // grad_scale folds the data-parallel 1/world averaging into the update.
 // ------------------------------------------------------------------------------------------
-__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+static __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
                                  float bc2_sqrt, float grad_scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {

@@ -98,37 +98,56 @@ def lib():
             fn.restype = _CT[ret]
             fn.argtypes = [_CT[c] for c in sig]
         L.tvae_abi_version.restype = ctypes.c_int
-        L.tvae_set_gemm_mode.restype = ctypes.c_int
-        L.tvae_set_gemm_mode.argtypes = [ctypes.c_int]
-        L.tvae_get_gemm_mode.restype = ctypes.c_int
+        if L.tvae_abi_version() != ABI_VERSION:
+            raise TvaeHipError(f'{LIB_PATH} has ABI version {L.tvae_abi_version()}, this package needs {ABI_VERSION}: rebuild')
         _lib = L
-        mode = os.environ.get('TVAE_GEMM', DEFAULT_GEMM_MODE)
-        set_gemm_mode(mode)
     return _lib
 
 
-GEMM_MODES = {'f32': 0, 'bf16x3': 1, 'x6': 2}
-DEFAULT_GEMM_MODE = 'x6'       # fp32-equivalent split convolution + fp32 MFMA dense layers; TVAE_GEMM=f32 for all-fp32 MFMA
+ABI_VERSION = 2
+# Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
+# entry points tvae.ops calls ('x6': *_x6 / *_dft, split-bf16 products with fp32-equivalent results; 'f32': the exact
+# fp32-MFMA entry points).  Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so
+# two models with different arithmetic coexist in one process.
+GEMM_MODES = ('f32', 'x6')
+_mode = os.environ.get('TVAE_GEMM', 'x6')
+if _mode not in GEMM_MODES:
+    raise TvaeHipError(f'TVAE_GEMM={_mode!r}: choose from {GEMM_MODES}')
 
 
 def set_gemm_mode(mode: str) -> None:
-    """'f32' = exact fp32 MFMA; 'x6' = lifting convolution on the bf16 matrix pipe with every operand split EXACTLY into
-    three bf16 numbers and six products (fp32-equivalent results, dense layers stay on the fp32 MFMA);
-    'bf16x3' = two-part split, three products everywhere (about 1e-5 relative, opt-in only)."""
+    global _mode
     if mode not in GEMM_MODES:
-        raise TvaeHipError(f'unknown GEMM mode {mode!r}; choose from {sorted(GEMM_MODES)}')
-    rc = lib().tvae_set_gemm_mode(GEMM_MODES[mode])
-    if rc != 0:
-        raise TvaeHipError(f'tvae_set_gemm_mode failed with {rc}')
+        raise TvaeHipError(f'unknown GEMM mode {mode!r}; choose from {GEMM_MODES}')
+    _mode = mode
 
 
 def get_gemm_mode() -> str:
-    v = lib().tvae_get_gemm_mode()
-    return {v_: k_ for k_, v_ in GEMM_MODES.items()}[v]
+    return _mode
+
+
+class arithmetic:
+    """Context manager: run the enclosed tvae.ops calls (forward AND the backward they record -- autograd Functions
+    capture the mode at forward time) in the given arithmetic."""
+
+    def __init__(self, mode: str):
+        if mode not in GEMM_MODES:
+            raise TvaeHipError(f'unknown GEMM mode {mode!r}; choose from {GEMM_MODES}')
+        self.mode = mode
+
+    def __enter__(self):
+        global _mode
+        self.old, _mode = _mode, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _mode
+        _mode = self.old
+        return False
 
 
 def exported_symbols():
-    return ['tvae_abi_version', 'tvae_get_gemm_mode', 'tvae_set_gemm_mode'] + sorted(SIGNATURES) + sorted(QUERIES)
+    return ['tvae_abi_version'] + sorted(SIGNATURES) + sorted(QUERIES)
 
 
 def query(name, *args) -> int:

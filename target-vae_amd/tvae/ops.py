@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import tables
-from ._lib import call, get_gemm_mode, query
+from ._lib import arithmetic, call, get_gemm_mode, query
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 LRELU_SLOPE = 0.01
@@ -62,6 +62,17 @@ class _timed:
             self.e.record()
             KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
         return False
+
+
+def _in_forward_arithmetic(backward):
+    """Run an autograd backward in the arithmetic its forward ran in (`ctx.arith`): the fused branches a forward takes
+    decide what it saves, so the backward must route the same way even when it executes outside the caller's
+    `arithmetic(...)` block."""
+    def wrapped(ctx, *grads):
+        with arithmetic(ctx.arith):
+            return backward(ctx, *grads)
+    wrapped.__doc__ = backward.__doc__
+    return wrapped
 
 
 PATH_LOG = None          # set to a set() to record which fused branches a step actually took (tests assert on it)
@@ -292,12 +303,14 @@ class GroupConvFn(torch.autograd.Function):
         Ho = n + 2 * pad - k + 1
         keep = {}
         out = conv1_forward(y, weight, bias, C, R, k, pad, ACT_NONE, keep)
+        ctx.arith = get_gemm_mode()
         ctx.save_for_backward(y)
         ctx.at = keep.get('at')
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, bias is not None)
         return out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
 
     @staticmethod
+    @_in_forward_arithmetic
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         C, Cin, k, R, pad, B, Ho, has_bias = ctx.cfg
@@ -345,10 +358,12 @@ class EncoderFn(torch.autograd.Function):
         else:
             call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
         ctx.save_for_backward(y, W2, Wh, A1, H)
+        ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
 
     @staticmethod
+    @_in_forward_arithmetic
     def backward(ctx, dheads):
         y, W2, Wh, A1, H = ctx.saved_tensors
         C, Cin, k, R, pad, B, Ho, act = ctx.cfg
@@ -553,9 +568,11 @@ class DecoderFn(torch.autograd.Function):
         ctx.save_for_backward(xr, z if Wl is not None else None, feat, LB if virt_act else None, *hs,
                               *[p for p in params if p is not None])
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
+        ctx.arith = get_gemm_mode()
         return yh
 
     @staticmethod
+    @_in_forward_arithmetic
     def backward(ctx, gy):
         act, resid, sigma, n_hidden, has_l, has_f, B, Np = ctx.meta
         sv = list(ctx.saved_tensors)

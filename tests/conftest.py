@@ -75,6 +75,24 @@ def assert_grad_close(a, b, tol=2e-4, floor=0.0, bad_rows=0.02, bad_tol=0.3, nam
         f'{name}: {nbad}/{err.numel()} rows > {tol} (allowed {allowed}), max {err.max().item():.3e}'
 
 
+def assert_encoder_grads(enc, fx, tol, prefix='ge.', kink_prefix=None, name='enc.', elbo_loss=True):
+    """Every encoder parameter gradient against the fixture.  `floor` = 1e-3 of the largest encoder gradient entry (tensors
+    whose gradients are tiny next to the others are compared on that scale).  `conv_a.bias` has an analytically ZERO
+    gradient (the softmax over its logits is shift invariant): both sides hold only the rounding noise of a cancelling
+    sum, so they are not compared with each other -- each must stay below 1e-5 of the largest gradient entry.
+    That holds for the ELBO (elbo_loss=True); a probe loss that reads `attn` directly gives conv_a.bias a real gradient.
+    kink_prefix: per-tensor conditioning the fixture measured on the reference itself (make_goldens.py:gen_hotpath)."""
+    gmax = max(float(np.abs(v).max()) for k_, v in fx.items() if k_.startswith(prefix))
+    for k_, t in enc.named_parameters():
+        want = fx[prefix + k_]
+        if k_ == 'conv_a.bias' and elbo_loss:
+            got = float(t.grad.detach().abs().max())
+            assert got <= 1e-5 * gmax and float(np.abs(want).max()) <= 1e-5 * gmax, (name + k_, got, want, gmax)
+            continue
+        tol_k = max(tol, 2 * float(fx[kink_prefix + k_])) if kink_prefix else tol
+        assert_grad_close(t.grad, want, tol=tol_k, floor=1e-3 * gmax, name=name + k_)
+
+
 def seeded_models(fx):
     """Models of a seed-based fixture (tests/golden/make_goldens.py:gen_hotpath): default init of the drop-in
     src.models classes under fx['seed'] (generator first, then encoder, head weights scaled), verified entry by entry
