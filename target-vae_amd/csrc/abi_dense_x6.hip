@@ -8,7 +8,7 @@ using namespace tvae;
 namespace tvae {
 int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
                      int N, int K, const TileMap& tm, const DenseBatch& bt, hipStream_t st) {
-    const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);
     if (N % 128 != 0 || !aligned16(w3)) return (int)hipErrorInvalidValue;
     return dense_x6_launch_v0((const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
                               ColDot{nullptr, nullptr, nullptr},
@@ -25,7 +25,7 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
                       tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;
     if (a3_bytes < tvae_dense_x6_bytes(rows, K) || !aligned16(a3)) return (int)hipErrorInvalidValue;
-    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const long total = (long)K8pad * Rpad;
     hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
                        Rpad, K, K8pad, transpose);
@@ -40,7 +40,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
-    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
     if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))

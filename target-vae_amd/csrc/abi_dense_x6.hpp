@@ -6,8 +6,10 @@
 
 namespace tvae {
 
+// k-octets of the weight cells: whole 16-k steps
+static inline int dense_k8pad(int K) { return x6_round_up((K + 7) / 8, 2); }
 static inline long dense_x6_bytes(int rows, int K) {
-    const long Rpad = x6_round_up(rows, DX6_ROWS), K8pad = x6_round_up((K + 7) / 8, 2);
+    const long Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     return 3 * K8pad * Rpad * 16;
 }
 
