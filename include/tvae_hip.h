@@ -117,7 +117,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
 /* ---- dense layers in the same "x6" arithmetic (nn.Linear of SpatialGenerator, src/models.py:78-93,119-120) -----------
  * tvae_dense_split3: W (row stride ldw) -> cells for A(row, k) = W[row][k] (transpose = 0: forward, rows = out
  *                    features) or A(row, k) = W[k][row] (transpose = 1: data gradient, rows = in features);
- *                    a3 needs tvae_dense_x6_bytes(rows, K) bytes (host query).
+ *                    a3 needs tvae_dense_x6_bytes(rows, K) bytes (host query).  scale [K] (optional): A(row, k) is
+ *                    multiplied by scale[k] before the split; rowsum [rows] (optional) receives sum_k A(row, k).
  * tvae_linear_fwd_x6 / tvae_linear_dgrad_x6: as tvae_linear_fwd / tvae_linear_dgrad with the split weight instead of
  *                    W (no per-image bias); N must be a multiple of 128 (else hipErrorInvalidValue: use the fp32 entry).
  *                    tvae_linear_fwd_x6 can also apply the NEXT layer when that is the single-output Linear
@@ -125,7 +126,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
  *                    M <= 512), which saves a separate pass over Y. */
 long tvae_dense_x6_bytes(int rows, int K);
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
-                      tvae_stream_t stream);
+                      const float* scale, float* rowsum, tvae_stream_t stream);
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
@@ -133,7 +134,8 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
-                         const float* vg_gy, const float* in_bc, const float* in_lb, int in_np, tvae_stream_t stream);
+                         const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
+                         tvae_stream_t stream);
 /* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
@@ -151,6 +153,13 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
  * dpre_eff[m][n] = vg_wo[m] * vg_gy[n] * act'(H[m][n])  (act = `mask` for the data gradient, vg_act for the weight
  * gradient), so the [hid][B*n^2] gradient tensor is never written; tvae_dec_out_bwd with D = NULL then only produces
  * the row sums.
+ * Two-valued form (LeakyReLU): act' = slope + (1 - slope) [H > 0], so the streamed operand can be the 0 / 1 matrix
+ * [H > 0] -- ONE exact bf16 part, three MFMAs per product block instead of six, no split arithmetic -- with the row /
+ * column factors moved out of the sum:
+ *   data gradient (vg_csum != NULL; w3t = tvae_dense_split3 of W^T with scale = vg_wo, vg_csum = its rowsum; vg_wo unused):
+ *       sum_m W[m][k] dpre_eff[m][n] = vg_gy[n] * (slope * vg_csum[k] + (1 - slope) * sum_m (W[m][k] vg_wo[m]) [H[m][n] > 0]);
+ *   weight gradient (vg_act = LeakyReLU, chosen by the library):
+ *       dW[m][k] = vg_wo[m] * (slope * s[k] + (1 - slope) * sum_n [H[m][n] > 0] vg_gy[n] X[k][n]),  s[k] = sum_n vg_gy[n] X[k][n].
  * Recomputed first-layer operand (va_xr != NULL in fwd / wgrad, in_bc != NULL in dgrad): the input of the layer is the
  * output of SpatialGenerator's coordinate layer without Fourier features (src/models.py:107-118),
  *   h0[f][n] = act(fma(Wc[f][1], xr[n][1], fma(Wc[f][0], xr[n][0], bc[f])) + LB[n / np][f])

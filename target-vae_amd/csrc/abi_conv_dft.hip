@@ -101,7 +101,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
-    int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, stream);
+    int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, nullptr, nullptr, stream);
     if (rc) return rc;
     {
         Epilogue ep;

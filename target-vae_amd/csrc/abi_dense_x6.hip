@@ -22,14 +22,19 @@ extern "C" {
 // ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
 long tvae_dense_x6_bytes(int rows, int K) { return dense_x6_bytes(rows, K); }
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
-                      tvae_stream_t stream) {
+                      const float* scale, float* rowsum, tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;
     if (a3_bytes < tvae_dense_x6_bytes(rows, K) || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const long total = (long)K8pad * Rpad;
     hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
-                       Rpad, K, K8pad, transpose);
+                       Rpad, K, K8pad, transpose, scale);
     TVAE_CHECK_LAUNCH();
+    if (rowsum) {
+        hipLaunchKernelGGL(dense_rowsum_kernel, dim3((rows + 63) / 64), dim3(64), 0, S(stream), W, ldw, rows, K, transpose,
+                           scale, rowsum);
+        TVAE_CHECK_LAUNCH();
+    }
     return 0;
 }
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
@@ -43,9 +48,10 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
-    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
+    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
         return (int)hipErrorInvalidValue;
     const DenseBatch nb{0, 0, 0};
+    if (vg.csum) return dense_x6_launch_v3((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
     if (va.xr) return dense_x6_launch_v2((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
     if (vg.wo) return dense_x6_launch_v1((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
     return dense_x6_launch_v0((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
@@ -66,7 +72,8 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
-                         const float* vg_gy, const float* in_bc, const float* in_lb, int in_np, tvae_stream_t stream) {
+                         const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
+                         tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -81,7 +88,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     }
     return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
                            InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
-                           VirtGrad{vg_wo, vg_gy, mask, slope});
+                           VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum});
 }
 
 

@@ -13,7 +13,7 @@ static inline long dense_x6_bytes(int rows, int K) {
     return 3 * K8pad * Rpad * 16;
 }
 
-// raw launchers of dense_x6_kernel<XV>, one translation unit each (abi_dense_x6_v0/1/2.hip): the kernel is the slowest
+// raw launchers of dense_x6_kernel<XV>, one translation unit each (abi_dense_x6_v0/1/2/3.hip): the kernel is the slowest
 // to compile in the library, so its instances build in parallel
 #define TVAE_DX6_LAUNCH_ARGS                                                                                          \
     const uint4 *a3, const float *X, long ldx, const Epilogue &ep, int M, int Mpad, int N, int K, int K8pad,          \
@@ -22,6 +22,7 @@ static inline long dense_x6_bytes(int rows, int K) {
 TVAE_INTERNAL int dense_x6_launch_v0(TVAE_DX6_LAUNCH_ARGS);
 TVAE_INTERNAL int dense_x6_launch_v1(TVAE_DX6_LAUNCH_ARGS);
 TVAE_INTERNAL int dense_x6_launch_v2(TVAE_DX6_LAUNCH_ARGS);
+TVAE_INTERNAL int dense_x6_launch_v3(TVAE_DX6_LAUNCH_ARGS);
 #define TVAE_DX6_LAUNCH_DEF(XV_)                                                                                      \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_(TVAE_DX6_LAUNCH_ARGS) {                                                                \

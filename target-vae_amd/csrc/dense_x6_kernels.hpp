@@ -24,9 +24,10 @@ namespace tvae {
 // Pre-pass: W fp32 -> cells [part][octet][row < Rpad].
 //   transpose == 0: A(row, k) = W[row*ldw + k]        (forward: rows = out features, k = in features)
 //   transpose == 1: A(row, k) = W[k*ldw + row]        (data gradient: rows = in features, k = out features)
-// Rows >= Rrows and k >= K are zero; K8pad octets (even).
+// Rows >= Rrows and k >= K are zero; K8pad octets (even).  scale (optional, [K]): A(row, k) is multiplied by scale[k]
+// before the split (one fp32 rounding, as an elementwise fp32 product would have).
 static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
-                                    int K, int K8pad, int transpose) {
+                                           int K, int K8pad, int transpose, const float* __restrict__ scale) {
     const long total = (long)K8pad * Rpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = (int)(i % Rpad);
@@ -36,6 +37,7 @@ static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * o + j;
             r[j] = (row < Rrows && k < K) ? (transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k]) : 0.f;
+            if (scale && k < K) r[j] *= scale[k];
         }
         Cell16 h, m, l;
         split3x8(r, h, m, l);
@@ -43,6 +45,20 @@ static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw
         A3[total + i] = m.u;
         A3[2 * total + i] = l.u;
     }
+}
+
+// rowsum[row] = sum_k A(row, k) of the (scaled) operand above, in k order (VirtGrad.csum).  One thread per row.
+static __global__ void dense_rowsum_kernel(const float* __restrict__ W, long ldw, int Rrows, int K, int transpose,
+                                           const float* __restrict__ scale, float* __restrict__ rowsum) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Rrows) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float v = transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k];
+        if (scale) v *= scale[k];
+        s += v;
+    }
+    rowsum[row] = s;
 }
 
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
@@ -53,6 +69,12 @@ struct VirtGrad {          // the streamed gradient operand given implicitly (ba
     const float* gy;       // with the saved activation H passed where the operand pointer is expected
     int act;
     float slope;
+    // LeakyReLU only -- the TWO-VALUED form (dense_x6_kernel<3>): act' = slope + (1 - slope) * [H > 0], so
+    //   sum_k W(m,k) wo[k] gy[n] act'(H[k][n]) = gy[n] * ( slope * csum[m] + (1 - slope) * sum_k W'(m,k) [H[k][n] > 0] )
+    // with W' = W diag(wo) (split by tvae_dense_split3 with scale = wo) and csum[m] = sum_k W'(m,k).  The streamed
+    // operand [H > 0] is 0 or 1: ONE exact bf16 part, so a product block is three MFMAs instead of six and the operand
+    // needs no split arithmetic at all.  wo is then unused by the kernel.
+    const float* csum;
 };
 __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
     const float dv = vg.act == ACT_LRELU ? (h > 0.f ? 1.f : vg.slope) : (vg.act == ACT_TANH ? 1.f - h * h : 1.f);
@@ -85,11 +107,12 @@ struct ColDot {            // optional fused skinny layer on the OUTPUT of this 
     float* y;
 };
 
-template <int ACT, int MASK, bool RES, bool AV>
+template <int ACT, int MASK, bool RES, bool AV, bool MB>
 __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
                                                   int n0, int M, int wave, int lane, const float* wsm,
                                                   float (&ysum)[4], const InTail& it, const float* wc2,
-                                                  float (&gsum)[4][2], int tile_n, const float* cbm) {
+                                                  float (&gsum)[4][2], int tile_n, const float* cbm,
+                                                  const float (&gyv)[4], float oms) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
@@ -137,7 +160,8 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 float rs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = acc[i][j][r] + bv;
+                    // MB (two-valued implicit gradient, see VirtGrad): bv = slope * csum[m], oms = 1 - slope
+                    float v = MB ? gyv[j] * __fmaf_rn(oms, acc[i][j][r], bv) : acc[i][j][r] + bv;
                     if (RES) v += rv[q][j];
                     if (ACT == ACT_LRELU) v = v > 0.f ? v : v * ep.slope;
                     else if (ACT == ACT_TANH) v = tanhf(v);
@@ -191,12 +215,13 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
     long c_stride;         // floats between the outputs (and aux / residual operands) of consecutive problems
 };
 
-// XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct)
+// XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct),
+//     3 = two-valued implicit gradient (VirtGrad.csum: X is the saved activation H, the operand is [H > 0])
 template <int XV>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                      int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
-    constexpr bool VIRT = XV == 1;
+    constexpr bool VIRT = XV == 1, MASKB = XV == 3;
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     __shared__ float wsm_[2 * DX6_ROWS];
@@ -219,7 +244,8 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const int m0 = m0g - batch * bt.tiles_per_batch * DX6_ROWS, n0 = tile_n * 128;   // row offset inside the problem
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
-    bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+    if (MASKB) bsm[tid] = (m0 + tid) < M ? vg.slope * vg.csum[m0 + tid] : 0.f;
+    else bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
     if (it.xr) {
         wsm_[2 * tid] = (m0 + tid) < M ? it.wc[2 * (m0 + tid)] : 0.f;
         wsm_[2 * tid + 1] = (m0 + tid) < M ? it.wc[2 * (m0 + tid) + 1] : 0.f;
@@ -293,10 +319,15 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         }
     };
     auto store_b = [&](int stage, const float (&x)[4]) {
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
+        if (MASKB) {                                     // [H > 0] as bf16: 1.0 = 0x3f80, one part (rows k >= K hold 0)
+            dst[0] = make_uint2((x[0] > 0.f ? 0x3f80u : 0u) | (x[1] > 0.f ? 0x3f800000u : 0u),
+                                (x[2] > 0.f ? 0x3f80u : 0u) | (x[3] > 0.f ? 0x3f800000u : 0u));
+            return;
+        }
         unsigned hw[2], mw[2], lw[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) split3_pair(x[2 * q], x[2 * q + 1], hw[q], mw[q], lw[q]);
-        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
         dst[0] = make_uint2(hw[0], hw[1]);
         dst[2 * 256] = make_uint2(mw[0], mw[1]);
         dst[2 * 512] = make_uint2(lw[0], lw[1]);
@@ -330,11 +361,21 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            Cell16 bf[3];
+            if (MASKB) {                                 // exact 0 / 1 operand: the three weight parts against ONE cell
+                Cell16 b0;
+                b0.u = bs[j * 32];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-            mfma6(acc[0][j], af[0], bf);
-            mfma6(acc[1][j], af[1], bf);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][p].v, b0.v, acc[i][j], 0, 0, 0);
+            } else {
+                Cell16 bf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
+                mfma6(acc[0][j], af[0], bf);
+                mfma6(acc[1][j], af[1], bf);
+            }
             if (j == 1) {                                // cells of step t+1
                 virt_x(t + 1 < nk ? t + 1 : t, x1);
                 store_b(cur ^ 1, x1);
@@ -353,8 +394,15 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const bool res = ep.res != nullptr;
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#define TVAE_DX6_EPI(A_, M_, R_, V_) \
-    dense_x6_epilogue<A_, M_, R_, V_>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_)
+    float gyv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MASKB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gyv[j] = vg.gy[n0 + j * 32 + (lane & 31)];
+    }
+    const float oms = 1.f - vg.slope;
+#define TVAE_DX6_EPI(A_, M_, R_, V_)                                                                                    \
+    dense_x6_epilogue<A_, M_, R_, V_, MASKB>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_, \
+                                             gyv, oms)
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
     if (ep.mask == ACT_NONE) {
@@ -444,10 +492,12 @@ constexpr ATile ATILE_PLAIN = {30, 0x3fffffff, 0};
 constexpr int WG_SLOT_BYTES = 4096 + 1024 + 256;      // A | X (or coordinates 256 + latent term 256) | gy
 constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 
-// LRF (implicit LeakyReLU gradient only): the implicit operand wo[m] * gy[n] * act'(H[m][n]) is factored -- gy[n] goes
-// into the X values before they are split, wo[m] onto the finished accumulator rows -- and what is left of the A operand
-// takes only the two values {1, slope}, whose three bf16 parts are constants: an A cell is two compares and three
-// selects per pair of elements instead of the 17 vector instructions of forming and splitting the product.
+// LRF (implicit LeakyReLU gradient only): the two-valued form of VirtGrad.  act' = slope + (1 - slope) [H > 0], so
+//   dW[m][k] = wo[m] * ( slope * s[k] + (1 - slope) * sum_n [H[m][n] > 0] * (gy[n] X[k][n]) ),   s[k] = sum_n gy[n] X[k][n]:
+// gy[n] goes into the X values before they are split, wo[m] onto the finished accumulator rows, and the streamed A operand
+// is the 0 / 1 matrix [H > 0] -- ONE exact bf16 part (1.0 = 0x3f80), built with one compare per element, and THREE MFMAs
+// per product block (the single A part against the three X parts) instead of six.  s[k] is accumulated by the threads
+// that build the X cells (each owns one feature row k of the tile) and joins the partial slab in the epilogue.
 template <bool VIRT, bool XVA, bool LRF>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
@@ -572,13 +622,6 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const int m = m0 + 64 * wave + 32 * i + (lane & 31);
         a_ok[i] = m < M ? ((VIRT && !LRF) ? vg.wo[m] : 1.f) : 0.f;
     }
-    unsigned lr_lo[3] = {0, 0, 0}, lr_hi[3] = {0, 0, 0};  // bf16 parts of the slope, in the low / high half of a word
-    if (LRF) {
-        unsigned hw, mw, lw;
-        split3_pair(vg.slope, vg.slope, hw, mw, lw);
-        lr_lo[0] = hw & 0xffffu; lr_lo[1] = mw & 0xffffu; lr_lo[2] = lw & 0xffffu;
-        lr_hi[0] = hw & 0xffff0000u; lr_hi[1] = mw & 0xffff0000u; lr_hi[2] = lw & 0xffff0000u;
-    }
     auto virt_a = [&](float4 (&r)[2][2], const float4 (&gq)[2]) {
         if (VIRT && !LRF) {
 #pragma unroll
@@ -590,17 +633,13 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
     };
     auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
-        if (LRF) {                                       // cells of act'(H) in {1, slope}: 1 = (0x3f80, 0, 0)
+        if (LRF) {                                       // cells of [H > 0]: 1.0 = 0x3f80, a single part
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float v[8] = {r[i][0].x, r[i][0].y, r[i][0].z, r[i][0].w, r[i][1].x, r[i][1].y, r[i][1].z, r[i][1].w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool c0 = v[2 * q] > 0.f, c1 = v[2 * q + 1] > 0.f;
-                    a[i][0].w[q] = (c0 ? 0x3f80u : lr_lo[0]) | (c1 ? 0x3f800000u : lr_hi[0]);
-                    a[i][1].w[q] = (c0 ? 0u : lr_lo[1]) | (c1 ? 0u : lr_hi[1]);
-                    a[i][2].w[q] = (c0 ? 0u : lr_lo[2]) | (c1 ? 0u : lr_hi[2]);
-                }
+                for (int q = 0; q < 4; ++q)
+                    a[i][0].w[q] = (v[2 * q] > 0.f ? 0x3f80u : 0u) | (v[2 * q + 1] > 0.f ? 0x3f800000u : 0u);
             }
             return;
         }
@@ -611,7 +650,8 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             split3x8(v, a[i][0], a[i][1], a[i][2]);
         }
     };
-    auto store_b = [&](int stage, const float4& x, int slot) {
+    float ssum = 0.f;
+    auto store_b = [&](int stage, const float4& x, int slot, bool real_step) {
         unsigned hw[2], mw[2], lw[2];
         float4 gm = make_float4(b_ok, b_ok, b_ok, b_ok);
         if (LRF) {                                       // gy of this thread's four columns joins the X values
@@ -619,6 +659,8 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             gm = make_float4(g4.x * b_ok, g4.y * b_ok, g4.z * b_ok, g4.w * b_ok);
         }
         const float v[4] = {x.x * gm.x, x.y * gm.y, x.z * gm.z, x.w * gm.w};
+        // s[k] of the two-valued form: this thread's share of row kr (the clamped step past the end must not count)
+        if (LRF && real_step) ssum += (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
@@ -646,7 +688,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         read_a(0, ar, g0);
         virt_a(ar, g0);
         split_a(ar, af);
-        store_b(0, read_x(0), 0);
+        store_b(0, read_x(0), 0, true);
     }
     __syncthreads();
     int s_next = 1, s_dma = 0;                           // slot of step t+1, slot the DMAs of step t+3 go to (= t % 3)
@@ -661,15 +703,23 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             Cell16 bf[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-            mfma6(acc[0][j], af[0], bf);
-            mfma6(acc[1][j], af[1], bf);
+            if (LRF) {                                   // exact 0 / 1 operand: ONE A part against the three X parts
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0].v, bf[p].v, acc[i][j], 0, 0, 0);
+            } else {
+                mfma6(acc[0][j], af[0], bf);
+                mfma6(acc[1][j], af[1], bf);
+            }
             if (j == 0) {                                // A cells of step t+1 from the ring
                 float4 ar[2][2], gn[2];
                 read_a(s_next, ar, gn);
                 virt_a(ar, gn);
                 split_a(ar, an);
             }
-            if (j == 1) store_b(cur ^ 1, read_x(s_next), s_next);   // B cells of step t+1
+            if (j == 1) store_b(cur ^ 1, read_x(s_next), s_next, t + 1 < nk);   // B cells of step t+1
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -681,6 +731,17 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's ring
+    float sk[4] = {0.f, 0.f, 0.f, 0.f};                  // slope * s[k] of this lane's four columns
+    if (LRF) {
+        float* ssm = reinterpret_cast<float*>(Bs);       // the B stages are free after the loop's last barrier
+        ssum += __shfl_xor(ssum, 1, 64);                 // the four n-quads (tid & 3) of feature row kr
+        ssum += __shfl_xor(ssum, 2, 64);
+        if (q4 == 0) ssm[kr] = ssum;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sk[j] = vg.slope * ssm[j * 32 + (lane & 31)];
+    }
+    const float oms = 1.f - vg.slope;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -691,7 +752,8 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = LRF ? acc[i][j][r] * wm : acc[i][j][r];
+                if (k0 + j * 32 + (lane & 31) < Kf)
+                    wrow[j * 32] = LRF ? wm * __fmaf_rn(oms, acc[i][j][r], sk[j]) : acc[i][j][r];
         }
 }
 

@@ -26,9 +26,9 @@ SIGNATURES = {
     'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
     'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
-    'tvae_dense_split3': 'plpliii',
+    'tvae_dense_split3': 'plpliiipp',
     'tvae_linear_fwd_x6': 'pppppiiillifpppppppi',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplppppi',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppi',
     'tvae_dec_in_total': 'piiippp',
     'tvae_linear_wgrad_x6': 'ppppliiillippifppppi',
     'tvae_linear_fwd': 'ppppippiiillif',

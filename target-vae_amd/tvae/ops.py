@@ -150,12 +150,15 @@ def _dense_x6_ok(rows: int, N: int) -> bool:
     return get_gemm_mode() == 'x6' and N % 128 == 0 and rows >= 256
 
 
-def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str) -> torch.Tensor:
-    """W (out, in) -> fragment-ready 3 x bf16 cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad)."""
+def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str, scale=None):
+    """W (out, in) -> fragment-ready 3 x bf16 cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad).
+    scale (K floats): A(row, k) *= scale[k] before the split; then also returns the row sums of the scaled operand
+    (the two-valued implicit-gradient form of tvae_linear_dgrad_x6, include/tvae_hip.h)."""
     W = W.contiguous()
     w3 = _scratch(W.device, key, query('tvae_dense_x6_bytes', rows, K) // 4)
-    call('tvae_dense_split3', W, W.shape[1], w3, w3.numel() * 4, rows, K, 1 if transpose else 0)
-    return w3
+    csum = torch.empty(rows, dtype=torch.float32, device=W.device) if scale is not None else None
+    call('tvae_dense_split3', W, W.shape[1], w3, w3.numel() * 4, rows, K, 1 if transpose else 0, scale, csum)
+    return w3 if scale is None else (w3, csum)
 
 
 def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0) -> torch.Tensor:
@@ -622,7 +625,13 @@ class DecoderFn(torch.autograd.Function):
                        _dense_x6_ok(F_, Nt))
             dprev = None if fuse_in else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
-                w3t = _split_weight(W, F_, F_, True, 'x6_dense_wt')
+                # LeakyReLU: the implicit gradient in its two-valued form (3 MFMAs per block instead of 6)
+                two_val = use_vg and act == ACT_LRELU
+                if two_val:
+                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt', scale=vg[0])
+                    _note('dec.virt_grad_2val')
+                else:
+                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt'), None
                 if fuse_in:
                     gxr_f = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
                     part_f = workspace(dev, (Nt // 128) * F_ * 3)
@@ -630,7 +639,7 @@ class DecoderFn(torch.autograd.Function):
                     call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
-                         vg[0] if use_vg else None, vg[1] if use_vg else None,
+                         vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
                          bc if va else None, LB if va else None, Np if va else 0)
                 fused_in = fuse_in
                 if fuse_in:
@@ -671,7 +680,7 @@ class DecoderFn(torch.autograd.Function):
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
-                         None, None, None, None, 0, None, None, None, None, 0)
+                         None, None, None, None, 0, None, None, None, None, None, 0)
             else:
                 call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)

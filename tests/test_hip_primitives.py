@@ -195,7 +195,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     ref = act_ref(ref, act)
     w3 = torch.empty(query('tvae_dense_x6_bytes', M, K) // 4, device=dev())
     Wd = W.to(dev())
-    call('tvae_dense_split3', Wd, K, w3, w3.numel() * 4, M, K, 0)
+    call('tvae_dense_split3', Wd, K, w3, w3.numel() * 4, M, K, 0, None, None)
     Y = torch.empty(M, N, device=dev())
     cw, cb = rnd(M, seed=11), rnd(1, seed=12)
     cy = torch.empty(N, device=dev())
@@ -214,10 +214,10 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
         refg = refg + add.double()
     refg = refg * dact_ref(aux.double(), act)
     w3t = torch.empty(query('tvae_dense_x6_bytes', K, M) // 4, device=dev())
-    call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1)
+    call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, 0)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0)
@@ -278,11 +278,11 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     xr, Wc = rnd(Nt, 2, seed=4), rnd(F_, 2, seed=5)
     d0 = (W.double().t() @ d.double()) * dact_ref(aux.double(), act)
     w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
-    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1)
+    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1, None, None)
     gxr = torch.empty(Nt, 2, device=dev())
     part = torch.empty((Nt // 128) * F_ * 3, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
-         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, 0)
+         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, None, 0)
     Simg = torch.empty(B, F_, device=dev())
     dbc = torch.empty(F_, device=dev())
     dWc = torch.empty(F_, 2, device=dev())
@@ -302,16 +302,29 @@ def test_linear_x6_implicit_gradient_operand():
     aux, X = rnd(K, N, seed=5).clamp(-0.9, 0.9), rnd(K, N, seed=6)
     d = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), 1)
     w3t = torch.empty(query('tvae_dense_x6_bytes', K, M) // 4, device=dev())
-    call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1)
+    call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, wo.to(dev()), gy.to(dev()), None, None, 0)
+         None, 0, wo.to(dev()), gy.to(dev()), None, None, None, 0)
     assert rel_err(dX, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
-    dW = torch.empty(M, K, device=dev())
+    # the same product in the two-valued form (LeakyReLU): weights scaled by wo before the split, 0 / 1 streamed operand
+    csum = torch.empty(K, device=dev())
+    call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1, wo.to(dev()), csum)
+    assert rel_err(csum, (W.double() * wo.double()[:, None]).sum(0)) < TOL
+    dX2 = torch.empty(K, N, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 1, SLOPE, None, None, None,
+         None, 0, None, gy.to(dev()), csum, None, None, 0)
+    assert rel_err(dX2, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
+    with pytest.raises(Exception):         # the two-valued form exists for LeakyReLU only
+        call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 2, SLOPE, None, None, None,
+             None, 0, None, gy.to(dev()), csum, None, None, 0)
     ws = torch.empty(1 << 24, device=dev())
-    call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
-         gy.to(dev()), 1, SLOPE, None, None, None, None, 0)
-    assert rel_err(dW, d @ X.double().t()) < GEMM_TOL['f32']
+    for vact in (1, 2):                    # LeakyReLU: two-valued weight gradient; tanh: generic implicit operand
+        dv = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), vact)
+        dW = torch.empty(M, K, device=dev())
+        call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
+             gy.to(dev()), vact, SLOPE, None, None, None, None, 0)
+        assert rel_err(dW, dv @ X.double().t()) < GEMM_TOL['f32'], vact
     # dec_out_bwd without the gradient tensor: sums only
     F_ = M
     part = torch.empty(((N + 1023) // 1024) * F_ * 2, device=dev())
@@ -337,8 +350,8 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     W, b, d = rnd(M, F_, seed=5, scale=F_ ** -0.5), rnd(M, seed=6), rnd(M, Nt, seed=7).to(dev())
     w3 = torch.empty(query('tvae_dense_x6_bytes', M, F_) // 4, device=dev())
     w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
-    call('tvae_dense_split3', W.to(dev()), F_, w3, w3.numel() * 4, M, F_, 0)
-    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1)
+    call('tvae_dense_split3', W.to(dev()), F_, w3, w3.numel() * 4, M, F_, 0, None, None)
+    call('tvae_dense_split3', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1, None, None)
     va = (xr, Wc, bc, LB, Np)
     # forward
     Y = [torch.empty(M, Nt, device=dev()) for _ in range(2)]
@@ -353,7 +366,7 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
         gxr = torch.empty(Nt, 2, device=dev())
         part = torch.empty((Nt // 128) * F_ * 3, device=dev())
         call('tvae_linear_dgrad_x6', w3t, d, None, None if virt else h0, None, M, Nt, F_, Nt, Nt, act, SLOPE, xr, Wc,
-             gxr, part, part.numel(), None, None, bc if virt else None, LB if virt else None, Np if virt else 0)
+             gxr, part, part.numel(), None, None, None, bc if virt else None, LB if virt else None, Np if virt else 0)
         outs.append((gxr, part))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     d0 = (W.double().t() @ d.double().cpu()) * dact_ref(h0.double().cpu(), act)
