@@ -42,7 +42,7 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     if (q.Ho <= 18 && q.Lh <= 32) { q.NS = 9; q.NRT = 2; }
     else if (q.Ho <= 34) { q.NS = 17; q.NRT = 4; }
     else { q.NS = 32; q.NRT = 4; }
-    q.tab_floats = 64L * 2 * 64 + 32L * 4 * 64;                // EO + ED (largest instances)
+    q.tab_floats = 64L * 2 * 64 + 32L * 4 * 64 + q.M;          // EO + ED (largest instances) + per-row bias-gradient sums
     q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
@@ -62,9 +62,9 @@ long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, in
 }
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
-    // forward: W + W3 + T + tables; backward: S' (= T) + slabs (2 x G) + G + tables
+    // forward: W + W3 + T + tables; backward: S' (= T) + split-K slabs of G + tables
     const long fwd = q.w_floats + q.w3_floats + q.t_floats + q.tab_floats + 64;
-    const long bwd = q.t_floats + (DFT_WG_SPLITS + 1) * q.g_floats + q.tab_floats + 64;
+    const long bwd = q.t_floats + DFT_WG_SPLITS * q.g_floats + q.tab_floats + 64;
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -86,18 +86,16 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     float* EO = tab;
     float* ED = EO + 64L * 2 * 64;
     const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    hipError_t e = allow_big_lds(dft_image_kernel, lds_img);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_image_kernel, dim3(B), dim3(256), lds_img, st, y, at, n, pad, q.L, q.Lh, q.Ho, q.NBpad);
-    TVAE_CHECK_LAUNCH();
     const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    e = allow_big_lds(dft_bank_kernel, lds_bank);
+    const size_t lds_sp = lds_img > lds_bank ? lds_img : lds_bank;
+    hipError_t e = allow_big_lds(dft_spectra_kernel, lds_sp);
     if (e != hipSuccess) return (int)e;
     if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
         e = hipMemsetAsync(W, 0, (size_t)q.w_floats * 4, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(dft_bank_kernel, dim3(q.M), dim3(256), lds_bank, st, bank, W, ksz, q.L, q.Lh, q.M, q.Mb);
+    hipLaunchKernelGGL(dft_spectra_kernel, dim3(B + q.M), dim3(256), lds_sp, st, y, at, B, n, pad, q.Ho, q.NBpad, bank, W,
+                       ksz, q.M, q.Mb, q.L, q.Lh);
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
@@ -152,8 +150,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     hipStream_t st = S(stream);
     float* Sp = ws;
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
-    float* G = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
-    float* tab = G + ((q.g_floats + 3) & ~3L);
+    float* tab = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
     float* EO = tab;
     float* ED = EO + 64L * 2 * 64;
     {
@@ -179,7 +176,10 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         TVAE_CHECK_LAUNCH();
     }
     if (dbias) {
-        hipLaunchKernelGGL(dft_dbias_kernel, dim3(C), dim3(256), 0, st, (const float*)Sp, dbias, R, q.Lh, q.NB, q.M);
+        float* dbpart = tab + 64L * 2 * 64 + 32L * 4 * 64;         // M floats behind the transform tables
+        hipLaunchKernelGGL(dft_dbias_rows_kernel, dim3(q.M), dim3(256), 0, st, (const float*)Sp, dbpart, q.Lh, q.NB, q.M);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dft_dbias_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)dbpart, dbias, R, C);
         TVAE_CHECK_LAUNCH();
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
@@ -193,19 +193,12 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
                                         128L, ATile{7, 127, (long)M2 * q.Lh * 128}, st);
         if (rc) return rc;
-        Epilogue ep;
-        ep.C = G; ep.ldc = q.K2;
-        const long per = (long)q.Lh * M2 * q.K2;
-        int blocks = cdiv(per, 64);
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, splits,
-                           q.Lh * M2, q.K2, ep);
-        TVAE_CHECK_LAUNCH();
     }
     const size_t lds_db = (size_t)q.L * q.Lh * 8 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * 8;
     hipError_t e = allow_big_lds(dft_dbank_kernel, lds_db);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M), dim3(256), lds_db, st, (const float*)G, dbank, ksz, q.L, q.Lh, q.M);
+    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M), dim3(256), lds_db, st, (const float*)slabs, DFT_WG_SPLITS, q.g_floats,
+                       dbank, ksz, q.L, q.Lh, q.M);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -31,7 +31,7 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
                        Rpad, K, K8pad, transpose, scale);
     TVAE_CHECK_LAUNCH();
     if (rowsum) {
-        hipLaunchKernelGGL(dense_rowsum_kernel, dim3((rows + 63) / 64), dim3(64), 0, S(stream), W, ldw, rows, K, transpose,
+        hipLaunchKernelGGL(dense_rowsum_kernel, dim3((rows + 63) / 64), dim3(1024), 0, S(stream), W, ldw, rows, K, transpose,
                            scale, rowsum);
         TVAE_CHECK_LAUNCH();
     }

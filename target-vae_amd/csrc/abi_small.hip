@@ -258,8 +258,8 @@ int tvae_latent_bias(const float* Wl, const float* z, float* LB, int B, int F, i
 int tvae_latent_bwd(const float* S_, const float* Wl, const float* z, float* dWl, float* dz, int B, int F, int zd,
                     tvae_stream_t stream) {
     const int tot = (F * zd > B * zd) ? F * zd : B * zd;
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, S(stream), S_, Wl, z, dWl, dz, B, F,
-                       zd);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((tot + 63) / 64), dim3(1024), 0, S(stream), S_, Wl, z, dWl, dz, B, F, zd);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

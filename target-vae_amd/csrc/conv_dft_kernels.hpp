@@ -12,8 +12,8 @@
 // The weight gradient is the same contraction transposed:
 //     dKh'[m][fy][fx] = sum_{(b,h)} conj(S[fx][m][(b,h)]) * A[fx][(b,h)][fy],   S = DFT over w of dY,
 // followed by a small inverse DFT per filter.  Everything else here is small streaming work:
-//   dft_image_kernel   y -> A^T[fx][(re/im, fy)][(b,h)]           (one workgroup per image, DFT by direct sums in LDS)
-//   dft_bank_kernel    bank -> W[fx][m | M+m][(re/im, fy)]         (one workgroup per filter)
+//   dft_spectra_kernel y -> A^T[fx][(re/im, fy)][(b,h)]           (one workgroup per image, DFT by direct sums in LDS)
+//                      bank -> W[fx][m | M+m][(re/im, fy)]         (one workgroup per filter; same launch)
 //   dft_out_mf_kernel  T -> out (+bias, activation)                (contraction over fx: fp32 MFMA, constant operand in LDS)
 //   dft_dy_mf_kernel   dY -> S'[m | M+m][fx][(b,h)]                (DFT over w: fp32 MFMA, constant operand in registers)
 //   dft_dbank_kernel   G[fx][m | M+m][(re/im, fy)] -> dbank        (inverse DFT per filter, cropped to ksz x ksz)
@@ -48,14 +48,12 @@ __device__ __forceinline__ void fill_twiddles(float2* tw, int L) {
 // AT[fx][fy][b*Ho + h] = Re(Yh[fy][fx] e^{+2 pi i fy h / L}),  AT[fx][L + fy][..] = Im(..).
 // LDS: image n*n floats, R n*Lh complex, Yh L*Lh complex, tw L complex.
 // ------------------------------------------------------------------------------------------
-static __global__ void dft_image_kernel(const float* __restrict__ y, float* __restrict__ AT, int n, int pad, int L, int Lh,
-                                 int Ho, long NBpad) {
-    extern __shared__ float sm_dft[];
+__device__ __forceinline__ void dft_image_body(float* sm_dft, int b, const float* __restrict__ y, float* __restrict__ AT,
+                                               int n, int pad, int L, int Lh, int Ho, long NBpad) {
     float* img = sm_dft;
     float2* R = reinterpret_cast<float2*>(img + n * n);
     float2* Yh = R + n * Lh;
     float2* tw = Yh + L * Lh;
-    const int b = blockIdx.x;
     fill_twiddles(tw, L);
     for (int i = threadIdx.x; i < n * n; i += blockDim.x) img[i] = y[(long)b * n * n + i];
     __syncthreads();
@@ -109,14 +107,12 @@ static __global__ void dft_image_kernel(const float* __restrict__ y, float* __re
 // One workgroup per filter m:  Kh = DFT2(filter at the origin of the L x L frame), fx < Lh, then the real operand
 // rows of the spectral GEMM:  W[fx][m][fy] = Kr, W[fx][m][L+fy] = Ki;  W[fx][M+m][fy] = -Ki, W[fx][M+m][L+fy] = Kr.
 // ------------------------------------------------------------------------------------------
-static __global__ void dft_bank_kernel(const float* __restrict__ bank, float* __restrict__ W, int ksz, int L, int Lh, int M,
-                                int Mb) {
-    extern __shared__ float sm_dft[];
+__device__ __forceinline__ void dft_bank_body(float* sm_dft, int m, const float* __restrict__ bank, float* __restrict__ W,
+                                              int ksz, int L, int Lh, int M, int Mb) {
     float* ker = sm_dft;
     float2* Q = reinterpret_cast<float2*>(ker + ksz * ksz);
     float2* Kh = Q + ksz * Lh;
     float2* tw = Kh + L * Lh;
-    const int m = blockIdx.x;
     fill_twiddles(tw, L);
     for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) ker[i] = bank[(long)m * ksz * ksz + i];
     __syncthreads();
@@ -159,6 +155,17 @@ static __global__ void dft_bank_kernel(const float* __restrict__ bank, float* __
         r1[fy] = -k.y;
         r1[L + fy] = k.x;
     }
+}
+
+// Image spectra and filter spectra in ONE launch (workgroups [0, B): images, [B, B + M): filters): the two are
+// independent, each alone fills only part of the chip (B = 256 workgroups of 256 threads for the images), and a launch
+// boundary between them cost 0.2 ms of the step.
+static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int n, int pad, int Ho,
+                                          long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz, int M,
+                                          int Mb, int L, int Lh) {
+    extern __shared__ float sm_dft[];
+    if ((int)blockIdx.x < B) dft_image_body(sm_dft, blockIdx.x, y, AT, n, pad, L, Lh, Ho, NBpad);
+    else dft_bank_body(sm_dft, blockIdx.x - B, bank, W, ksz, L, Lh, M, Mb);
 }
 
 // ==========================================================================================
@@ -410,15 +417,22 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 }
 
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
-// db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  One workgroup per channel.
-static __global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __restrict__ db, int R, int Lh, long NB, int M) {
+// db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  Two stages: one workgroup per
+// filter row m (1 024 of them: the single-stage version had 128 workgroups walking 51 MB-strided runs), then R sums.
+static __global__ void dft_dbias_rows_kernel(const float* __restrict__ Sp, float* __restrict__ part, int Lh, long NB, int M) {
     __shared__ float sm[16];
-    const int c = blockIdx.x;
+    const int m = blockIdx.x;
     float acc[1] = {0.f};
-    for (int r = 0; r < R; ++r)
-        for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += Sp[dft_t_off(n, c * R + r, 2 * M, Lh)];
+    for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += Sp[dft_t_off(n, m, 2 * M, Lh)];
     block_sum<1>(acc, sm);
-    if (threadIdx.x == 0) db[c] = acc[0];
+    if (threadIdx.x == 0) part[m] = acc[0];
+}
+static __global__ void dft_dbias_kernel(const float* __restrict__ part, float* __restrict__ db, int R, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[c * R + r];
+    db[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -426,7 +440,10 @@ static __global__ void dft_dbias_kernel(const float* __restrict__ Sp, float* __r
 //   Re = G[m][fy] + G[M+m][L+fy],  Im = G[m][L+fy] - G[M+m][fy]
 // then dbank[m][u][v] = 1/L^2 sum_fx c_fx Re( e^{2 pi i fx v/L} sum_fy dKh'[fy][fx] e^{2 pi i fy u/L} ),  u, v < ksz.
 // ------------------------------------------------------------------------------------------
-static __global__ void dft_dbank_kernel(const float* __restrict__ G, float* __restrict__ dbank, int ksz, int L, int Lh, int M) {
+// G arrives as `nsl` split-K slabs (slab stride `gs` floats) of the weight-gradient GEMM; they are summed, in slab order,
+// while the filter's rows are loaded -- the spectral gradient is never finalised into a tensor of its own.
+static __global__ void dft_dbank_kernel(const float* __restrict__ G, int nsl, long gs, float* __restrict__ dbank, int ksz,
+                                        int L, int Lh, int M) {
     extern __shared__ float sm_dft[];
     float2* Kh = reinterpret_cast<float2*>(sm_dft);
     float2* Z = Kh + L * Lh;
@@ -438,7 +455,14 @@ static __global__ void dft_dbank_kernel(const float* __restrict__ G, float* __re
         const int fy = i % L, fx = i / L;
         const float* r0 = G + ((long)fx * 2 * M + m) * rowlen;
         const float* r1 = G + ((long)fx * 2 * M + M + m) * rowlen;
-        Kh[fy * Lh + fx] = make_float2(r0[fy] + r1[L + fy], r0[L + fy] - r1[fy]);
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+        for (int sl = 0; sl < nsl; ++sl) {
+            a += r0[sl * gs + fy];
+            b += r1[sl * gs + L + fy];
+            c += r0[sl * gs + L + fy];
+            d += r1[sl * gs + fy];
+        }
+        Kh[fy * Lh + fx] = make_float2(a + b, c - d);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ksz * Lh; i += blockDim.x) {

@@ -47,18 +47,29 @@ static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw
     }
 }
 
-// rowsum[row] = sum_k A(row, k) of the (scaled) operand above, in k order (VirtGrad.csum).  One thread per row.
-static __global__ void dense_rowsum_kernel(const float* __restrict__ W, long ldw, int Rrows, int K, int transpose,
-                                           const float* __restrict__ scale, float* __restrict__ rowsum) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= Rrows) return;
+// rowsum[row] = sum_k A(row, k) of the (scaled) operand above (VirtGrad.csum).  Block = 64 rows x 16 k-slices; the slice
+// sums are added in slice order (deterministic).
+static __global__ __launch_bounds__(1024) void dense_rowsum_kernel(const float* __restrict__ W, long ldw, int Rrows, int K,
+                                                                   int transpose, const float* __restrict__ scale,
+                                                                   float* __restrict__ rowsum) {
+    __shared__ float part[16][64];
+    const int r = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + r;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) {
-        float v = transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k];
-        if (scale) v *= scale[k];
-        s += v;
+    if (row < Rrows)
+        for (int k = sl; k < K; k += 16) {
+            float v = transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k];
+            if (scale) v *= scale[k];
+            s += v;
+        }
+    part[sl][r] = s;
+    __syncthreads();
+    if (sl == 0 && row < Rrows) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][r];
+        rowsum[row] = t;
     }
-    rowsum[row] = s;
 }
 
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
@@ -271,7 +282,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     };
     // B build role: k-quad kq (4 consecutive k = half a cell), column nb
     const int kq = tid >> 7, nb = tid & 127;
-    const float* x_ptr = X + (long)(4 * kq) * ldx + n0 + nb;
+    const float* x_col = X + n0 + nb;
     // VIRT (compile time, so that the plain instance keeps its straight-line load stream): the operand is the saved
     // activation and the gradient wo[k] * gy[n] * act'(h) is formed when the cells are built (store_b)
     const float vg_g = VIRT ? vg.gy[n0 + nb] : 0.f;
@@ -296,9 +307,12 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = 0.f;
         } else {
-            const float* q = x_ptr + (long)(16 * t) * ldx;
+            // unconditional loads from a CLAMPED row and no masking: rows k >= K meet all-zero weight cells, so any
+            // finite value will do (the clamped row is real data).  A load under an exec-mask branch, or a select on its
+            // result, makes the compiler wait for it on the spot -- these loads are issued two steps ahead on purpose
+            const int kb = 16 * t + 4 * kq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = (16 * t + 4 * kq + j < K) ? q[(long)j * ldx] : 0.f;
+            for (int j = 0; j < 4; ++j) x[j] = x_col[(long)min(kb + j, K - 1) * ldx];
         }
     };
     auto virt_x = [&](int t, float (&x)[4]) {
@@ -341,23 +355,26 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Cell16 af[2][3];
-    float x1[4], x2[4];
+    // Two register sets for the weight cells and two for the X values, alternating by step parity (the loop is unrolled by
+    // two so that the set is a compile-time choice): a step issues the loads of the NEXT step's cells and of the X values
+    // THREE steps ahead into the set it has just finished with, and nothing is copied -- a register copy at the end of a
+    // step would make the wave wait there for loads it does not need yet.
+    Cell16 afA[2][3], afB[2][3];
+    float xA[4], xB[4];                                  // X values of the next even / odd step
     if (XV != 0) __syncthreads();                       // vwo_ is read by the prologue's virt_x
     {
         float x0[4];
         load_x(0, x0);
-        load_a(0, af);
-        load_x(nk > 1 ? 1 : 0, x1);
+        load_a(0, afA);
+        load_x(nk > 1 ? 1 : 0, xB);
+        load_x(nk > 2 ? 2 : 0, xA);
         virt_x(0, x0);
         store_b(0, x0);
     }
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
+    auto step = [&](int t, Cell16 (&afc)[2][3], Cell16 (&afn)[2][3], float (&xn)[4]) {
         const int cur = t & 1;
-        Cell16 an[2][3];
-        load_a(t + 1 < nk ? t + 1 : t, an);             // A cells of the next step, X values two steps ahead
-        load_x(t + 2 < nk ? t + 2 : t, x2);
+        load_a(t + 1 < nk ? t + 1 : t, afn);            // weight cells of the next step
         const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -368,28 +385,31 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][p].v, b0.v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[i][p].v, b0.v, acc[i][j], 0, 0, 0);
             } else {
                 Cell16 bf[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-                mfma6(acc[0][j], af[0], bf);
-                mfma6(acc[1][j], af[1], bf);
+                mfma6(acc[0][j], afc[0], bf);
+                mfma6(acc[1][j], afc[1], bf);
             }
-            if (j == 1) {                                // cells of step t+1
-                virt_x(t + 1 < nk ? t + 1 : t, x1);
-                store_b(cur ^ 1, x1);
+            if (j == 1) {                                // cells of step t+1, then its buffer takes the values of step t+3
+                virt_x(t + 1 < nk ? t + 1 : t, xn);
+                store_b(cur ^ 1, xn);
+                load_x(t + 3 < nk ? t + 3 : t, xn);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x1[j] = x2[j];
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+    };
+    // both steps of a trip are unconditional: a step under `if` lets the compiler sink the loads issued for it into the
+    // branch, i.e. to just before their use
+    int tt = 0;
+    for (; tt + 1 < nk; tt += 2) {
+        step(tt, afA, afB, xB);
+        step(tt + 1, afB, afA, xA);
     }
+    if (nk & 1) step(nk - 1, afA, afB, xB);
     // epilogue specialised on (activation, mask, residual): no per-element branches
     const bool res = ep.res != nullptr;
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};

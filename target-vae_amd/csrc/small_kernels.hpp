@@ -276,21 +276,32 @@ static __global__ void latent_bias_kernel(const float* __restrict__ Wl, const fl
     LB[i] = s;
 }
 // From S[img][f] = sum_{pix in img} dpre0[f][pix]:  dWl[f][d] = sum_img S*z,  dz[img][d] = sum_f Wl[f][d]*S
-static __global__ void latent_bwd_kernel(const float* __restrict__ S, const float* __restrict__ Wl,
-                                  const float* __restrict__ z, float* __restrict__ dWl, float* __restrict__ dz, int B,
-                                  int F, int zd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Block = 64 outputs x 16 reduction slices (the sums run over the batch resp. the features: a thread per output walking
+// all of them was a 128 us latency chain); slice sums are added in slice order.
+static __global__ __launch_bounds__(1024) void latent_bwd_kernel(const float* __restrict__ S, const float* __restrict__ Wl,
+                                                                 const float* __restrict__ z, float* __restrict__ dWl,
+                                                                 float* __restrict__ dz, int B, int F, int zd) {
+    __shared__ float part[2][16][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float s0 = 0.f, s1 = 0.f;
     if (i < F * zd) {
         const int f = i / zd, d = i - f * zd;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += S[(long)b * F + f] * z[b * zd + d];
-        dWl[i] = s;
+        for (int b = sl; b < B; b += 16) s0 += S[(long)b * F + f] * z[b * zd + d];
     }
     if (i < B * zd) {
         const int b = i / zd, d = i - b * zd;
-        float s = 0.f;
-        for (int f = 0; f < F; ++f) s += Wl[f * zd + d] * S[(long)b * F + f];
-        dz[i] = s;
+        for (int f = sl; f < F; f += 16) s1 += Wl[f * zd + d] * S[(long)b * F + f];
+    }
+    part[0][sl][o] = s0;
+    part[1][sl][o] = s1;
+    __syncthreads();
+    if (sl < 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[sl][q][o];
+        if (sl == 0 && i < F * zd) dWl[i] = t;
+        if (sl == 1 && i < B * zd) dz[i] = t;
     }
 }
 
