@@ -125,9 +125,19 @@ def cpu_baseline(batch=32, steps=4):
                      theta_prior=np.pi, normal_prior_over_r=False, num_layers=c['layers'], likelihood='gauss')
         ts.append(time.perf_counter() - t0)
     best = min(ts[1:])
+    # encoder forward only (the north-star roofline target is stated on it): same oracle, no gradients
+    te = []
+    sd = {k_: v.detach() for k_, v in encp.items()}
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            O.encoder_forward(sd, y, noise['E'], c['R'], c['pad'], True, np.pi, False)
+            te.append(time.perf_counter() - t0)
     return dict(value=batch / best, unit='images/sec', cores=cores, kind='port',
                 sample=f'oracle train step (fwd+bwd+Adam), {batch} images/step, 1 warm-up + {steps} timed steps, '
-                       f'min; torch {torch.__version__} CPU, {cores} threads')
+                       f'min; torch {torch.__version__} CPU, {cores} threads',
+                encoder_forward={'value': batch / min(te[1:]), 'unit': 'images/sec',
+                                 'sample': f'oracle encoder forward, {batch} images, 1 warm-up + 2 timed, min'})
 
 
 def spawn_ranks(n: int) -> int:
@@ -252,6 +262,40 @@ def main():
                      'conv1_wgrad_frac_of_f32_peak':
                          fl1 / (kev1['tvae_conv1_wgrad']['mean_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
                          if 'tvae_conv1_wgrad' in kev1 else None}
+    # encoder forward only (SURVEY 8d "Metric"; BASELINE north_star states its roofline target on it): the same 256
+    # images through conv1 -> conv2 -> heads -> attention head in training mode (the two activations a backward needs are
+    # written), timed with events on the launch stream
+    enc_fwd = None
+    if world == 1 and args.workload == 'S64':
+        ho = c['n'] + 2 * c['pad'] - c['k'] + 1
+        yb = data[:B]
+        with torch.no_grad():
+            for _ in range(2):
+                enc(yb, dev)
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS = {}
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                enc(yb, dev)
+            e1.record()
+            torch.cuda.synchronize()
+            kev_e = ops.kernel_event_ms()
+            ops.KERNEL_EVENTS = None
+        ms_e = e0.elapsed_time(e1) / args.steps
+        P = c['R'] * ho * ho
+        # algorithmic bytes per image, training mode: input + heads + both saved activations + bank / B
+        bytes_img = 4.0 * (c['cin'] * c['n'] ** 2 + (3 + 2 * c['zd']) * P + 2 * c['C'] * P) + \
+            4.0 * c['C'] * c['R'] * c['cin'] * c['k'] ** 2 / B
+        fl_img = conv1_flops_per_image(c) + 2.0 * c['C'] * c['C'] * P + 2.0 * c['C'] * (3 + 2 * c['zd']) * P
+        enc_fwd = {'value': B / (ms_e * 1e-3), 'unit': 'images/sec', 'ms': ms_e,
+                   'algorithmic_bytes_per_image': bytes_img,
+                   'hbm': {'achieved': bytes_img * B / (ms_e * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                           'frac': bytes_img * B / (ms_e * 1e-3) / 8.0e12},
+                   'mfma': {'direct_form_tflops': fl_img * B / (ms_e * 1e-3) / 1e12,
+                            'note': 'direct-form FLOPs (2*C*R*k^2*Ho^2 + 1x1x1 layers) over the measured time; the '
+                                    'frequency-domain convolution executes 7x fewer, so this exceeds every peak'},
+                   'conv1_fwd_ms': kev_e.get('tvae_conv1_fwd', {}).get('mean_ms')}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -276,15 +320,23 @@ def main():
             'tvae_linear_wgrad_x6': (dense_flops, 'dense_wgrad_x6_kernel'),
         }
         timed = {k_: v for k_, v in kev.items() if k_ in entries}
-        # the roofline object describes the dominant KERNEL.  In the default arithmetic that is dense_x6_kernel (the
-        # split-pipe GEMM: decoder layers and the spectral contraction of the convolution); its forward decoder launch
-        # is the measured instance.  In fp32 mode it is the direct lifting-convolution weight gradient.
-        if mode == 'x6' and 'tvae_linear_fwd_x6' in timed:
-            dom = 'tvae_linear_fwd_x6'
+        # the roofline object describes the dominant KERNEL FAMILY of the step, the split-pipe dense GEMM (decoder layers
+        # and the spectral contraction of the convolution), on its LARGEST decoder launch (not its best one), with the
+        # call-weighted aggregate over the three decoder launches beside it.  bf16 MFMAs per product block: 6 in the
+        # exact-split arithmetic, 3 where the streamed operand is the exact 0 / 1 matrix [H > 0] (two-valued implicit
+        # LeakyReLU gradient: data / weight gradient of the last hidden layer).  In fp32 mode the dominant kernel is the
+        # direct lifting-convolution weight gradient.
+        two_val = c['layers'] >= 2 and c['n_out'] == 1          # ops.DecoderFn: virt + LeakyReLU (bench models)
+        products = {'tvae_linear_fwd_x6': 6, 'tvae_linear_dgrad_x6': 3 if two_val else 6,
+                    'tvae_linear_wgrad_x6': 3 if two_val else 6}
+        dense = [k_ for k_ in products if k_ in timed]
+        if mode == 'x6' and dense:
+            dom = max(dense, key=lambda k_: kev[k_]['total_ms'])
         else:
             dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
         flops = entries[dom][0]
         ach = flops / (kev[dom]['mean_ms'] * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS / products[dom] if (mode == 'x6' and dom in products) else info['peak']
         out = {
             'metric': 'training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU' if args.workload == 'S64' else
                       'training images/sec (fwd+bwd+Adam), extra workload ' + args.workload,
@@ -298,10 +350,11 @@ def main():
                        'lifting_conv': ('frequency domain: DFT + batched split-pipe GEMM (326 GFLOP of matrix work per '
                                         'launch instead of 2339)' if conv_dft else 'direct implicit GEMM')},
             'roofline': {'kernel': dom + ' (' + entries[dom][1] + ', ' + info['insn'] + ')', 'bound': 'mfma',
-                         'achieved': ach, 'peak': info['peak'], 'unit': 'TFLOP/s',
-                         'frac': ach / info['peak'],
-                         'peak_note': 'algorithmic (fp32-equivalent) FLOP/s; x6 peak = 2500 TFLOP/s dense bf16 / 6 '
-                                      'products per block' if mode == 'x6' else 'dense f32 MFMA peak',
+                         'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': ach / peak,
+                         'peak_note': 'algorithmic (fp32-equivalent) FLOP/s; peak = 2500 TFLOP/s dense bf16 / bf16 MFMAs per '
+                                      'product block of this launch (dense_launches)' if mode == 'x6' else
+                                      'dense f32 MFMA peak',
                          'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
                          # dense_x6_kernel is launched with several shapes: pick the decoder-layer launch by its grid
                          # (512 threads x 8*ceil(tiles_n/8) workgroups; forward and data-gradient launches averaged)
@@ -311,9 +364,26 @@ def main():
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
                          'entry_points_ms': {k_: round(v['mean_ms'], 3) for k_, v in sorted(timed.items())},
+                         'dense_launches': {k_: {'ms_per_step': round(kev[k_]['total_ms'] / args.steps, 3),
+                                                 'launches_per_step': kev[k_]['launches'] / args.steps,
+                                                 'bf16_mfma_per_product_block': products[k_],
+                                                 'algorithmic_tflops': dense_flops * kev[k_]['launches'] /
+                                                 (kev[k_]['total_ms'] * 1e-3) / 1e12,
+                                                 'executed_bf16_pflops': products[k_] * dense_flops * kev[k_]['launches'] /
+                                                 (kev[k_]['total_ms'] * 1e-3) / 1e15,
+                                                 'frac_of_bf16_peak': products[k_] * dense_flops * kev[k_]['launches'] /
+                                                 (kev[k_]['total_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+                                            for k_ in dense} if mode == 'x6' else None,
+                         'dense_aggregate': ({'algorithmic_tflops': sum(dense_flops * kev[k_]['launches'] for k_ in dense) /
+                                              (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12,
+                                              'frac_of_x6_peak': sum(dense_flops * kev[k_]['launches'] for k_ in dense) /
+                                              (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12 / info['peak']}
+                                             if (mode == 'x6' and dense) else None),
                          'conv_direct_form_tflops': {k_: conv_flops / (kev[k_]['mean_ms'] * 1e-3) / 1e12
                                                      for k_ in ('tvae_conv1_fwd', 'tvae_conv1_wgrad') if k_ in kev}},
         }
+        if enc_fwd is not None:
+            out['encoder_forward'] = enc_fwd
         if companion is not None:
             out['exact_f32_mode'] = companion
         if world == 1 and not args.no_cpu_baseline and args.workload == 'S64':
