@@ -110,9 +110,9 @@ long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, in
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);
 int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
                        long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
-                       tvae_stream_t stream);
+                       int parts, tvae_stream_t stream);
 int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* dbias, float* ws, long ws_floats, int B,
-                         int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream);
+                         int Cin, int n, int ksz, int pad, int C, int R, int parts, tvae_stream_t stream);
 
 /* ---- dense layers in the same "x6" arithmetic (nn.Linear of SpatialGenerator, src/models.py:78-93,119-120) -----------
  * tvae_dense_split3: W (row stride ldw) -> cells for A(row, k) = W[row][k] (transpose = 0: forward, rows = out
@@ -130,12 +130,12 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, tvae_stream_t stream);
+                       int va_np, int parts, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
-                         tvae_stream_t stream);
+                         int parts, tvae_stream_t stream);
 /* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
@@ -147,8 +147,12 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, tvae_stream_t stream);
-/* Implicit gradient operand (vg_wo != NULL, both entries): dpre is then NOT the gradient but the saved activation H of
+                         int va_np, int parts, tvae_stream_t stream);
+/* `parts` (every *_x6 / *_dft compute entry): 3 = the exact three-part bf16 split (six products per block, fp32-equivalent
+ * results: the default of the Python layer); 1 = operands rounded to ONE bf16 number (a single product per block, fp32
+ * accumulate): the bf16 throughput mode BASELINE.json names for configs 2 and 5 -- about 3 significant digits per
+ * product, NOT held to the fp32 parity tolerances.  Anything else: hipErrorInvalidValue.
+ * Implicit gradient operand (vg_wo != NULL, both entries): dpre is then NOT the gradient but the saved activation H of
  * the layer in front of the single-output last Linear, and the gradient is formed on the fly,
  * dpre_eff[m][n] = vg_wo[m] * vg_gy[n] * act'(H[m][n])  (act = `mask` for the data gradient, vg_act for the weight
  * gradient), so the [hid][B*n^2] gradient tensor is never written; tvae_dec_out_bwd with D = NULL then only produces

@@ -12,6 +12,7 @@ set_gemm_mode(os.environ.get('MODE', 'f32'))
 print('mode', os.environ.get('MODE', 'f32'))
 dev = torch.device('cuda:0')
 reps = int(os.environ.get('REPS', '5'))
+PARTS = int(os.environ.get('PARTS', '3'))      # 3 = exact split, 1 = bf16 throughput mode
 B = int(os.environ.get('B', '256'))
 only = os.environ.get('ONLY', '')
 
@@ -83,18 +84,18 @@ w3 = torch.empty(query('tvae_dense_x6_bytes', F_, F_) // 4, device=dev)
 call('tvae_dense_split3', W, F_, w3, w3.numel() * 4, F_, F_, 0, None, None)
 w3t = torch.empty_like(w3)
 call('tvae_dense_split3', W, F_, w3t, w3t.numel() * 4, F_, F_, 1, None, None)
-timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0))
-timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0))
-timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None, None, None, None, 0))
-timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0))
-timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0))
+timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, PARTS))
 if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
     at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev)
     wsd = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev)
     A1d = torch.empty(C, N, device=dev)
-    timeit('dft_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_dft', y, bank, bias, A1d, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 1, 0.01))
+    timeit('dft_conv1_fwd', fl_conv, lambda: call('tvae_conv1_fwd_dft', y, bank, bias, A1d, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 1, 0.01, PARTS))
     dbd = torch.empty_like(bank)
-    timeit('dft_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_dft', dA1, at, dbd, None, wsd, wsd.numel(), B, Cin, n, k, pad, C, R))
+    timeit('dft_conv1_wgrad', fl_conv, lambda: call('tvae_conv1_wgrad_dft', dA1, at, dbd, None, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, PARTS))
     if not only or 'dft' in only:
         call('tvae_conv1_fwd', y, bank, bias, A1, B, Cin, n, k, pad, C, R, 1, 0.01)
         call('tvae_conv1_wgrad', y, dA1, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
@@ -102,26 +103,26 @@ if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
 if only and 'zero' in only:
     w3z = torch.zeros_like(w3)
     hz = torch.zeros_like(h1)
-    timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0))
-    timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0))
-    timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0))
+    timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+    timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+    timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
 if only and 'tail' in only:
     xr2 = torch.randn(Nt, 2, device=dev); wc2 = torch.randn(F_, 2, device=dev)
     gxr = torch.empty(Nt, 2, device=dev); partf = torch.empty((Nt // 128) * F_ * 3, device=dev)
     wo1 = torch.randn(F_, device=dev); gy1 = torch.randn(Nt, device=dev)
     fl = 2.0 * F_ * F_ * Nt
-    timeit('tail_dgrad_plain', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0))
-    timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None, None, None, None, 0))
-    timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, None, 0))
-    timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, None, 0))
-    timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0))
+    timeit('tail_dgrad_plain', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
+    timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None, None, None, None, 0, PARTS))
+    timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, None, 0, PARTS))
+    timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, None, 0, PARTS))
+    timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, PARTS))
     Np_ = n * n
     bc2 = torch.randn(F_, device=dev); lb2 = torch.randn(B, F_, device=dev)
     va = (xr2, wc2, bc2, lb2, Np_)
     # the step's actual launches: forward with the recomputed first layer (+ fused output column), data gradient with the
     # implicit gradient + fused first-layer backward + recomputed mask, weight gradient with both implicit operands
     cy = torch.empty(Nt, device=dev)
-    timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va))
-    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_))
-    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va))
-    timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0))
+    timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, PARTS))
+    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, PARTS))
+    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, PARTS))
+    timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0, PARTS))

@@ -70,7 +70,7 @@ long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, in
 
 int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
                        long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
-                       tvae_stream_t stream) {
+                       int parts, tvae_stream_t stream) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
@@ -110,7 +110,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, 128};
-        rc = dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, st);
+        rc = dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st);
         if (rc) return rc;
     }
     {
@@ -143,7 +143,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
 }
 
 int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float* dbias, float* ws, long ws_floats, int B,
-                         int Cin, int n, int ksz, int pad, int C, int R, tvae_stream_t stream) {
+                         int Cin, int n, int ksz, int pad, int C, int R, int parts, tvae_stream_t stream) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
@@ -191,7 +191,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
-                                        128L, ATile{7, 127, (long)M2 * q.Lh * 128}, st);
+                                        128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st);
         if (rc) return rc;
     }
     const size_t lds_db = (size_t)q.L * q.Lh * 8 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * 8;

@@ -4,16 +4,17 @@
 
 using namespace tvae;
 
+TVAE_WG_LAUNCH_DEF(3)
+
 namespace tvae {
 int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M, int Kf, int N,
                            int nchunk, const TileMap& tm, const DenseBatch& bt, long dy_stride, const ATile& atile,
-                           hipStream_t st) {
-    hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<false, false, false>, WG_RING_BYTES);
-    if (e_ != hipSuccess) return (int)e_;
-    hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<false, false, false>), dim3(tm.grid()), dim3(DX6_THREADS), WG_RING_BYTES,
-                       st, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, VirtGrad{nullptr, nullptr, 0, 0.f},
-                       VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, atile);
-    return (int)hipGetLastError();
+                           int parts, hipStream_t st) {
+    const VirtGrad vg{nullptr, nullptr, 0, 0.f};
+    const VirtAct va{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f};
+    if (parts == 1) return dense_wgrad_x6_launch_p1(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st);
+    if (parts == 3) return dense_wgrad_x6_launch_p3(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st);
+    return (int)hipErrorInvalidValue;
 }
 }  // namespace tvae
 
@@ -22,9 +23,10 @@ extern "C" {
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, tvae_stream_t stream) {
+                         int va_np, int parts, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
+    if (parts != 1 && parts != 3) return (int)hipErrorInvalidValue;
     if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || !aligned16(dpre) || !ws) return (int)hipErrorInvalidValue;
     if (va_xr ? (va_np % 16 != 0 || !aligned16(va_xr))      // the DMA ring moves 16 columns of one image per step
             : (ldx % 4 != 0 || !X || !aligned16(X)))
@@ -43,23 +45,13 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     splits = cdiv(N, nchunk);
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
-#define TVAE_WG_LAUNCH(V_, X_, L_)                                                                                  \
-    do {                                                                                                            \
-        hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, L_>, WG_RING_BYTES);                        \
-        if (e_ != hipSuccess) return (int)e_;                                                                       \
-        hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_, L_>), dim3(tmk.grid()), dim3(DX6_THREADS),             \
-                           WG_RING_BYTES, S(stream), dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk,                   \
-                           DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN);                                         \
-    } while (0)
-    // the implicit LeakyReLU gradient is factored (row factor x column factor x two-valued matrix, see the kernel)
+    // the implicit LeakyReLU gradient runs in its two-valued form (0 / 1 streamed operand, see the kernel)
     const bool lrf = vg_wo && vg_act == ACT_LRELU;
-    if (vg_wo) {
-        if (va_xr) { if (lrf) TVAE_WG_LAUNCH(true, true, true); else TVAE_WG_LAUNCH(true, true, false); }
-        else { if (lrf) TVAE_WG_LAUNCH(true, false, true); else TVAE_WG_LAUNCH(true, false, false); }
-    } else {
-        if (va_xr) TVAE_WG_LAUNCH(false, true, false); else TVAE_WG_LAUNCH(false, false, false);
-    }
-#undef TVAE_WG_LAUNCH
+    const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? 4 : 0);
+    const int rc = parts == 1
+        ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream))
+        : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream));
+    if (rc) return rc;
     TVAE_CHECK_LAUNCH();
     Epilogue ep;
     ep.C = dW; ep.ldc = K;

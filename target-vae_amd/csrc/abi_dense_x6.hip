@@ -7,13 +7,14 @@ using namespace tvae;
 
 namespace tvae {
 int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
-                     int N, int K, const TileMap& tm, const DenseBatch& bt, hipStream_t st) {
+                     int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st) {
     const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);
     if (N % 128 != 0 || !aligned16(w3)) return (int)hipErrorInvalidValue;
-    return dense_x6_launch_v0((const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
-                              ColDot{nullptr, nullptr, nullptr},
-                              InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
-                              VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st);
+    if (parts != 1 && parts != 3) return (int)hipErrorInvalidValue;
+    return TVAE_DX6_DISPATCH(0, parts, (const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
+                             ColDot{nullptr, nullptr, nullptr},
+                             InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
+                             VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st);
 }
 }  // namespace tvae
 
@@ -37,35 +38,35 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
     }
     return 0;
 }
-static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K,
+static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K, int parts,
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
                            InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
                            VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f},
                            VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
-    if (N % 128 != 0 || !aligned16(a3)) return (int)hipErrorInvalidValue;
+    if (N % 128 != 0 || !aligned16(a3) || (parts != 1 && parts != 3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
     if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
         return (int)hipErrorInvalidValue;
     const DenseBatch nb{0, 0, 0};
-    if (vg.csum) return dense_x6_launch_v3((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    if (va.xr) return dense_x6_launch_v2((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    if (vg.wo) return dense_x6_launch_v1((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    return dense_x6_launch_v0((const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    return TVAE_DX6_DISPATCH(0, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
 }
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, tvae_stream_t stream) {
+                       int va_np, int parts, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
     ep.bias = bias;
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
-    return launch_dense_x6(w3, X, ldx, ep, M, N, K, S(stream), ColDot{col_w, col_b, col_y},
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, parts, S(stream), ColDot{col_w, col_b, col_y},
                            InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
                            VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
 }
@@ -73,7 +74,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
-                         tvae_stream_t stream) {
+                         int parts, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -86,7 +87,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     } else if (!dX) {
         return (int)hipErrorInvalidValue;
     }
-    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, S(stream), ColDot{nullptr, nullptr, nullptr},
+    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
                            InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
                            VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum});
 }

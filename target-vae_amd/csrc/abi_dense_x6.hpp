@@ -13,32 +13,67 @@ static inline long dense_x6_bytes(int rows, int K) {
     return 3 * K8pad * Rpad * 16;
 }
 
-// raw launchers of dense_x6_kernel<XV>, one translation unit each (abi_dense_x6_v0/1/2/3.hip): the kernel is the slowest
-// to compile in the library, so its instances build in parallel
+// raw launchers of dense_x6_kernel<XV, NP>, one translation unit each (abi_dense_x6_v<XV>.hip: exact three-part split,
+// abi_dense_x6_v<XV>b.hip: one-part bf16 throughput mode): the kernel is the slowest to compile in the library, so its
+// instances build in parallel
 #define TVAE_DX6_LAUNCH_ARGS                                                                                          \
     const uint4 *a3, const float *X, long ldx, const Epilogue &ep, int M, int Mpad, int N, int K, int K8pad,          \
         const TileMap &tm, const DenseBatch &bt, const ColDot &cd, const InTail &it, const VirtGrad &vg,              \
         const VirtAct &va, hipStream_t st
-TVAE_INTERNAL int dense_x6_launch_v0(TVAE_DX6_LAUNCH_ARGS);
-TVAE_INTERNAL int dense_x6_launch_v1(TVAE_DX6_LAUNCH_ARGS);
-TVAE_INTERNAL int dense_x6_launch_v2(TVAE_DX6_LAUNCH_ARGS);
-TVAE_INTERNAL int dense_x6_launch_v3(TVAE_DX6_LAUNCH_ARGS);
-#define TVAE_DX6_LAUNCH_DEF(XV_)                                                                                      \
+#define TVAE_DX6_DECL(XV_)                                              \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##_p3(TVAE_DX6_LAUNCH_ARGS); \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##_p1(TVAE_DX6_LAUNCH_ARGS);
+TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3)
+#define TVAE_DX6_LAUNCH_DEF(XV_, NP_)                                                                                 \
     namespace tvae {                                                                                                  \
-    int dense_x6_launch_v##XV_(TVAE_DX6_LAUNCH_ARGS) {                                                                \
-        hipLaunchKernelGGL(dense_x6_kernel<XV_>, dim3(tm.grid()), dim3(DX6_THREADS), 0, st, a3, X, ldx, ep, M, Mpad,  \
-                           N, K, K8pad, tm, bt, cd, it, vg, va);                                                      \
+    int dense_x6_launch_v##XV_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                       \
+        hipLaunchKernelGGL((dense_x6_kernel<XV_, NP_>), dim3(tm.grid()), dim3(DX6_THREADS), 0, st, a3, X, ldx, ep, M, \
+                           Mpad, N, K, K8pad, tm, bt, cd, it, vg, va);                                                \
         return (int)hipGetLastError();                                                                                \
+    }                                                                                                                 \
+    }
+// parts = 3 (exact split) or 1 (bf16 throughput mode); anything else is rejected by the entry points
+#define TVAE_DX6_DISPATCH(XV_, parts_, ...) \
+    ((parts_) == 1 ? dense_x6_launch_v##XV_##_p1(__VA_ARGS__) : dense_x6_launch_v##XV_##_p3(__VA_ARGS__))
+
+// weight-gradient launchers (abi_dense_wgrad_x6.hip: three parts, abi_dense_wgrad_x6_b.hip: one part)
+#define TVAE_WG_LAUNCH_ARGS                                                                                           \
+    int variant, const float *dY, long ldd, const float *X, long ldx, float *ws, int M, int Kf, int N, int nchunk,     \
+        const TileMap &tm, const DenseBatch &bt, long dy_stride, const VirtGrad &vg, const VirtAct &va,               \
+        const ATile &atile, hipStream_t st
+TVAE_INTERNAL int dense_wgrad_x6_launch_p3(TVAE_WG_LAUNCH_ARGS);
+TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
+// variant = VIRT | XVA << 1 | LRF << 2
+#define TVAE_WG_ONE(V_, X_, L_, NP_)                                                                                  \
+    do {                                                                                                              \
+        hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, L_, NP_>, WG_RING_BYTES);                     \
+        if (e_ != hipSuccess) return (int)e_;                                                                         \
+        hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_, L_, NP_>), dim3(tm.grid()), dim3(DX6_THREADS),           \
+                           WG_RING_BYTES, st, dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile); \
+        return (int)hipGetLastError();                                                                                \
+    } while (0)
+#define TVAE_WG_LAUNCH_DEF(NP_)                                                                                       \
+    namespace tvae {                                                                                                  \
+    int dense_wgrad_x6_launch_p##NP_(TVAE_WG_LAUNCH_ARGS) {                                                           \
+        switch (variant) {                                                                                            \
+            case 0: TVAE_WG_ONE(false, false, false, NP_);                                                            \
+            case 1: TVAE_WG_ONE(true, false, false, NP_);                                                             \
+            case 2: TVAE_WG_ONE(false, true, false, NP_);                                                             \
+            case 3: TVAE_WG_ONE(true, true, false, NP_);                                                              \
+            case 5: TVAE_WG_ONE(true, false, true, NP_);                                                              \
+            case 7: TVAE_WG_ONE(true, true, true, NP_);                                                               \
+            default: return (int)hipErrorInvalidValue;                                                                \
+        }                                                                                                             \
     }                                                                                                                 \
     }
 
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
-                                   int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt,
+                                   int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
                                    hipStream_t st);
 // batched weight-gradient GEMM into split-K slabs (abi_dense_wgrad_x6.hip)
 TVAE_INTERNAL int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M,
                                          int Kf, int N, int nchunk, const TileMap& tm, const DenseBatch& bt,
-                                         long dy_stride, const ATile& atile, hipStream_t st);
+                                         long dy_stride, const ATile& atile, int parts, hipStream_t st);
 
 }  // namespace tvae

@@ -72,6 +72,20 @@ static __global__ __launch_bounds__(1024) void dense_rowsum_kernel(const float* 
     }
 }
 
+// NP = bf16 parts per operand: 3 = the exact split (six partial products), 1 = plain bf16 operands (round to nearest, ONE
+// product, fp32 accumulate): the throughput mode BASELINE.json configs 2 and 5 name -- NOT fp32-equivalent (2^-9 per
+// operand), never the default, its own tolerance in the tests.
+template <int NP>
+__device__ __forceinline__ void mfma_np(f32x16& acc, const Cell16 (&a)[3], const Cell16 (&b)[3]) {
+    if (NP == 3) mfma6(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, acc, 0, 0, 0);
+}
+// rounds two values to bf16 (RNE), packed (x0 in the low half): the whole "split" of the one-part mode
+__device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
+    const f32x2v x = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
+}
+
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
 constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
 
@@ -228,7 +242,7 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 
 // XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct),
 //     3 = two-valued implicit gradient (VirtGrad.csum: X is the saved activation H, the operand is [H > 0])
-template <int XV>
+template <int XV, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                      int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
@@ -278,7 +292,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[i][p].u = q[p * part_cells + i * 32];
+            for (int p = 0; p < NP; ++p) a[i][p].u = q[p * part_cells + i * 32];
     };
     // B build role: k-quad kq (4 consecutive k = half a cell), column nb
     const int kq = tid >> 7, nb = tid & 127;
@@ -339,6 +353,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
                                 (x[2] > 0.f ? 0x3f80u : 0u) | (x[3] > 0.f ? 0x3f800000u : 0u));
             return;
         }
+        if (NP == 1) {
+            dst[0] = make_uint2(bf16_pair(x[0], x[1]), bf16_pair(x[2], x[3]));
+            return;
+        }
         unsigned hw[2], mw[2], lw[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) split3_pair(x[2 * q], x[2 * q + 1], hw[q], mw[q], lw[q]);
@@ -384,14 +402,14 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < NP; ++p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[i][p].v, b0.v, acc[i][j], 0, 0, 0);
             } else {
                 Cell16 bf[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-                mfma6(acc[0][j], afc[0], bf);
-                mfma6(acc[1][j], afc[1], bf);
+                for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
+                mfma_np<NP>(acc[0][j], afc[0], bf);
+                mfma_np<NP>(acc[1][j], afc[1], bf);
             }
             if (j == 1) {                                // cells of step t+1, then its buffer takes the values of step t+3
                 virt_x(t + 1 < nk ? t + 1 : t, xn);
@@ -518,7 +536,7 @@ constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 // is the 0 / 1 matrix [H > 0] -- ONE exact bf16 part (1.0 = 0x3f80), built with one compare per element, and THREE MFMAs
 // per product block (the single A part against the three X parts) instead of six.  s[k] is accumulated by the threads
 // that build the X cells (each owns one feature row k of the tile) and joins the partial slab in the epilogue.
-template <bool VIRT, bool XVA, bool LRF>
+template <bool VIRT, bool XVA, bool LRF, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
@@ -667,7 +685,12 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         for (int i = 0; i < 2; ++i) {
             const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
                                 r[i][1].x * a_ok[i], r[i][1].y * a_ok[i], r[i][1].z * a_ok[i], r[i][1].w * a_ok[i]};
-            split3x8(v, a[i][0], a[i][1], a[i][2]);
+            if (NP == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[i][0].w[q] = bf16_pair(v[2 * q], v[2 * q + 1]);
+            } else {
+                split3x8(v, a[i][0], a[i][1], a[i][2]);
+            }
         }
     };
     float ssum = 0.f;
@@ -681,9 +704,13 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const float v[4] = {x.x * gm.x, x.y * gm.y, x.z * gm.z, x.w * gm.w};
         // s[k] of the two-valued form: this thread's share of row kr (the clamped step past the end must not count)
         if (LRF && real_step) ssum += (v[0] + v[1]) + (v[2] + v[3]);
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
+        if (NP == 1) {
+            dst[0] = make_uint2(bf16_pair(v[0], v[1]), bf16_pair(v[2], v[3]));
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
-        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
         dst[0] = make_uint2(hw[0], hw[1]);
         dst[2 * 256] = make_uint2(mw[0], mw[1]);
         dst[2 * 512] = make_uint2(lw[0], lw[1]);
@@ -722,16 +749,16 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         for (int j = 0; j < 4; ++j) {
             Cell16 bf[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p].u = bs[p * 256 + j * 32];
-            if (LRF) {                                   // exact 0 / 1 operand: ONE A part against the three X parts
+            for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
+            if (LRF) {                                   // exact 0 / 1 operand: ONE A part against the X parts
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < NP; ++p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0].v, bf[p].v, acc[i][j], 0, 0, 0);
             } else {
-                mfma6(acc[0][j], af[0], bf);
-                mfma6(acc[1][j], af[1], bf);
+                mfma_np<NP>(acc[0][j], af[0], bf);
+                mfma_np<NP>(acc[1][j], af[1], bf);
             }
             if (j == 0) {                                // A cells of step t+1 from the ring
                 float4 ar[2][2], gn[2];

@@ -24,13 +24,13 @@ SIGNATURES = {
     'tvae_conv1_fwd_x6': 'ppppiiiiiiiif',
     'tvae_dy_split3': 'ppliiiiiii',
     'tvae_conv1_wgrad_x6': 'ppppliiiiiii',
-    'tvae_conv1_fwd_dft': 'ppppppliiiiiiiif',
-    'tvae_conv1_wgrad_dft': 'pppppliiiiiii',
+    'tvae_conv1_fwd_dft': 'ppppppliiiiiiiifi',
+    'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
-    'tvae_linear_fwd_x6': 'pppppiiillifpppppppi',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppi',
+    'tvae_linear_fwd_x6': 'pppppiiillifpppppppii',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppii',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippifppppi',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppii',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -107,9 +107,10 @@ def lib():
 ABI_VERSION = 2
 # Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
 # entry points tvae.ops calls ('x6': *_x6 / *_dft, split-bf16 products with fp32-equivalent results; 'f32': the exact
-# fp32-MFMA entry points).  Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so
+# fp32-MFMA entry points; 'bf16': the *_x6 / *_dft entry points with parts = 1 -- operands rounded to one bf16 number, the
+# throughput mode of BASELINE.json configs 2 / 5, not fp32-equivalent and never the default).  Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so
 # two models with different arithmetic coexist in one process.
-GEMM_MODES = ('f32', 'x6')
+GEMM_MODES = ('f32', 'x6', 'bf16')
 _mode = os.environ.get('TVAE_GEMM', 'x6')
 if _mode not in GEMM_MODES:
     raise TvaeHipError(f'TVAE_GEMM={_mode!r}: choose from {GEMM_MODES}')
@@ -124,6 +125,16 @@ def set_gemm_mode(mode: str) -> None:
 
 def get_gemm_mode() -> str:
     return _mode
+
+
+def split_pipe() -> bool:
+    """True when matrix products go to the bf16 matrix pipe (*_x6 / *_dft entry points)."""
+    return _mode in ('x6', 'bf16')
+
+
+def parts() -> int:
+    """bf16 parts per operand for the *_x6 / *_dft entry points in the current mode."""
+    return 1 if _mode == 'bf16' else 3
 
 
 class arithmetic:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import tables
-from ._lib import arithmetic, call, get_gemm_mode, query
+from ._lib import arithmetic, call, get_gemm_mode, parts, query, split_pipe
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 LRELU_SLOPE = 0.01
@@ -147,7 +147,7 @@ def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None)
 
 def _dense_x6_ok(rows: int, N: int) -> bool:
     """Dense layers on the split bf16 pipe: wide layers only (the 512-row tile would waste a 128-row layer)."""
-    return get_gemm_mode() == 'x6' and N % 128 == 0 and rows >= 256
+    return split_pipe() and N % 128 == 0 and rows >= 256
 
 
 def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str, scale=None):
@@ -167,11 +167,11 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0) -> torch.Tensor:
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
     ws = workspace(dpre.device, max(need, 1 << 24))
-    if get_gemm_mode() == 'x6' and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
+    if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
         with _timed('tvae_linear_wgrad_x6'):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
-                 *(va if va else (None, None, None, None, 0)))
+                 *(va if va else (None, None, None, None, 0)), parts())
         return dW
     _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
@@ -201,7 +201,7 @@ def rotate_bank_bwd(dbank: torch.Tensor, C: int, Cin: int, k: int, R: int) -> to
 
 def _use_x6(Cin, n, k, pad) -> bool:
     """Lifting convolution on the bf16 matrix pipe (exact 3 x bf16 operand split, six products; fp32-equivalent)."""
-    return get_gemm_mode() == 'x6' and bool(query('tvae_conv1_x6_supported', Cin, n, k, pad))
+    return split_pipe() and bool(query('tvae_conv1_x6_supported', Cin, n, k, pad))
 
 
 def _scratch(device, key, floats: int) -> torch.Tensor:
@@ -224,7 +224,7 @@ FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
     """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): 7x fewer matrix FLOPs than the direct
     form; same arithmetic mode as 'x6' (TVAE_CONV_DFT=0 keeps the direct x6 kernels)."""
-    return CONV_DFT and get_gemm_mode() == 'x6' and bool(query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R))
+    return CONV_DFT and split_pipe() and bool(query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R))
 
 
 def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
@@ -241,7 +241,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
         _note('conv1.dft')
         with _timed('tvae_conv1_fwd'):
             call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,
-                 LRELU_SLOPE)
+                 LRELU_SLOPE, parts())
         if keep is not None:
             keep['at'] = at
         return out
@@ -266,7 +266,7 @@ def conv1_wgrad(y, dpre, C, R, k, pad, at=None, dbias=None):
     if at is not None:
         wsd = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
         with _timed('tvae_conv1_wgrad'):
-            call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, wsd, wsd.numel(), B, Cin, n, k, pad, C, R)
+            call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, parts())
         return dbank
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     if _use_x6(Cin, n, k, pad):
@@ -542,7 +542,7 @@ class DecoderFn(torch.autograd.Function):
                 w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
-                         None, None, None, None, None, None, None, 0)
+                         None, None, None, None, None, None, None, 0, parts())
             else:
                 call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
         else:
@@ -559,7 +559,7 @@ class DecoderFn(torch.autograd.Function):
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
-                         *(va if va and li == 0 else (None, None, None, None, 0)))
+                         *(va if va and li == 0 else (None, None, None, None, 0)), parts())
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
@@ -640,7 +640,7 @@ class DecoderFn(torch.autograd.Function):
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
-                         bc if va else None, LB if va else None, Np if va else 0)
+                         bc if va else None, LB if va else None, Np if va else 0, parts())
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
@@ -680,7 +680,7 @@ class DecoderFn(torch.autograd.Function):
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
-                         None, None, None, None, 0, None, None, None, None, None, 0)
+                         None, None, None, None, 0, None, None, None, None, None, 0, parts())
             else:
                 call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)

@@ -166,8 +166,9 @@ def test_step_golden(name):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
 
 
-HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.fuse_in'}),
-       'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad'})}
+HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
+                                'dec.fuse_in'}),
+       'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val'})}
 
 
 @pytest.mark.parametrize('name', sorted(HOT))
@@ -205,6 +206,40 @@ def test_step_hot_widths_golden(name, gemm_mode):
     assert_encoder_grads(enc, fx, GRAD_TOL, kink_prefix='ke.')
     for k_, t in gen.named_parameters():
         assert_grad_close(t.grad, fx['gd.' + k_], tol=max(GRAD_TOL, 2 * float(fx['kd.' + k_])), name='gen.' + k_)
+
+
+@pytest.mark.parametrize('name', sorted(HOT))
+def test_bf16_throughput_mode(name):
+    """The opt-in bf16 throughput mode (operands rounded to ONE bf16 number, one MFMA per product block, fp32
+    accumulate; BASELINE.json configs 2 / 5) on the same full-width steps and the same fused branches.  It is NOT
+    fp32-equivalent and is held to its own, stated tolerance: ELBO terms within 2e-2 relative of the reference, the
+    gradient of every parameter tensor within 25 % of its max-norm and at a cosine of >= 0.98 to the reference's."""
+    from tvae import _lib, ops, step
+    fx = load_golden(name)
+    lik, want = HOT[name]
+    enc, gen, n = seeded_models(fx)
+    enc, gen = enc.to(dev()), gen.to(dev())
+    x = O.image_coords(n).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    ops.PATH_LOG = set()
+    try:
+        with _lib.arithmetic('bf16'):
+            elbo, logp, kl = step.elbo_terms(x, torch.from_numpy(fx['y']).to(dev()), gen, enc, lik, noise)
+        (-elbo).backward()                  # outside the block: the backward runs in its forward's arithmetic
+        torch.cuda.synchronize()
+        took = set(ops.PATH_LOG)
+    finally:
+        ops.PATH_LOG = None
+    assert want <= took, (want - took, took)
+    for got, key in ((elbo, 'elbo'), (logp, 'log_p'), (kl, 'kl')):
+        assert abs(float(got) - float(fx[key])) / abs(float(fx[key])) < 2e-2, (key, float(got), float(fx[key]))
+    for prefix, mod in (('ge.', enc), ('gd.', gen)):
+        for k_, t in mod.named_parameters():
+            if k_ == 'conv_a.bias':
+                continue                    # analytically zero
+            a, b = t.grad.double().cpu().reshape(-1), torch.from_numpy(fx[prefix + k_]).double().reshape(-1)
+            assert float((a - b).abs().max() / b.abs().max()) < 0.25, (k_, float((a - b).abs().max() / b.abs().max()))
+            assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.98, k_
 
 
 def test_step_hot_widths_intermediates_vs_oracle():

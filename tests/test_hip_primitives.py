@@ -201,7 +201,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     cy = torch.empty(N, device=dev())
     fuse = M <= 512
     call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), res.to(dev()) if use_res else None, Y, M, N, K, N, N, act,
-         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None, None, None, None, None, 0)
+         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None, None, None, None, None, 0, 3)
     if fuse:
         assert rel_err(cy, cw.double() @ ref + cb.double()) < GEMM_TOL['f32']
     assert rel_err(Y, ref) < GEMM_TOL['f32']
@@ -217,10 +217,10 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0, 3)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0)
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0, 3)
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(512, 20000 // 16 * 16, 512, 0), (128, 8192, 128, 0), (300, 1600, 70, 1), (512, 4096, 512, 1)])
@@ -230,10 +230,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
-    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0)
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, 3)
     assert rel_err(dW, ref) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0)
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, 3)
 
 
 @pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
@@ -255,7 +255,7 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
     ws = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
     call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, ws, ws.numel(), B, Cin, n, k, pad,
-         C, R, act, SLOPE)
+         C, R, act, SLOPE, 3)
     got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
     assert rel_err(got, ref) < GEMM_TOL['f32']
     g = rnd(B, C, R, Ho, Ho, seed=4)
@@ -263,7 +263,7 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
     dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
     dbank = torch.empty(C * R, Cin * k * k, device=dev())
     dbias = torch.empty(C, device=dev())
-    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R)
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, 3)
     assert rel_err(dbias, g.double().sum(dim=(0, 2, 3, 4))) < TOL
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
@@ -282,7 +282,7 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     gxr = torch.empty(Nt, 2, device=dev())
     part = torch.empty((Nt // 128) * F_ * 3, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
-         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, None, 0)
+         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, None, 0, 3)
     Simg = torch.empty(B, F_, device=dev())
     dbc = torch.empty(F_, device=dev())
     dWc = torch.empty(F_, 2, device=dev())
@@ -305,7 +305,7 @@ def test_linear_x6_implicit_gradient_operand():
     call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, wo.to(dev()), gy.to(dev()), None, None, None, 0)
+         None, 0, wo.to(dev()), gy.to(dev()), None, None, None, 0, 3)
     assert rel_err(dX, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
     # the same product in the two-valued form (LeakyReLU): weights scaled by wo before the split, 0 / 1 streamed operand
     csum = torch.empty(K, device=dev())
@@ -313,17 +313,17 @@ def test_linear_x6_implicit_gradient_operand():
     assert rel_err(csum, (W.double() * wo.double()[:, None]).sum(0)) < TOL
     dX2 = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, None, gy.to(dev()), csum, None, None, 0)
+         None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
     assert rel_err(dX2, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
     with pytest.raises(Exception):         # the two-valued form exists for LeakyReLU only
         call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 2, SLOPE, None, None, None,
-             None, 0, None, gy.to(dev()), csum, None, None, 0)
+             None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
     ws = torch.empty(1 << 24, device=dev())
     for vact in (1, 2):                    # LeakyReLU: two-valued weight gradient; tanh: generic implicit operand
         dv = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), vact)
         dW = torch.empty(M, K, device=dev())
         call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
-             gy.to(dev()), vact, SLOPE, None, None, None, None, 0)
+             gy.to(dev()), vact, SLOPE, None, None, None, None, 0, 3)
         assert rel_err(dW, dv @ X.double().t()) < GEMM_TOL['f32'], vact
     # dec_out_bwd without the gradient tensor: sums only
     F_ = M
@@ -356,8 +356,8 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     # forward
     Y = [torch.empty(M, Nt, device=dev()) for _ in range(2)]
     call('tvae_linear_fwd_x6', w3, h0, b.to(dev()), None, Y[0], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
-         None, None, None, None, 0)
-    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va)
+         None, None, None, None, 0, 3)
+    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va, 3)
     assert torch.equal(Y[0], Y[1])
     assert rel_err(Y[0], act_ref(W.double() @ h0.double().cpu() + b.double()[:, None], act)) < GEMM_TOL['f32']
     # data gradient with the fused coordinate-layer backward
@@ -366,7 +366,7 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
         gxr = torch.empty(Nt, 2, device=dev())
         part = torch.empty((Nt // 128) * F_ * 3, device=dev())
         call('tvae_linear_dgrad_x6', w3t, d, None, None if virt else h0, None, M, Nt, F_, Nt, Nt, act, SLOPE, xr, Wc,
-             gxr, part, part.numel(), None, None, None, bc if virt else None, LB if virt else None, Np if virt else 0)
+             gxr, part, part.numel(), None, None, None, bc if virt else None, LB if virt else None, Np if virt else 0, 3)
         outs.append((gxr, part))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     d0 = (W.double().t() @ d.double().cpu()) * dact_ref(h0.double().cpu(), act)
@@ -375,14 +375,14 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     ws = torch.empty(1 << 24, device=dev())
     dW = [torch.empty(M, F_, device=dev()) for _ in range(2)]
     call('tvae_linear_wgrad_x6', d, h0, dW[0], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE,
-         None, None, None, None, 0)
-    call('tvae_linear_wgrad_x6', d, None, dW[1], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE, *va)
+         None, None, None, None, 0, 3)
+    call('tvae_linear_wgrad_x6', d, None, dW[1], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE, *va, 3)
     assert torch.equal(dW[0], dW[1])
     assert rel_err(dW[1], d.double().cpu() @ h0.double().cpu().t()) < GEMM_TOL['f32']
     # images that are not whole column tiles are refused
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
-             xr, Wc, bc, LB, 96)
+             xr, Wc, bc, LB, 96, 3)
 
 
 def test_reductions():
@@ -642,7 +642,7 @@ def test_implicit_wgrad_and_multi_tile_dft_fp64():
     wo = torch.randn(M, generator=g); gy = torch.randn(N, generator=g)
     dW = torch.empty(M, K, device=dev()); ws = torch.empty(1 << 24, device=dev())
     call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()), gy.to(dev()), 1, 0.01,
-         None, None, None, None, 0)
+         None, None, None, None, 0, 3)
     d = wo.double()[:, None] * gy.double()[None, :] * torch.where(H.double() > 0, 1.0, 0.01)
     e1 = rel(dW, d @ X.double().t())
     # frequency-domain convolution, forward + weight gradient, a batch whose (image, row) columns span several tiles
@@ -652,13 +652,13 @@ def test_implicit_wgrad_and_multi_tile_dft_fp64():
     at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev())
     wsd = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
-    call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 0, 0.01)
+    call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, 0, 0.01, 3)
     ref = torch.nn.functional.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), padding=pad).view(B, C, R, Ho, Ho) + bias.double().view(1, C, 1, 1, 1)
     e2 = rel(out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4), ref)
     gg = torch.randn(B, C, R, Ho, Ho, generator=g)
     dbank = torch.empty(C * R, k * k, device=dev()); dbias = torch.empty(C, device=dev())
     call('tvae_conv1_wgrad_dft', gg.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev()), at, dbank, dbias, wsd, wsd.numel(),
-         B, Cin, n, k, pad, C, R)
+         B, Cin, n, k, pad, C, R, 3)
     refg = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), gg.double().view(B, C * R, Ho, Ho), padding=pad)
     e3 = rel(dbank.view(C * R, Cin, k, k), refg)
     torch.cuda.synchronize()
