@@ -208,13 +208,17 @@ int tvae_heads_bwd(const float* W, const float* dY, long ldy, const float* X, lo
 int tvae_attn_head_fwd(const float* heads, long ldh, const float* E, const float* eps_z, const float* eps_t,
                        const float* p_r, const float* off, const float* p_tr, const float* grid, int B, int R, int P,
                        int zd, float sigma_p, float theta_off_scale, float* attn, float* q, float* a, float* z,
-                       float* theta, float* dx, float* kl, tvae_stream_t stream);
-/* upstream gz [B][zd], gth [B], gdx [B][2], gkl [B]; optional g_attn/g_q/g_a [B][R*P] (NULL = zero) -> dheads */
+                       float* theta, float* dx, float* kl, float* part, long part_floats, tvae_stream_t stream);
+/* part (optional workspace, both entries): with few images of very many positions (B < 128, R*P >= 16 384: the galaxy
+ * configuration has 8 x 266 256) an image is spread over up to 1024/B workgroups and the partial (max, sum) pairs /
+ * pooled sums go through it: forward needs B * G * (7 + 3*(zd+1)) floats, backward 2 * B * G; NULL or too small = one
+ * workgroup per image.
+ * upstream gz [B][zd], gth [B], gdx [B][2], gkl [B]; optional g_attn/g_q/g_a [B][R*P] (NULL = zero) -> dheads */
 int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float* a, const float* eps_z,
                        const float* eps_t, const float* p_r, const float* off, const float* p_tr, const float* grid,
                        int B, int R, int P, int zd, float sigma_p, float theta_off_scale, const float* gz,
                        const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
-                       const float* g_a, float* dheads, tvae_stream_t stream);
+                       const float* g_a, float* dheads, float* part, long part_floats, tvae_stream_t stream);
 
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */

@@ -190,12 +190,38 @@ static HeadParams make_head(const float* heads, long ldh, const float* E, const 
     return hp;
 }
 
+// Few images with very many positions (cfg5: 8 x 266 256): G workgroups per image, partial results through `part`.
+// With many images (B >= 128) one workgroup per image already fills the chip.
+static int head_chunks(int B, int RP, int zd, long part_floats, int per_chunk_floats, int& chunk) {
+    chunk = RP;
+    if (B >= 128 || RP < 16384 || zd > 64) return 1;
+    int G = (RP + 4095) / 4096;
+    const int cap = 1024 / (B > 0 ? B : 1);
+    if (G > cap) G = cap;
+    if (G < 2 || part_floats < (long)B * G * per_chunk_floats) return 1;
+    chunk = (RP + G - 1) / G;
+    return (RP + chunk - 1) / chunk;
+}
+
 int tvae_attn_head_fwd(const float* heads, long ldh, const float* E, const float* eps_z, const float* eps_t,
                        const float* p_r, const float* off, const float* p_tr, const float* grid, int B, int R, int P,
                        int zd, float sigma_p, float theta_off_scale, float* attn, float* q, float* a, float* z,
-                       float* theta, float* dx, float* kl, tvae_stream_t stream) {
+                       float* theta, float* dx, float* kl, float* part, long part_floats, tvae_stream_t stream) {
     if (B <= 0) return 0;
     HeadParams hp = make_head(heads, ldh, E, eps_z, eps_t, p_r, off, p_tr, grid, R, P, zd, sigma_p, theta_off_scale);
+    int chunk;
+    const int G = part ? head_chunks(B, R * P, zd, part_floats, head_part_floats(zd), chunk) : 1;
+    if (G > 1) {
+        hipLaunchKernelGGL(attn_head_fwd_a_kernel, dim3(B * G), dim3(1024), 0, S(stream), hp, G, chunk, attn, part);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_head_fwd_b_kernel, dim3(B * G), dim3(1024), 0, S(stream), hp, G, chunk, (const float*)attn,
+                           q, a, part);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_head_fwd_c_kernel, dim3(B), dim3(256), 0, S(stream), hp, B, G, (const float*)part, z, theta,
+                           dx, kl);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_head_fwd_kernel, dim3(B), dim3(1024), 0, S(stream), hp, attn, q, a, z, theta, dx, kl);
     TVAE_CHECK_LAUNCH();
     return 0;
@@ -205,10 +231,21 @@ int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float
                        const float* eps_t, const float* p_r, const float* off, const float* p_tr, const float* grid,
                        int B, int R, int P, int zd, float sigma_p, float theta_off_scale, const float* gz,
                        const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
-                       const float* g_a, float* dheads, tvae_stream_t stream) {
+                       const float* g_a, float* dheads, float* part, long part_floats, tvae_stream_t stream) {
     if (B <= 0) return 0;
     HeadParams hp = make_head(heads, ldh, nullptr, eps_z, eps_t, p_r, off, p_tr, grid, R, P, zd, sigma_p,
                               theta_off_scale);
+    int chunk;
+    const int G = part ? head_chunks(B, R * P, zd, part_floats, 2, chunk) : 1;
+    if (G > 1) {
+        hipLaunchKernelGGL(attn_head_bwd_a_kernel, dim3(B * G), dim3(1024), 0, S(stream), hp, G, chunk, q, a, gz, gth, gdx,
+                           gkl, g_q, g_a, part);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_head_bwd_b_kernel, dim3(B * G), dim3(1024), 0, S(stream), hp, G, chunk, q, a, gz, gth, gdx,
+                           gkl, g_attn, g_q, g_a, (const float*)part, dheads);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_head_bwd_kernel, dim3(B), dim3(1024), 0, S(stream), hp, q, a, gz, gth, gdx, gkl, g_attn,
                        g_q, g_a, dheads);
     TVAE_CHECK_LAUNCH();

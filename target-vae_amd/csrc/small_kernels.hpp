@@ -469,35 +469,31 @@ struct HeadParams {
     float theta_off_scale; // 1 if offsets are added to theta_mu (rot_refinement), else 0
 };
 
-static __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, float* __restrict__ q,
-                                     float* __restrict__ a, float* __restrict__ zs, float* __restrict__ th,
-                                     float* __restrict__ dxo, float* __restrict__ kl) {
-    __shared__ float sm[4 * 16];
-    const int b = blockIdx.x;
-    const int RP = hp.R * hp.P;
-    const long base = (long)b * RP;
+// ---- phases of the head over a range [j0, j1) of one image's R*P positions: shared by the one-workgroup-per-image
+// kernels (small R*P: 256 images x 8 712 positions at cfg4) and the chunked ones (cfg5: 8 images x 266 256 positions) ----
+__device__ __forceinline__ void head_p1(const HeadParams& hp, long base, int j0, int j1, float* __restrict__ attn,
+                                        float& m1, float& m2) {
     const float* logit = hp.heads + base;
-    float m1 = -INFINITY, m2 = -INFINITY;
-    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
         const float l = logit[j] + hp.p_r[j / hp.P];
         attn[base + j] = l;
         m1 = fmaxf(m1, l);
         m2 = fmaxf(m2, l - logf(hp.E[base + j]));
     }
-    m1 = block_max(m1, sm);
-    m2 = block_max(m2, sm);
-    float s[2] = {0.f, 0.f};
-    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+}
+__device__ __forceinline__ void head_p2(const HeadParams& hp, long base, int j0, int j1, const float* __restrict__ attn,
+                                        float m1, float m2, float (&s)[2]) {
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
         const float l = attn[base + j];
         s[0] += expf(l - m1);
         s[1] += expf(l - logf(hp.E[base + j]) - m2);
     }
-    block_sum<2>(s, sm);
-    const float lse = m1 + logf(s[0]);
-    const float inv2 = 1.f / s[1];
-    // translation pooling + val1
-    float t[3] = {0.f, 0.f, 0.f};
-    for (int j = threadIdx.x; j < RP; j += blockDim.x) {
+}
+// q, a and the translation pooling + val1 sums
+__device__ __forceinline__ void head_p3(const HeadParams& hp, long base, int j0, int j1, const float* __restrict__ attn,
+                                        float lse, float m2, float inv2, float* __restrict__ q, float* __restrict__ a,
+                                        float (&t)[3]) {
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
         const float l = attn[base + j];
         const float qq = l - lse;
         const float aa = expf(l - logf(hp.E[base + j]) - m2) * inv2;
@@ -508,37 +504,61 @@ static __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ a
         t[1] += aa * hp.grid[2 * hw + 1];
         t[2] += expf(qq) * (qq - hp.p_tr[j]);
     }
+}
+// theta (c = -1) or latent dim c: pooled mean / std and E_q[KL] sums
+__device__ __forceinline__ void head_p4(const HeadParams& hp, long base, int j0, int j1, int c, const float* __restrict__ q,
+                                        const float* __restrict__ a, float (&u)[3]) {
+    const float* mu_p = hp.heads + (long)(c < 0 ? 1 : 3 + c) * hp.ldh + base;
+    const float* ls_p = hp.heads + (long)(c < 0 ? 2 : 3 + hp.zd + c) * hp.ldh + base;
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const float aa = a[base + j];
+        const float eq = expf(q[base + j]);
+        float mu = mu_p[j];
+        float sd = expf(ls_p[j]) + EPS_STD;
+        float klv;
+        if (c < 0) {
+            const float o = hp.off[j / hp.P];
+            mu += hp.theta_off_scale * o;
+            u[0] += aa * mu;
+            u[1] += aa * sd;
+            if (eq == 0.f) { mu = 0.f; sd = 1.f; }
+            const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
+            const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
+            klv = 0.5f * (vr + t1 - 1.f - logf(vr));
+        } else {
+            u[0] += aa * mu;
+            u[1] += aa * sd;
+            if (eq == 0.f) { mu = 0.f; sd = 1.f; }
+            klv = 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
+        }
+        u[2] += eq * klv;
+    }
+}
+
+static __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ attn, float* __restrict__ q,
+                                     float* __restrict__ a, float* __restrict__ zs, float* __restrict__ th,
+                                     float* __restrict__ dxo, float* __restrict__ kl) {
+    __shared__ float sm[4 * 16];
+    const int b = blockIdx.x;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    head_p1(hp, base, 0, RP, attn, m1, m2);
+    m1 = block_max(m1, sm);
+    m2 = block_max(m2, sm);
+    float s[2] = {0.f, 0.f};
+    head_p2(hp, base, 0, RP, attn, m1, m2, s);
+    block_sum<2>(s, sm);
+    const float lse = m1 + logf(s[0]);
+    const float inv2 = 1.f / s[1];
+    float t[3] = {0.f, 0.f, 0.f};
+    head_p3(hp, base, 0, RP, attn, lse, m2, inv2, q, a, t);
     block_sum<3>(t, sm);
     float klsum = t[2];
     if (threadIdx.x == 0) { dxo[2 * b] = t[0]; dxo[2 * b + 1] = t[1]; }
-    // theta (c = -1) and the zd latent dims: pooled mean / std and E_q[KL]
     for (int c = -1; c < hp.zd; ++c) {
-        const float* mu_p = hp.heads + (long)(c < 0 ? 1 : 3 + c) * hp.ldh + base;
-        const float* ls_p = hp.heads + (long)(c < 0 ? 2 : 3 + hp.zd + c) * hp.ldh + base;
         float u[3] = {0.f, 0.f, 0.f};
-        for (int j = threadIdx.x; j < RP; j += blockDim.x) {
-            const float aa = a[base + j];
-            const float eq = expf(q[base + j]);
-            float mu = mu_p[j];
-            float sd = expf(ls_p[j]) + EPS_STD;
-            float klv;
-            if (c < 0) {
-                const float o = hp.off[j / hp.P];
-                mu += hp.theta_off_scale * o;
-                u[0] += aa * mu;
-                u[1] += aa * sd;
-                if (eq == 0.f) { mu = 0.f; sd = 1.f; }
-                const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
-                const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
-                klv = 0.5f * (vr + t1 - 1.f - logf(vr));
-            } else {
-                u[0] += aa * mu;
-                u[1] += aa * sd;
-                if (eq == 0.f) { mu = 0.f; sd = 1.f; }
-                klv = 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
-            }
-            u[2] += eq * klv;
-        }
+        head_p4(hp, base, 0, RP, c, q, a, u);
         block_sum<3>(u, sm);
         klsum += u[2];
         if (threadIdx.x == 0) {
@@ -549,8 +569,171 @@ static __global__ void attn_head_fwd_kernel(HeadParams hp, float* __restrict__ a
     if (threadIdx.x == 0) kl[b] = klsum;
 }
 
+// ---- chunked forward: G workgroups per image, three launches.  part layout per (image, chunk):
+//   [0..3]  = (m1, s0 relative to m1, m2, s1 relative to m2)      written by _a
+//   [4..]   = t[3], then u[3] for c = -1 .. zd-1                   written by _b
+// The chunk results are combined in chunk order (deterministic); a softmax over chunks is rescaled to the common maximum.
+constexpr int HEAD_PART_A = 4;
+__host__ __device__ inline int head_part_floats(int zd) { return HEAD_PART_A + 3 + 3 * (zd + 1); }
+
+static __global__ void attn_head_fwd_a_kernel(HeadParams hp, int G, int chunk, float* __restrict__ attn,
+                                              float* __restrict__ part) {
+    __shared__ float sm[4 * 16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    const int j0 = g * chunk, j1 = min(RP, j0 + chunk);
+    float m1 = -INFINITY, m2 = -INFINITY;
+    head_p1(hp, base, j0, j1, attn, m1, m2);
+    m1 = block_max(m1, sm);
+    m2 = block_max(m2, sm);
+    float s[2] = {0.f, 0.f};
+    head_p2(hp, base, j0, j1, attn, m1, m2, s);
+    block_sum<2>(s, sm);
+    if (threadIdx.x == 0) {
+        float* p = part + (long)blockIdx.x * head_part_floats(hp.zd);
+        p[0] = m1; p[1] = s[0]; p[2] = m2; p[3] = s[1];
+    }
+}
+// combined (max, sum) over the G chunks of image b
+__device__ __forceinline__ void head_combine(const float* __restrict__ part, int b, int G, int pf, float& m1, float& s0,
+                                             float& m2, float& s1) {
+    m1 = -INFINITY; m2 = -INFINITY;
+    for (int g = 0; g < G; ++g) {
+        const float* p = part + ((long)b * G + g) * pf;
+        m1 = fmaxf(m1, p[0]);
+        m2 = fmaxf(m2, p[2]);
+    }
+    s0 = 0.f; s1 = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float* p = part + ((long)b * G + g) * pf;
+        s0 += p[1] * expf(p[0] - m1);
+        s1 += p[3] * expf(p[2] - m2);
+    }
+}
+static __global__ void attn_head_fwd_b_kernel(HeadParams hp, int G, int chunk, const float* __restrict__ attn,
+                                              float* __restrict__ q, float* __restrict__ a, float* __restrict__ part) {
+    __shared__ float sm[4 * 16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int RP = hp.R * hp.P;
+    const long base = (long)b * RP;
+    const int j0 = g * chunk, j1 = min(RP, j0 + chunk);
+    const int pf = head_part_floats(hp.zd);
+    float m1, s0, m2, s1;
+    head_combine(part, b, G, pf, m1, s0, m2, s1);
+    const float lse = m1 + logf(s0);
+    const float inv2 = 1.f / s1;
+    float* p = part + (long)blockIdx.x * pf + HEAD_PART_A;
+    float t[3] = {0.f, 0.f, 0.f};
+    head_p3(hp, base, j0, j1, attn, lse, m2, inv2, q, a, t);
+    block_sum<3>(t, sm);
+    if (threadIdx.x == 0) { p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; }
+    for (int c = -1; c < hp.zd; ++c) {
+        float u[3] = {0.f, 0.f, 0.f};
+        head_p4(hp, base, j0, j1, c, q, a, u);
+        block_sum<3>(u, sm);
+        if (threadIdx.x == 0) { p[3 + 3 * (c + 1)] = u[0]; p[4 + 3 * (c + 1)] = u[1]; p[5 + 3 * (c + 1)] = u[2]; }
+    }
+}
+// one thread per (image, output): sums the chunk partials in chunk order
+static __global__ void attn_head_fwd_c_kernel(HeadParams hp, int B, int G, const float* __restrict__ part,
+                                              float* __restrict__ zs, float* __restrict__ th, float* __restrict__ dxo,
+                                              float* __restrict__ kl) {
+    const int pf = head_part_floats(hp.zd);
+    const int nout = 3 + 3 * (hp.zd + 1);
+    __shared__ float tot[3 + 3 * 65];
+    const int b = blockIdx.x;
+    for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += part[((long)b * G + g) * pf + HEAD_PART_A + o];
+        tot[o] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dxo[2 * b] = tot[0];
+        dxo[2 * b + 1] = tot[1];
+        float klsum = tot[2];
+        for (int c = -1; c < hp.zd; ++c) {
+            const float u0 = tot[3 + 3 * (c + 1)], u1 = tot[4 + 3 * (c + 1)];
+            klsum += tot[5 + 3 * (c + 1)];
+            if (c < 0) th[b] = u1 * hp.eps_t[b] + u0;
+            else zs[b * hp.zd + c] = u1 * hp.eps_z[b * hp.zd + c] + u0;
+        }
+        kl[b] = klsum;
+    }
+}
+
 // Backward of the head.  Upstream: gz[B][zd], gth[B], gdx[B][2], gkl[B] and (optional, may be null)
 // g_attn, g_q, g_a [B][RP] for the module-level 7-tuple API.  Output dheads[ch][img*RP + j].
+// One pass over [j0, j1): pass 0 accumulates acc = (sum a*da, sum dq); pass 1 writes dheads given (sa, sq).
+__device__ __forceinline__ void head_bwd_pass(const HeadParams& hp, int b, long base, int j0, int j1, int pass, float sa,
+                                              float sq, const float* __restrict__ q, const float* __restrict__ a,
+                                              const float* __restrict__ gz, const float* __restrict__ gth,
+                                              const float* __restrict__ gdx, const float* __restrict__ gkl,
+                                              const float* __restrict__ g_attn, const float* __restrict__ g_q,
+                                              const float* __restrict__ g_a, float* __restrict__ dheads, float (&acc)[2]) {
+    const float w = gkl[b];
+    const float gt = gth[b];
+    const float et = hp.eps_t[b];
+    const float gd0 = gdx[2 * b], gd1 = gdx[2 * b + 1];
+    const float isp2 = 1.f / (hp.sigma_p * hp.sigma_p);
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const float aa = a[base + j];
+        const float qq = q[base + j];
+        const float eq = expf(qq);
+        const bool dead = (eq == 0.f);
+        const int r = j / hp.P, hw = j - r * hp.P;
+        const float o = hp.off[r];
+        // theta
+        const float tmu_raw = hp.heads[1 * hp.ldh + base + j];
+        const float tls = hp.heads[2 * hp.ldh + base + j];
+        const float tmu = tmu_raw + hp.theta_off_scale * o;
+        const float tex = expf(tls);
+        const float tsd = tex + EPS_STD;
+        float da = gt * (tmu + et * tsd) + gd0 * hp.grid[2 * hw] + gd1 * hp.grid[2 * hw + 1];
+        float klsum;
+        {
+            const float mu = dead ? 0.f : tmu, sd = dead ? 1.f : tsd;
+            const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
+            const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
+            klsum = 0.5f * (vr + t1 - 1.f - logf(vr));
+        }
+        if (pass == 1) {
+            float dmu = aa * gt, dsd = aa * gt * et;
+            if (!dead) { dmu += w * eq * (tmu - o) * isp2; dsd += w * eq * (tsd * isp2 - 1.f / tsd); }
+            dheads[1 * hp.ldh + base + j] = dmu;
+            dheads[2 * hp.ldh + base + j] = dsd * tex;
+        }
+        for (int d = 0; d < hp.zd; ++d) {
+            const float zmu = hp.heads[(long)(3 + d) * hp.ldh + base + j];
+            const float zls = hp.heads[(long)(3 + hp.zd + d) * hp.ldh + base + j];
+            const float zex = expf(zls);
+            const float zsd = zex + EPS_STD;
+            const float g = gz[b * hp.zd + d], ez = hp.eps_z[b * hp.zd + d];
+            da += g * (zmu + ez * zsd);
+            const float mu = dead ? 0.f : zmu, sd = dead ? 1.f : zsd;
+            klsum += 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
+            if (pass == 1) {
+                float dmu = aa * g, dsd = aa * g * ez;
+                if (!dead) { dmu += w * eq * zmu; dsd += w * eq * (zsd - 1.f / zsd); }
+                dheads[(long)(3 + d) * hp.ldh + base + j] = dmu;
+                dheads[(long)(3 + hp.zd + d) * hp.ldh + base + j] = dsd * zex;
+            }
+        }
+        if (g_a) da += g_a[base + j];
+        float dq = w * eq * (qq - hp.p_tr[j] + 1.f + klsum);
+        if (g_q) dq += g_q[base + j];
+        if (pass == 0) {
+            acc[0] += aa * da;
+            acc[1] += dq;
+        } else {
+            float dl = aa * (da - sa) + dq - eq * sq;
+            if (g_attn) dl += g_attn[base + j];
+            dheads[base + j] = dl;
+        }
+    }
+}
+
 static __global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restrict__ q, const float* __restrict__ a,
                                      const float* __restrict__ gz, const float* __restrict__ gth,
                                      const float* __restrict__ gdx, const float* __restrict__ gkl,
@@ -560,76 +743,40 @@ static __global__ void attn_head_bwd_kernel(HeadParams hp, const float* __restri
     const int b = blockIdx.x;
     const int RP = hp.R * hp.P;
     const long base = (long)b * RP;
-    const float w = gkl[b];
-    const float gt = gth[b];
-    const float et = hp.eps_t[b];
-    const float gd0 = gdx[2 * b], gd1 = gdx[2 * b + 1];
-    const float isp2 = 1.f / (hp.sigma_p * hp.sigma_p);
-    float red[2] = {0.f, 0.f};
-    for (int pass = 0; pass < 2; ++pass) {
-        const float sa = red[0], sq = red[1];   // valid in pass 1
-        float acc[2] = {0.f, 0.f};
-        for (int j = threadIdx.x; j < RP; j += blockDim.x) {
-            const float aa = a[base + j];
-            const float qq = q[base + j];
-            const float eq = expf(qq);
-            const bool dead = (eq == 0.f);
-            const int r = j / hp.P, hw = j - r * hp.P;
-            const float o = hp.off[r];
-            // theta
-            const float tmu_raw = hp.heads[1 * hp.ldh + base + j];
-            const float tls = hp.heads[2 * hp.ldh + base + j];
-            const float tmu = tmu_raw + hp.theta_off_scale * o;
-            const float tex = expf(tls);
-            const float tsd = tex + EPS_STD;
-            float da = gt * (tmu + et * tsd) + gd0 * hp.grid[2 * hw] + gd1 * hp.grid[2 * hw + 1];
-            float klsum;
-            {
-                const float mu = dead ? 0.f : tmu, sd = dead ? 1.f : tsd;
-                const float vr = (sd / hp.sigma_p) * (sd / hp.sigma_p);
-                const float t1 = ((mu - o) / hp.sigma_p) * ((mu - o) / hp.sigma_p);
-                klsum = 0.5f * (vr + t1 - 1.f - logf(vr));
-            }
-            if (pass == 1) {
-                float dmu = aa * gt, dsd = aa * gt * et;
-                if (!dead) { dmu += w * eq * (tmu - o) * isp2; dsd += w * eq * (tsd * isp2 - 1.f / tsd); }
-                dheads[1 * hp.ldh + base + j] = dmu;
-                dheads[2 * hp.ldh + base + j] = dsd * tex;
-            }
-            for (int d = 0; d < hp.zd; ++d) {
-                const float zmu = hp.heads[(long)(3 + d) * hp.ldh + base + j];
-                const float zls = hp.heads[(long)(3 + hp.zd + d) * hp.ldh + base + j];
-                const float zex = expf(zls);
-                const float zsd = zex + EPS_STD;
-                const float g = gz[b * hp.zd + d], ez = hp.eps_z[b * hp.zd + d];
-                da += g * (zmu + ez * zsd);
-                const float mu = dead ? 0.f : zmu, sd = dead ? 1.f : zsd;
-                klsum += 0.5f * (sd * sd + mu * mu - 1.f - logf(sd * sd));
-                if (pass == 1) {
-                    float dmu = aa * g, dsd = aa * g * ez;
-                    if (!dead) { dmu += w * eq * zmu; dsd += w * eq * (zsd - 1.f / zsd); }
-                    dheads[(long)(3 + d) * hp.ldh + base + j] = dmu;
-                    dheads[(long)(3 + hp.zd + d) * hp.ldh + base + j] = dsd * zex;
-                }
-            }
-            if (g_a) da += g_a[base + j];
-            float dq = w * eq * (qq - hp.p_tr[j] + 1.f + klsum);
-            if (g_q) dq += g_q[base + j];
-            if (pass == 0) {
-                acc[0] += aa * da;
-                acc[1] += dq;
-            } else {
-                float dl = aa * (da - sa) + dq - eq * sq;
-                if (g_attn) dl += g_attn[base + j];
-                dheads[base + j] = dl;
-            }
-        }
-        if (pass == 0) {
-            block_sum<2>(acc, sm);
-            red[0] = acc[0];
-            red[1] = acc[1];
-        }
-    }
+    float acc[2] = {0.f, 0.f};
+    head_bwd_pass(hp, b, base, 0, RP, 0, 0.f, 0.f, q, a, gz, gth, gdx, gkl, g_attn, g_q, g_a, dheads, acc);
+    block_sum<2>(acc, sm);
+    float dummy[2] = {0.f, 0.f};
+    head_bwd_pass(hp, b, base, 0, RP, 1, acc[0], acc[1], q, a, gz, gth, gdx, gkl, g_attn, g_q, g_a, dheads, dummy);
+}
+// chunked backward: _a writes the (sum a*da, sum dq) partial of its chunk, _b sums the G partials and writes dheads
+static __global__ void attn_head_bwd_a_kernel(HeadParams hp, int G, int chunk, const float* __restrict__ q,
+                                              const float* __restrict__ a, const float* __restrict__ gz,
+                                              const float* __restrict__ gth, const float* __restrict__ gdx,
+                                              const float* __restrict__ gkl, const float* __restrict__ g_q,
+                                              const float* __restrict__ g_a, float* __restrict__ part) {
+    __shared__ float sm[2 * 16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int RP = hp.R * hp.P;
+    const int j0 = g * chunk, j1 = min(RP, j0 + chunk);
+    float acc[2] = {0.f, 0.f};
+    head_bwd_pass(hp, b, (long)b * RP, j0, j1, 0, 0.f, 0.f, q, a, gz, gth, gdx, gkl, nullptr, g_q, g_a, nullptr, acc);
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = acc[0]; part[2 * blockIdx.x + 1] = acc[1]; }
+}
+static __global__ void attn_head_bwd_b_kernel(HeadParams hp, int G, int chunk, const float* __restrict__ q,
+                                              const float* __restrict__ a, const float* __restrict__ gz,
+                                              const float* __restrict__ gth, const float* __restrict__ gdx,
+                                              const float* __restrict__ gkl, const float* __restrict__ g_attn,
+                                              const float* __restrict__ g_q, const float* __restrict__ g_a,
+                                              const float* __restrict__ part, float* __restrict__ dheads) {
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int RP = hp.R * hp.P;
+    const int j0 = g * chunk, j1 = min(RP, j0 + chunk);
+    float sa = 0.f, sq = 0.f;
+    for (int gg = 0; gg < G; ++gg) { sa += part[2 * (b * G + gg)]; sq += part[2 * (b * G + gg) + 1]; }
+    float dummy[2] = {0.f, 0.f};
+    head_bwd_pass(hp, b, (long)b * RP, j0, j1, 1, sa, sq, q, a, gz, gth, gdx, gkl, g_attn, g_q, g_a, dheads, dummy);
 }
 
 

@@ -43,8 +43,8 @@ SIGNATURES = {
     'tvae_dec_in_bwd': 'plppiiipppppl',
     'tvae_heads_fwd': 'pplppliil',
     'tvae_heads_bwd': 'pplplpliilifplp',
-    'tvae_attn_head_fwd': 'plpppppppiiiiffppppppp',
-    'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppp',
+    'tvae_attn_head_fwd': 'plpppppppiiiiffppppppppl',
+    'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppppl',
     'tvae_get_latent': 'plpppiiiifppp',
     'tvae_coord_fwd': 'ppppii',
     'tvae_coord_bwd': 'ppppppii',

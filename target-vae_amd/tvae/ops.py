@@ -438,8 +438,9 @@ class HeadFn(torch.autograd.Function):
         kl = torch.empty(B, dtype=torch.float32, device=dev)
         heads = heads.contiguous()
         E, eps_z, eps_t = E.contiguous(), eps_z.contiguous(), eps_t.contiguous()
+        part = _scratch(dev, 'head_part', 1024 * (7 + 3 * (zd + 1)))     # chunk partials (few images, many positions)
         call('tvae_attn_head_fwd', heads, heads.shape[1], E, eps_z, eps_t, tb.p_r, tb.off, tb.p_tr, tb.grid, B, tb.R,
-             tb.P, zd, tb.sigma_p, tb.theta_off_scale, attn, q, a, z, th, dx, kl)
+             tb.P, zd, tb.sigma_p, tb.theta_off_scale, attn, q, a, z, th, dx, kl, part, part.numel())
         ctx.save_for_backward(heads, q, a, eps_z, eps_t)
         ctx.tb, ctx.B, ctx.zd = tb, B, zd
         return attn, q, a, z, th, dx, kl
@@ -456,8 +457,10 @@ class HeadFn(torch.autograd.Function):
         g_z, g_th, g_dx, g_kl = dense(g_z, (B, zd)), dense(g_th, (B,)), dense(g_dx, (B, 2)), dense(g_kl, (B,))
         opt = [None if g is None else g.contiguous() for g in (g_attn, g_q, g_a)]
         dheads = torch.empty_like(heads)
+        part = _scratch(dev, 'head_part', 1024 * (7 + 3 * (zd + 1)))
         call('tvae_attn_head_bwd', heads, heads.shape[1], q, a, eps_z, eps_t, tb.p_r, tb.off, tb.p_tr, tb.grid, B,
-             tb.R, tb.P, zd, tb.sigma_p, tb.theta_off_scale, g_z, g_th, g_dx, g_kl, opt[0], opt[1], opt[2], dheads)
+             tb.R, tb.P, zd, tb.sigma_p, tb.theta_off_scale, g_z, g_th, g_dx, g_kl, opt[0], opt[1], opt[2], dheads,
+             part, part.numel())
         return dheads, None, None, None, None, None, None
 
 

@@ -560,7 +560,10 @@ def _head_reference(hd, E, eps_z, eps_t, R, Ho, zd, refine, theta_prior, normal,
 
 
 @pytest.mark.parametrize('R,Ho,zd,refine,normal,scale', [(8, 17, 2, True, False, 1.0), (4, 9, 3, False, False, 4.0),
-                                                         (16, 5, 2, True, True, 8.0), (8, 33, 2, True, False, 30.0)])
+                                                         (16, 5, 2, True, True, 8.0), (8, 33, 2, True, False, 30.0),
+                                                         # few images x many positions: the chunked (several workgroups
+                                                         # per image) kernels, R*P = 17 424 / 34 848
+                                                         (16, 33, 5, True, False, 6.0), (8, 66, 2, True, False, 20.0)])
 def test_attn_head(R, Ho, zd, refine, normal, scale):
     from tvae import ops
     B = 3
