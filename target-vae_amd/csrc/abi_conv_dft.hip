@@ -7,28 +7,37 @@
 using namespace tvae;
 
 // Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
-constexpr int DFT_WG_SPLITS = 8;
 struct DftPlan {
-    int L, Lh, Ho, M, K2;      // frame, half spectrum, output size, rows C*R, reduction 2L
-    int LHP, NT, REM1;         // forward w-transform instance: frequencies processed, 32-row output tiles, extra row
-    int NS, NRT;               // backward w-transform instance: k2-steps (pairs of w), 32-row tiles of (fx, ri)
+    int L, Lh, Ho, M, K2, Cin; // frame, half spectrum, output size, rows C*R, reduction 2*L*Cin
+    bool gen;                  // generic transforms along w (Lh > 64 or Ho > 64: no specialised instance)
+    int LHP, NT, REM1;         // forward w-transform: frequencies processed, 32-row output tiles, extra row
+    int NS, NRT;               // backward w-transform: k2-steps (pairs of w), 32-row tiles of (fx, ri)
+    int FXB, nblk;             // spectra: frequencies per workgroup, blocks per plane
+    int FXBd;                  // inverse transform of the weight gradient: frequencies per pass
+    int splits;                // reduction slices of the weight-gradient GEMM
     int Mb;                    // rows per fx in the stacked spectral weight (2M rounded up to the 512-row tile)
     long NB, NBpad;            // (image, output row) columns
-    long at_floats;            // A^T [Lh][2L][NBpad]
-    long w_floats;             // W   [Lh][2M][2L]
+    long at_floats;            // A^T [Lh][K2][NBpad]
+    long w_floats;             // W   [Lh][Mb][K2]
     long w3_floats;            // split cells of W
     long t_floats;             // T / S' [Lh][2M][NBpad]
-    long tab_floats;
-    long g_floats;             // G [Lh][2M][2L] (finalised spectral weight gradient)
+    long eo_floats, ed_floats, tab_floats;
+    long g_floats;             // one split-K slab of G [Lh][2M][K2]
+    size_t lds_sp, lds_db;
     bool ok;
 };
+static size_t dft_lds_spectra(int S, int L, int FXB) {
+    return (size_t)S * FXB * 8 + (size_t)L * FXB * 8 + (size_t)L * 8;
+}
+constexpr size_t DFT_LDS_TARGET = 50 * 1024;       // three workgroups per CU for the latency-bound direct-sum transforms
 static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     DftPlan q;
+    q.Cin = Cin;
     q.L = n + 2 * pad;
     q.Lh = q.L / 2 + 1;
     q.Ho = q.L - ksz + 1;
     q.M = C * R;
-    q.K2 = 2 * q.L;
+    q.K2 = 2 * q.L * Cin;
     q.NB = (long)B * q.Ho;
     q.NBpad = (q.NB + 127) / 128 * 128;
     q.Mb = x6_round_up(2 * q.M, DX6_ROWS);
@@ -36,18 +45,41 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.w_floats = (long)q.Lh * q.Mb * q.K2;
     q.w3_floats = dense_x6_bytes(q.Lh * q.Mb, q.K2) / 4;
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
-    q.LHP = q.Lh == 23 ? 23 : (q.Lh == 49 ? 49 : 64);          // exact instances of the two reference frames, else generic
-    q.NT = q.Ho <= 33 ? 1 : 2;
-    q.REM1 = q.Ho == 33 ? 1 : 0;
-    if (q.Ho <= 18 && q.Lh <= 32) { q.NS = 9; q.NRT = 2; }
-    else if (q.Ho <= 34) { q.NS = 17; q.NRT = 4; }
-    else { q.NS = 32; q.NRT = 4; }
-    q.tab_floats = 64L * 2 * 64 + 32L * 4 * 64 + q.M;          // EO + ED (largest instances) + per-row bias-gradient sums
+    q.gen = q.Lh > 64 || q.Ho > DFT_WROWS;
+    if (q.gen) {                                               // whole 32-row tiles, zero rows beyond Ho
+        q.LHP = q.Lh; q.NT = (q.Ho + 31) / 32; q.REM1 = 0;
+        q.NS = (q.Ho + 1) / 2; q.NRT = (2 * q.Lh + 31) / 32;
+    } else {
+        q.LHP = q.Lh == 23 ? 23 : (q.Lh == 49 ? 49 : 64);      // exact instances of the two reference frames, else generic
+        q.NT = q.Ho <= 33 ? 1 : 2;
+        q.REM1 = q.Ho == 33 ? 1 : 0;
+        if (q.Ho <= 18 && q.Lh <= 32) { q.NS = 9; q.NRT = 2; }
+        else if (q.Ho <= 34) { q.NS = 17; q.NRT = 4; }
+        else { q.NS = 32; q.NRT = 4; }
+    }
+    q.eo_floats = (long)q.LHP * (q.NT + q.REM1) * 64;
+    q.ed_floats = (long)q.NS * q.NRT * 64;
+    q.tab_floats = ((q.eo_floats + 3) & ~3L) + ((q.ed_floats + 3) & ~3L) + q.M;   // EO + ED + per-row bias-gradient sums
     q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
-    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    q.ok = Cin == 1 && q.Ho >= 1 && q.Ho <= DFT_WROWS && q.Lh <= 64 && lds_img <= 150 * 1024 &&
-           lds_bank <= 150 * 1024 && (long)q.Lh * 2 * q.M < 2000000000L / 1;
+    q.splits = (int)(q.NBpad / 1024);                          // 8 slices deal one to each XCD; short reductions take fewer
+    if (q.splits < 1) q.splits = 1;
+    if (q.splits > 8) q.splits = 8;
+    // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)
+    const int S = n > ksz ? n : ksz;
+    q.nblk = 1;
+    q.FXB = q.Lh;
+    while (q.nblk < 16 && dft_lds_spectra(S, q.L, q.FXB) > DFT_LDS_TARGET) {
+        ++q.nblk;
+        q.FXB = (q.Lh + q.nblk - 1) / q.nblk;
+    }
+    q.lds_sp = dft_lds_spectra(S, q.L, q.FXB);
+    q.FXBd = q.Lh;
+    auto lds_db = [&](int f) { return (size_t)q.L * f * 8 + (size_t)ksz * f * 8 + (size_t)q.L * 8 + (size_t)ksz * ksz * 4; };
+    for (int nb = 1; nb < 16 && lds_db(q.FXBd) > DFT_LDS_TARGET; ++nb) q.FXBd = (q.Lh + nb) / (nb + 1);
+    q.lds_db = lds_db(q.FXBd);
+    q.ok = Cin >= 1 && q.Ho >= 1 && q.NT <= 5 && q.lds_sp <= 152 * 1024 && q.lds_db <= 152 * 1024 &&
+           (long)q.Lh * q.Mb < 2000000000L && (size_t)4 * 32 * ((2 * q.NS) | 1) * 4 <= 150 * 1024 &&
+           (long)B * Cin * q.nblk + (long)q.M * Cin * q.nblk < 2000000000L;
     return q;
 }
 
@@ -64,7 +96,7 @@ long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, in
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     // forward: W + W3 + T + tables; backward: S' (= T) + split-K slabs of G + tables
     const long fwd = q.w_floats + q.w3_floats + q.t_floats + q.tab_floats + 64;
-    const long bwd = q.t_floats + DFT_WG_SPLITS * q.g_floats + q.tab_floats + 64;
+    const long bwd = q.t_floats + q.splits * q.g_floats + q.tab_floats + 64;
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -84,18 +116,15 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         if (e != hipSuccess) return (int)e;
     }
     float* EO = tab;
-    float* ED = EO + 64L * 2 * 64;
-    const size_t lds_img = (size_t)n * n * 4 + (size_t)n * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    const size_t lds_bank = (size_t)ksz * ksz * 4 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * q.Lh * 8 + (size_t)q.L * 8;
-    const size_t lds_sp = lds_img > lds_bank ? lds_img : lds_bank;
-    hipError_t e = allow_big_lds(dft_spectra_kernel, lds_sp);
+    float* ED = EO + ((q.eo_floats + 3) & ~3L);
+    hipError_t e = allow_big_lds(dft_spectra_kernel, q.lds_sp);
     if (e != hipSuccess) return (int)e;
     if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
         e = hipMemsetAsync(W, 0, (size_t)q.w_floats * 4, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(dft_spectra_kernel, dim3(B + q.M), dim3(256), lds_sp, st, y, at, B, n, pad, q.Ho, q.NBpad, bank, W,
-                       ksz, q.M, q.Mb, q.L, q.Lh);
+    hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
+                       n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk);
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
@@ -114,13 +143,29 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         if (rc) return rc;
     }
     {
-        // contraction over fx on the fp32 matrix pipe (dft_out_mf_kernel)
+        // contraction over fx on the fp32 matrix pipe
         const int NTT = q.NT + q.REM1;
-        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT, NTT, q.NS,
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(64), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT, NTT, q.NS,
                            q.NRT);
         TVAE_CHECK_LAUNCH();
-        const size_t lds_o = ((size_t)q.LHP * NTT * 64 + (size_t)4 * 32 * (q.Ho | 1)) * 4;
         const long ntiles = (long)q.M * (q.NBpad / 32);
+        if (q.gen) {
+            const int grid = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
+#define TVAE_OUT_GEN(N_)                                                                                            \
+    hipLaunchKernelGGL(dft_out_gen_kernel<N_>, dim3(grid), dim3(256), 0, st, (const float*)T, (const float*)EO, bias, out, \
+                       q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope)
+            switch (q.NT) {
+                case 1: TVAE_OUT_GEN(1); break;
+                case 2: TVAE_OUT_GEN(2); break;
+                case 3: TVAE_OUT_GEN(3); break;
+                case 4: TVAE_OUT_GEN(4); break;
+                default: TVAE_OUT_GEN(5); break;
+            }
+#undef TVAE_OUT_GEN
+            TVAE_CHECK_LAUNCH();
+            return 0;
+        }
+        const size_t lds_o = ((size_t)q.LHP * NTT * 64 + (size_t)4 * 32 * (q.Ho | 1)) * 4;
         const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
         const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
 #define TVAE_OUT_MF(L_, N_, R_)                                                                                     \
@@ -150,15 +195,24 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     hipStream_t st = S(stream);
     float* Sp = ws;
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
-    float* tab = slabs + ((DFT_WG_SPLITS * q.g_floats + 3) & ~3L);
+    float* tab = slabs + (((long)q.splits * q.g_floats + 3) & ~3L);
     float* EO = tab;
-    float* ED = EO + 64L * 2 * 64;
+    float* ED = EO + ((q.eo_floats + 3) & ~3L);
     {
-        hipLaunchKernelGGL(dft_wtab_kernel, dim3(32), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT,
+        hipLaunchKernelGGL(dft_wtab_kernel, dim3(64), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT,
                            q.NT + q.REM1, q.NS, q.NRT);
         TVAE_CHECK_LAUNCH();
-        const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
         const long ntiles = (long)q.M * (q.NBpad / 32);
+        if (q.gen) {
+            const size_t lds_g = (size_t)4 * 32 * ((2 * q.NS) | 1) * 4;
+            hipError_t eg = allow_big_lds(dft_dy_gen_kernel, lds_g);
+            if (eg != hipSuccess) return (int)eg;
+            const int gridg = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
+            hipLaunchKernelGGL(dft_dy_gen_kernel, dim3(gridg), dim3(256), lds_g, st, dpre, (const float*)ED, Sp, q.M, R, B,
+                               q.Ho, q.Lh, q.NBpad, q.NS, q.NRT);
+            TVAE_CHECK_LAUNCH();
+        } else {
+        const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
         const int grid = (int)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);
         const int iters = (int)((ntiles + 4L * grid - 1) / (4L * grid));
         hipError_t e0 = hipSuccess;
@@ -174,9 +228,10 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         else TVAE_DY_MF(32, 4, 0, false);
 #undef TVAE_DY_MF
         TVAE_CHECK_LAUNCH();
+        }
     }
     if (dbias) {
-        float* dbpart = tab + 64L * 2 * 64 + 32L * 4 * 64;         // M floats behind the transform tables
+        float* dbpart = ED + ((q.ed_floats + 3) & ~3L);           // M floats behind the transform tables
         hipLaunchKernelGGL(dft_dbias_rows_kernel, dim3(q.M), dim3(256), 0, st, (const float*)Sp, dbpart, q.Lh, q.NB, q.M);
         TVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(dft_dbias_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)dbpart, dbias, R, C);
@@ -185,8 +240,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
     {
         const int M2 = 2 * q.M, tiles_b = q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
-        // 8 reduction slices: TileMap deals the slices round-robin to the 8 XCDs, fewer would leave XCDs idle
-        const int splits = DFT_WG_SPLITS;
+        // 8 reduction slices at the 64x64 configuration: TileMap deals the slices round-robin to the 8 XCDs
+        const int splits = q.splits;
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
@@ -194,11 +249,10 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
                                         128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st);
         if (rc) return rc;
     }
-    const size_t lds_db = (size_t)q.L * q.Lh * 8 + (size_t)ksz * q.Lh * 8 + (size_t)q.L * 8;
-    hipError_t e = allow_big_lds(dft_dbank_kernel, lds_db);
+    hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M), dim3(256), lds_db, st, (const float*)slabs, DFT_WG_SPLITS, q.g_floats,
-                       dbank, ksz, q.L, q.Lh, q.M);
+    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits, q.g_floats,
+                       dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

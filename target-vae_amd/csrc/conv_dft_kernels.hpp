@@ -44,128 +44,100 @@ __device__ __forceinline__ void fill_twiddles(float2* tw, int L) {
 }
 
 // ------------------------------------------------------------------------------------------
-// One workgroup per image:  Yh = DFT2(padded image) restricted to fx < Lh, then
-// AT[fx][fy][b*Ho + h] = Re(Yh[fy][fx] e^{+2 pi i fy h / L}),  AT[fx][L + fy][..] = Im(..).
-// LDS: image n*n floats, R n*Lh complex, Yh L*Lh complex, tw L complex.
+// Spectra of the images and of the rotated filters, ONE launch.  A workgroup owns one (image b | filter m, input channel
+// ci, block of FXB frequencies fx0 .. fx0+FXB): it transforms its plane by direct sums in LDS (rows, then columns) and
+// writes the operands of the spectral GEMM.  The reduction index of that GEMM is k = (ci*2 + ri)*L + fy (K2 = 2*L*Cin):
+//   images : AT[fx][k][b*Ho + h] = Re / Im ( Yh[b][ci][fy][fx] e^{+2 pi i fy h / L} )
+//   filters: W[fx][m][k] = (Kr | Ki),  W[fx][M+m][k] = (-Ki | Kr)    (the complex product folded into a real GEMM)
+// One block of all Lh frequencies for the 96-wide frame of the 64x64 configuration (80 KB of LDS); the 192-wide frame of
+// the galaxy configuration (n = 128) takes more, smaller blocks (the host sizes FXB for >= 3 workgroups per CU).  LDS: row
+// transform S*FXB complex, plane spectrum L*FXB complex, twiddles L complex (S = n for images, ksz for filters).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dft_image_body(float* sm_dft, int b, const float* __restrict__ y, float* __restrict__ AT,
-                                               int n, int pad, int L, int Lh, int Ho, long NBpad) {
-    float* img = sm_dft;
-    float2* R = reinterpret_cast<float2*>(img + n * n);
-    float2* Yh = R + n * Lh;
-    float2* tw = Yh + L * Lh;
+__device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* __restrict__ pl, int S, int pad, int L,
+                                                   int fx0, int nfx, int FXB, float2*& Yh, float2*& tw) {
+    float2* Rw = reinterpret_cast<float2*>(sm_dft);
+    Yh = Rw + S * FXB;
+    tw = Yh + L * FXB;
     fill_twiddles(tw, L);
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) img[i] = y[(long)b * n * n + i];
     __syncthreads();
-    // R[yy][fx] = sum_x img[yy][x] e^{-2 pi i fx (x+pad) / L}
-    for (int i = threadIdx.x; i < n * Lh; i += blockDim.x) {
-        const int yy = i / Lh, fx = i - yy * Lh;
+    // Rw[yy][f] = sum_x pl[yy][x] e^{-2 pi i fx (x+pad) / L},  fx = fx0 + f.  The plane is read straight from memory:
+    // consecutive threads share yy, so a load is one broadcast line (L1), and the 16-64 KB an LDS copy would take
+    // decides how many workgroups fit a CU -- these loops are latency chains that need the occupancy.
+    for (int i = threadIdx.x; i < S * nfx; i += blockDim.x) {
+        const int yy = i / nfx, f = i - yy * nfx, fx = fx0 + f;
+        const float* row = pl + yy * S;
         float re = 0.f, im = 0.f;
         int ph = (fx * pad) % L;
-        for (int x = 0; x < n; ++x) {
-            const float v = img[yy * n + x];
+#pragma unroll 4
+        for (int x = 0; x < S; ++x) {
+            const float v = row[x];
             const float2 t = tw[ph];
             re += v * t.x;
             im -= v * t.y;
             ph += fx;
             if (ph >= L) ph -= L;
         }
-        R[i] = make_float2(re, im);
+        Rw[yy * FXB + f] = make_float2(re, im);
     }
     __syncthreads();
-    // Yh[fy][fx] = sum_y R[y][fx] e^{-2 pi i fy (y+pad) / L}
-    for (int i = threadIdx.x; i < L * Lh; i += blockDim.x) {
-        const int fy = i / Lh, fx = i - fy * Lh;
+    // Yh[fy][f] = sum_y Rw[y][f] e^{-2 pi i fy (y+pad) / L}
+    for (int i = threadIdx.x; i < L * nfx; i += blockDim.x) {
+        const int fy = i / nfx, f = i - fy * nfx;
         float2 acc = make_float2(0.f, 0.f);
         int ph = (fy * pad) % L;
-        for (int yy = 0; yy < n; ++yy) {
-            const float2 r = R[yy * Lh + fx];
-            const float2 t = make_float2(tw[ph].x, -tw[ph].y);
-            const float2 p = cmul(r, t);
+#pragma unroll 4
+        for (int yy = 0; yy < S; ++yy) {
+            const float2 p = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));
             acc.x += p.x;
             acc.y += p.y;
             ph += fy;
             if (ph >= L) ph -= L;
         }
-        Yh[i] = acc;
+        Yh[fy * FXB + f] = acc;
     }
     __syncthreads();
-    // AT[fx][ri*L + fy][b*Ho + h]
-    const int total = Lh * L * Ho;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int h = i % Ho;
-        const int t2 = i / Ho;
-        const int fy = t2 % L, fx = t2 / L;
-        const float2 v = cmul(Yh[fy * Lh + fx], tw[(fy * h) % L]);
-        float* dst = AT + ((long)fx * 2 * L + fy) * NBpad + (long)b * Ho + h;
-        dst[0] = v.x;
-        dst[(long)L * NBpad] = v.y;
-    }
 }
 
-// ------------------------------------------------------------------------------------------
-// One workgroup per filter m:  Kh = DFT2(filter at the origin of the L x L frame), fx < Lh, then the real operand
-// rows of the spectral GEMM:  W[fx][m][fy] = Kr, W[fx][m][L+fy] = Ki;  W[fx][M+m][fy] = -Ki, W[fx][M+m][L+fy] = Kr.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dft_bank_body(float* sm_dft, int m, const float* __restrict__ bank, float* __restrict__ W,
-                                              int ksz, int L, int Lh, int M, int Mb) {
-    float* ker = sm_dft;
-    float2* Q = reinterpret_cast<float2*>(ker + ksz * ksz);
-    float2* Kh = Q + ksz * Lh;
-    float2* tw = Kh + L * Lh;
-    fill_twiddles(tw, L);
-    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) ker[i] = bank[(long)m * ksz * ksz + i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < ksz * Lh; i += blockDim.x) {
-        const int u = i / Lh, fx = i - u * Lh;
-        float re = 0.f, im = 0.f;
-        int ph = 0;
-        for (int v = 0; v < ksz; ++v) {
-            const float k = ker[u * ksz + v];
-            re += k * tw[ph].x;
-            im -= k * tw[ph].y;
-            ph += fx;
-            if (ph >= L) ph -= L;
-        }
-        Q[i] = make_float2(re, im);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L * Lh; i += blockDim.x) {
-        const int fy = i / Lh, fx = i - fy * Lh;
-        float2 acc = make_float2(0.f, 0.f);
-        int ph = 0;
-        for (int u = 0; u < ksz; ++u) {
-            const float2 p = cmul(Q[u * Lh + fx], make_float2(tw[ph].x, -tw[ph].y));
-            acc.x += p.x;
-            acc.y += p.y;
-            ph += fy;
-            if (ph >= L) ph -= L;
-        }
-        Kh[i] = acc;
-    }
-    __syncthreads();
-    const long rowlen = 2L * L;
-    for (int i = threadIdx.x; i < Lh * L; i += blockDim.x) {
-        const int fy = i % L, fx = i / L;
-        const float2 k = Kh[fy * Lh + fx];
-        float* r0 = W + ((long)fx * Mb + m) * rowlen;            // Mb >= 2M rows per fx (padding rows stay zero)
-        float* r1 = W + ((long)fx * Mb + M + m) * rowlen;
-        r0[fy] = k.x;
-        r0[L + fy] = k.y;
-        r1[fy] = -k.y;
-        r1[L + fy] = k.x;
-    }
-}
-
-// Image spectra and filter spectra in ONE launch (workgroups [0, B): images, [B, B + M): filters): the two are
-// independent, each alone fills only part of the chip (B = 256 workgroups of 256 threads for the images), and a launch
-// boundary between them cost 0.2 ms of the step.
-static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int n, int pad, int Ho,
-                                          long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz, int M,
-                                          int Mb, int L, int Lh) {
+static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
+                                          int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
+                                          int M, int Mb, int L, int Lh, int FXB, int nblk) {
     extern __shared__ float sm_dft[];
-    if ((int)blockIdx.x < B) dft_image_body(sm_dft, blockIdx.x, y, AT, n, pad, L, Lh, Ho, NBpad);
-    else dft_bank_body(sm_dft, blockIdx.x - B, bank, W, ksz, L, Lh, M, Mb);
+    const int nimg = B * Cin * nblk;
+    int id = blockIdx.x;
+    const bool is_img = id < nimg;
+    if (!is_img) id -= nimg;
+    const int blk = id % nblk;
+    const int ci = (id / nblk) % Cin;
+    const int outer = id / (nblk * Cin);                 // image b or filter m
+    const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
+    float2 *Yh, *tw;
+    if (is_img) {
+        dft_plane_spectrum(sm_dft, y + ((long)outer * Cin + ci) * n * n, n, pad, L, fx0, nfx, FXB, Yh, tw);
+        const int total = nfx * L * Ho;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int h = i % Ho;
+            const int t2 = i / Ho;
+            const int fy = t2 % L, f = t2 / L;
+            const float2 v = cmul(Yh[fy * FXB + f], tw[(fy * h) % L]);
+            float* dst = AT + ((long)(fx0 + f) * 2 * L * Cin + (long)(2 * ci) * L + fy) * NBpad + (long)outer * Ho + h;
+            dst[0] = v.x;
+            dst[(long)L * NBpad] = v.y;
+        }
+    } else {
+        const int m = outer;
+        dft_plane_spectrum(sm_dft, bank + ((long)m * Cin + ci) * ksz * ksz, ksz, 0, L, fx0, nfx, FXB, Yh, tw);
+        const long rowlen = 2L * L * Cin;
+        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
+            const int fy = i % L, f = i / L;
+            const float2 k = Yh[fy * FXB + f];
+            float* r0 = W + ((long)(fx0 + f) * Mb + m) * rowlen + (long)(2 * ci) * L;   // Mb >= 2M rows per fx (padding rows stay zero)
+            float* r1 = W + ((long)(fx0 + f) * Mb + M + m) * rowlen + (long)(2 * ci) * L;
+            r0[fy] = k.x;
+            r0[L + fy] = k.y;
+            r1[fy] = -k.y;
+            r1[L + fy] = k.x;
+        }
+    }
 }
 
 // ==========================================================================================
@@ -416,6 +388,129 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Generic forms of the two transforms along w for frames the specialised instances above do not cover (Lh > 64 or
+// Ho > 64: the 192-wide frame of the galaxy configuration has Lh = 97, Ho = 129).  Same tile walk (one wave owns 32
+// columns of one filter row), same tables (dft_wtab_kernel with NT = ceil(Ho/32) whole 32-row tiles, zero rows beyond
+// Ho), but nothing is sized at compile time except the number of output tiles: the constant operand is read from
+// global memory (a 256-byte line per MFMA, L1 / L2 resident: one load per 64-cycle matrix instruction), the values
+// arrive in chunks of eight frequencies, and the output tile goes through a 32 x 33 LDS patch per 32 rows of w.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __restrict__ T, const float* __restrict__ EO,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int M, int R, int B, int Ho, int Lh, long NBpad, int act,
+                                                                 float slope) {
+    __shared__ float stg_all[4 * 32 * 33];
+    float* stg = stg_all + (threadIdx.x >> 6) * 32 * 33;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, ri = lane >> 5;
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
+    const int P = Ho * Ho;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        if (n0 >= NB) continue;                          // a tile of pure padding columns
+        const float* tp = T + dft_t_off(n0 + j, ri * M + m, 2 * M, Lh);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        float vn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn[e] = tp[(long)min(e, Lh - 1) * 128];
+        for (int fx0 = 0; fx0 < Lh; fx0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vn[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vn[e] = tp[(long)min(fx0 + 8 + e, Lh - 1) * 128];     // next chunk in flight
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int fx = fx0 + e;
+                if (fx < Lh) {                           // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(EO[((long)fx * NT + t) * 64 + lane], v[e], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        const int c = m / R, r_ = m - c * R;
+        const float bv = bias ? bias[c] : 0.f;
+        const int tmax = (int)(NB - n0 < 32 ? NB - n0 : 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // rows w = 32 t + (r & 3) + 8 (r >> 2) + 4 ri of column j -> stg[j][w - 32 t]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[t][r] + bv;
+                if (act == ACT_LRELU) x = x > 0.f ? x : x * slope;
+                else if (act == ACT_TANH) x = tanhf(x);
+                stg[j * 33 + (r & 3) + 8 * (r >> 2) + 4 * ri] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int wn = min(32, Ho - 32 * t);         // valid rows of this w-tile
+            for (int e = lane; e < tmax * 32; e += 64) {
+                const int col = e >> 5, w = e & 31;
+                if (w < wn) {
+                    const long nn = n0 + col;
+                    const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
+                    out[(((long)c * B + b) * R + r_) * P + (long)h * Ho + 32 * t + w] = stg[col * 33 + w];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w], generic frame: the 32 x Ho values of a tile go through this
+// wave's LDS patch ([32 columns][2*NS | 1]) into the B-operand layout; one 32-row tile of (fx, ri) at a time.
+static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+                                                                float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
+                                                                long NBpad, int NS, int NRT) {
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    const int SWD = (2 * NS) | 1;
+    float* stg = sm_w + (threadIdx.x >> 6) * (32 * SWD);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
+    const int P = Ho * Ho;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const int c = m / R, r_ = m - c * R;
+        // stage the tile: column t (n = n0 + t) is Ho consecutive floats of dY; columns past the batch are zero
+        for (int e = lane; e < 32 * SWD; e += 64) {
+            const int t = e / SWD, w = e - t * SWD;
+            const long nn = n0 + t;
+            float v = 0.f;
+            if (nn < NB && w < Ho) {
+                const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
+                v = dY[(((long)c * B + b) * R + r_) * P + (long)h * Ho + w];
+            }
+            stg[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* p0 = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);
+        float* p1 = Sp + dft_t_off(n0 + j, M + m, 2 * M, Lh);
+        for (int rt = 0; rt < NRT; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int s_ = 0; s_ < NS; ++s_)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ED[((long)s_ * NRT + rt) * 64 + lane], stg[j * SWD + 2 * s_ + kh],
+                                                           acc, 0, 0, 0);
+            // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int fx = kk >> 1;
+                if (fx < Lh) ((kk & 1) ? p1 : p0)[(long)fx * 128] = acc[r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
 // db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  Two stages: one workgroup per
 // filter row m (1 024 of them: the single-stage version had 128 workgroups walking 51 MB-strided runs), then R sums.
@@ -436,63 +531,74 @@ static __global__ void dft_dbias_kernel(const float* __restrict__ part, float* _
 }
 
 // ------------------------------------------------------------------------------------------
-// One workgroup per filter m:  dKh'[fy][fx] from the four real blocks of G[fx][m | M+m][(re/im, fy)]
-//   Re = G[m][fy] + G[M+m][L+fy],  Im = G[m][L+fy] - G[M+m][fy]
-// then dbank[m][u][v] = 1/L^2 sum_fx c_fx Re( e^{2 pi i fx v/L} sum_fy dKh'[fy][fx] e^{2 pi i fy u/L} ),  u, v < ksz.
-// ------------------------------------------------------------------------------------------
+// One workgroup per (filter m, input channel ci):  dKh'[fy][fx] from the four real blocks of G[fx][m | M+m][k],
+//   Re = G[m][(ci,0,fy)] + G[M+m][(ci,1,fy)],  Im = G[m][(ci,1,fy)] - G[M+m][(ci,0,fy)],
+// then dbank[m][ci][u][v] = 1/L^2 sum_fx c_fx Re( e^{2 pi i fx v/L} sum_fy dKh'[fy][fx] e^{2 pi i fy u/L} ),  u, v < ksz,
+// accumulated over blocks of FXB frequencies (the plane spectrum of a 192-wide frame does not fit LDS at once).
 // G arrives as `nsl` split-K slabs (slab stride `gs` floats) of the weight-gradient GEMM; they are summed, in slab order,
 // while the filter's rows are loaded -- the spectral gradient is never finalised into a tensor of its own.
+// LDS: Kh L*FXB complex, Z ksz*FXB complex, tw L complex, out ksz*ksz floats.
+// ------------------------------------------------------------------------------------------
 static __global__ void dft_dbank_kernel(const float* __restrict__ G, int nsl, long gs, float* __restrict__ dbank, int ksz,
-                                        int L, int Lh, int M) {
+                                        int L, int Lh, int M, int Cin, int FXB) {
     extern __shared__ float sm_dft[];
     float2* Kh = reinterpret_cast<float2*>(sm_dft);
-    float2* Z = Kh + L * Lh;
-    float2* tw = Z + ksz * Lh;
-    const int m = blockIdx.x;
+    float2* Z = Kh + L * FXB;
+    float2* tw = Z + ksz * FXB;
+    float* outp = reinterpret_cast<float*>(tw + L);
+    const int m = blockIdx.x / Cin, ci = blockIdx.x - m * Cin;
     fill_twiddles(tw, L);
-    const long rowlen = 2L * L;
-    for (int i = threadIdx.x; i < Lh * L; i += blockDim.x) {
-        const int fy = i % L, fx = i / L;
-        const float* r0 = G + ((long)fx * 2 * M + m) * rowlen;
-        const float* r1 = G + ((long)fx * 2 * M + M + m) * rowlen;
-        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-        for (int sl = 0; sl < nsl; ++sl) {
-            a += r0[sl * gs + fy];
-            b += r1[sl * gs + L + fy];
-            c += r0[sl * gs + L + fy];
-            d += r1[sl * gs + fy];
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) outp[i] = 0.f;
+    const long rowlen = 2L * L * Cin;
+    for (int fx0 = 0; fx0 < Lh; fx0 += FXB) {
+        const int nfx = min(FXB, Lh - fx0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
+            const int fy = i % L, f = i / L;
+            const float* r0 = G + ((long)(fx0 + f) * 2 * M + m) * rowlen + (long)(2 * ci) * L;
+            const float* r1 = G + ((long)(fx0 + f) * 2 * M + M + m) * rowlen + (long)(2 * ci) * L;
+            float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+            for (int sl = 0; sl < nsl; ++sl) {
+                a += r0[sl * gs + fy];
+                b += r1[sl * gs + L + fy];
+                c += r0[sl * gs + L + fy];
+                d += r1[sl * gs + fy];
+            }
+            Kh[fy * FXB + f] = make_float2(a + b, c - d);
         }
-        Kh[fy * Lh + fx] = make_float2(a + b, c - d);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ksz * Lh; i += blockDim.x) {
-        const int u = i / Lh, fx = i - u * Lh;
-        float2 acc = make_float2(0.f, 0.f);
-        int ph = 0;
-        for (int fy = 0; fy < L; ++fy) {
-            const float2 p = cmul(Kh[fy * Lh + fx], tw[ph]);
-            acc.x += p.x;
-            acc.y += p.y;
-            ph += u;
-            if (ph >= L) ph -= L;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ksz * nfx; i += blockDim.x) {
+            const int u = i / nfx, f = i - u * nfx;
+            float2 acc = make_float2(0.f, 0.f);
+            int ph = 0;
+#pragma unroll 4
+            for (int fy = 0; fy < L; ++fy) {
+                const float2 p = cmul(Kh[fy * FXB + f], tw[ph]);
+                acc.x += p.x;
+                acc.y += p.y;
+                ph += u;
+                if (ph >= L) ph -= L;
+            }
+            Z[u * FXB + f] = acc;
         }
-        Z[i] = acc;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) {
+            const int u = i / ksz, v = i - u * ksz;
+            float acc = 0.f;
+            int ph = (int)(((long)fx0 * v) % L);
+            for (int f = 0; f < nfx; ++f) {
+                const int fx = fx0 + f;
+                const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
+                const float2 z = Z[u * FXB + f];
+                acc += cf * (z.x * tw[ph].x - z.y * tw[ph].y);
+                ph += v;
+                if (ph >= L) ph -= L;
+            }
+            outp[i] += acc;                              // thread i owns element i in every block: no race
+        }
     }
-    __syncthreads();
     const float inv = 1.f / ((float)L * (float)L);
-    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) {
-        const int u = i / ksz, v = i - u * ksz;
-        float acc = 0.f;
-        int ph = 0;
-        for (int fx = 0; fx < Lh; ++fx) {
-            const float cf = ((fx == 0) || (2 * fx == L)) ? 1.f : 2.f;
-            const float2 z = Z[u * Lh + fx];
-            acc += cf * (z.x * tw[ph].x - z.y * tw[ph].y);
-            ph += v;
-            if (ph >= L) ph -= L;
-        }
-        dbank[(long)m * ksz * ksz + i] = acc * inv;
-    }
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) dbank[((long)m * Cin + ci) * ksz * ksz + i] = outp[i] * inv;
 }
 
 }  // namespace tvae

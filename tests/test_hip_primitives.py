@@ -236,12 +236,17 @@ def test_linear_wgrad_x6(M, N, K, acc):
         call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, 3)
 
 
-@pytest.mark.parametrize('B,n,k,pad,C,R,act', [(2, 28, 28, 8, 32, 8, 1), (3, 64, 64, 16, 32, 8, 1), (5, 40, 32, 6, 64, 4, 0),
-                                               (17, 64, 64, 16, 64, 8, 1), (4, 32, 32, 8, 16, 8, 1), (3, 20, 9, 2, 5, 4, 0)])
-def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act):
+@pytest.mark.parametrize('B,n,k,pad,C,R,act,Cin', [
+    (2, 28, 28, 8, 32, 8, 1, 1), (3, 64, 64, 16, 32, 8, 1, 1), (5, 40, 32, 6, 64, 4, 0, 1), (17, 64, 64, 16, 64, 8, 1, 1),
+    (4, 32, 32, 8, 16, 8, 1, 1), (3, 20, 9, 2, 5, 4, 0, 1),
+    # several input channels (they join the reduction of the spectral GEMM)
+    (3, 28, 28, 8, 16, 8, 1, 3), (2, 20, 9, 2, 5, 4, 0, 2),
+    # frames beyond the specialised transforms along w (Lh > 64 or Ho > 64): spectra in frequency blocks, generic
+    # transforms -- the galaxy configuration's shape class (192-wide frame, 3 channels) at a small size
+    (2, 96, 32, 16, 4, 4, 1, 2), (2, 128, 64, 32, 2, 16, 1, 3)])
+def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin):
     """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64."""
     from tvae._lib import query
-    Cin = 1
     if not query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
         pytest.skip('geometry not handled by the frequency-domain path')
     y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
