@@ -114,6 +114,92 @@ class ShardedBatches:
             yield (self.data.index_select(0, idx),) + tuple(t.index_select(0, idx) for t in self.extra)
 
 
+# ---------------------------------------------------------------------------------------------
+# per-rank RESIDENT shards: a rank keeps only its contiguous slice of the dataset on its GPU
+# ---------------------------------------------------------------------------------------------
+def shard_bounds(n_items: int, rank: int, world: int):
+    """Rows [r0, r1) of the dataset that rank `rank` keeps resident (contiguous, sizes differ by at most one: the split
+    src.mrc.read_shard makes on disk)."""
+    base, extra = divmod(n_items, world)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def shard_plan(n_items: int, global_batch: int, world: int):
+    """Batch plan of the shard-resident loop, identical on every rank without communication: counts[i][r] images of
+    rank r's shard go into global minibatch i.  Rank r contributes its even share of the global batch (shard_slices'
+    split) until its shard is exhausted; the number of minibatches is what the largest shard needs."""
+    quota = [hi - lo for lo, hi, _ in (next(shard_slices(global_batch, global_batch, r, world)) for r in range(world))]
+    sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+    nb = max((sizes[r] + quota[r] - 1) // quota[r] if quota[r] > 0 else 0 for r in range(world)) if n_items > 0 else 0
+    return [[max(0, min(quota[r], sizes[r] - i * quota[r])) for r in range(world)] for i in range(nb)]
+
+
+def local_permutation(n_local: int, seed: int, epoch: int, rank: int, shuffle: bool = True) -> torch.Tensor:
+    if not shuffle:
+        return torch.arange(n_local)
+    gen = torch.Generator()
+    gen.manual_seed((int(seed) * 1000003 + int(epoch)) * 8191 + int(rank) + 1)
+    return torch.randperm(n_local, generator=gen)
+
+
+def resident_global_batches(n_items: int, global_batch: int, world: int, seed: int, epoch: int, shuffle: bool = True):
+    """The global minibatches of the shard-resident loop as dataset row indices (rank 0's rows first): what a single
+    process must iterate over to reproduce a `world`-rank run (tests), and the definition of the sampling order --
+    a shuffle stratified by shard: every global minibatch draws its even share from every rank's slice."""
+    plan = shard_plan(n_items, global_batch, world)
+    perms = [local_permutation(shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0], seed, epoch, r,
+                               shuffle) + shard_bounds(n_items, r, world)[0] for r in range(world)]
+    pos = [0] * world
+    out = []
+    for counts in plan:
+        idx = []
+        for r, c in enumerate(counts):
+            idx.append(perms[r][pos[r]:pos[r] + c])
+            pos[r] += c
+        out.append(torch.cat(idx))
+    return out
+
+
+class ResidentShardBatches:
+    """Iterator of (y,) minibatch shards over THIS RANK'S slice of the dataset only (`shard` = rows shard_bounds(..) of
+    the full set, already on the device): nothing but the gradient all-reduce crosses ranks, and a GPU holds 1/world of
+    the data.  With world = 1 this is the plain shuffled loop of the reference.  Empty contributions (a shard that ran
+    out one minibatch early) are yielded with reducer weight 0, as in ShardedBatches."""
+
+    def __init__(self, shard, n_items: int, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
+                 seed: int = 0, reducer: GradReducer = None):
+        self.extra = tuple(shard[1:]) if isinstance(shard, (tuple, list)) else ()
+        self.data = shard[0] if isinstance(shard, (tuple, list)) else shard
+        self.n_items, self.gb, self.rank, self.world = n_items, global_batch, rank, world
+        self.shuffle, self.seed, self.reducer = shuffle, seed, reducer
+        self.epoch = 0
+        r0, r1 = shard_bounds(n_items, rank, world)
+        if self.data.shape[0] != r1 - r0:
+            raise ValueError(f'rank {rank} holds {self.data.shape[0]} rows, its shard of {n_items} has {r1 - r0}')
+        self.plan = shard_plan(n_items, global_batch, world)
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self):
+        return len(self.plan)
+
+    def local_count(self) -> int:
+        return self.data.shape[0]
+
+    def __iter__(self):
+        perm = local_permutation(self.data.shape[0], self.seed, self.epoch, self.rank, self.shuffle).to(self.data.device)
+        pos = 0
+        for counts in self.plan:
+            c = counts[self.rank]
+            if self.reducer is not None:
+                self.reducer.set_local_fraction(c, sum(counts))
+            idx = perm[pos:pos + c]
+            pos += c
+            yield (self.data.index_select(0, idx),) + tuple(t.index_select(0, idx) for t in self.extra)
+
+
 def allreduce_stats(values, device, group=None):
     """Sum a short list of python floats over ranks (logging scalars: sum b*elbo, sum b*err, sum b*kl, sum b)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

@@ -85,9 +85,24 @@ def build_parser(kind: str) -> argparse.ArgumentParser:
     return p
 
 
-def _load_arrays(kind, args):
-    """Returns (train, test) float tensors shaped (N, Cin, n, n), the dataset name used in the log dir and the image
-    side BEFORE --crop (the particles CTF kernels are sized from it, train_particles.py:540-577)."""
+def _load_arrays(kind, args, shard=None):
+    """Returns (train, test) float tensors shaped (N, Cin, n, n), the dataset name used in the log dir, the image side
+    BEFORE --crop (the particles CTF kernels are sized from it, train_particles.py:540-577) and the sizes of the two
+    FULL sets.  shard = (rank, world): the tensors hold only that rank's rows dp.shard_bounds(N, rank, world) of each
+    set."""
+    out = _load_arrays_full(kind, args, shard)
+    if len(out) == 6:                                    # the loader sliced on disk already
+        return out
+    tr, te, name, n_raw = out
+    n_tr, n_te = tr.shape[0], te.shape[0]
+    if shard is not None:
+        from . import dp
+        (a0, a1), (b0, b1) = dp.shard_bounds(n_tr, *shard), dp.shard_bounds(n_te, *shard)
+        tr, te = tr[a0:a1], te[b0:b1]
+    return tr, te, name, n_raw, n_tr, n_te
+
+
+def _load_arrays_full(kind, args, shard=None):
     if args.synthetic > 0:
         n = getattr(args, 'image_dim', None) or getattr(args, 'crop', 0) or 64    # particles: --crop sets the side
         cin = args.in_channels
@@ -124,13 +139,14 @@ def _load_arrays(kind, args):
         te = torch.from_numpy(np.load(args.test_path)[:100]).float()
         n = args.image_dim
         return tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n), 'dsprites', n
-    # particles: .npy stacks or MRC/MRCS stacks (train_particles.py:454-461)
+    # particles: .npy stacks or MRC/MRCS stacks (train_particles.py:454-461), opened LAZILY (np.load mmap / the MRC
+    # memmap of src.mrc): with several ranks each one reads only its contiguous slice from disk (the split of
+    # dp.shard_bounds = src.mrc.read_shard) before cropping / normalising, which are per-image operations
     def load(path):
         if path.endswith('.npy'):
-            return np.load(path)
+            return np.load(path, mmap_mode='r')
         from src import mrc
-        mm, _ = mrc.open_stack(path)
-        return np.asarray(mm, dtype=np.float32)
+        return mrc.open_stack(path)[0]
     if not args.train_path:
         raise SystemExit('please provide the train_path and/or test_path')
     if args.test_path:
@@ -140,6 +156,12 @@ def _load_arrays(kind, args):
         k = int(allim.shape[0] * args.train_portion)
         a, b = allim[:k], allim[k:]
     n_raw = a.shape[-1]
+    n_tr, n_te = a.shape[0], b.shape[0]
+    if shard is not None:
+        from . import dp
+        (a0, a1), (b0, b1) = dp.shard_bounds(n_tr, *shard), dp.shard_bounds(n_te, *shard)
+        a, b = a[a0:a1], b[b0:b1]
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
     if args.crop > 0:
         def crop(s, m):
             n0 = s.shape[-1]
@@ -152,26 +174,31 @@ def _load_arrays(kind, args):
             return (s - f.mean(1)[:, None, None]) / f.std(1)[:, None, None]
         a, b = norm(a), norm(b)
     n = a.shape[-1]
-    tr, te = torch.from_numpy(a).float(), torch.from_numpy(b).float()
+    tr, te = torch.from_numpy(np.ascontiguousarray(a)).float(), torch.from_numpy(np.ascontiguousarray(b)).float()
     # log directory name: the training path with '/' -> '-' (train_particles.py:729-731)
     return (tr.view(-1, args.in_channels, n, n), te.view(-1, args.in_channels, n, n),
-            args.train_path.replace('/', '-'), n_raw)
+            args.train_path.replace('/', '-'), n_raw, n_tr, n_te)
 
 
-def _load_ctf(args, n_train, n_test, n):
+def _load_ctf(args, n_train, n_test, n, shard=None):
     """Real-space CTF kernels per image (train_particles.py:540-577): odd size n-1 for even images, where n is the
-    side of the stack as loaded, BEFORE --crop (the reference sizes the kernels first and crops afterwards)."""
+    side of the stack as loaded, BEFORE --crop (the reference sizes the kernels first and crops afterwards).
+    shard = (rank, world): only the filters of that rank's rows are built."""
     if not getattr(args, 'ctf_train', None):
         return None, None
     from src import ctf as C
+    from . import dp
     kn = n - 1 if n % 2 == 0 else n
     if args.ctf_test:
-        ftr = C.ctf_filter(C.parse_ctf(args.ctf_train), kn, kn, scale=args.scale)
-        fte = C.ctf_filter(C.parse_ctf(args.ctf_test), kn, kn, scale=args.scale)
+        ptr, pte = C.parse_ctf(args.ctf_train), C.parse_ctf(args.ctf_test)
     else:
-        allf = C.ctf_filter(C.parse_ctf(args.ctf_train), kn, kn, scale=args.scale)
-        ftr, fte = allf[:n_train], allf[n_train:]
-    assert len(ftr) == n_train and len(fte) == n_test, 'one CTF parameter row per image is required'
+        allp = C.parse_ctf(args.ctf_train)
+        ptr, pte = allp.iloc[:n_train].reset_index(drop=True), allp.iloc[n_train:].reset_index(drop=True)
+    assert len(ptr) == n_train and len(pte) == n_test, 'one CTF parameter row per image is required'
+    if shard is not None:
+        (a0, a1), (b0, b1) = dp.shard_bounds(n_train, *shard), dp.shard_bounds(n_test, *shard)
+        ptr, pte = ptr.iloc[a0:a1].reset_index(drop=True), pte.iloc[b0:b1].reset_index(drop=True)
+    ftr, fte = C.ctf_filter(ptr, kn, kn, scale=args.scale), C.ctf_filter(pte, kn, kn, scale=args.scale)
     return torch.from_numpy(ftr).float().unsqueeze(1), torch.from_numpy(fte).float().unsqueeze(1)
 
 
@@ -185,7 +212,7 @@ def run(kind: str, argv=None):
     digits = int(np.log10(num_epochs)) + 1
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    y_train, y_test, dataset_name, n_raw = _load_arrays(kind, args)
+    y_train, y_test, dataset_name, n_raw, N, N_test = _load_arrays(kind, args, (rank, world))   # this rank's rows only
     image_dim = y_train.shape[-1]
     in_channels = y_train.shape[1]
     if not torch.cuda.is_available() or args.device == -1:
@@ -197,10 +224,9 @@ def run(kind: str, argv=None):
         print('# using device:', device, f'(rank {rank}/{world})', file=sys.stderr)
     ctf_train = ctf_test = None
     if kind == 'particles' and not args.synthetic:
-        ctf_train, ctf_test = _load_ctf(args, len(y_train), len(y_test), n_raw)
-    y_train, y_test = y_train.to(device), y_test.to(device)        # whole dataset resident (train_mnist.py:495)
-    if ctf_train is not None:
-        ctf_train, ctf_test = ctf_train.to(device), ctf_test.to(device)
+        ctf_train, ctf_test = _load_ctf(args, N, N_test, n_raw, (rank, world))
+    # the arrays stay on the host here: each rank moves only its own slice to its GPU below (the reference keeps the whole
+    # set on its one device, train_mnist.py:495)
     x_coord = torch.from_numpy(tables.image_coords(image_dim)).to(device)
 
     z_dim = args.z_dim
@@ -248,7 +274,6 @@ def run(kind: str, argv=None):
         print(encoder_model)
         print(generator_model)
 
-    N = len(y_train)
     params = list(generator_model.parameters()) + list(encoder_model.parameters())
     reducer = dp.GradReducer() if world > 1 else None
     optimizer = optim.FlatAdam(params, lr=args.learning_rate, reducer=reducer)
@@ -266,13 +291,17 @@ def run(kind: str, argv=None):
     scheduler = ReduceLROnPlateau(optimizer, mode='max', factor=0.5, patience=patience, threshold=1e-4,
                                   threshold_mode='abs', cooldown=0, min_lr=min_lr, eps=1e-08)
     seed = args.seed if args.seed is not None else 0
-    train_src = (y_train, ctf_train) if ctf_train is not None else y_train
-    test_src = (y_test, ctf_test) if ctf_test is not None else y_test
-    train_it = dp.ShardedBatches(train_src, args.minibatch_size, rank, world, shuffle=True, seed=seed, reducer=reducer)
-    test_it = dp.ShardedBatches(test_src, args.minibatch_size, rank, world, shuffle=False, seed=seed)
+    # every rank keeps only ITS contiguous slice of the two sets on its GPU
+    to_dev = lambda t: None if t is None else t.to(device)
+    train_src = to_dev(y_train) if ctf_train is None else (to_dev(y_train), to_dev(ctf_train))
+    test_src = to_dev(y_test) if ctf_test is None else (to_dev(y_test), to_dev(ctf_test))
+    del y_train, y_test, ctf_train, ctf_test
+    train_it = dp.ResidentShardBatches(train_src, N, args.minibatch_size, rank, world, shuffle=True, seed=seed,
+                                       reducer=reducer)
+    test_it = dp.ResidentShardBatches(test_src, N_test, args.minibatch_size, rank, world, shuffle=False, seed=seed)
     likelihood = {'mnist': 'bce', 'dsprites': 'bce', 'galaxy': 'bce3'}.get(kind, 'gauss_var' if n_out == 2 else 'gauss')
     mask_radius = args.mask_radius if kind == 'particles' else None
-    if kind == 'particles' and n_out == 2 and (ctf_train is not None or args.mask_radius > 0):
+    if kind == 'particles' and n_out == 2 and (isinstance(train_src, tuple) or args.mask_radius > 0):
         raise SystemExit('--fit-noise together with CTF filters or --mask-radius does not broadcast in the reference '
                          '(train_particles.py:303-307,330-333) and is not built')
     step_dim = args.encoder_padding if kind == 'particles' else image_dim   # reference positional argument
@@ -320,13 +349,13 @@ def run(kind: str, argv=None):
 
     for epoch in range(num_epochs):
         train_it.set_epoch(epoch)
-        n_local = sum(hi - lo for lo, hi, _ in dp.shard_slices(N, args.minibatch_size, rank, world))
+        n_local = train_it.local_count()
         e, err, kl = step.train_epoch(train_it, x_coord, generator_model, encoder_model, optimizer, t_inf, r_inf, epoch,
                                       num_epochs, max(n_local, 1), device, params, theta_prior, group_conv, step_dim,
                                       likelihood=likelihood, progress=is_main, mask_radius=mask_radius)
         e, err, kl = global_means(e, err, kl, n_local)
         emit('\t'.join([str(epoch + 1), 'train', str(e), str(err), str(kl)]))
-        n_test = sum(hi - lo for lo, hi, _ in dp.shard_slices(len(y_test), args.minibatch_size, rank, world))
+        n_test = test_it.local_count()
         e, err, kl = step.eval_model(test_it, x_coord, generator_model, encoder_model, t_inf, r_inf, epoch, device,
                                      theta_prior, group_conv, step_dim, likelihood=likelihood, mask_radius=mask_radius)
         e, err, kl = global_means(e, err, kl, n_test)

@@ -115,6 +115,85 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# shard-RESIDENT loop (what the drivers use): a rank holds only its contiguous slice of the dataset; the global
+# minibatches are a shuffle stratified by shard.  Two gloo ranks == one process walking dp.resident_global_batches.
+def _train_resident(rank, world, emulate=2, epochs=2):
+    from oracle import tvae_oracle as O
+    from tvae import dp, optim
+    gen, enc = _make_params()
+    params = list(gen.parameters()) + list(enc.parameters())
+    reducer = dp.GradReducer() if world > 1 else None
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    data, E, ez, et = _data_and_noise()
+    x = O.image_coords(NPIX)
+    n_img = N_IMG - 3                                   # 8 images, global minibatches of 6: ragged tail, quota 3 per rank
+    data, E, ez, et = data[:n_img], E[:n_img], ez[:n_img], et[:n_img]
+    r0, r1 = dp.shard_bounds(n_img, rank, world)
+    it = dp.ResidentShardBatches(data[r0:r1].clone(), n_img, GB, rank, world, shuffle=True, seed=5, reducer=reducer)
+    stats = [0.0, 0.0]
+    for ep in range(epochs):
+        it.set_epoch(ep)
+        glob = dp.resident_global_batches(n_img, GB, emulate, 5, ep)
+        if world > 1:                                    # this rank's part of every global minibatch, as row indices
+            lperm = dp.local_permutation(r1 - r0, 5, ep, rank) + r0
+            plan, pos, mine = dp.shard_plan(n_img, GB, world), 0, []
+            for counts in plan:
+                mine.append(lperm[pos:pos + counts[rank]])
+                pos += counts[rank]
+            for gidx, counts, m_ in zip(glob, plan, mine):      # the ranks' parts tile the global minibatch
+                off = sum(counts[:rank])
+                assert torch.equal(gidx[off:off + counts[rank]], m_)
+        else:
+            mine = glob
+        for (y,), idx in zip(it if world > 1 else [(data[i],) for i in glob], mine):
+            assert torch.equal(y, data[idx])
+            if world > 1:
+                reducer_ok = True                        # fraction set by the iterator
+            if len(idx) > 0:
+                elbo, _, _ = O.elbo_step(x, y, dict(enc.named_parameters()), dict(gen.named_parameters()),
+                                         likelihood='bce', E=E[idx], eps_z=ez[idx], eps_theta=et[idx], **CFG)
+                (-elbo).backward()
+                stats[0] += float(elbo) * len(idx)
+                stats[1] += len(idx)
+            opt.step()
+            opt.zero_grad()
+    stats = dp.allreduce_stats(stats, torch.device('cpu'))
+    named = {'d.' + k_: v.detach().clone() for k_, v in gen.named_parameters()}
+    named.update({'e.' + k_: v.detach().clone() for k_, v in enc.named_parameters()})
+    return named, stats
+
+
+def _worker_resident(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tvae import dp
+    dp.init_from_env(backend='gloo')
+    flat, stats = _train_resident(rank, world)
+    torch.save(dict(flat=flat, stats=stats), os.path.join(out_dir, f'res_rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_resident_shards_match_single_process(tmp_path):
+    torch.set_num_threads(4)
+    flat1, stats1 = _train_resident(0, 1)
+    mp.spawn(_worker_resident, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'res_rank0.pt')
+    r1 = torch.load(tmp_path / 'res_rank1.pt')
+    for k_ in flat1:
+        assert torch.equal(r0['flat'][k_], r1['flat'][k_]), k_
+        if k_ == 'e.conv_a.bias':
+            continue
+        assert rel_err(r0['flat'][k_], flat1[k_]) < 2e-4, k_
+    assert r0['stats'][1] == stats1[1] == 2 * (N_IMG - 3)
+    assert abs(r0['stats'][0] - stats1[0]) / abs(stats1[0]) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # ragged tail smaller than the number of ranks (empty shard) + random Fourier BUFFERS that differ per rank at
 # construction: the product's train_epoch / eval_model / broadcast_buffers must keep the replicas identical and equal to
 # the single-process run

@@ -192,6 +192,23 @@ def test_flat_adam_views_and_update_cpu():
     assert opt.param_groups[0]['lr'] == pytest.approx(5e-3)
 
 
+def test_resident_shard_plan_visits_every_image_once():
+    """Shard-resident batches: every image exactly once per epoch, each rank only its own rows, global minibatch sizes
+    known to every rank without communication."""
+    from tvae import dp
+    for n, gb, world in ((37, 16, 2), (100, 32, 8), (5, 6, 4), (64, 16, 1), (13, 6, 2)):
+        plan = dp.shard_plan(n, gb, world)
+        assert sum(sum(c) for c in plan) == n
+        for r in range(world):
+            r0, r1 = dp.shard_bounds(n, r, world)
+            assert sum(c[r] for c in plan) == r1 - r0
+        glob = dp.resident_global_batches(n, gb, world, 3, 1)
+        assert sorted(torch.cat(glob).tolist()) == list(range(n))
+        assert [len(g) for g in glob] == [sum(c) for c in plan]
+        assert all(len(g) <= gb for g in glob)
+    assert dp.shard_bounds(10, 3, 4) == (8, 10) and dp.shard_bounds(10, 0, 4) == (0, 3)
+
+
 def test_shard_slices_cover_every_minibatch():
     from tvae import dp
     for n, gb, world in ((10, 4, 2), (37, 8, 4), (5, 8, 2), (256, 256, 8)):
