@@ -6,7 +6,7 @@
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): counters are collected in separate --pmc passes together with
 --kernel-trace only; FETCH_SIZE / WRITE_SIZE are in KiB (x1024 -> bytes here); on gfx950 FETCH_SIZE under-reports
 streamed reads by 2x, which this script re-checks on every run with a kernel whose read volume is known exactly
-(dec_out_bwd_kernel<1> / outer_mask_kernel<1> read the 2.147e9-byte hidden activation H once and write as much): the `calibration` entry
+(dec_out_bwd_kernel<1> reads the 2.147e9-byte hidden activation H once): the `calibration` entry
 shows raw and corrected figures side by side.  hbm_bytes_per_launch = 2 * FETCH + WRITE, mean over launches.
 """
 import csv
@@ -17,14 +17,17 @@ from collections import defaultdict
 ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tvae_conv1_wgrad',
          'conv1_fwd_x6_kernel': 'tvae_conv1_fwd_x6', 'conv1_wgrad_x6_kernel': 'tvae_conv1_wgrad_x6',
          'dy_split3_kernel': 'tvae_dy_split3',
-         # dense_x6_kernel<XV>: 0 = operand from memory (spectral GEMM of the convolution, decoder layers without the
-         # recomputed first layer), 2 = forward with the recomputed first-layer operand, 1 = data gradient with the implicit
-         # gradient operand; the bench line looks its launch up by grid size
-         'dense_x6_kernel<0>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2>': 'tvae_linear_fwd_x6',
-         'dense_x6_kernel<1>': 'tvae_linear_dgrad_x6',
-         'dense_wgrad_x6_kernel': 'tvae_linear_wgrad_x6', 'dft_out_kernel': 'tvae_dft_out',
-         'dft_out_mf_kernel': 'tvae_dft_out', 'dft_dy_kernel': 'tvae_dft_dy', 'dft_dy_mf_kernel': 'tvae_dft_dy',
-         'outer_mask_kernel<1>': 'calibration_outer_mask', 'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
+         # dense_x6_kernel<XV, parts>: XV 0 = operand from memory (spectral GEMM of the convolution, decoder layers
+         # without the recomputed first layer), 2 = forward with the recomputed first-layer operand, 1 / 3 = data gradient
+         # with the implicit gradient operand (generic / two-valued); the bench line looks its launch up by grid size
+         'dense_x6_kernel<0, 3>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2, 3>': 'tvae_linear_fwd_x6',
+         'dense_x6_kernel<1, 3>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<3, 3>': 'tvae_linear_dgrad_x6',
+         'dense_wgrad_x6_dma_kernel<true': 'tvae_linear_wgrad_x6', 'dense_wgrad_x6_dma_kernel<false': 'tvae_spectral_wgrad',
+         'dft_out_mf_kernel': 'tvae_dft_out', 'dft_dy_mf_kernel': 'tvae_dft_dy',
+         'dft_out_gen_kernel': 'tvae_dft_out', 'dft_dy_gen_kernel': 'tvae_dft_dy',
+         'gemm_f32_glds_kernel': 'tvae_conv2_fwd', 'gemm_f32_glds2_kernel': 'tvae_conv2_dgrad',
+         'heads_fwd_kernel': 'tvae_heads_fwd', 'heads_bwd_kernel': 'tvae_heads_bwd',
+         'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
 def per_kernel(path, counter):
