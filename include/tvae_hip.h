@@ -130,7 +130,7 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, int parts, tvae_stream_t stream);
+                       int va_np, void* sign_bits, int parts, tvae_stream_t stream);
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
@@ -147,7 +147,7 @@ int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, flo
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, int parts, tvae_stream_t stream);
+                         int va_np, const void* vg_bits, int parts, tvae_stream_t stream);
 /* `parts` (every *_x6 / *_dft compute entry): 3 = the exact three-part bf16 split (six products per block, fp32-equivalent
  * results: the default of the Python layer); 1 = operands rounded to ONE bf16 number (a single product per block, fp32
  * accumulate): the bf16 throughput mode BASELINE.json names for configs 2 and 5 -- about 3 significant digits per
@@ -164,6 +164,10 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
  *       sum_m W[m][k] dpre_eff[m][n] = vg_gy[n] * (slope * vg_csum[k] + (1 - slope) * sum_m (W[m][k] vg_wo[m]) [H[m][n] > 0]);
  *   weight gradient (vg_act = LeakyReLU, chosen by the library):
  *       dW[m][k] = vg_wo[m] * (slope * s[k] + (1 - slope) * sum_n [H[m][n] > 0] vg_gy[n] X[k][n]),  s[k] = sum_n vg_gy[n] X[k][n].
+ *   Sign bits: a LeakyReLU tvae_linear_fwd_x6 launch can store [Y > 0] as one bit per element (sign_bits: uint32
+ *   [M][N/32], bit n & 31 of word n / 32; N % 32 == 0); passed as vg_bits to tvae_linear_wgrad_x6 the 0 / 1 operand is
+ *   read from them -- 1/32 of the bytes, two 4-byte LDS-DMAs per wave and step instead of four 1 KB ones -- and dpre
+ *   (the activation) may be NULL.
  * Recomputed first-layer operand (va_xr != NULL in fwd / wgrad, in_bc != NULL in dgrad): the input of the layer is the
  * output of SpatialGenerator's coordinate layer without Fourier features (src/models.py:107-118),
  *   h0[f][n] = act(fma(Wc[f][1], xr[n][1], fma(Wc[f][0], xr[n][0], bc[f])) + LB[n / np][f])

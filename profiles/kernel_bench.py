@@ -84,11 +84,11 @@ w3 = torch.empty(query('tvae_dense_x6_bytes', F_, F_) // 4, device=dev)
 call('tvae_dense_split3', W, F_, w3, w3.numel() * 4, F_, F_, 0, None, None)
 w3t = torch.empty_like(w3)
 call('tvae_dense_split3', W, F_, w3t, w3t.numel() * 4, F_, F_, 1, None, None)
-timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
 timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
 timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
-timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
-timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, PARTS))
+timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
+timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, None, PARTS))
 if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
     at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev)
     wsd = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev)
@@ -103,9 +103,9 @@ if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
 if only and 'zero' in only:
     w3z = torch.zeros_like(w3)
     hz = torch.zeros_like(h1)
-    timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
-    timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
-    timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, PARTS))
+    timeit('zero_w_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
+    timeit('zero_wx_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3z, hz, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
+    timeit('zero_ref_x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
 if only and 'tail' in only:
     xr2 = torch.randn(Nt, 2, device=dev); wc2 = torch.randn(F_, 2, device=dev)
     gxr = torch.empty(Nt, 2, device=dev); partf = torch.empty((Nt // 128) * F_ * 3, device=dev)
@@ -115,14 +115,14 @@ if only and 'tail' in only:
     timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None, None, None, None, 0, PARTS))
     timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, None, 0, PARTS))
     timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, None, 0, PARTS))
-    timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, PARTS))
+    timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, None, PARTS))
     Np_ = n * n
     bc2 = torch.randn(F_, device=dev); lb2 = torch.randn(B, F_, device=dev)
     va = (xr2, wc2, bc2, lb2, Np_)
     # the step's actual launches: forward with the recomputed first layer (+ fused output column), data gradient with the
     # implicit gradient + fused first-layer backward + recomputed mask, weight gradient with both implicit operands
     cy = torch.empty(Nt, device=dev)
-    timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, PARTS))
+    timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, None, PARTS))
     timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, PARTS))
-    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, PARTS))
-    timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0, PARTS))
+    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, None, PARTS))
+    timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0, None, PARTS))

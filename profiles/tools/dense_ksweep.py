@@ -20,7 +20,7 @@ for K in [int(v) for v in os.environ.get('KS', '128,256,512,1024,2048').split(',
     w3 = torch.empty(query('tvae_dense_x6_bytes', M, K) // 4, device=dev)
     call('tvae_dense_split3', W, K, w3, w3.numel() * 4, M, K, 0, None, None)
     for name, act, store in (('fwd_lrelu', 1, True),):
-        fn = lambda: call('tvae_linear_fwd_x6', w3, X, bb, None, out, M, Nt, K, Nt, Nt, act, 0.01, None, None, None, None, None, None, None, 0, 3)
+        fn = lambda: call('tvae_linear_fwd_x6', w3, X, bb, None, out, M, Nt, K, Nt, Nt, act, 0.01, None, None, None, None, None, None, None, 0, None, 3)
         fn(); torch.cuda.synchronize()
         s, e = torch.cuda.Event(True), torch.cuda.Event(True)
         s.record()

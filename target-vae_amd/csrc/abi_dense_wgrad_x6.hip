@@ -23,15 +23,18 @@ extern "C" {
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, int parts, tvae_stream_t stream) {
+                         int va_np, const void* vg_bits, int parts, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
     if (parts != 1 && parts != 3) return (int)hipErrorInvalidValue;
-    if (N <= 0 || N % 16 != 0 || ldd % 4 != 0 || !aligned16(dpre) || !ws) return (int)hipErrorInvalidValue;
+    const bool from_bits = vg_bits && vg_wo && vg_act == ACT_LRELU;        // two-valued form from stored sign bits: dpre unused
+    if (vg_bits && !from_bits) return (int)hipErrorInvalidValue;
+    if (N <= 0 || N % 16 != 0 || !ws || (from_bits ? N % 32 != 0 : (ldd % 4 != 0 || !dpre || !aligned16(dpre))))
+        return (int)hipErrorInvalidValue;
     if (va_xr ? (va_np % 16 != 0 || !aligned16(va_xr))      // the DMA ring moves 16 columns of one image per step
             : (ldx % 4 != 0 || !X || !aligned16(X)))
         return (int)hipErrorInvalidValue;
-    const VirtGrad vgs{vg_wo, vg_gy, vg_act, vg_slope};
+    const VirtGrad vgs{vg_wo, vg_gy, vg_act, vg_slope, nullptr, (const unsigned*)vg_bits};
     const VirtAct vas{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, vg_act, vg_slope};
     const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
     const long per = (long)M * K;
@@ -47,7 +50,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     const TileMap tmk{tilesM, tilesK, splits};
     // the implicit LeakyReLU gradient runs in its two-valued form (0 / 1 streamed operand, see the kernel)
     const bool lrf = vg_wo && vg_act == ACT_LRELU;
-    const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? 4 : 0);
+    const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? (from_bits ? 8 : 4) : 0);
     const int rc = parts == 1
         ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream))
         : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream));

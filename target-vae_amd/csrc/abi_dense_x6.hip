@@ -60,13 +60,14 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, int parts, tvae_stream_t stream) {
+                       int va_np, void* sign_bits, int parts, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
+    if (sign_bits && (act != ACT_LRELU || N % 32 != 0)) return (int)hipErrorInvalidValue;
     ep.bias = bias;
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
-    return launch_dense_x6(w3, X, ldx, ep, M, N, K, parts, S(stream), ColDot{col_w, col_b, col_y},
+    return launch_dense_x6(w3, X, ldx, ep, M, N, K, parts, S(stream), ColDot{col_w, col_b, col_y, (unsigned*)sign_bits},
                            InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
                            VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
 }
@@ -89,7 +90,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     }
     return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
                            InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
-                           VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum});
+                           VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, nullptr});
 }
 
 

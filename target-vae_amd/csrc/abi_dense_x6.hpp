@@ -43,7 +43,7 @@ TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3)
         const ATile &atile, hipStream_t st
 TVAE_INTERNAL int dense_wgrad_x6_launch_p3(TVAE_WG_LAUNCH_ARGS);
 TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
-// variant = VIRT | XVA << 1 | LRF << 2
+// variant = VIRT | XVA << 1 | LRF << 2   (LRF: 0 off, 1 two-valued from H, 2 two-valued from sign bits)
 #define TVAE_WG_ONE(V_, X_, L_, NP_)                                                                                  \
     do {                                                                                                              \
         hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, L_, NP_>, WG_RING_BYTES);                     \
@@ -56,12 +56,14 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
     namespace tvae {                                                                                                  \
     int dense_wgrad_x6_launch_p##NP_(TVAE_WG_LAUNCH_ARGS) {                                                           \
         switch (variant) {                                                                                            \
-            case 0: TVAE_WG_ONE(false, false, false, NP_);                                                            \
-            case 1: TVAE_WG_ONE(true, false, false, NP_);                                                             \
-            case 2: TVAE_WG_ONE(false, true, false, NP_);                                                             \
-            case 3: TVAE_WG_ONE(true, true, false, NP_);                                                              \
-            case 5: TVAE_WG_ONE(true, false, true, NP_);                                                              \
-            case 7: TVAE_WG_ONE(true, true, true, NP_);                                                               \
+            case 0: TVAE_WG_ONE(false, false, 0, NP_);                                                            \
+            case 1: TVAE_WG_ONE(true, false, 0, NP_);                                                             \
+            case 2: TVAE_WG_ONE(false, true, 0, NP_);                                                             \
+            case 3: TVAE_WG_ONE(true, true, 0, NP_);                                                              \
+            case 5: TVAE_WG_ONE(true, false, 1, NP_);                                                                 \
+            case 7: TVAE_WG_ONE(true, true, 1, NP_);                                                                  \
+            case 9: TVAE_WG_ONE(true, false, 2, NP_);                                                                 \
+            case 11: TVAE_WG_ONE(true, true, 2, NP_);                                                                 \
             default: return (int)hipErrorInvalidValue;                                                                \
         }                                                                                                             \
     }                                                                                                                 \

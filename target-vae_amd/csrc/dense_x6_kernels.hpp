@@ -100,6 +100,10 @@ struct VirtGrad {          // the streamed gradient operand given implicitly (ba
     // operand [H > 0] is 0 or 1: ONE exact bf16 part, so a product block is three MFMAs instead of six and the operand
     // needs no split arithmetic at all.  wo is then unused by the kernel.
     const float* csum;
+    // weight gradient only (LRF = 2): the operand given as the sign bits a forward launch stored (ColDot.bits),
+    // bits[m * (N/32) + n/32]; the saved activation itself is then not read.  (The data gradient keeps reading H: its
+    // operand loads are one instruction per k-row either way, and the bit form measured 0.2 ms slower.)
+    const unsigned* bits;
 };
 __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
     const float dv = vg.act == ACT_LRELU ? (h > 0.f ? 1.f : vg.slope) : (vg.act == ACT_TANH ? 1.f - h * h : 1.f);
@@ -130,6 +134,10 @@ struct ColDot {            // optional fused skinny layer on the OUTPUT of this 
     const float* w;        //   y[n] = b[0] + sum_m w[m] * Y[m][n]   (SpatialGenerator's last Linear, src/models.py:121-123)
     const float* b;
     float* y;
+    // optional second output of a LeakyReLU layer: the SIGN of every output element, one bit each,
+    // bits[m * (N / 32) + n / 32] bit (n & 31) = [Y[m][n] > 0].  The two-valued implicit gradient (VirtGrad.csum,
+    // dense_wgrad_x6_dma_kernel LRF) needs nothing else of Y: its data / weight gradient then stream 1/32 of the bytes.
+    unsigned* bits;
 };
 
 template <int ACT, int MASK, bool RES, bool AV, bool MB>
@@ -137,7 +145,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                                                   int n0, int M, int wave, int lane, const float* wsm,
                                                   float (&ysum)[4], const InTail& it, const float* wc2,
                                                   float (&gsum)[4][2], int tile_n, const float* cbm,
-                                                  const float (&gyv)[4], float oms) {
+                                                  const float (&gyv)[4], float oms, unsigned* sbits, long bitw) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
@@ -183,6 +191,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 const float bv = bsm[row];
                 float* crow = ep.C ? ep.C + mrow[q] * ep.ldc + coff : nullptr;
                 float rs[3] = {0.f, 0.f, 0.f};
+                unsigned sw[4] = {0u, 0u, 0u, 0u};               // sign words of this row's four 32-column groups
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // MB (two-valued implicit gradient, see VirtGrad): bv = slope * csum[m], oms = 1 - slope
@@ -201,6 +210,10 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         if (MASK == ACT_LRELU) v *= a > 0.f ? 1.f : ep.slope;
                         else v *= 1.f - a * a;
                     }
+                    if (sbits) {                                 // sign bits (ColDot.bits): lanes 0-31 hold one row, 32-63 the row + 4
+                        const unsigned long long bl = __ballot(v > 0.f);
+                        sw[j] = (unsigned)(lane < 32 ? bl : bl >> 32);
+                    }
                     if (m < M) {
                         if (crow) crow[j * 32] = v;
                         if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
@@ -213,6 +226,8 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         }
                     }
                 }
+                if (sbits && (lane & 31) == 0 && m < M)          // the tile's 128 columns of a row are ONE aligned 16-byte store
+                    *reinterpret_cast<uint4*>(sbits + (long)m * bitw + (n0 >> 5)) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
                 if (it.xr) {
                     // row sums over this panel's 128 columns: the 32 lanes of a half wave hold the same row
 #pragma unroll
@@ -348,7 +363,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     };
     auto store_b = [&](int stage, const float (&x)[4]) {
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
-        if (MASKB) {                                     // [H > 0] as bf16: 1.0 = 0x3f80, one part (rows k >= K hold 0)
+        if (MASKB) {                                     // [H > 0] as bf16: 1.0 = 0x3f80, one part (rows k >= K meet zero weights)
             dst[0] = make_uint2((x[0] > 0.f ? 0x3f80u : 0u) | (x[1] > 0.f ? 0x3f800000u : 0u),
                                 (x[2] > 0.f ? 0x3f80u : 0u) | (x[3] > 0.f ? 0x3f800000u : 0u));
             return;
@@ -440,7 +455,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const float oms = 1.f - vg.slope;
 #define TVAE_DX6_EPI(A_, M_, R_, V_)                                                                                    \
     dense_x6_epilogue<A_, M_, R_, V_, MASKB>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_, \
-                                             gyv, oms)
+                                             gyv, oms, cd.bits, (long)(N >> 5))
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
     if (ep.mask == ACT_NONE) {
@@ -536,12 +551,14 @@ constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 // is the 0 / 1 matrix [H > 0] -- ONE exact bf16 part (1.0 = 0x3f80), built with one compare per element, and THREE MFMAs
 // per product block (the single A part against the three X parts) instead of six.  s[k] is accumulated by the threads
 // that build the X cells (each owns one feature row k of the tile) and joins the partial slab in the epilogue.
-template <bool VIRT, bool XVA, bool LRF, int NP>
+// LRF: 0 = off, 1 = two-valued form with [H > 0] taken from the saved activation (dY = H), 2 = from the sign bits a forward
+// launch stored (VirtGrad.bits: one word per row and 32 columns, two dword DMAs per wave and step instead of four 1 KB ones)
+template <bool VIRT, bool XVA, int LRF, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
                                VirtAct va, ATile atile) {
-    constexpr int NDMA = 4 + (XVA ? 2 : 1) + (VIRT ? 1 : 0);              // DMA instructions per wave and step
+    constexpr int NDMA = (LRF == 2 ? 2 : 4) + (XVA ? 2 : 1) + (VIRT ? 1 : 0);   // DMA instructions per wave and step
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_ring[];   // [wave][slot < 3][WG_SLOT_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,6 +600,12 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const int row = m0 + 64 * wave + 16 * g + (lane >> 2);
         d_ptr[g] = dY + (long)min(row, M - 1) * ldd + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
     }
+    const unsigned* b_ptr[2] = {nullptr, nullptr};       // LRF == 2: the bit row of this lane's fragment row i
+    if (LRF == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            b_ptr[i] = vg.bits + (long)min(m0 + 64 * wave + 32 * i + (lane & 31), M - 1) * (N >> 5);
+    }
     const int kr = tid >> 2, q4 = tid & 3;               // B build role: feature row kr, n-quad q4
     const int kx = min(k0 + kr, Kf - 1);
     const float b_ok = (k0 + kr) < Kf ? 1.f : 0.f;
@@ -599,11 +622,20 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const int na = nbeg + 16 * t;                    // wave-uniform; a 16-wide step never straddles a column tile
         const long off = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
         const unsigned sl = ring_lds + (unsigned)(slot * WG_SLOT_BYTES);
+        if (LRF == 2) {                                  // each lane fetches the word that holds its row's 16 columns
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float* src = d_ptr[g] + off;
-            const unsigned dst = sl + (unsigned)(g * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+            for (int i = 0; i < 2; ++i) {
+                const unsigned* src = b_ptr[i] + (na >> 5);
+                const unsigned dst = sl + (unsigned)(i * 256);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dst), "v"(src) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* src = d_ptr[g] + off;
+                const unsigned dst = sl + (unsigned)(g * 1024);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+            }
         }
         if (XVA) {
             const float* sx = x_src + 32 * t;
@@ -632,6 +664,11 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             a_at[i][h] = (2 * i + ((lane >> 4) & 1)) * 1024 + (lane & 15) * 64 + (((2 * khalf + h) ^ ((lane >> 2) & 3)) * 16);
     auto read_a = [&](int slot, float4 (&r)[2][2], float4 (&gq)[2]) {
         const unsigned char* sl = ring + slot * WG_SLOT_BYTES;
+        if (LRF == 2) {                                  // the word this lane fetched for fragment i (bit-cast into r[i][0].x)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i][0].x = *reinterpret_cast<const float*>(sl + i * 256 + 4 * lane);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -670,7 +707,18 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
                                           virt_value(vg, r[i][h].z, 1.f, gq[h].z), virt_value(vg, r[i][h].w, 1.f, gq[h].w));
         }
     };
-    auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3]) {
+    auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3], int t) {
+        if (LRF == 2) {                                  // eight sign bits of the word -> one cell of 0 / 1.0
+            const int sh = ((nbeg + 16 * t) & 31) + 8 * khalf;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned b = __float_as_uint(r[i][0].x) >> sh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    a[i][0].w[q] = ((b >> (2 * q)) & 1u) * 0x3f80u | ((b >> (2 * q + 1)) & 1u) * 0x3f800000u;
+            }
+            return;
+        }
         if (LRF) {                                       // cells of [H > 0]: 1.0 = 0x3f80, a single part
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -734,7 +782,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         float4 ar[2][2], g0[2];
         read_a(0, ar, g0);
         virt_a(ar, g0);
-        split_a(ar, af);
+        split_a(ar, af, 0);
         store_b(0, read_x(0), 0, true);
     }
     __syncthreads();
@@ -764,7 +812,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
                 float4 ar[2][2], gn[2];
                 read_a(s_next, ar, gn);
                 virt_a(ar, gn);
-                split_a(ar, an);
+                split_a(ar, an, min(t + 1, tl));
             }
             if (j == 1) store_b(cur ^ 1, read_x(s_next), s_next, t + 1 < nk);   // B cells of step t+1
         }

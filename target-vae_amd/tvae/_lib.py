@@ -27,10 +27,10 @@ SIGNATURES = {
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiifi',
     'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
-    'tvae_linear_fwd_x6': 'pppppiiillifpppppppii',
+    'tvae_linear_fwd_x6': 'pppppiiillifpppppppipi',
     'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppii',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippifppppii',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipi',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',

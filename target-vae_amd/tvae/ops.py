@@ -161,7 +161,7 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0) -> torch.Tensor:
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None) -> torch.Tensor:
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only)."""
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
@@ -171,7 +171,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0) -> torch.Tensor:
         with _timed('tvae_linear_wgrad_x6'):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
-                 *(va if va else (None, None, None, None, 0)), parts())
+                 *(va if va else (None, None, None, None, 0)), bits, parts())
         return dW
     _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
@@ -219,6 +219,7 @@ FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
 FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
 FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
 FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
+FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -545,7 +546,7 @@ class DecoderFn(torch.autograd.Function):
                 w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
-                         None, None, None, None, None, None, None, 0, parts())
+                         None, None, None, None, None, None, None, 0, None, parts())
             else:
                 call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
         else:
@@ -553,16 +554,24 @@ class DecoderFn(torch.autograd.Function):
         hs = [h]
         yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
         fused_out = False
+        sbits = None
         for li, (W, b) in enumerate(hidden):
             hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 w3 = _split_weight(W, F_, F_, False, 'x6_dense_w')
                 # the last hidden layer also applies the single-output Linear that follows it (one pass less over h)
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
+                # the backward of the single-output Linear behind the last hidden layer needs only the SIGN of this
+                # layer's LeakyReLU output (two-valued implicit gradient): one bit per element, stored by this launch
+                if (li == n_hidden - 1 and FUSE_SIGN_BITS and FUSE_VIRT_GRAD and n_out == 1 and not resid and act == ACT_LRELU
+                        and F_ >= 256 and Nt % 32 == 0):
+                    sbits = torch.empty(F_, Nt // 32, dtype=torch.int32, device=dev)
+                    _note('dec.sign_bits')
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
-                         *(va if va and li == 0 else (None, None, None, None, 0)), parts())
+                         *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
+                         parts())
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
@@ -575,6 +584,7 @@ class DecoderFn(torch.autograd.Function):
                               *[p for p in params if p is not None])
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
         ctx.arith = get_gemm_mode()
+        ctx.sbits = sbits
         return yh
 
     @staticmethod
@@ -619,7 +629,8 @@ class DecoderFn(torch.autograd.Function):
             use_vg = vg is not None and li == n_hidden - 1
             dsrc = hs[-1] if use_vg else d             # implicit operand: pass the saved activation instead
             va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if hprev is None else None   # recomputed first layer
-            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act)
+            sbits = ctx.sbits if (use_vg and act == ACT_LRELU) else None      # [h > 0] as stored bits (two-valued form)
+            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits)
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue

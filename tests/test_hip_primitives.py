@@ -201,7 +201,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     cy = torch.empty(N, device=dev())
     fuse = M <= 512
     call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), res.to(dev()) if use_res else None, Y, M, N, K, N, N, act,
-         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None, None, None, None, None, 0, 3)
+         SLOPE, cw.to(dev()) if fuse else None, cb.to(dev()) if fuse else None, cy if fuse else None, None, None, None, None, 0, None, 3)
     if fuse:
         assert rel_err(cy, cw.double() @ ref + cb.double()) < GEMM_TOL['f32']
     assert rel_err(Y, ref) < GEMM_TOL['f32']
@@ -220,7 +220,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
          dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0, 3)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0, 3)
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0, None, 3)
 
 
 @pytest.mark.parametrize('M,N,K,acc', [(512, 20000 // 16 * 16, 512, 0), (128, 8192, 128, 0), (300, 1600, 70, 1), (512, 4096, 512, 1)])
@@ -230,10 +230,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
     ws = torch.empty(1 << 24, device=dev())
-    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, 3)
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
     assert rel_err(dW, ref) < GEMM_TOL['f32']
     with pytest.raises(Exception):
-        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, 3)
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
 
 
 @pytest.mark.parametrize('B,n,k,pad,C,R,act,Cin', [
@@ -320,6 +320,12 @@ def test_linear_x6_implicit_gradient_operand():
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 1, SLOPE, None, None, None,
          None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
     assert rel_err(dX2, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
+    # packed sign bits of the activation (the weight gradient below can read its 0 / 1 operand from them)
+    def pack_bits(t):                      # bit (n & 31) of word n / 32 = [t[m][n] > 0]
+        b = (t > 0).to(torch.int64).view(t.shape[0], -1, 32)
+        w = (b << torch.arange(32)).sum(-1)
+        return (w - ((w >> 31) << 32)).to(torch.int32).contiguous()
+    hb = pack_bits(H).to(dev())
     with pytest.raises(Exception):         # the two-valued form exists for LeakyReLU only
         call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 2, SLOPE, None, None, None,
              None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
@@ -328,8 +334,21 @@ def test_linear_x6_implicit_gradient_operand():
         dv = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), vact)
         dW = torch.empty(M, K, device=dev())
         call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
-             gy.to(dev()), vact, SLOPE, None, None, None, None, 0, 3)
+             gy.to(dev()), vact, SLOPE, None, None, None, None, 0, None, 3)
         assert rel_err(dW, dv @ X.double().t()) < GEMM_TOL['f32'], vact
+        if vact == 1:                      # the same from the packed sign bits: bitwise the same sums
+            dWb = torch.empty(M, K, device=dev())
+            call('tvae_linear_wgrad_x6', None, X.to(dev()), dWb, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()),
+                 gy.to(dev()), 1, SLOPE, None, None, None, None, 0, hb, 3)
+            assert torch.equal(dWb, dW)
+    # a LeakyReLU forward launch stores the sign bits of its output
+    w3 = torch.empty(query('tvae_dense_x6_bytes', M, K) // 4, device=dev())
+    call('tvae_dense_split3', W.to(dev()), K, w3, w3.numel() * 4, M, K, 0, None, None)
+    Y = torch.empty(M, N, device=dev())
+    yb = torch.empty(M, N // 32, dtype=torch.int32, device=dev())
+    call('tvae_linear_fwd_x6', w3, X.to(dev()), None, None, Y, M, N, K, N, N, 1, SLOPE, None, None, None, None, None,
+         None, None, 0, yb, 3)
+    assert torch.equal(yb.cpu(), pack_bits(Y.cpu()))
     # dec_out_bwd without the gradient tensor: sums only
     F_ = M
     part = torch.empty(((N + 1023) // 1024) * F_ * 2, device=dev())
@@ -361,8 +380,8 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     # forward
     Y = [torch.empty(M, Nt, device=dev()) for _ in range(2)]
     call('tvae_linear_fwd_x6', w3, h0, b.to(dev()), None, Y[0], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
-         None, None, None, None, 0, 3)
-    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va, 3)
+         None, None, None, None, 0, None, 3)
+    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va, None, 3)
     assert torch.equal(Y[0], Y[1])
     assert rel_err(Y[0], act_ref(W.double() @ h0.double().cpu() + b.double()[:, None], act)) < GEMM_TOL['f32']
     # data gradient with the fused coordinate-layer backward
@@ -380,14 +399,14 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     ws = torch.empty(1 << 24, device=dev())
     dW = [torch.empty(M, F_, device=dev()) for _ in range(2)]
     call('tvae_linear_wgrad_x6', d, h0, dW[0], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE,
-         None, None, None, None, 0, 3)
-    call('tvae_linear_wgrad_x6', d, None, dW[1], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE, *va, 3)
+         None, None, None, None, 0, None, 3)
+    call('tvae_linear_wgrad_x6', d, None, dW[1], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE, *va, None, 3)
     assert torch.equal(dW[0], dW[1])
     assert rel_err(dW[1], d.double().cpu() @ h0.double().cpu().t()) < GEMM_TOL['f32']
     # images that are not whole column tiles are refused
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y[1], M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None,
-             xr, Wc, bc, LB, 96, 3)
+             xr, Wc, bc, LB, 96, None, 3)
 
 
 def test_reductions():
@@ -650,7 +669,7 @@ def test_implicit_wgrad_and_multi_tile_dft_fp64():
     wo = torch.randn(M, generator=g); gy = torch.randn(N, generator=g)
     dW = torch.empty(M, K, device=dev()); ws = torch.empty(1 << 24, device=dev())
     call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()), gy.to(dev()), 1, 0.01,
-         None, None, None, None, 0, 3)
+         None, None, None, None, 0, None, 3)
     d = wo.double()[:, None] * gy.double()[None, :] * torch.where(H.double() > 0, 1.0, 0.01)
     e1 = rel(dW, d @ X.double().t())
     # frequency-domain convolution, forward + weight gradient, a batch whose (image, row) columns span several tiles
