@@ -123,6 +123,13 @@ if only and 'tail' in only:
     # implicit gradient + fused first-layer backward + recomputed mask, weight gradient with both implicit operands
     cy = torch.empty(Nt, device=dev)
     timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, None, PARTS))
-    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, PARTS))
-    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, None, PARTS))
+    # the step's data gradient: two-valued implicit gradient (weights scaled by wo before the split, 0 / 1 operand)
+    csum2 = torch.empty(F_, device=dev)
+    w3s = torch.empty_like(w3)
+    call('tvae_dense_split3', W, F_, w3s, w3s.numel() * 4, F_, F_, 1, wo1, csum2)
+    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3s, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, gy1, csum2, bc2, lb2, Np_, PARTS))
+    timeit('tail_dgrad_generic', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, PARTS))
+    hbits = torch.zeros(F_, Nt // 32, dtype=torch.int32, device=dev).random_(-2 ** 31, 2 ** 31 - 1)
+    timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', None, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, hbits, PARTS))
+    timeit('tail_wgrad_from_H', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, None, PARTS))
     timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0, None, PARTS))

@@ -2,7 +2,7 @@
 # SQ-level diagnosis of the GEMM-shaped kernels (one --pmc pass, kernel-trace only):
 #   gpurun -- 'bash profiles/pmc_sq.sh <ONLY-filter> <tag>'
 set -u
-export TMPDIR=/tmp ONLY=${1:-dec} REPS=2
+export TMPDIR=/tmp ONLY=${1:-dec} REPS=2 MODE=x6
 OUT=$PWD/gpurun_out/sq_${2:-x}
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/p" -o q -- python3 profiles/kernel_bench.py > "$OUT/log.txt" 2>&1

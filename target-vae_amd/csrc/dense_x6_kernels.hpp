@@ -140,6 +140,21 @@ struct ColDot {            // optional fused skinny layer on the OUTPUT of this 
     unsigned* bits;
 };
 
+// Sum over the 32 lanes of each half wave, left in every lane of the half: four DPP adds inside the 16-lane rows (quad
+// swaps, half-mirror, mirror: vector-ALU only) and ONE cross-row exchange, instead of five dependent ds_bpermute round
+// trips per value (the fused first-layer backward reduces 96 values per lane and tile this way).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float x) {
+    x = dpp_add<0xB1>(x);                                // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);                                // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);                               // row_half_mirror: the other quad of each 8
+    x = dpp_add<0x140>(x);                               // row_mirror: the other 8 of each 16
+    return x + __shfl_xor(x, 16, 64);                    // the other row of the half wave
+}
+
 template <int ACT, int MASK, bool RES, bool AV, bool MB>
 __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epilogue& ep, const float* bsm, int m0,
                                                   int n0, int M, int wave, int lane, const float* wsm,
@@ -231,10 +246,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                 if (it.xr) {
                     // row sums over this panel's 128 columns: the 32 lanes of a half wave hold the same row
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) rs[k] += __shfl_xor(rs[k], o, 64);
-                    }
+                    for (int k = 0; k < 3; ++k) rs[k] = half_wave_sum(rs[k]);
                     if ((lane & 31) == 0 && m < M) {
                         float* pp = it.part + ((long)tile_n * M + m) * 3;
                         pp[0] = rs[0];
