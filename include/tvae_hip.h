@@ -224,6 +224,15 @@ int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float
                        const float* gth, const float* gdx, const float* gkl, const float* g_attn, const float* g_q,
                        const float* g_a, float* dheads, float* part, long part_floats, tvae_stream_t stream);
 
+/* ---- rotation pooling of the translation-attention encoder: fc_r = nn.Linear(R, 1) over the rotation axis of
+ * act(conv1(x)), src/models.py:301-304.  A1 [C][B][R][P] (the feature-major conv1 output),
+ * X [C][B*P] = fb[0] + sum_r fw[r] A1[.][.][r][.].  Backward: dA1 = fw[r] * dX * act'(A1), dtot [R + 1] = (dfw | dfb);
+ * part: workspace >= (R + 1) * min(1024, ceil(C*B*P / 256)) floats.  R <= 16. */
+int tvae_rot_pool_fwd(const float* A1, const float* fw, const float* fb, float* X, int C, int B, int R, int P,
+                      tvae_stream_t stream);
+int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* dA1, float* part, long part_floats,
+                      float* dtot, int C, int B, int R, int P, int act, float slope, tvae_stream_t stream);
+
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

@@ -252,6 +252,29 @@ int tvae_attn_head_bwd(const float* heads, long ldh, const float* q, const float
     return 0;
 }
 
+int tvae_rot_pool_fwd(const float* A1, const float* fw, const float* fb, float* X, int C, int B, int R, int P,
+                      tvae_stream_t stream) {
+    if ((long)C * B * P <= 0) return 0;
+    if (R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rot_pool_fwd_kernel, dim3(grid1d((long)C * B * P, 256)), dim3(256), 0, S(stream), A1, fw, fb, X, C, B,
+                       R, P);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* dA1, float* part, long part_floats,
+                      float* dtot, int C, int B, int R, int P, int act, float slope, tvae_stream_t stream) {
+    if ((long)C * B * P <= 0) return 0;
+    const int nb = grid1d((long)C * B * P, 256, 1024);
+    if (R < 1 || R > 16 || part_floats < (long)(R + 1) * nb) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rot_pool_bwd_kernel, dim3(nb), dim3(256), 0, S(stream), A1, dX, fw, dA1, part, C, B, R, P, act, slope);
+    TVAE_CHECK_LAUNCH();
+    // dtot[0..R) = d fw, dtot[R] = d fb: the per-block partials [nb][R + 1] summed in block order
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(64), 0, S(stream), (const float*)part, nb, (long)(R + 1), dtot, 1.f, 0);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,
                     int P, int zd, float theta_off_scale, float* zc, float* theta_mu, float* dx, tvae_stream_t stream) {
     if (B <= 0) return 0;

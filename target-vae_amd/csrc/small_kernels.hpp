@@ -781,6 +781,56 @@ static __global__ void attn_head_bwd_b_kernel(HeadParams hp, int G, int chunk, c
 
 
 // ------------------------------------------------------------------------------------------
+// Rotation pooling of the translation-attention encoder (reference src/models.py:301-304: fc_r = nn.Linear(R, 1) applied
+// over the rotation axis of act(conv1(x))):  X[c][b*P + p] = fb + sum_r fw[r] * A1[c][(b*R + r)*P + p].
+// Backward: dA1 = fw[r] * dX * act'(A1)  (the activation sits between conv1 and the pooling), and per-block partial sums
+// part[block][0..R) = sum A1 * dX  (= d fw),  part[block][R] = sum dX  (= d fb), reduced by seg_sum_kernel.
+// ------------------------------------------------------------------------------------------
+static __global__ void rot_pool_fwd_kernel(const float* __restrict__ A1, const float* __restrict__ fw,
+                                           const float* __restrict__ fb, float* __restrict__ X, int C, int B, int R, int P) {
+    const long total = (long)C * B * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const long cb = i / P;                           // c*B + b
+        const float* a = A1 + cb * R * P + p;
+        float s = fb[0];
+        for (int r = 0; r < R; ++r) s += fw[r] * a[(long)r * P];
+        X[i] = s;
+    }
+}
+static __global__ __launch_bounds__(256) void rot_pool_bwd_kernel(const float* __restrict__ A1, const float* __restrict__ dX,
+                                                                  const float* __restrict__ fw, float* __restrict__ dA1,
+                                                                  float* __restrict__ part, int C, int B, int R, int P,
+                                                                  int act, float slope) {
+    __shared__ float sm[17 * 16];
+    const long total = (long)C * B * P;
+    float acc[17];
+#pragma unroll
+    for (int r = 0; r < 17; ++r) acc[r] = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const long cb = i / P;
+        const float g = dX[i];
+        acc[16] += g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < R) {
+                const long j = (cb * R + r) * P + p;
+                const float a = A1[j];
+                acc[r] += a * g;
+                const float d = act == ACT_LRELU ? (a > 0.f ? 1.f : slope) : (act == ACT_TANH ? 1.f - a * a : 1.f);
+                dA1[j] = fw[r] * g * d;
+            }
+        }
+    }
+    block_sum<17>(acc, sm);
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < R; ++r) part[(long)blockIdx.x * (R + 1) + r] = acc[r];
+        part[(long)blockIdx.x * (R + 1) + R] = acc[16];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Inference epilogue get_latent (reference clustering_mnist.py:123-161): per image, the most probable (r,h,w) under
 // attn = logit + log p(r); content vector (z_mu, exp(z_logstd)) and theta_mu gathered there; translation = expected
 // grid position under softmax(attn) summed over rotations.  One workgroup per image; first index wins ties.

@@ -193,7 +193,8 @@ class InferenceNetwork_UnimodalTranslation_UnimodalRotation(nn.Module):
 
 class InferenceNetwork_AttentionTranslation_UnimodalRotation(nn.Module):
     """Translation-attention encoder, rotation pooled by fc_r (reference src/models.py:268-319); secondary
-    encoder: conv1 runs on the HIP GroupConv, the 2-D 1x1 tail on generic torch."""
+    encoder: the whole encoder on the HIP kernels, the pooled-posterior tail in
+    tvae/secondary.py on generic torch."""
 
     def __init__(self, n, in_channels, latent_dim, kernels_num=128, activation=nn.LeakyReLU, groupconv=0):
         super().__init__()
@@ -216,19 +217,27 @@ class InferenceNetwork_AttentionTranslation_UnimodalRotation(nn.Module):
 
     def forward(self, x, device, E=None):
         """Reference 4-tuple (attn, a_sampled, theta, z).  `E` optionally injects the Exp(1) draws of the
-        Gumbel-softmax (reference: F.gumbel_softmax, models.py:311)."""
-        if self.groupconv > 0:
-            x = self.activation(self.conv1(x, device))
-            x = self.fc_r(x.permute(0, 1, 3, 4, 2)).squeeze(4)
-        else:
-            x = self.activation(self.conv1(x))
-        h = self.activation(self.conv2(x))
-        attn = self.conv_a(h)
-        logits = attn.reshape(attn.shape[0], -1)
+        Gumbel-softmax (reference: F.gumbel_softmax, models.py:311).  conv1 (lifting or plain convolution), the fc_r
+        rotation pooling, conv2 and the three 1x1 heads run on the HIP kernels (`ops.TransAttnEncoderFn`)."""
+        _require_gpu(x, 'InferenceNetwork_AttentionTranslation_UnimodalRotation')
+        zd = self.latent_dim
+        C = self.kernels_num
+        Wh = torch.cat([self.conv_a.weight.view(1, C), self.conv_r.weight.view(2, C), self.conv_z.weight.view(2 * zd, C)], 0)
+        bh = torch.cat([self.conv_a.bias, self.conv_r.bias, self.conv_z.bias], 0)
+        gc = self.groupconv
+        fw, fb = (self.fc_r.weight, self.fc_r.bias) if gc > 0 else (None, None)
+        heads = _ops.TransAttnEncoderFn.apply(x, self.conv1.weight, self.conv1.bias, fw, fb, self.conv2.weight.view(C, C),
+                                              self.conv2.bias, Wh, bh, gc, self.input_size // 2,
+                                              _ops.act_code(self.activation))
+        b = x.shape[0]
+        Ho = int(round((heads.shape[1] // b) ** 0.5))
+        hv = heads.view(3 + 2 * zd, b, Ho, Ho).permute(1, 0, 2, 3)
+        attn = hv[:, 0:1]
+        logits = attn.reshape(b, -1)
         if E is None:
             E = torch.empty_like(logits).exponential_()
         a = torch.softmax(logits - torch.log(E.reshape(logits.shape)), dim=-1)
-        return attn, a.view(h.shape[0], h.shape[2], h.shape[3]), self.conv_r(h), self.conv_z(h)
+        return attn, a.view(b, Ho, Ho), hv[:, 1:3], hv[:, 3:]
 
 
 class InferenceNetwork_AttentionTranslation_AttentionRotation(nn.Module):

@@ -46,6 +46,8 @@ SIGNATURES = {
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppppl',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppppl',
     'tvae_get_latent': 'plpppiiiifppp',
+    'tvae_rot_pool_fwd': 'ppppiiii',
+    'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',
     'tvae_coord_bwd': 'ppppppii',
     'tvae_dec_l0_fwd': 'pppppliliif',   # xr, Wc, bc, LB, h, ldh(l), F(i), Ntot(l), Np(i), act(i), slope(f)

@@ -228,11 +228,13 @@ def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
     return CONV_DFT and split_pipe() and bool(query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R))
 
 
-def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None):
-    """Rotated bank + lifting convolution.  `keep` (a dict) receives what the weight gradient can reuse."""
+def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
+    """Rotated bank + lifting convolution.  `keep` (a dict) receives what the weight gradient can reuse.  `bank`: a ready
+    [C*R][Cin*k*k] bank (the plain convolution of --groupconv 0 is the R = 1 case with the weight itself as the bank)."""
     B, Cin, n, _ = y.shape
     Ho = n + 2 * pad - k + 1
-    bank = rotate_bank(weight, R)
+    if bank is None:
+        bank = rotate_bank(weight, R)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
     if _use_dft(B, Cin, n, k, pad, C, R):
         # zeros: the columns that pad (image, row) to a multiple of 128 must stay finite
@@ -396,6 +398,93 @@ class EncoderFn(torch.autograd.Function):
         dbank = conv1_wgrad(y, dA1, C, R, k, pad, ctx.at, db1 if ctx.at is not None else None)
         dw1 = rotate_bank_bwd(dbank, C, Cin, k, R)
         return None, dw1, db1, dW2, db2, dWh, dbh, None, None, None
+
+
+class TransAttnEncoderFn(torch.autograd.Function):
+    """Translation-attention encoder with pooled rotation (reference src/models.py:268-319) on the
+    same kernels as the main encoder: conv1 (lifting convolution, or the plain R = 1 convolution of --groupconv 0) ->
+    act -> fc_r rotation pooling (`tvae_rot_pool_*`) -> conv2 (1x1) -> act -> {conv_a, conv_r, conv_z} stacked.
+    Output: heads [1 + 2 + 2*zd][B*Ho*Ho] feature-major."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, fw, fb, W2, b2, Wh, bh, R, pad, act):
+        C = w1.shape[0]
+        plain = w1.dim() == 4                            # nn.Conv2d weight (C, Cin, k, k): groupconv = 0
+        Cin, k = w1.shape[1], w1.shape[-1]
+        y = y.contiguous().view(y.shape[0], Cin, y.shape[-2], y.shape[-1])
+        B, n = y.shape[0], y.shape[-1]
+        Ho = n + 2 * pad - k + 1
+        _expect(Ho >= 1 and (plain or R in (4, 8, 16)), 'translation-attention encoder geometry')
+        Re = 1 if plain else R
+        P = Ho * Ho
+        keep = {}
+        A1 = conv1_forward(y, None if plain else w1, b1, C, Re, k, pad, act, keep,
+                           bank=w1.contiguous().view(C, Cin * k * k) if plain else None)
+        _note('trans_attn.plain' if plain else 'trans_attn.rot_pool')
+        if plain:
+            X = A1                                       # [C][B*P]
+        else:
+            X = torch.empty(C, B * P, dtype=torch.float32, device=y.device)
+            call('tvae_rot_pool_fwd', A1, fw.contiguous().view(-1), fb.contiguous(), X, C, B, R, P)
+        N = B * P
+        C2, nh = W2.shape[0], Wh.shape[0]
+        H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        call('tvae_linear_fwd', W2.contiguous(), X, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
+        heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
+        if nh <= SKINNY_MAX:
+            call('tvae_heads_fwd', Wh.contiguous(), H, N, bh, heads, N, nh, C2, N)
+        else:
+            call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
+        ctx.save_for_backward(y, w1, fw, W2, Wh, A1, X, H)
+        ctx.at = keep.get('at')
+        ctx.cfg = (C, Cin, k, R, pad, B, Ho, act, plain)
+        ctx.arith = get_gemm_mode()
+        return heads
+
+    @staticmethod
+    @_in_forward_arithmetic
+    def backward(ctx, dheads):
+        y, w1, fw, W2, Wh, A1, X, H = ctx.saved_tensors
+        C, Cin, k, R, pad, B, Ho, act, plain = ctx.cfg
+        P = Ho * Ho
+        N = B * P
+        C2, nh = W2.shape[0], Wh.shape[0]
+        dev = y.device
+        dheads = dheads.contiguous()
+        dbh = _rowsum(dheads, nh, N)
+        dH = torch.empty(C2, N, dtype=torch.float32, device=dev)
+        if nh <= SKINNY_MAX:
+            npan = (N + 511) // 512
+            part = workspace(dev, npan * C2 * (nh + 1))
+            tot = torch.empty(nh + 1, C2, dtype=torch.float32, device=dev)
+            call('tvae_heads_bwd', Wh.contiguous(), dheads, N, H, N, dH, N, nh, C2, N, act, LRELU_SLOPE, part,
+                 part.numel(), tot)
+            dWh, db2 = tot[:nh], tot[nh]
+        else:
+            dWh = _wgrad(dheads, H, nh, N, C2)
+            call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
+            db2 = _rowsum(dH, C2, N)
+        dW2 = _wgrad(dH, X, C2, N, C)
+        dX = torch.empty(C, N, dtype=torch.float32, device=dev)
+        # the pooled tensor is not an activation output: plain data gradient (groupconv 0: X = act(conv1), masked)
+        call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1 if plain else None, dX, C2, N, C, N, N,
+             act if plain else ACT_NONE, LRELU_SLOPE)
+        dfw = dfb = None
+        Re = 1 if plain else R
+        if plain:
+            dA1 = dX
+        else:
+            dA1 = torch.empty_like(A1)
+            nb = min(1024, (C * N + 255) // 256)
+            partp = workspace(dev, (R + 1) * nb)
+            dtot = torch.empty(R + 1, dtype=torch.float32, device=dev)
+            call('tvae_rot_pool_bwd', A1, dX, fw.contiguous().view(-1), dA1, partp, partp.numel(), dtot, C, B, R, P, act,
+                 LRELU_SLOPE)
+            dfw, dfb = dtot[:R].view(1, R), dtot[R:]
+        db1 = torch.empty(C, dtype=torch.float32, device=dev) if ctx.at is not None else _rowsum(dA1, C, dA1.shape[1])
+        dbank = conv1_wgrad(y, dA1, C, Re, k, pad, ctx.at, db1 if ctx.at is not None else None)
+        dw1 = dbank.view(C, Cin, k, k) if plain else rotate_bank_bwd(dbank, C, Cin, k, R)
+        return None, dw1, db1, dfw, dfb, dW2, db2, dWh, dbh, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -81,6 +81,31 @@ def test_cli_two_epochs(script, tmp_path):
     assert np.isfinite([e, err, kl]).all() and abs(e + err + kl) < 1e-6 * abs(e)
 
 
+def test_particles_cli_from_mrc_stack(tmp_path):
+    """MRC/MRCS stack -> device-resident dataset: train_particles on a stack written by src.mrc.write
+    (byte-identical to the reference writer, tests/test_host_cpu.py), split by --train-portion, cropped and normalised,
+    two epochs; the same run from the .npy copy of the stack gives the same TSV numbers."""
+    import src.mrc as mrc
+    g = np.random.default_rng(1)
+    stack = (g.normal(size=(24, 22, 22)) * 3 + 1).astype(np.float32)
+    with open(tmp_path / 'p.mrcs', 'wb') as f:
+        mrc.write(f, stack)
+    np.save(tmp_path / 'p.npy', stack)
+    outs = []
+    for path in ('p.mrcs', 'p.npy'):
+        cmd = [sys.executable, os.path.join(PKG, 'train_particles.py'), '--train-path', str(tmp_path / path),
+               '--train-portion', '0.75', '--crop', '20', '--normalize', '-z', '2', '--minibatch-size', '6', '--num-epochs',
+               '2', '--encoder-kernel-number', '8', '--generator-hidden-dim', '32', '--encoder-kernel-size', '20',
+               '--encoder-padding', '4', '--seed', '3', '--log-root', str(tmp_path / ('logs_' + path))]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        rows = [ln.split('\t') for ln in r.stdout.splitlines() if '\t' in ln]
+        assert rows[0] == ['Epoch', 'Split', 'ELBO', 'Error', 'KL'] and len(rows) == 5
+        outs.append(np.array([[float(v) for v in b[2:]] for b in rows[1:]]))
+        assert np.isfinite(outs[-1]).all()
+    assert np.allclose(outs[0], outs[1], rtol=1e-5), (outs[0], outs[1])
+
+
 def test_eval_model_matches_oracle():
     """eval_model (train_mnist.py:352-387): no-grad twin of train_epoch -- batch-weighted running means of the three
     ELBO terms over a ragged pair of minibatches, against the oracle with the same injected noise; parameters and

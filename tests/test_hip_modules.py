@@ -459,8 +459,16 @@ def test_secondary_branches_golden(name, t_inf, r_inf):
     enc.load_state_dict(tdict(fx, 'e.'))
     gen.load_state_dict(tdict(fx, 'd.'))
     enc, gen = enc.to(dev()), gen.to(dev())
-    elbo, logp, kl = step.eval_minibatch(O.image_coords(n).to(dev()), torch.from_numpy(fx['y']).to(dev()), gen, enc,
-                                         t_inf, r_inf, 0, dev(), np.pi, gc, n, noise=noise)
+    from tvae import ops
+    ops.PATH_LOG = set()
+    try:
+        elbo, logp, kl = step.eval_minibatch(O.image_coords(n).to(dev()), torch.from_numpy(fx['y']).to(dev()), gen, enc,
+                                             t_inf, r_inf, 0, dev(), np.pi, gc, n, noise=noise)
+        taken = ops.PATH_LOG
+    finally:
+        ops.PATH_LOG = None
+    if t_inf == 'attention':                             # the whole encoder ran on the kernels
+        assert ('trans_attn.rot_pool' if gc else 'trans_attn.plain') in taken, taken
     assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
     assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
     assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL

@@ -506,6 +506,31 @@ def test_heads_fwd_bwd(nh, C, N, act):
         call('tvae_heads_fwd', W.to(dev()), X.to(dev()), N, b.to(dev()), Y, N, 9, C, N)
 
 
+@pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
+def test_rot_pool(C, B, R, Ho, act):
+    """fc_r pooling over the rotation axis (reference models.py:303-305) and its backward through the activation."""
+    P = Ho * Ho
+    A1 = rnd(C, B, R, P, seed=1).clamp(-0.9, 0.9)
+    fw, fb = rnd(R, seed=2), rnd(1, seed=3)
+    X = torch.empty(C, B * P, device=dev())
+    call('tvae_rot_pool_fwd', A1.to(dev()), fw.to(dev()), fb.to(dev()), X, C, B, R, P)
+    ref = torch.einsum('cbrp,r->cbp', A1.double(), fw.double()) + fb.double()
+    assert rel_err(X.view(C, B, P), ref) < TOL
+    dX = rnd(C, B, P, seed=4)
+    dA1 = torch.empty(C, B, R, P, device=dev())
+    nb = min(1024, (C * B * P + 255) // 256)
+    part = torch.empty(nb * (R + 1), device=dev())
+    dtot = torch.empty(R + 1, device=dev())
+    call('tvae_rot_pool_bwd', A1.to(dev()), dX.to(dev()), fw.to(dev()), dA1, part, part.numel(), dtot, C, B, R, P, act,
+         SLOPE)
+    dref = dX.double()[:, :, None, :] * fw.double()[None, None, :, None] * dact_ref(A1.double(), act)
+    assert rel_err(dA1, dref) < TOL
+    assert rel_err(dtot[:R], torch.einsum('cbrp,cbp->r', A1.double(), dX.double())) < TOL
+    assert rel_err(dtot[R], dX.double().sum()) < 1e-4
+    with pytest.raises(Exception):                       # short partial-sum workspace
+        call('tvae_rot_pool_bwd', A1.to(dev()), dX.to(dev()), fw.to(dev()), dA1, part, R, dtot, C, B, R, P, act, SLOPE)
+
+
 def test_coord():
     B, n = 3, 9
     xc = O.image_coords(n)

@@ -278,6 +278,30 @@ def test_mrc_codec_against_reference_written_files(tmp_path):
     assert [p[1][:2] for p in parts] == [(0, 3), (3, 5)]
 
 
+def test_driver_loads_only_its_shard_from_mrc_and_npy(tmp_path):
+    """The particles driver opens MRC / .npy stacks lazily and reads, crops and normalises only the rows of its rank
+    (dp.shard_bounds); the shards of two ranks tile what a single process loads, for both file formats."""
+    import src.mrc as mrc
+    from tvae import dp, driver
+    g = np.random.default_rng(0)
+    stack = g.normal(size=(11, 24, 24)).astype(np.float32)
+    with open(tmp_path / 's.mrcs', 'wb') as f:
+        mrc.write(f, stack)
+    np.save(tmp_path / 's.npy', stack)
+    for path in ('s.mrcs', 's.npy'):
+        args = driver.build_parser('particles').parse_args(['--train-path', str(tmp_path / path), '--train-portion', '0.75',
+                                                            '--crop', '20', '--normalize'])
+        tr, te, name, n_raw, n_tr, n_te = driver._load_arrays('particles', args)
+        assert (n_tr, n_te, n_raw) == (8, 3, 24) and tuple(tr.shape) == (8, 1, 20, 20) and tuple(te.shape) == (3, 1, 20, 20)
+        ref = stack[:8, 2:22, 2:22]
+        ref = (ref - ref.reshape(8, -1).mean(1)[:, None, None]) / ref.reshape(8, -1).std(1)[:, None, None]
+        assert np.allclose(tr[:, 0].numpy(), ref, atol=1e-6)
+        parts = [driver._load_arrays('particles', args, (r, 2)) for r in range(2)]
+        assert torch.equal(torch.cat([p[0] for p in parts]), tr) and torch.equal(torch.cat([p[1] for p in parts]), te)
+        assert [tuple(p[0].shape)[0] for p in parts] == [b - a for a, b in (dp.shard_bounds(8, r, 2) for r in range(2))]
+        assert all(p[4:] == (8, 3) for p in parts)
+
+
 def test_shape_validation_happens_before_any_launch():
     """Mis-shaped operands raise on the host (ValueError) without touching the GPU library."""
     from tvae import ops
