@@ -169,7 +169,8 @@ class GroupConv(nn.Module):
 
 
 class InferenceNetwork_UnimodalTranslation_UnimodalRotation(nn.Module):
-    """MLP encoder without attention (reference src/models.py:229-260); off the hot path, generic torch."""
+    """MLP encoder without attention (reference src/models.py:229-260); secondary encoder: the Linear /
+    ResidLinear stack runs on the GEMM kernels (`ops.MlpFn`); `self.layers` keeps the reference's parameter names."""
 
     def __init__(self, n, latent_dim, hidden_dim, num_layers=1, activation=nn.LeakyReLU, resid=False):
         super().__init__()
@@ -187,7 +188,11 @@ class InferenceNetwork_UnimodalTranslation_UnimodalRotation(nn.Module):
         self.layers = nn.Sequential(*stack)
 
     def forward(self, x):
-        out = self.layers(x)
+        _require_gpu(x, 'InferenceNetwork_UnimodalTranslation_UnimodalRotation')
+        lins = [(m.linear, True) if isinstance(m, ResidLinear) else (m, False) for m in self.layers
+                if isinstance(m, (nn.Linear, ResidLinear))]
+        params = [t for lin, _ in lins for t in (lin.weight, lin.bias)]
+        out = _ops.MlpFn.apply(x.float(), _ops.act_code(self.layers[1]), tuple(r for _, r in lins), *params)
         return out[:, :self.latent_dim], out[:, self.latent_dim:]
 
 

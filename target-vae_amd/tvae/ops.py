@@ -487,6 +487,50 @@ class TransAttnEncoderFn(torch.autograd.Function):
         return None, dw1, db1, dfw, dfb, dW2, db2, dWh, dbh, None, None, None
 
 
+class MlpFn(torch.autograd.Function):
+    """Linear / ResidLinear stack of the MLP encoder (reference src/models.py:229-260) on the GEMM kernels, feature-major:
+    h0 = act(W0 x + b0); hi = act(Wi h + bi [+ h]); out = Wl h + bl.  x is data (no input gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, act, resid, *params):
+        nl = len(params) // 2
+        _expect(nl >= 2 and len(resid) == nl and x.dim() == 2 and params[0].shape[1] == x.shape[1], 'MLP encoder shapes')
+        B = x.shape[0]
+        xt = x.t().contiguous()                          # [n][B]
+        hs = [xt]
+        for i in range(nl):
+            W, b = params[2 * i], params[2 * i + 1]
+            M, K = W.shape
+            _expect(K == hs[-1].shape[0] and (not resid[i] or M == K), 'MLP encoder layer widths')
+            h = torch.empty(M, B, dtype=torch.float32, device=x.device)
+            call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid[i] else None, h, M, B, K, B, B,
+                 act if i + 1 < nl else ACT_NONE, LRELU_SLOPE)
+            hs.append(h)
+        _note('mlp_encoder.kernels')
+        ctx.save_for_backward(*hs[:-1], *params[0::2])
+        ctx.cfg = (act, tuple(resid), nl, B)
+        ctx.arith = get_gemm_mode()
+        return hs[-1].t()
+
+    @staticmethod
+    @_in_forward_arithmetic
+    def backward(ctx, dout):
+        act, resid, nl, B = ctx.cfg
+        hs, Ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        d = dout.t().contiguous()                        # gradient of layer i's pre-activation, [M][B]
+        grads = [None] * (2 * nl)
+        for i in range(nl - 1, -1, -1):
+            M, K = Ws[i].shape
+            grads[2 * i] = _wgrad(d, hs[i], M, B, K)
+            grads[2 * i + 1] = _rowsum(d, M, B)
+            if i > 0:
+                dprev = torch.empty(K, B, dtype=torch.float32, device=d.device)
+                call('tvae_linear_dgrad', Ws[i].contiguous(), d, d if resid[i] else None, hs[i], dprev, M, B, K, B, B, act,
+                     LRELU_SLOPE)
+                d = dprev
+        return (None, None, None, *grads)
+
+
 # ---------------------------------------------------------------------------------------------
 # attention head
 # ---------------------------------------------------------------------------------------------

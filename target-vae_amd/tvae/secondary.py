@@ -2,9 +2,10 @@
 unimodal` (MLP encoder) and `--t-inf attention --r-inf unimodal` (translation attention; rotation pooled by `fc_r`
 over the HIP GroupConv, or a plain convolution with `--groupconv 0`).
 
-They are not in any BASELINE configuration, so the tail after the encoder is GENERIC torch on
-whatever device the tensors live on; the lifting convolution of the groupconv variant, the decoder and the
-likelihood still run on the HIP kernels.  Noise can be injected for parity tests.
+They are not in any BASELINE configuration.  Both encoders, the coordinate transform, the decoder
+and the likelihood run on the HIP kernels (ops.MlpFn, ops.TransAttnEncoderFn: SURVEY 8f row 4); only the small
+posterior tail between them (reductions over (B, Ho^2) tensors) is generic torch.  Noise can be injected for parity
+tests.
 """
 from __future__ import annotations
 

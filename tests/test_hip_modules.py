@@ -440,6 +440,33 @@ def test_get_latent_golden(name):
     assert rel_err(dx, fx['dx']) < OUT_TOL
 
 
+@pytest.mark.parametrize('resid,layers,act', [(False, 1, 'leakyrelu'), (True, 3, 'leakyrelu'), (False, 2, 'tanh')])
+def test_mlp_encoder_matches_torch_stack(resid, layers, act):
+    """MLP encoder (reference models.py:229-260) on the GEMM kernels against the same nn.Sequential evaluated by torch."""
+    import src.models as M
+    from tvae import ops
+    torch.manual_seed(3)
+    A = torch.nn.LeakyReLU if act == 'leakyrelu' else torch.nn.Tanh
+    enc = M.InferenceNetwork_UnimodalTranslation_UnimodalRotation(49, 5, 40, num_layers=layers, activation=A,
+                                                                  resid=resid).to(dev())
+    x = torch.randn(37, 49, device=dev())
+    w = torch.randn(37, 10, device=dev())
+    ops.PATH_LOG = set()
+    try:
+        mu, ls = enc(x)
+        assert 'mlp_encoder.kernels' in ops.PATH_LOG
+    finally:
+        ops.PATH_LOG = None
+    (torch.cat([mu, ls], 1) * w).sum().backward()
+    got = {k_: t.grad.clone() for k_, t in enc.named_parameters()}
+    enc.zero_grad()
+    ref = enc.layers(x.double().float())
+    assert rel_err(torch.cat([mu, ls], 1), ref) < OUT_TOL
+    (ref * w).sum().backward()
+    for k_, t in enc.named_parameters():
+        assert rel_err(got[k_], t.grad) < GRAD_TOL, k_
+
+
 @pytest.mark.parametrize('name,t_inf,r_inf', [('step_unimodal_unimodal', 'unimodal', 'unimodal'),
                                               ('step_attention_unimodal_gc4', 'attention', 'unimodal'),
                                               ('step_attention_unimodal_gc0', 'attention', 'unimodal')])
@@ -469,6 +496,8 @@ def test_secondary_branches_golden(name, t_inf, r_inf):
         ops.PATH_LOG = None
     if t_inf == 'attention':                             # the whole encoder ran on the kernels
         assert ('trans_attn.rot_pool' if gc else 'trans_attn.plain') in taken, taken
+    else:
+        assert 'mlp_encoder.kernels' in taken, taken
     assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
     assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
     assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
