@@ -233,6 +233,14 @@ int tvae_rot_pool_fwd(const float* A1, const float* fw, const float* fb, float* 
 int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* dA1, float* part, long part_floats,
                       float* dtot, int C, int B, int R, int P, int act, float slope, tvae_stream_t stream);
 
+/* ---- encoder tail fused per direction on the split bf16 pipe: conv2 (1x1x1, src/models.py:347-351,356) + the stacked
+ * head projection conv_a / conv_r / conv_z (:357-358, 390-392).  C = 128 channels in and out, nh <= 7 head rows,
+ * feature-major operands, N = B*R*Ho*Ho columns (any N).  w3 = tvae_dense_split3(W2, rows 128, K 128, transpose 0).
+ *   forward: H = act(W2 A1 + b2) [128][N],  heads = Wh H + bh [nh][N]; one pass over A1, one over H. */
+int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
+                         int nh, float* H, long ldh, float* heads, long ldo, int C, long N, int act, float slope,
+                         int parts, tvae_stream_t stream);
+
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

@@ -133,3 +133,19 @@ if only and 'tail' in only:
     timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', None, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, hbits, PARTS))
     timeit('tail_wgrad_from_H', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, None, PARTS))
     timeit('tail_wgrad_virt', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, None, None, None, None, 0, None, PARTS))
+if only and 'enc' in only:
+    # encoder tail (conv2 1x1x1 + head projection), current separate launches vs the fused split-pipe kernels
+    nh = 7
+    Wh = torch.randn(nh, C, device=dev) * 0.1
+    bh = torch.randn(nh, device=dev)
+    heads = torch.empty(nh, N, device=dev)
+    A1.normal_()
+    fl2 = 2.0 * C * C * N
+    timeit('enc_conv2_fwd_f32', fl2, lambda: call('tvae_linear_fwd', W2, A1, b2, None, 1, None, H, C, N, C, N, N, 1, 0.01))
+    timeit('enc_heads_fwd', 2.0 * nh * C * N, lambda: call('tvae_heads_fwd', Wh, H, N, bh, heads, N, nh, C, N))
+    w23 = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev)
+    call('tvae_dense_split3', W2, C, w23, w23.numel() * 4, C, C, 0, None, None)
+    H2 = torch.empty(C, N, device=dev)
+    heads2 = torch.empty(nh, N, device=dev)
+    timeit('enc_tail_fwd_x6', fl2, lambda: call('tvae_enc_tail_fwd_x6', w23, A1, N, b2, Wh, bh, nh, H2, N, heads2, N, C, N, 1, 0.01, PARTS))
+    print('fused fwd vs separate: H %.3e heads %.3e' % (float((H2 - H).norm() / H.norm()), float((heads2 - heads).norm() / heads.norm())))

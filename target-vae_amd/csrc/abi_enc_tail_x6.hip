@@ -1,0 +1,51 @@
+// libtvae_hip.so: the encoder tail (conv2 1x1x1 + the stacked head projection) fused per direction on the bf16 matrix
+// pipe with exactly split operands (enc_tail_x6_kernels.hpp).
+#include "abi_dense_x6.hpp"
+#include "enc_tail_x6_kernels.hpp"
+
+using namespace tvae;
+
+namespace {
+int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+// persistent grid: one workgroup per CU, never more workgroups than there are 64-column chunks for their eight waves
+int et_grid(long N) {
+    const long chunks = (N + ET_CHUNK - 1) / ET_CHUNK;
+    const long want = (chunks + ET_THREADS / 64 - 1) / (ET_THREADS / 64);
+    const int cus = cu_count();
+    return (int)(want < cus ? want : cus);
+}
+}  // namespace
+
+extern "C" {
+
+int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
+                         int nh, float* H, long ldh, float* heads, long ldo, int C, long N, int act, float slope,
+                         int parts, tvae_stream_t stream) {
+    if (N <= 0) return 0;
+    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 3) || !A1 || !H || !heads || !Wh ||
+        !bh)
+        return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(ET_C, DX6_ROWS);
+    const size_t lds = (size_t)parts * 16 * ET_C * 16;
+    hipError_t e;
+    if (parts == 3) {
+        e = allow_big_lds(enc_tail_fwd_x6_kernel<3>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<3>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope);
+    } else {
+        e = allow_big_lds(enc_tail_fwd_x6_kernel<1>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<1>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope);
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -46,6 +46,7 @@ SIGNATURES = {
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppppl',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppppl',
     'tvae_get_latent': 'plpppiiiifppp',
+    'tvae_enc_tail_fwd_x6': 'pplpppiplplilifi',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',

@@ -220,6 +220,7 @@ FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
 FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
 FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
 FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
+FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -333,6 +334,11 @@ class GroupConvFn(torch.autograd.Function):
         return None, dW, db, None, None
 
 
+def _enc_tail_fused(C: int, C2: int, nh: int) -> bool:
+    """Fused encoder tail (enc_tail_x6_kernels.hpp): the reference's default 128 channels, <= 7 head rows, split pipe."""
+    return FUSE_ENC_TAIL and split_pipe() and C == 128 and C2 == 128 and nh <= 7
+
+
 class EncoderFn(torch.autograd.Function):
     """conv1 -> act -> conv2 (1x1x1) -> act -> {conv_a, conv_r, conv_z} (src/models.py:354-358,390-392).
 
@@ -357,12 +363,21 @@ class EncoderFn(torch.autograd.Function):
         A1 = conv1_forward(y, w1, b1, C, R, k, pad, act, keep)
         ctx.at = keep.get('at')
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
-        call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
-        if nh <= SKINNY_MAX:
-            call('tvae_heads_fwd', Wh.contiguous(), H, N, bh, heads, N, nh, C2, N)
+        if _enc_tail_fused(C, C2, nh):
+            # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
+            w3 = _split_weight(W2, C2, C, False, 'enc_w2')
+            _note('enc.tail_fwd_x6')
+            with _timed('tvae_enc_tail_fwd_x6'):
+                call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N, C, N, act,
+                     LRELU_SLOPE, parts())
         else:
-            call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE, LRELU_SLOPE)
+            call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
+            if nh <= SKINNY_MAX:
+                call('tvae_heads_fwd', Wh.contiguous(), H, N, bh, heads, N, nh, C2, N)
+            else:
+                call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE,
+                     LRELU_SLOPE)
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)

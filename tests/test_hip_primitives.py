@@ -32,6 +32,11 @@ def call(*a):
     return c(*a)
 
 
+def query(*a):
+    from tvae._lib import query as q
+    return q(*a)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale)
@@ -504,6 +509,35 @@ def test_heads_fwd_bwd(nh, C, N, act):
     assert rel_err(tot[nh], ref.sum(1)) < TOL
     with pytest.raises(Exception):
         call('tvae_heads_fwd', W.to(dev()), X.to(dev()), N, b.to(dev()), Y, N, 9, C, N)
+
+
+def _split_w(W, rows, K, transpose):
+    a3 = torch.empty(query('tvae_dense_x6_bytes', rows, K) // 4, device=dev())
+    call('tvae_dense_split3', W.contiguous(), W.shape[1], a3, a3.numel() * 4, rows, K, transpose, None, None)
+    return a3
+
+
+@pytest.mark.parametrize('N,nh,act,parts', [(64 * 40, 7, 1, 3), (64 * 2048 + 37, 7, 1, 3), (1000, 5, 2, 3), (31, 1, 0, 3),
+                                            (64 * 300, 7, 1, 1)])
+def test_enc_tail_fwd_x6(N, nh, act, parts):
+    """Fused conv2 + head projection (reference models.py:356-358, 390-392) against fp64."""
+    C = 128
+    W2, b2 = rnd(C, C, seed=1, scale=C ** -0.5), rnd(C, seed=2)
+    Wh, bh = rnd(nh, C, seed=3, scale=C ** -0.5), rnd(nh, seed=4)
+    A1 = rnd(C, N, seed=5)
+    H = torch.full((C, N), float('nan'), device=dev())
+    heads = torch.full((nh, N), float('nan'), device=dev())
+    w3 = _split_w(W2.to(dev()), C, C, 0)
+    call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, C, N,
+         act, SLOPE, parts)
+    Hr = act_ref(W2.double() @ A1.double() + b2.double()[:, None], act)
+    hr = Wh.double() @ Hr + bh.double()[:, None]
+    tol = TOL if parts == 3 else 2e-2
+    assert rel_err(H, Hr) < tol
+    assert rel_err(heads, hr) < tol
+    with pytest.raises(Exception):                       # only the 128-channel layer is built
+        call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, 64,
+             N, act, SLOPE, parts)
 
 
 @pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
