@@ -236,11 +236,20 @@ int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* 
 /* ---- encoder tail fused per direction on the split bf16 pipe: conv2 (1x1x1, src/models.py:347-351,356) + the stacked
  * head projection conv_a / conv_r / conv_z (:357-358, 390-392).  C = 128 channels in and out, nh <= 7 head rows,
  * feature-major operands, N = B*R*Ho*Ho columns (any N).  w3 = tvae_dense_split3(W2, rows 128, K 128, transpose 0).
- *   forward: H = act(W2 A1 + b2) [128][N],  heads = Wh H + bh [nh][N]; one pass over A1, one over H. */
+ *   forward: H = act(W2 A1 + b2) [128][N],  heads = Wh H + bh [nh][N]; one pass over A1, one over H.  bits_h / bits_a
+ *     (LeakyReLU only, both or neither; [N][4] uint32 each): bit (r & 31) of word r >> 5 of column n = [H[r][n] > 0]
+ *     resp. [A1[r][n] > 0] -- all the data gradient needs of the two tensors.
+ *   data gradient (LeakyReLU): dA1 = act'(A1) . W2^T (act'(H) . Wh^T dheads) from dheads [nh][N] and the sign words; dH is
+ *     never stored.  w3p = tvae_dense_split3 (rows 128, K 128, transpose 0) of W2^T with its columns permuted:
+ *     column 16 u + 8 h + j (u < 8, h < 2, j < 8) holds W2[16 u + 8 (j >> 2) + 4 h + (j & 3)][.] (the order in which
+ *     the first GEMM's accumulators feed the second; tvae/ops.py:_enc_tail_perm); wh3 = tvae_dense_split3(Wh, ldw 128,
+ *     rows 128, K nh, transpose 1). */
 int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
-                         int nh, float* H, long ldh, float* heads, long ldo, int C, long N, int act, float slope,
-                         int parts, tvae_stream_t stream);
-
+                         int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
+                         int act, float slope, int parts, tvae_stream_t stream);
+int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads, long ldd, int nh, const void* bits_h,
+                           const void* bits_a, float* dA1, long lda, int C, long N, float slope, int parts,
+                           tvae_stream_t stream);
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

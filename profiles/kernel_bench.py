@@ -147,5 +147,25 @@ if only and 'enc' in only:
     call('tvae_dense_split3', W2, C, w23, w23.numel() * 4, C, C, 0, None, None)
     H2 = torch.empty(C, N, device=dev)
     heads2 = torch.empty(nh, N, device=dev)
-    timeit('enc_tail_fwd_x6', fl2, lambda: call('tvae_enc_tail_fwd_x6', w23, A1, N, b2, Wh, bh, nh, H2, N, heads2, N, C, N, 1, 0.01, PARTS))
+    timeit('enc_tail_fwd_x6', fl2, lambda: call('tvae_enc_tail_fwd_x6', w23, A1, N, b2, Wh, bh, nh, H2, N, heads2, N, None, None, C, N, 1, 0.01, PARTS))
+    bits = torch.zeros(2, N, 4, dtype=torch.int32, device=dev)
+    timeit('enc_tail_fwd_x6+bits', fl2, lambda: call('tvae_enc_tail_fwd_x6', w23, A1, N, b2, Wh, bh, nh, H2, N, heads2, N, bits[0], bits[1], C, N, 1, 0.01, PARTS))
     print('fused fwd vs separate: H %.3e heads %.3e' % (float((H2 - H).norm() / H.norm()), float((heads2 - heads).norm() / heads.norm())))
+    # backward: separate launches (head projection backward, conv2 data gradient, conv2 weight gradient) vs fused
+    dheads = torch.randn(nh, N, device=dev)
+    dH = torch.empty(C, N, device=dev)
+    npan = (N + 511) // 512
+    part = torch.empty(npan * C * (nh + 1), device=dev)
+    tot = torch.empty(nh + 1, C, device=dev)
+    timeit('enc_heads_bwd', 2.0 * nh * C * N, lambda: call('tvae_heads_bwd', Wh, dheads, N, H, N, dH, N, nh, C, N, 1, 0.01, part, part.numel(), tot))
+    dA1b = torch.empty(C, N, device=dev)
+    timeit('enc_conv2_dgrad_f32', fl2, lambda: call('tvae_linear_dgrad', W2, dH, None, A1, dA1b, C, N, C, N, N, 1, 0.01))
+    timeit('enc_conv2_wgrad_f32', fl2, lambda: call('tvae_linear_wgrad', dH, A1, dW2, ws, ws.numel(), C, N, C, N, N, 0))
+    from tvae.ops import _enc_tail_perm
+    w2p = torch.empty_like(w23)
+    call('tvae_dense_split3', W2.t()[:, _enc_tail_perm(dev)].contiguous(), C, w2p, w2p.numel() * 4, C, C, 0, None, None)
+    wh3 = torch.empty(query('tvae_dense_x6_bytes', C, nh) // 4, device=dev)
+    call('tvae_dense_split3', Wh, C, wh3, wh3.numel() * 4, C, nh, 1, None, None)
+    dA1c = torch.empty(C, N, device=dev)
+    timeit('enc_tail_dgrad_x6', fl2, lambda: call('tvae_enc_tail_dgrad_x6', w2p, wh3, dheads, N, nh, bits[0], bits[1], dA1c, N, C, N, 0.01, PARTS))
+    print('fused dgrad vs separate: %.3e' % float((dA1c - dA1b).norm() / dA1b.norm()))

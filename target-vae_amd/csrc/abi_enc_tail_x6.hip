@@ -24,11 +24,11 @@ int et_grid(long N) {
 extern "C" {
 
 int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
-                         int nh, float* H, long ldh, float* heads, long ldo, int C, long N, int act, float slope,
-                         int parts, tvae_stream_t stream) {
+                         int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
+                         int act, float slope, int parts, tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 3) || !A1 || !H || !heads || !Wh ||
-        !bh)
+        !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
     const size_t lds = (size_t)parts * 16 * ET_C * 16;
@@ -37,12 +37,39 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
         e = allow_big_lds(enc_tail_fwd_x6_kernel<3>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<3>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
-                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope);
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a);
     } else {
         e = allow_big_lds(enc_tail_fwd_x6_kernel<1>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<1>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
-                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope);
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a);
+    }
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads, long ldd, int nh, const void* bits_h,
+                           const void* bits_a, float* dA1, long lda, int C, long N, float slope, int parts,
+                           tvae_stream_t stream) {
+    if (N <= 0) return 0;
+    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3p) || !aligned16(wh3) || !aligned16(bits_h) || !aligned16(bits_a) ||
+        (parts != 1 && parts != 3) || !dheads || !bits_h || !bits_a || !dA1)
+        return (int)hipErrorInvalidValue;
+    const int Rpad = x6_round_up(ET_C, DX6_ROWS);
+    const size_t lds = (size_t)parts * 18 * ET_C * 16;
+    hipError_t e;
+    if (parts == 3) {
+        e = allow_big_lds(enc_tail_dgrad_x6_kernel<3>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_dgrad_x6_kernel<3>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream),
+                           (const uint4*)w3p, Rpad, (const uint4*)wh3, Rpad, dheads, ldd, nh, (const uint4*)bits_h,
+                           (const uint4*)bits_a, dA1, lda, N, slope);
+    } else {
+        e = allow_big_lds(enc_tail_dgrad_x6_kernel<1>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_dgrad_x6_kernel<1>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream),
+                           (const uint4*)w3p, Rpad, (const uint4*)wh3, Rpad, dheads, ldd, nh, (const uint4*)bits_h,
+                           (const uint4*)bits_a, dA1, lda, N, slope);
     }
     TVAE_CHECK_LAUNCH();
     return 0;

@@ -14,7 +14,7 @@
 // of 32 columns through all 128 output rows (wave tile 128 x 32: 4 MFMA tiles, 24 MFMAs per 16-k step, 8 steps):
 //   * the streamed operand goes global -> registers directly in B-fragment order (lane = column, 8 k-rows per lane:
 //     8 dword loads, each two full 128-byte lines per wave instruction), is split in registers, and never touches LDS;
-//     a step's registers are refilled with the SAME step of the wave's next chunk as soon as they have been split, i.e.
+
 //     loads run one whole chunk (8 steps, 16 KB per wave, 128 KB per CU) ahead: with two waves per SIMD the kernel is
 //     bound by HBM latency x bytes in flight, and a two-step lead (the 128 x 64 tile's register budget) measured
 //     3.6 TB/s where this pattern alone streams 5.9 TB/s (profiles/experiments/stream_patterns.hip);
@@ -29,19 +29,11 @@
 namespace tvae {
 
 constexpr int ET_C = 128;                 // channels of both layers (reference default kernels_num; other widths: unfused path)
-#ifndef ET_WAVES
-#define ET_WAVES 8
-#endif
-#ifndef ET_DEPTH
-#define ET_DEPTH 8
-#endif
-constexpr int ET_THREADS = 64 * ET_WAVES; // waves per workgroup (one workgroup per CU)
-constexpr int ET_D = ET_DEPTH;            // k-steps the operand loads run ahead (2, 4 or 8 = one whole chunk)
+constexpr int ET_WAVES = 8;               // waves per workgroup (one workgroup per CU): two per SIMD
+constexpr int ET_THREADS = 64 * ET_WAVES;
+constexpr int ET_D = 4;                   // k-steps the operand loads run ahead (ring of register sets; 2, 4 or 8)
 constexpr int ET_CHUNK = 32;              // columns per wave chunk
 constexpr int ET_MAXH = 7;                // head rows (3 + 2 z_dim)
-#ifndef ET_ABL
-#define ET_ABL 0                          // ablation switches of profiles/experiments/enc_tail_ablate.hip (0 in the library)
-#endif
 
 template <int ACT>
 __device__ __forceinline__ float et_act(float v, float slope) {
@@ -69,7 +61,6 @@ __device__ __forceinline__ void et_split(const float (&x)[8], Cell16 (&bf)[3]) {
 // hoisting all twelve LDS reads, which would spill the accumulators)
 template <int NP>
 __device__ __forceinline__ void et_load_a(const uint4* __restrict__ Ws, int t, int i, int kh, int nl, Cell16 (&a)[3]) {
-    if (ET_ABL & 16) return;
     const uint4* wp = Ws + (2 * t + kh) * ET_C + nl + 32 * i;
 #pragma unroll
     for (int p = 0; p < NP; ++p) a[p].u = wp[p * 16 * ET_C];
@@ -77,17 +68,6 @@ __device__ __forceinline__ void et_load_a(const uint4* __restrict__ Ws, int t, i
 template <int NP>
 __device__ __forceinline__ void et_step_mfma(f32x16 (&acc)[4], const uint4* __restrict__ Ws, int t, int kh, int nl,
                                              Cell16 (&a0)[3], Cell16 (&a1)[3], const Cell16 (&bf)[3]) {
-    if (ET_ABL & 32) {                                   // weight reads without the MFMAs
-        et_load_a<NP>(Ws, t, 1, kh, nl, a1);
-        acc[0][0] += __uint_as_float(a0[0].w[0] ^ a0[NP - 1].w[3] ^ bf[0].w[1]);
-        et_load_a<NP>(Ws, t, 2, kh, nl, a0);
-        acc[1][0] += __uint_as_float(a1[0].w[0] ^ a1[NP - 1].w[3]);
-        et_load_a<NP>(Ws, t, 3, kh, nl, a1);
-        acc[2][0] += __uint_as_float(a0[0].w[0] ^ a0[NP - 1].w[3]);
-        et_load_a<NP>(Ws, (t + 1) & 7, 0, kh, nl, a0);
-        acc[3][0] += __uint_as_float(a1[0].w[0] ^ a1[NP - 1].w[3]);
-        return;
-    }
     et_load_a<NP>(Ws, t, 1, kh, nl, a1);
     mfma_np<NP>(acc[0], a0, bf);
     __builtin_amdgcn_sched_barrier(0);
@@ -106,8 +86,10 @@ __device__ __forceinline__ void et_step_mfma(f32x16 (&acc)[4], const uint4* __re
 template <int ACT, bool FULL>
 __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* __restrict__ whs, float* __restrict__ H,
                                                 long ldh, float* __restrict__ heads, long ldo, const float* __restrict__ bh,
-                                                int nh, long n0, long N, int nl, int kh, float slope) {
+                                                int nh, long n0, long N, int nl, int kh, float slope,
+                                                uint4* __restrict__ bitsH) {
     float hs[8];
+    unsigned hb[4] = {0u, 0u, 0u, 0u};                   // sign bits of this lane's column, word i = rows 32 i .. 32 i + 31
 #pragma unroll
     for (int o = 0; o < 8; ++o) hs[o] = 0.f;
     const bool in0 = FULL || n0 + nl < N;
@@ -139,8 +121,8 @@ __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* _
             const float4 w0 = wq[cur][u][0], w1 = wq[cur][u][1];           // w1.w = b2[row]
             char* hrow = reinterpret_cast<char*>(H + (long)et_row(i, r, 0) * ldh + n0);
             const float v = et_act<ACT>(acc[i][r] + w1.w, slope);
-            if (in0 && !(ET_ABL & 1)) *reinterpret_cast<float*>(hrow + loff) = v;
-            if (ET_ABL & 2) { hs[0] += v; continue; }
+            if (ACT == ACT_LRELU) hb[i] |= v > 0.f ? (1u << (8 * (r >> 2) + (r & 3))) : 0u;   // + 4 kh: shifted below
+            if (in0) *reinterpret_cast<float*>(hrow + loff) = v;
             hs[0] = __fmaf_rn(w0.x, v, hs[0]);
             hs[1] = __fmaf_rn(w0.y, v, hs[1]);
             hs[2] = __fmaf_rn(w0.z, v, hs[2]);
@@ -154,6 +136,14 @@ __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* _
 #pragma unroll
         for (int o = 0; o < ET_MAXH; ++o) asm volatile("" : "+v"(hs[o]));
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ACT == ACT_LRELU && bitsH) {                     // halves hold rows (.., +4): merge, one 16-byte store per column
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hb[i] <<= 4 * kh;
+            hb[i] |= (unsigned)__shfl_xor((int)hb[i], 32, 64);
+        }
+        if (kh == 0 && in0) bitsH[n0 + nl] = make_uint4(hb[0], hb[1], hb[2], hb[3]);
     }
     // the two lane halves hold disjoint rows of the same 32 columns: half 0 stores the even head rows, half 1 the odd ones
     float* hp = heads + n0 + nl;
@@ -172,7 +162,7 @@ static __global__ __launch_bounds__(ET_THREADS, ET_WAVES / 4)
 void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float* __restrict__ X, long ldx,
                             const float* __restrict__ b2, const float* __restrict__ Wh, const float* __restrict__ bh, int nh,
                             float* __restrict__ H, long ldh, float* __restrict__ heads, long ldo, long N, int act,
-                            float slope) {
+                            float slope, uint4* __restrict__ bitsH, uint4* __restrict__ bitsA) {
     extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128]
     __shared__ __attribute__((aligned(16))) float whs[ET_C * 8];          // row m: Wh[0..6][m], b2[m]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -209,34 +199,152 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
 #pragma unroll
     for (int t = 0; t < ET_D; ++t) load_x(0, t, x[t]);
     Cell16 a0[3], a1[3];
-    if (ET_ABL & 16) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a0[p].u = a1[p].u = make_uint4(0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
-    }
     et_load_a<NP>(Ws, 0, 0, kh, nl, a0);
     for (long ci = 0; ci < my; ++ci) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        unsigned ab[4] = {0u, 0u, 0u, 0u};               // sign bits of the INPUT column (rows 16 t + 8 kh + j)
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             Cell16 bf[3];
+            if (bitsA) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ab[t >> 1] |= x[t % ET_D][j] > 0.f ? (1u << (16 * (t & 1) + j)) : 0u;
+            }
             et_split<NP>(x[t % ET_D], bf);
-            if (!(ET_ABL & 8)) load_x(ci + (t + ET_D) / 8, (t + ET_D) % 8, x[t % ET_D]);
-            if (ET_ABL & 4) { acc[t & 3][0] += __uint_as_float(bf[0].w[0] ^ bf[NP - 1].w[3]); continue; }
+            load_x(ci + (t + ET_D) / 8, (t + ET_D) % 8, x[t % ET_D]);
             et_step_mfma<NP>(acc, Ws, t, kh, nl, a0, a1, bf);
         }
         const long n0 = (gw + ci * gstride) * ET_CHUNK;
+        if (bitsA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ab[i] <<= 8 * kh;
+                ab[i] |= (unsigned)__shfl_xor((int)ab[i], 32, 64);
+            }
+            if (kh == 0 && n0 + nl < N) bitsA[n0 + nl] = make_uint4(ab[0], ab[1], ab[2], ab[3]);
+        }
 #define TVAE_ET_EPI(A_)                                                                                    \
     do {                                                                                                  \
-        if (n0 + ET_CHUNK <= N) et_fwd_epilogue<A_, true>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope); \
-        else et_fwd_epilogue<A_, false>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope);      \
+        if (n0 + ET_CHUNK <= N) et_fwd_epilogue<A_, true>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
+        else et_fwd_epilogue<A_, false>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
     } while (0)
         if (act == ACT_LRELU) TVAE_ET_EPI(ACT_LRELU);
         else if (act == ACT_TANH) TVAE_ET_EPI(ACT_TANH);
         else TVAE_ET_EPI(ACT_NONE);
 #undef TVAE_ET_EPI
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Data gradient through the tail (LeakyReLU):  dA1 = act'(A1) . W2^T dH,  dH = act'(H) . Wh^T dheads  -- dH is never
+// stored.  Inputs per column: nh head gradients and the two 128-bit sign words the forward kernel wrote; the only large
+// tensor touched is the output.  Two chained GEMMs per 32-column chunk with a register hand-off:
+//   G = Wh^T dheads   (128 x 32, k = head row: 24 MFMAs) lands in the accumulator layout (lane = column, register r of
+//   row tile i = row 32 i + 8 (r >> 2) + (r & 3) + 4 kh); registers 8 u' .. 8 u' + 7 of a tile, masked by the sign of H,
+//   ARE the B fragment of a 16-k step over rows 16 u .. 16 u + 15 in the k order
+//       slot (kh, j)  <->  row 16 u + 8 (j >> 2) + 4 kh + (j & 3),
+//   so the host splits W2^T with its k columns permuted the same way (W3p) and nothing is transposed or exchanged.
+// Per iteration: [steps of chunk c] [inputs of chunk c + 1 consumed, loads of c + 2 issued] [G of c + 1] [stores of c]:
+// every load is consumed before the stores that follow it are issued (loads and stores share one in-order counter per
+// kind, and a wait behind mixed traffic drains both).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float et_mask(unsigned w, int bit, float slope) { return (w >> bit) & 1u ? 1.f : slope; }
+
+template <int NP>
+static __global__ __launch_bounds__(ET_THREADS, ET_WAVES / 4)
+void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uint4* __restrict__ Wh3, int Rpadh,
+                              const float* __restrict__ dheads, long ldd, int nh, const uint4* __restrict__ bitsH,
+                              const uint4* __restrict__ bitsA, float* __restrict__ dA1, long lda, long N, float slope) {
+    extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128] W2^T (permuted k), then [NP][2][128] Wh^T
+    uint4* Whs = Ws + NP * 16 * ET_C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < NP * 16 * ET_C; i += ET_THREADS) Ws[i] = W3p[(long)(i >> 7) * Rpad + (i & (ET_C - 1))];
+    for (int i = tid; i < NP * 2 * ET_C; i += ET_THREADS) Whs[i] = Wh3[(long)(i >> 7) * Rpadh + (i & (ET_C - 1))];
+    __syncthreads();
+
+    const long nchunks = (N + ET_CHUNK - 1) / ET_CHUNK;
+    const long gw = (long)blockIdx.x * (ET_THREADS / 64) + wave, gstride = (long)gridDim.x * (ET_THREADS / 64);
+    if (gw >= nchunks) return;
+    const long my = (nchunks - 1 - gw) / gstride + 1;
+
+    float dh[8];
+    uint4 wHn, wAn;
+    auto load_in = [&](long ci) {
+        if (ci >= my) ci = my - 1;
+        const long n = min((gw + ci * gstride) * ET_CHUNK + nl, N - 1);
+#pragma unroll
+        for (int o = 0; o < ET_MAXH; ++o) dh[o] = o < nh ? dheads[(long)o * ldd + n] : 0.f;
+        dh[7] = 0.f;
+        wHn = bitsH[n];
+        wAn = bitsA[n];
+    };
+    Cell16 dcell[3];
+    unsigned wHs[4], wAs[4], wAsn[4];
+    auto consume = [&]() {                               // everything loaded is read here (before the next stores)
+        et_split<NP>(dh, dcell);
+        if (kh) {                                        // k slots 8 .. 15 of the head-row reduction do not exist
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dcell[p].u = make_uint4(0u, 0u, 0u, 0u);
+        }
+        wHs[0] = wHn.x >> (4 * kh); wHs[1] = wHn.y >> (4 * kh); wHs[2] = wHn.z >> (4 * kh); wHs[3] = wHn.w >> (4 * kh);
+        wAsn[0] = wAn.x >> (4 * kh); wAsn[1] = wAn.y >> (4 * kh); wAsn[2] = wAn.z >> (4 * kh); wAsn[3] = wAn.w >> (4 * kh);
+    };
+    f32x16 acc[4], G[4];
+    auto g_phase = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Cell16 wc[3];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) wc[p].u = Whs[(p * 2 + kh) * ET_C + 32 * i + nl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[i][r] = 0.f;
+            mfma_np<NP>(G[i], wc, dcell);
+        }
+    };
+    load_in(0);
+    consume();
+    load_in(1);
+    g_phase();
+    Cell16 a0[3], a1[3];
+    et_load_a<NP>(Ws, 0, 0, kh, nl, a0);
+    const unsigned loff = (unsigned)(4 * kh * lda + nl) * 4u;               // bytes: 32-bit register offset form
+    for (long ci = 0; ci < my; ++ci) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wAs[i] = wAsn[i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * (u & 1) + j;
+                xv[j] = G[u >> 1][r] * et_mask(wHs[u >> 1], 8 * (r >> 2) + (r & 3), slope);
+            }
+            Cell16 bf[3];
+            et_split<NP>(xv, bf);
+            et_step_mfma<NP>(acc, Ws, u, kh, nl, a0, a1, bf);
+        }
+        consume();
+        load_in(ci + 2);
+        g_phase();
+        const long n0 = (gw + ci * gstride) * ET_CHUNK;
+        const bool in0 = n0 + nl < N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                char* drow = reinterpret_cast<char*>(dA1 + (long)et_row(i, r, 0) * lda + n0);
+                const float v = acc[i][r] * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
+                if (in0) *reinterpret_cast<float*>(drow + loff) = v;
+            }
     }
 }
 

@@ -46,7 +46,8 @@ SIGNATURES = {
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppppl',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppppl',
     'tvae_get_latent': 'plpppiiiifppp',
-    'tvae_enc_tail_fwd_x6': 'pplpppiplplilifi',
+    'tvae_enc_tail_fwd_x6': 'pplpppiplplppilifi',
+    'tvae_enc_tail_dgrad_x6': 'ppplippplilfi',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',

@@ -334,6 +334,16 @@ class GroupConvFn(torch.autograd.Function):
         return None, dW, db, None, None
 
 
+def _enc_tail_perm(device) -> torch.Tensor:
+    """Column order of W2^T for tvae_enc_tail_dgrad_x6 (include/tvae_hip.h): slot 16 u + 8 h + j holds row
+    16 u + 8 (j >> 2) + 4 h + (j & 3) -- the order in which the first GEMM's accumulator registers feed the second."""
+    def build():
+        s_ = np.arange(128)
+        u, h, j = s_ // 16, (s_ % 16) // 8, s_ % 8
+        return (16 * u + 8 * (j // 4) + 4 * h + (j % 4),)
+    return _dev_table(('enc_tail_perm',), device, build)[0]
+
+
 def _enc_tail_fused(C: int, C2: int, nh: int) -> bool:
     """Fused encoder tail (enc_tail_x6_kernels.hpp): the reference's default 128 channels, <= 7 head rows, split pipe."""
     return FUSE_ENC_TAIL and split_pipe() and C == 128 and C2 == 128 and nh <= 7
@@ -364,12 +374,16 @@ class EncoderFn(torch.autograd.Function):
         ctx.at = keep.get('at')
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
+        bits = None
         if _enc_tail_fused(C, C2, nh):
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
             w3 = _split_weight(W2, C2, C, False, 'enc_w2')
             _note('enc.tail_fwd_x6')
+            if act == ACT_LRELU:                         # sign words of H and A1: all the fused data gradient reads of them
+                bits = torch.empty(2, N, 4, dtype=torch.int32, device=y.device)
             with _timed('tvae_enc_tail_fwd_x6'):
-                call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N, C, N, act,
+                call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N,
+                     bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act,
                      LRELU_SLOPE, parts())
         else:
             call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
@@ -379,6 +393,7 @@ class EncoderFn(torch.autograd.Function):
                 call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE,
                      LRELU_SLOPE)
         ctx.save_for_backward(y, W2, Wh, A1, H)
+        ctx.bits = bits
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
@@ -392,6 +407,17 @@ class EncoderFn(torch.autograd.Function):
         C2, nh = W2.shape[0], Wh.shape[0]
         dheads = dheads.contiguous()
         dbh = _rowsum(dheads, nh, N)
+        dA1 = None
+        if ctx.bits is not None:
+            # dA1 straight from the head gradients and the sign words (dH is formed in registers, never stored)
+            w3p = _split_weight(W2.t()[:, _enc_tail_perm(y.device)], C, C2, False, 'enc_w2p')
+            wh3 = _scratch(y.device, 'enc_wh3', query('tvae_dense_x6_bytes', C2, nh) // 4)
+            call('tvae_dense_split3', Wh.contiguous(), C2, wh3, wh3.numel() * 4, C2, nh, 1, None, None)
+            dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
+            _note('enc.tail_dgrad_x6')
+            with _timed('tvae_enc_tail_dgrad_x6'):
+                call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, ctx.bits[0], ctx.bits[1], dA1, N, C, N,
+                     LRELU_SLOPE, parts())
         dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         if nh <= SKINNY_MAX:
             # one pass over H: masked dgrad + dWh + the row sums of dH (= db2)
@@ -406,8 +432,9 @@ class EncoderFn(torch.autograd.Function):
             call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
             db2 = _rowsum(dH, C2, N)
         dW2 = _wgrad(dH, A1, C2, N, C)
-        dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
-        call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
+        if dA1 is None:
+            dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
+            call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)
         del dH
         db1 = torch.empty(C, dtype=torch.float32, device=y.device) if ctx.at is not None else _rowsum(dA1, C, N)
         dbank = conv1_wgrad(y, dA1, C, R, k, pad, ctx.at, db1 if ctx.at is not None else None)

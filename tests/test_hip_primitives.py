@@ -517,10 +517,15 @@ def _split_w(W, rows, K, transpose):
     return a3
 
 
+def _enc_tail_perm():
+    from tvae.ops import _enc_tail_perm as f
+    return f(dev())
+
+
 @pytest.mark.parametrize('N,nh,act,parts', [(64 * 40, 7, 1, 3), (64 * 2048 + 37, 7, 1, 3), (1000, 5, 2, 3), (31, 1, 0, 3),
-                                            (64 * 300, 7, 1, 1)])
-def test_enc_tail_fwd_x6(N, nh, act, parts):
-    """Fused conv2 + head projection (reference models.py:356-358, 390-392) against fp64."""
+                                            (64 * 300, 7, 1, 1), (64 * 1024 + 36, 3, 1, 3), (4, 7, 1, 3)])
+def test_enc_tail_x6(N, nh, act, parts):
+    """Fused conv2 + head projection (reference models.py:356-358, 390-392) and its fused data gradient against fp64."""
     C = 128
     W2, b2 = rnd(C, C, seed=1, scale=C ** -0.5), rnd(C, seed=2)
     Wh, bh = rnd(nh, C, seed=3, scale=C ** -0.5), rnd(nh, seed=4)
@@ -528,16 +533,41 @@ def test_enc_tail_fwd_x6(N, nh, act, parts):
     H = torch.full((C, N), float('nan'), device=dev())
     heads = torch.full((nh, N), float('nan'), device=dev())
     w3 = _split_w(W2.to(dev()), C, C, 0)
-    call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, C, N,
-         act, SLOPE, parts)
+    lrelu = act == 1
+    bits_h = torch.zeros(N, 4, dtype=torch.int32, device=dev()) if lrelu else None
+    bits_a = torch.zeros(N, 4, dtype=torch.int32, device=dev()) if lrelu else None
+    call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, bits_h,
+         bits_a, C, N, act, SLOPE, parts)
     Hr = act_ref(W2.double() @ A1.double() + b2.double()[:, None], act)
     hr = Wh.double() @ Hr + bh.double()[:, None]
     tol = TOL if parts == 3 else 2e-2
     assert rel_err(H, Hr) < tol
     assert rel_err(heads, hr) < tol
     with pytest.raises(Exception):                       # only the 128-channel layer is built
-        call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, 64,
-             N, act, SLOPE, parts)
+        call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, None,
+             None, 64, N, act, SLOPE, parts)
+    if not lrelu:
+        with pytest.raises(Exception):                   # the sign words describe a LeakyReLU
+            junk = torch.zeros(N, 4, dtype=torch.int32, device=dev())
+            call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N,
+                 junk, junk, C, N, act, SLOPE, parts)
+        return
+    # sign words: bit (r & 31) of word r >> 5 of column n
+    def unpack(b):
+        w = b.cpu().numpy().astype(np.uint32)                              # [N][4]
+        return torch.from_numpy(((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(N, 128).T.copy()).bool()
+    assert torch.equal(unpack(bits_a), A1 > 0)
+    assert torch.equal(unpack(bits_h), H.cpu() > 0)
+    dheads = rnd(nh, N, seed=6)
+    w3p = _split_w(W2.t()[:, _enc_tail_perm().cpu()].contiguous().to(dev()), C, C, 0)
+    wh3 = torch.empty(query('tvae_dense_x6_bytes', C, nh) // 4, device=dev())
+    call('tvae_dense_split3', Wh.to(dev()), C, wh3, wh3.numel() * 4, C, nh, 1, None, None)
+    dA1 = torch.full((C, N), float('nan'), device=dev())
+    call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads.to(dev()), N, nh, bits_h, bits_a, dA1, N, C, N, SLOPE, parts)
+    Hs = H.cpu().double()                                # the mask of the kernel's own forward (kinks of fp64 H may differ)
+    dH = (Wh.double().t() @ dheads.double()) * dact_ref(Hs, 1)
+    ref = (W2.double().t() @ dH) * dact_ref(A1.double(), 1)
+    assert rel_err(dA1, ref) < tol
 
 
 @pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
