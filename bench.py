@@ -40,14 +40,14 @@ MODE_INFO = {
     'x6': dict(peak=PEAK_BF16_MFMA_TFLOPS / 6.0, insn='6 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
                dtype='f32 (matrix products: operands split exactly into 3 x bf16, 6 bf16 MFMAs per product, fp32 '
-                     'accumulate -- fp32-equivalent, same parity tolerances; the 512-wide decoder layers likewise, the '
-                     '128-wide encoder 1x1x1 layers on the fp32 MFMA)'),
+                     'accumulate -- fp32-equivalent, same parity tolerances; the 512-wide decoder layers and the forward / data '
+                     'gradient of the 128-wide encoder 1x1x1 layers likewise, their weight gradient on the fp32 MFMA)'),
     # opt-in throughput mode (TVAE_GEMM=bf16; BASELINE.json configs 2 / 5): NOT the headline, not fp32-equivalent
     'bf16': dict(peak=PEAK_BF16_MFMA_TFLOPS, insn='1 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                  kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
                  dtype='bf16 (matrix products of the convolution and the 512-wide decoder layers: operands rounded to one '
-                       'bf16 number, fp32 accumulate -- the opt-in throughput mode, tolerance 2e-2 on the ELBO; the '
-                       '128-wide encoder 1x1x1 layers on the fp32 MFMA)'),
+                       'bf16 number, fp32 accumulate -- the opt-in throughput mode, tolerance 2e-2 on the ELBO; the weight '
+                       'gradient of the 128-wide encoder 1x1x1 layers on the fp32 MFMA)'),
 }
 
 
@@ -349,7 +349,22 @@ def main():
             'tvae_linear_dgrad_x6': (dense_flops, 'dense_x6_kernel'),
             'tvae_linear_wgrad_x6': (dense_flops, 'dense_wgrad_x6_kernel'),
         }
+        # fused encoder tail (conv2 + head projection; csrc/enc_tail_x6_kernels.hpp): HBM-bound side kernels
+        ho_ = c['n'] + 2 * c['pad'] - c['k'] + 1
+        ncol = B * c['R'] * ho_ * ho_
+        nh_ = 3 + 2 * c['zd']
+        tail_flops = 2.0 * c['C'] * (c['C'] + nh_) * ncol
+        entries['tvae_enc_tail_fwd_x6'] = (tail_flops, 'enc_tail_fwd_x6_kernel')
+        entries['tvae_enc_tail_dgrad_x6'] = (tail_flops, 'enc_tail_dgrad_x6_kernel')
+        tail_bytes = {'tvae_enc_tail_fwd_x6': (2 * 4 * c['C'] + 4 * nh_ + 32) * ncol,       # A1 in, H out, heads, sign words
+                      'tvae_enc_tail_dgrad_x6': (4 * c['C'] + 4 * nh_ + 32) * ncol}         # dA1 out, head gradients, sign words
         timed = {k_: v for k_, v in kev.items() if k_ in entries}
+        enc_tail = {k_: {'ms': round(kev[k_]['mean_ms'], 3), 'bound': 'hbm',
+                         'algorithmic_bytes_per_launch': float(tail_bytes[k_]),
+                         'achieved_GBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 1e9,
+                         'frac_of_8TBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 8.0e12,
+                         'executed_bf16_pflops': (1 if mode == 'bf16' else 6) * entries[k_][0] / (kev[k_]['mean_ms'] * 1e-3) / 1e15}
+                    for k_ in tail_bytes if k_ in kev}
         # the roofline object describes the dominant KERNEL FAMILY of the step, the split-pipe dense GEMM (decoder layers
         # and the spectral contraction of the convolution), on its LARGEST decoder launch (not its best one), with the
         # call-weighted aggregate over the three decoder launches beside it.  bf16 MFMAs per product block: 6 in the
@@ -417,6 +432,8 @@ def main():
         }
         if enc_fwd is not None:
             out['encoder_forward'] = enc_fwd
+        if enc_tail:
+            out['encoder_tail'] = enc_tail
         if companion is not None:
             out['exact_f32_mode'] = companion
         if companion_bf16 is not None:

@@ -27,6 +27,8 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          'dft_out_gen_kernel': 'tvae_dft_out', 'dft_dy_gen_kernel': 'tvae_dft_dy',
          'gemm_f32_glds_kernel': 'tvae_conv2_fwd', 'gemm_f32_glds2_kernel': 'tvae_conv2_dgrad',
          'heads_fwd_kernel': 'tvae_heads_fwd', 'heads_bwd_kernel': 'tvae_heads_bwd',
+         'enc_tail_fwd_x6_kernel': 'tvae_enc_tail_fwd_x6', 'enc_tail_dgrad_x6_kernel': 'tvae_enc_tail_dgrad_x6',
+         'gemm_f32_kernel<': 'tvae_conv2_wgrad',
          'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
