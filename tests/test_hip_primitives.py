@@ -570,6 +570,47 @@ def test_enc_tail_x6(N, nh, act, parts):
     assert rel_err(dA1, ref) < tol
 
 
+def test_enc_tail_x6_full_size_properties():
+    """The fused encoder tail at the benchmark's full size (N = 256 * 8 * 33 * 33 columns): two runs are bitwise
+    identical (persistent workgroups, no atomics), a random sample of columns matches fp64, and every sign word equals
+    the sign of what was stored."""
+    C, nh, N = 128, 7, 256 * 8 * 33 * 33
+    g = torch.Generator(device=dev()).manual_seed(11)
+    W2 = torch.randn(C, C, device=dev(), generator=g) * C ** -0.5
+    b2 = torch.randn(C, device=dev(), generator=g)
+    Wh = torch.randn(nh, C, device=dev(), generator=g) * C ** -0.5
+    bh = torch.randn(nh, device=dev(), generator=g)
+    A1 = torch.randn(C, N, device=dev(), generator=g)
+    dheads = torch.randn(nh, N, device=dev(), generator=g)
+    w3 = _split_w(W2, C, C, 0)
+    w3p = _split_w(W2.t()[:, _enc_tail_perm()].contiguous(), C, C, 0)
+    wh3 = torch.empty(query('tvae_dense_x6_bytes', C, nh) // 4, device=dev())
+    call('tvae_dense_split3', Wh, C, wh3, wh3.numel() * 4, C, nh, 1, None, None)
+    outs = []
+    for _ in range(2):
+        H = torch.empty(C, N, device=dev())
+        heads = torch.empty(nh, N, device=dev())
+        bits = torch.zeros(2, N, 4, dtype=torch.int32, device=dev())
+        dA1 = torch.empty(C, N, device=dev())
+        call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh, bh, nh, H, N, heads, N, bits[0], bits[1], C, N, 1, SLOPE, 3)
+        call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, bits[0], bits[1], dA1, N, C, N, SLOPE, 3)
+        outs.append((H, heads, bits, dA1))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    H, heads, bits, dA1 = outs[0]
+    cols = torch.randint(0, N, (4096,), device=dev(), generator=g)
+    cols[:64] = torch.arange(N - 64, N, device=dev())                      # the last chunks too
+    Hr = act_ref(W2.double() @ A1[:, cols].double() + b2.double()[:, None], 1)
+    assert rel_err(H[:, cols], Hr) < TOL
+    assert rel_err(heads[:, cols], Wh.double() @ Hr + bh.double()[:, None]) < TOL
+    dH = (Wh.double().t() @ dheads[:, cols].double()) * dact_ref(H[:, cols].double(), 1)
+    assert rel_err(dA1[:, cols], (W2.double().t() @ dH) * dact_ref(A1[:, cols].double(), 1)) < TOL
+    shifts = torch.arange(32, device=dev(), dtype=torch.int32)
+    for t, w in ((H, bits[0]), (A1, bits[1])):
+        got = ((w[cols][:, :, None] >> shifts) & 1).reshape(-1, 128).t().bool()
+        assert torch.equal(got, t[:, cols] > 0)
+
+
 @pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
 def test_rot_pool(C, B, R, Ho, act):
     """fc_r pooling over the rotation axis (reference models.py:303-305) and its backward through the activation."""
