@@ -609,6 +609,30 @@ def test_enc_tail_x6_full_size_properties():
     for t, w in ((H, bits[0]), (A1, bits[1])):
         got = ((w[cols][:, :, None] >> shifts) & 1).reshape(-1, 128).t().bool()
         assert torch.equal(got, t[:, cols] > 0)
+    # the weight gradients of the same step at full size (every CU busy): dH, dWh, db2 from tvae_heads_bwd, dW2 from the
+    # fp32-MFMA reduction over all 2.2 M columns, against fp64 sums
+    dH = torch.empty(C, N, device=dev())
+    npan = (N + 511) // 512
+    part = torch.empty(npan * C * (nh + 1), device=dev())
+    tot = torch.empty(nh + 1, C, device=dev())
+    call('tvae_heads_bwd', Wh, dheads, N, H, N, dH, N, nh, C, N, 1, SLOPE, part, part.numel(), tot)
+    dW2 = torch.empty(C, C, device=dev())
+    ws = torch.empty(1 << 24, device=dev())
+    call('tvae_linear_wgrad', dH, A1, dW2, ws, ws.numel(), C, N, C, N, N, 0)
+    dHr = torch.zeros(C, C, dtype=torch.float64, device=dev())
+    dWhr = torch.zeros(nh, C, dtype=torch.float64, device=dev())
+    dbr = torch.zeros(C, dtype=torch.float64, device=dev())
+    step = 1 << 18                                       # fp64 references in column slices (memory)
+    for c0 in range(0, N, step):
+        sl = slice(c0, min(N, c0 + step))
+        Hd = H[:, sl].double()
+        dHd = (Wh.double().t() @ dheads[:, sl].double()) * dact_ref(Hd, 1)
+        dHr += dHd @ A1[:, sl].double().t()
+        dWhr += dheads[:, sl].double() @ Hd.t()
+        dbr += dHd.sum(1)
+    assert rel_err(tot[:nh], dWhr) < TOL
+    assert rel_err(tot[nh], dbr) < 1e-4
+    assert rel_err(dW2, dHr) < TOL
 
 
 @pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
