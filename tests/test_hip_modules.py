@@ -341,6 +341,32 @@ def test_full_size_properties():
         _, _, _, aux_s = step.elbo_terms(x, y[sub], gen, enc, 'gauss', tuple(t[sub] for t in noise), return_aux=True)
         assert rel_err(aux_s['y_hat'], aux['y_hat'][sub]) < 1e-5
         assert rel_err(aux_s['kl_per_image'], aux['kl_per_image'][sub]) < 1e-5
+    # gradients at the full size (every CU busy, persistent kernels with several workgroups per CU): two backward passes
+    # are BITWISE identical (no atomics, fixed reduction orders -- a sporadic hazard would show here), and the default
+    # arithmetic agrees with exact fp32 products within max(1e-3, 2 x the step's own conditioning under a 1e-6 relative
+    # perturbation of the input)
+    from tvae import _lib
+    params = list(enc.named_parameters()) + list(gen.named_parameters())
+
+    def grads(yy, mode):
+        for _, p in params:
+            p.grad = None
+        with _lib.arithmetic(mode):
+            e_, _, _ = step.elbo_terms(x, yy, gen, enc, 'gauss', noise)
+        (-e_).backward()
+        return {nm: p.grad.clone() for nm, p in params}
+    g1, g2 = grads(y, 'x6'), grads(y, 'x6')
+    for nm, _ in params:
+        assert torch.equal(g1[nm], g2[nm]), nm
+    gf = grads(y, 'f32')
+    gp = grads(y * (1 + 1e-6 * torch.randn_like(y)), 'f32')
+    for nm, _ in params:
+        if nm == 'conv_a.bias':                          # analytically zero (softmax shift invariance): noise over noise
+            continue
+        scale = float(gf[nm].abs().max())
+        cond = float((gp[nm] - gf[nm]).abs().max()) / scale
+        diff = float((g1[nm] - gf[nm]).abs().max()) / scale
+        assert diff < max(1e-3, 2 * cond), (nm, diff, cond)
 
 
 def test_galaxy_full_size_runs(gemm_mode):
