@@ -209,6 +209,69 @@ def test_step_hot_widths_golden(name, gemm_mode):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=max(GRAD_TOL, 2 * float(fx['kd.' + k_])), name='gen.' + k_)
 
 
+@pytest.mark.parametrize('cfg', ['small', 'small_fourier', 'S28', 'S28F', 'S64'])
+def test_step_does_not_read_out_of_bounds(cfg):
+    """Out-of-bounds READ detector.  Every float tensor the step allocates (torch.empty / torch.zeros, workspaces
+    included) becomes a view into the middle of a larger allocation; ELBO and every gradient must be bitwise independent
+    of what the guard bands hold (0, 1e4, NaN) -- a kernel that reads past a row end, a padded tile or an unwritten
+    workspace slab, and lets it into a result with any weight, fails here.  Full kernel widths (C = 128, hidden 512) at
+    small batches."""
+    import src.models as M
+    from tvae import ops, step, tables
+    n, zd, R, B, C, hid, k, pad, four = {'small': (20, 2, 8, 8, 8, 32, 20, 4, False),
+                                         'small_fourier': (20, 2, 8, 8, 8, 32, 20, 4, True),
+                                         'S28': (28, 2, 8, 16, 128, 512, 28, 14, False),
+                                         'S28F': (28, 2, 16, 8, 128, 512, 28, 14, True),
+                                         'S64': (64, 2, 8, 4, 128, 512, 64, 16, False)}[cfg]
+    torch.manual_seed(0)
+    gen = M.SpatialGenerator(zd, hid, num_layers=2, fourier_expansion=four, sigma=2.0 / (n - 1)).to(dev())
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 1, zd, kernels_num=C, kernels_size=k, padding=pad, groupconv=R, rot_refinement=True, theta_prior=np.pi,
+        normal_prior_over_r=False).to(dev())
+    x = torch.from_numpy(tables.image_coords(n)).to(dev())
+    y = torch.randn(B, 1, n, n, device=dev())
+    nz = step.draw_noise(B, R * enc.output_size() ** 2, zd, dev())
+    params = list(gen.named_parameters()) + list(enc.named_parameters())
+    real_empty, real_zeros = torch.empty, torch.zeros
+    guard, fill = 8192, [0.0]
+
+    def guarded(real):
+        def f(*a, **kw):
+            t = real(*a, **kw)
+            if not (t.is_cuda and t.is_floating_point() and t.dim() >= 1 and t.numel() > 0):
+                return t
+            big = real_empty(t.numel() + 2 * guard, dtype=t.dtype, device=t.device)
+            big[:guard].fill_(fill[0])
+            big[guard + t.numel():].fill_(fill[0])
+            v = big[guard:guard + t.numel()].view(t.shape)
+            if real is real_zeros:
+                v.zero_()
+            return v
+        return f
+
+    def run(g):
+        fill[0] = g
+        saved = dict(ops._WS)
+        ops._WS.clear()                                  # workspaces are re-created under guard too
+        torch.empty, torch.zeros = guarded(real_empty), guarded(real_zeros)
+        try:
+            for _, p in params:
+                p.grad = None
+            e, _, _ = step.elbo_terms(x, y, gen, enc, 'gauss', nz)
+            (-e).backward()
+            return float(e.detach()), {k_: p.grad.clone() for k_, p in params}
+        finally:
+            torch.empty, torch.zeros = real_empty, real_zeros
+            ops._WS.clear()
+            ops._WS.update(saved)
+    e0, g0 = run(0.0)
+    for g in (1e4, float('nan')):
+        e1, g1 = run(g)
+        assert e1 == e0, (g, e0, e1)
+        for k_ in g0:
+            assert torch.equal(g0[k_], g1[k_]), (g, k_)
+
+
 @pytest.mark.parametrize('name', sorted(HOT))
 def test_bf16_throughput_mode(name):
     """The opt-in bf16 throughput mode (operands rounded to ONE bf16 number, one MFMA per product block, fp32
