@@ -27,6 +27,7 @@ int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* t
                          int ksz, int R, tvae_stream_t stream) {
     const int k2 = ksz * ksz;
     const long total = (long)C * R * Cin * k2;
+    if (total >= 2147483647L || !aligned16(tap_idx) || !aligned16(tap_w)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight, tap_idx,
                        tap_w, bank, C, Cin, k2, R);
     TVAE_CHECK_LAUNCH();
@@ -38,6 +39,7 @@ int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_
                          tvae_stream_t stream) {
     const int k2 = ksz * ksz;
     const long total = (long)C * Cin * k2;
+    if (total * R >= 2147483647L) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(rotate_bank_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), dbank, csr_ptr,
                        csr_r, csr_dst, csr_w, dweight, C, Cin, k2, R, accumulate);
     TVAE_CHECK_LAUNCH();

@@ -238,8 +238,8 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
         bank = rotate_bank(weight, R)
     out = torch.empty(C, B * R * Ho * Ho, dtype=torch.float32, device=y.device)
     if _use_dft(B, Cin, n, k, pad, C, R):
-        # zeros: the columns that pad (image, row) to a multiple of 128 must stay finite
-        at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), dtype=torch.float32,
+        # (the columns that pad (image, row) to a multiple of 128 are zeroed by the entry point when there are any)
+        at = torch.empty(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), dtype=torch.float32,
                          device=y.device)
         ws = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
         _note('conv1.dft')
