@@ -36,15 +36,25 @@ __device__ __forceinline__ void store4(float* __restrict__ row, long col, long c
 }
 __device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
-// out[v*M + m] = sum_panel part[(panel*M + m)*NV + v]      (one workgroup per row m)
+// out[v*M + m] = sum_panel part[(panel*M + m)*NV + v]      (one workgroup per row m; NV <= 16)
+// A thread reads the NV contiguous values of its panels in one go (one cache line per panel instead of one per value).
 static __global__ void part_total_kernel(const float* __restrict__ part, int npanels, int M, int NV, float* __restrict__ out) {
-    __shared__ float sm[16];
+    __shared__ float sm[16 * 16];
     const int m = blockIdx.x;
-    for (int v = 0; v < NV; ++v) {
-        float s[1] = {0.f};
-        for (int p = threadIdx.x; p < npanels; p += blockDim.x) s[0] += part[((long)p * M + m) * NV + v];
-        block_sum<1>(s, sm);
-        if (threadIdx.x == 0) out[(long)v * M + m] = s[0];
+    float s[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s[v] = 0.f;
+    for (int p = threadIdx.x; p < npanels; p += blockDim.x) {
+        const float* q = part + ((long)p * M + m) * NV;
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            if (v < NV) s[v] += q[v];
+    }
+    block_sum<16>(s, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            if (v < NV) out[(long)v * M + m] = s[v];
     }
 }
 
@@ -178,6 +188,7 @@ static __global__ __launch_bounds__(256) void dec_in_bwd_kernel(const float* __r
 }
 
 // Simg[b][f] = sum_c part[b*cpi + c][f][0];  dbc[f] = sum_b Simg[b][f];  dWc[f][j] = sum_{b,c} part[..][f][1+j]
+// (one workgroup per feature; a variant with 8 features per workgroup and 96-byte reads measured slower: 64 workgroups)
 static __global__ void dec_in_total_kernel(const float* __restrict__ part, int B, int cpi, int F, float* __restrict__ Simg,
                                     float* __restrict__ dbc, float* __restrict__ dWc) {
     __shared__ float sm[3 * 16];
