@@ -116,6 +116,44 @@ def test_encoder_golden(name):
     assert_encoder_grads(enc, fx, GRAD_TOL, prefix='g.', name='', elbo_loss=False)
 
 
+@pytest.mark.parametrize('actname', ['leakyrelu', 'tanh'])
+def test_encoder_tail_paths_agree(actname):
+    """128-channel encoder in the default arithmetic: the fused tail (conv2 + heads in one kernel; LeakyReLU: fused data
+    gradient from the sign words; tanh: fused forward, unfused backward) against the unfused kernels on the same input --
+    head outputs within 1e-5, every encoder gradient within 2e-4 (LeakyReLU rows with a flipped kink allowed as in
+    assert_grad_close)."""
+    import src.models as M
+    from tvae import _lib, ops
+    torch.manual_seed(4)
+    act = torch.nn.LeakyReLU if actname == 'leakyrelu' else torch.nn.Tanh
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        28, 1, 2, kernels_num=128, kernels_size=28, padding=14, groupconv=8, rot_refinement=True, theta_prior=np.pi,
+        normal_prior_over_r=False, activation=act).to(dev())
+    y = torch.randn(6, 1, 28, 28, device=dev())
+    w = torch.randn(7, 6 * 8 * 29 * 29, device=dev())
+
+    def run(fused):
+        for p in enc.parameters():
+            p.grad = None
+        old, ops.FUSE_ENC_TAIL, ops.PATH_LOG = ops.FUSE_ENC_TAIL, fused, set()
+        try:
+            with _lib.arithmetic('x6'):
+                heads = enc.encode_heads(y)
+            (heads * w).sum().backward()
+            took = set(ops.PATH_LOG)
+        finally:
+            ops.FUSE_ENC_TAIL, ops.PATH_LOG = old, None
+        return heads.detach().clone(), {k_: p.grad.clone() for k_, p in enc.named_parameters() if p.grad is not None}, took
+    h1, g1, t1 = run(True)
+    h0, g0, t0 = run(False)
+    assert 'enc.tail_fwd_x6' in t1 and 'enc.tail_fwd_x6' not in t0
+    assert ('enc.tail_dgrad_x6' in t1) == (actname == 'leakyrelu')
+    assert rel_err(h1, h0) < 1e-5
+    assert set(g1) == set(g0) and len(g1) >= 6
+    for k_ in g0:
+        assert_grad_close(g1[k_], g0[k_], tol=GRAD_TOL, name=k_)
+
+
 @pytest.mark.parametrize('name', ['decoder_plain', 'decoder_plain512', 'decoder_fourier', 'decoder_resid',
                                   'decoder_nout2', 'decoder_nout3_z50_L4', 'decoder_z0_L1'])
 def test_decoder_golden(name):
