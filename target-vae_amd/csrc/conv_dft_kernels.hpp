@@ -81,19 +81,55 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
     }
     __syncthreads();
     // Yh[fy][f] = sum_y Rw[y][f] e^{-2 pi i fy (y+pad) / L}
-    for (int i = threadIdx.x; i < L * nfx; i += blockDim.x) {
-        const int fy = i / nfx, f = i - fy * nfx;
-        float2 acc = make_float2(0.f, 0.f);
-        int ph = (fy * pad) % L;
-#pragma unroll 4
-        for (int yy = 0; yy < S; ++yy) {
-            const float2 p = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));
-            acc.x += p.x;
-            acc.y += p.y;
-            ph += fy;
-            if (ph >= L) ph -= L;
+    if ((L & 3) == 0) {
+        // radix-4 step over the output index: the four outputs fy + q L/4 share their twiddles up to (-i)^(q (y+pad)), so
+        // one pass builds the four partial sums by (y + pad) mod 4 and a 4-point DFT combines them (a quarter of the MACs)
+        const int Lq = L >> 2;
+        for (int i = threadIdx.x; i < Lq * nfx; i += blockDim.x) {
+            const int fy = i / nfx, f = i - fy * nfx;
+            float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int ph = (fy * pad) % L;
+            int yy = 0;
+            auto term = [&](int r) {                     // r = (yy + pad) & 3 (a compile-time constant in the main loop)
+                const float2 p = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));
+                if (r == 0) { a0.x += p.x; a0.y += p.y; }
+                else if (r == 1) { a1.x += p.x; a1.y += p.y; }
+                else if (r == 2) { a2.x += p.x; a2.y += p.y; }
+                else { a3.x += p.x; a3.y += p.y; }
+                ph += fy;
+                if (ph >= L) ph -= L;
+                ++yy;
+            };
+            // bring (yy + pad) to a multiple of 4 first: the residue of every later term is then known at compile time
+            int r0 = pad & 3;
+            while (r0 != 0 && r0 < 4 && yy < S) term(r0++);
+            while (yy + 3 < S) { term(0); term(1); term(2); term(3); }
+            r0 = 0;
+            while (yy < S) term(r0++);
+            const float2 a[4] = {a0, a1, a2, a3};
+            // Y[fy + q Lq] = sum_r a[r] (-i)^(q r):   (-i)^0 = 1, (-i)^1 = -i, (-i)^2 = -1, (-i)^3 = i
+            const float2 s02 = make_float2(a[0].x + a[2].x, a[0].y + a[2].y), d02 = make_float2(a[0].x - a[2].x, a[0].y - a[2].y);
+            const float2 s13 = make_float2(a[1].x + a[3].x, a[1].y + a[3].y), d13 = make_float2(a[1].x - a[3].x, a[1].y - a[3].y);
+            Yh[fy * FXB + f] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            Yh[(fy + Lq) * FXB + f] = make_float2(d02.x + d13.y, d02.y - d13.x);          // a0 - i a1 - a2 + i a3
+            Yh[(fy + 2 * Lq) * FXB + f] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            Yh[(fy + 3 * Lq) * FXB + f] = make_float2(d02.x - d13.y, d02.y + d13.x);      // a0 + i a1 - a2 - i a3
         }
-        Yh[fy * FXB + f] = acc;
+    } else {
+        for (int i = threadIdx.x; i < L * nfx; i += blockDim.x) {
+            const int fy = i / nfx, f = i - fy * nfx;
+            float2 acc = make_float2(0.f, 0.f);
+            int ph = (fy * pad) % L;
+#pragma unroll 4
+            for (int yy = 0; yy < S; ++yy) {
+                const float2 p = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));
+                acc.x += p.x;
+                acc.y += p.y;
+                ph += fy;
+                if (ph >= L) ph -= L;
+            }
+            Yh[fy * FXB + f] = acc;
+        }
     }
     __syncthreads();
 }
