@@ -135,11 +135,14 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         ep.C = T; ep.ldc = (long)q.Lh * 128;              // T is [n >> 7][m'][fx][n & 127] (dft_t_off)
         ep.ctile = (long)2 * q.M * q.Lh * 128;
         const int Rpad = x6_round_up(rows, DX6_ROWS);
-        TileMap tm{Rpad / DX6_ROWS, (int)(q.NBpad / 128), 1};
-        tm.bt = q.Mb / DX6_ROWS;                       // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
+        // short reductions (K2 <= 256: twelve k-steps at the 64 x 64 shape): 256-row tiles, two 4-wave workgroups per CU
+        const int TR = q.K2 <= 256 ? DX4_ROWS : DX6_ROWS;
+        TileMap tm{Rpad / TR, (int)(q.NBpad / 128), 1};
+        tm.bt = q.Mb / TR;                             // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
-        const DenseBatch bt{q.Mb / DX6_ROWS, (long)q.K2 * q.NBpad, 128};
-        rc = dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st);
+        const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
+        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st)
+                            : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st);
         if (rc) return rc;
     }
     {

@@ -69,6 +69,10 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
     }                                                                                                                 \
     }
 
+// the same with the 256-row / four-wave tile (dense_x6_plain4_kernel: short reductions); tm / bt count 256-row tiles
+TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
+                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
+                                    hipStream_t st);
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,

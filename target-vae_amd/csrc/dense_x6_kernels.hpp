@@ -516,6 +516,133 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Plain instance with a 256 x 128 tile and FOUR waves for SHORT reductions (the spectral contraction of the
+// frequency-domain convolution: K = 2 L Cin = 192, twelve 16-k steps per tile).  With so few steps the tile's output
+// (here 128 KB of T) takes as long to drain as its MFMAs take to run, and one 8-wave workgroup owns a whole CU: all eight
+// waves store at the same time while the matrix pipe idles.  Two 4-wave workgroups per CU run out of phase -- one
+// workgroup's stores drain under the other's k-loop.  Same arithmetic, cells, B stage and epilogue as dense_x6_kernel<0>;
+// a thread builds two k-quads of the B stage per step instead of one.
+// ------------------------------------------------------------------------------------------
+constexpr int DX4_THREADS = 256;
+constexpr int DX4_ROWS = 256;
+
+template <int NP>
+static __global__ __launch_bounds__(DX4_THREADS, 2)
+void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
+                            int N, int K, int K8pad, TileMap tm, DenseBatch bt) {
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
+    __shared__ float bsm[DX4_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n, split_unused;
+    if (!tm.decode(blockIdx.x, tile_m, tile_n, split_unused)) return;
+    int batch = 0;
+    if (bt.tiles_per_batch > 0) {
+        batch = tile_m / bt.tiles_per_batch;
+        X += batch * bt.x_stride;
+        ep.C += batch * bt.c_stride;
+    }
+    const int m0g = tile_m * DX4_ROWS;
+    const int m0 = m0g - batch * bt.tiles_per_batch * DX4_ROWS, n0 = tile_n * 128;
+    const int khalf = lane >> 5;
+    const int nk = K8pad >> 1;
+    bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+
+    const long part_cells = (long)K8pad * Mpad;
+    const uint4* a_ptr = A3 + (long)khalf * Mpad + m0g + 64 * wave + (lane & 31);
+    auto load_a = [&](int t, Cell16 (&a)[2][3]) {
+        const uint4* q = a_ptr + (long)(2 * t) * Mpad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[i][p].u = q[p * part_cells + i * 32];
+    };
+    // B build role: k-quads kq and kq + 2 (4 consecutive k each = half a cell), column nb
+    const int kq = tid >> 7, nb = tid & 127;
+    const float* x_col = X + n0 + nb;
+    auto load_x = [&](int t, float (&x)[2][4]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kb = 16 * t + 4 * (kq + 2 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[h][j] = x_col[(long)min(kb + j, K - 1) * ldx];     // clamped rows meet zero weights
+        }
+    };
+    auto store_b = [&](int stage, const float (&x)[2][4]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + h * 128 + nb) + kq;
+            if (NP == 1) {
+                dst[0] = make_uint2(bf16_pair(x[h][0], x[h][1]), bf16_pair(x[h][2], x[h][3]));
+                continue;
+            }
+            unsigned hw[2], mw[2], lw[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) split3_pair(x[h][2 * q], x[h][2 * q + 1], hw[q], mw[q], lw[q]);
+            dst[0] = make_uint2(hw[0], hw[1]);
+            dst[2 * 256] = make_uint2(mw[0], mw[1]);
+            dst[2 * 512] = make_uint2(lw[0], lw[1]);
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Cell16 afA[2][3], afB[2][3];
+    float xA[2][4], xB[2][4];
+    {
+        float x0[2][4];
+        load_x(0, x0);
+        load_a(0, afA);
+        load_x(nk > 1 ? 1 : 0, xB);
+        load_x(nk > 2 ? 2 : 0, xA);
+        store_b(0, x0);
+    }
+    __syncthreads();
+    auto step = [&](int t, Cell16 (&afc)[2][3], Cell16 (&afn)[2][3], float (&xn)[2][4]) {
+        const int cur = t & 1;
+        load_a(t + 1 < nk ? t + 1 : t, afn);
+        const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Cell16 bf[3];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
+            mfma_np<NP>(acc[0][j], afc[0], bf);
+            mfma_np<NP>(acc[1][j], afc[1], bf);
+            if (j == 1) {
+                store_b(cur ^ 1, xn);
+                load_x(t + 3 < nk ? t + 3 : t, xn);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    int tt = 0;
+    for (; tt + 1 < nk; tt += 2) {
+        step(tt, afA, afB, xB);
+        step(tt + 1, afB, afA, xA);
+    }
+    if (nk & 1) step(nk - 1, afA, afB, xB);
+    float ysum[4] = {0.f, 0.f, 0.f, 0.f};
+    float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const float gyv[4] = {0.f, 0.f, 0.f, 0.f};
+    const InTail it{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    if (ep.act == ACT_LRELU)
+        dense_x6_epilogue<ACT_LRELU, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
+                                                                     gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+    else if (ep.act == ACT_TANH)
+        dense_x6_epilogue<ACT_TANH, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
+                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+    else
+        dense_x6_epilogue<ACT_NONE, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
+                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------
 // Weight gradient of a dense layer in the same arithmetic:  dW[m][k] = sum_n dY[m][n] X[k][n].
 // Both operands are row-major with the reduction index n contiguous, so a fragment cell (8 consecutive n of one row)
 // is 32 contiguous bytes of its row.  Tile 512 (m) x 128 (k), eight waves stacked along m (64 x 128 each); the
