@@ -123,6 +123,9 @@ if only and 'tail' in only:
     # implicit gradient + fused first-layer backward + recomputed mask, weight gradient with both implicit operands
     cy = torch.empty(Nt, device=dev)
     timeit('tail_fwd_step', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, None, PARTS))
+    sb = torch.zeros(F_, Nt // 32, dtype=torch.int32, device=dev)
+    timeit('tail_fwd_step+bits', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, sb, PARTS))
+    timeit('tail_fwd_step_nostore', fl, lambda: call('tvae_linear_fwd_x6', w3, None, bb, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, wo1, bb[:1].contiguous(), cy, *va, None, PARTS))
     # the step's data gradient: two-valued implicit gradient (weights scaled by wo before the split, 0 / 1 operand)
     csum2 = torch.empty(F_, device=dev)
     w3s = torch.empty_like(w3)
