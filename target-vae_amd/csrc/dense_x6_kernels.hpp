@@ -713,7 +713,6 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         X += batch * bt.x_stride;
     }
     const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
-    const int ncol = min(4, (Kf - k0 + 31) >> 5);        // 32-column MFMA tiles of this k tile that hold columns < Kf
     const int nbeg = split * nchunk;
     const int nend = min(N, nbeg + nchunk);
     const int nk = (nend - nbeg) >> 4;
@@ -935,20 +934,18 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const uint4* bs = Bs + cur * 768 + khalf * 128 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < ncol) {                              // column tiles beyond Kf hold nothing (Kf = 192: the second tile is half empty)
-                Cell16 bf[3];
+            Cell16 bf[3];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
-                if (LRF) {                               // exact 0 / 1 operand: ONE A part against the X parts
+            for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
+            if (LRF) {                                   // exact 0 / 1 operand: ONE A part against the X parts
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0].v, bf[p].v, acc[i][j], 0, 0, 0);
-                } else {
-                    mfma_np<NP>(acc[0][j], af[0], bf);
-                    mfma_np<NP>(acc[1][j], af[1], bf);
-                }
+                    for (int p = 0; p < NP; ++p)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0].v, bf[p].v, acc[i][j], 0, 0, 0);
+            } else {
+                mfma_np<NP>(acc[0][j], af[0], bf);
+                mfma_np<NP>(acc[1][j], af[1], bf);
             }
             if (j == 0) {                                // A cells of step t+1 from the ring
                 float4 ar[2][2], gn[2];
