@@ -23,6 +23,106 @@ for _p in (ROOT, os.path.join(ROOT, 'target-vae_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+
+
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT any HIP / torch call (the spawning parent must stay GPU-free: a process that
+    has initialised the GPU must not be replaced or forked into ranks): the KFD topology lists one node per agent and
+    GPU agents are the nodes with simd_count > 0; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    restrict that set when present."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != '':
+            return len([t for t in v.split(',') if t.strip() != ''])
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    n = 0
+    try:
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, 'properties')).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                f = line.split()
+                if len(f) == 2 and f[0] == 'simd_count' and int(f[1]) > 0:
+                    n += 1
+    except OSError:
+        return 0
+    return n
+
+
+def spawn_ranks(n: int, timeout_s: float = 3600.0) -> int:
+    """`python bench.py --gpus N` without a torchrun environment.  This parent never touches the GPU and never imports
+    torch (it runs BEFORE the module-level `import torch` below; devices are counted from sysfs / the *_VISIBLE_DEVICES
+    variables); it starts one child per GPU with the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    lets rank 0 print the JSON line and POLLS the children: when one exits non-zero (RCCL init failure, out of memory)
+    the others -- which would otherwise block forever in their next collective -- are terminated and that exit code is
+    returned; the same after `timeout_s`."""
+    import socket
+    import subprocess
+    have = visible_gpu_count()
+    if have < n:
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) are visible', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    t_end = time.monotonic() + timeout_s
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+        if live and (rc != 0 or time.monotonic() > t_end):
+            if rc == 0:
+                rc = 124
+                print(f'bench.py: ranks still running after {timeout_s:.0f} s, terminating them', file=sys.stderr)
+            for pr in live:
+                pr.terminate()
+            for pr in live:
+                try:
+                    pr.wait(timeout=15)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            break
+        if live:
+            time.sleep(0.2)
+    return rc
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (BASELINE: 256; S128G: 8)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-companion', action='store_true',
+                    help="skip the extra measurements of the same steps in the all-fp32-MFMA mode (TVAE_GEMM=f32) and in "
+                         "the opt-in bf16 throughput mode")
+    ap.add_argument('--no-strong', action='store_true',
+                    help='N > 1: skip the extra strong-scaling measurement (global batch fixed at the per-GPU batch)')
+    ap.add_argument('--workload', choices=['S128G', 'S28', 'S28F', 'S64'], default='S64',
+                    help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
+    return ap.parse_args()
+
+
+if __name__ == '__main__' and 'WORLD_SIZE' not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:                       # become the GPU-free parent of N ranks before torch is even imported
+        sys.exit(spawn_ranks(_a.gpus))
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -146,44 +246,9 @@ def cpu_baseline(batch=32, steps=4):
                                  'sample': f'oracle encoder forward, {batch} images, 1 warm-up + 2 timed, min'})
 
 
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without a torchrun environment: this parent never touches the GPU (device_count does
-    not initialise HIP); it starts one child per GPU with the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_*), lets rank 0 print the JSON line and returns the worst exit code."""
-    import socket
-    import subprocess
-    have = torch.cuda.device_count()
-    if have < n:
-        print(f'bench.py: --gpus {n} but only {have} GPU(s) are visible', file=sys.stderr)
-        return 2
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
-    return rc
-
-
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (BASELINE: 256; S128G: 8)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-f32-companion', action='store_true',
-                    help="skip the extra measurement of the same steps in the all-fp32-MFMA mode (TVAE_GEMM=f32)")
-    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='S64',
-                    help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
-    args = ap.parse_args()
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
+    args = parse_args()
+    assert sorted(WORKLOADS) == ['S128G', 'S28', 'S28F', 'S64']
 
     from tvae import dp, ops, optim, step
     from tvae import _lib
@@ -201,7 +266,7 @@ def main():
     gen, enc = build_models(dev, wl)
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
-    opt = optim.FlatAdam(params, lr=2e-4, reducer=reducer)
+    opt = optim.FlatAdam(params, lr=2e-4, reducer=reducer, early_params=len(list(gen.parameters())))
     if world > 1:                                   # identical replicas: rank 0's flat parameters and every buffer
         dist.broadcast(opt.flat_p, src=0)
         dp.broadcast_buffers(gen, enc)
@@ -217,9 +282,10 @@ def main():
     x = torch.from_numpy(__import__('tvae.tables', fromlist=['x']).image_coords(c['n'])).to(dev)
     step.pixel_spacing(x)                           # cached once (the reference syncs for it every step)
 
-    def one_step(i):
+    def one_step(i, b=None):
+        b = B if b is None else b
         lo = (i % (n_img // B)) * B
-        y = data[lo:lo + B]
+        y = data[lo:lo + b]
         elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, c['lik'])
         (-elbo).backward()
         opt.step()
@@ -244,6 +310,25 @@ def main():
     dt = time.perf_counter() - t0
     kev = ops.kernel_event_ms()
     ops.KERNEL_EVENTS = None
+    # N > 1: the same number of steps again with the GLOBAL batch fixed at the per-GPU batch of the weak run (strong
+    # scaling, SURVEY 8d: "B=256 per GPU (weak) and global-B=256 (strong) separately and label them")
+    strong = None
+    if world > 1 and not args.no_strong and B >= world:
+        bs = B // world
+        for i in range(2):
+            one_step(i, bs)
+        barrier()
+        ts0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i, bs)
+        barrier()
+        dts = time.perf_counter() - ts0
+        tt = torch.tensor([dts], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dts = float(tt.item())
+        strong = {'scaling': 'strong', 'global_batch': bs * world, 'per_gpu_batch': bs,
+                  'value': world * bs * args.steps / dts, 'unit': 'images/sec', 'ms_per_step': 1e3 * dts / args.steps,
+                  'steps': args.steps, 'warmup': 2}
     # companion measurement: the same number of steps with every matrix product on the exact fp32 MFMA
     companion = None
     if world == 1 and mode == 'x6' and not args.no_f32_companion:
@@ -394,6 +479,11 @@ def main():
             'elbo': elbo_last,
             'config': {'workload': c['desc'],
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
+                       'collective': ({'backend': dist.get_backend() + ' (RCCL)', 'world_size_seen': dist.get_world_size(),
+                                       'payload_bytes_per_step': int(opt.flat_g.numel()) * 4,
+                                       'buckets': 'decoder segment posted from the backward, encoder segment at the '
+                                                  'optimizer step (tvae/optim.py)'}
+                                      if world > 1 else None),
                        'arithmetic_mode': mode,
                        'lifting_conv': ('frequency domain: DFT + batched split-pipe GEMM (326 GFLOP of matrix work per '
                                         'launch instead of 2339)' if conv_dft else 'direct implicit GEMM')},
@@ -424,12 +514,19 @@ def main():
                                             for k_ in dense} if mode in ('x6', 'bf16') else None,
                          'dense_aggregate': ({'algorithmic_tflops': sum(dense_flops * kev[k_]['launches'] for k_ in dense) /
                                               (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12,
-                                              'frac_of_x6_peak': sum(dense_flops * kev[k_]['launches'] for k_ in dense) /
-                                              (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12 / info['peak']}
+                                              'executed_bf16_pflops':
+                                              sum(products[k_] * dense_flops * kev[k_]['launches'] for k_ in dense) /
+                                              (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e15,
+                                              'frac_of_bf16_peak':
+                                              sum(products[k_] * dense_flops * kev[k_]['launches'] for k_ in dense) /
+                                              (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12 /
+                                              PEAK_BF16_MFMA_TFLOPS}
                                              if (mode in ('x6', 'bf16') and dense) else None),
                          'conv_direct_form_tflops': {k_: conv_flops / (kev[k_]['mean_ms'] * 1e-3) / 1e12
                                                      for k_ in ('tvae_conv1_fwd', 'tvae_conv1_wgrad') if k_ in kev}},
         }
+        if strong is not None:
+            out['strong_scaling'] = strong
         if enc_fwd is not None:
             out['encoder_forward'] = enc_fwd
         if enc_tail:

@@ -19,6 +19,11 @@ int et_grid(long N) {
     const int cus = cu_count();
     return (int)(want < cus ? want : cus);
 }
+// the kernels form lane offsets as 32-bit BYTE offsets of up to 32 rows: 32 * ld * 4 must stay below 2^32
+constexpr long ET_MAX_LD = 1L << 25;
+inline bool et_ld_ok(long N, long a, long b, long c) {
+    return N < ET_MAX_LD && a < ET_MAX_LD && b < ET_MAX_LD && c < ET_MAX_LD;
+}
 }  // namespace
 
 extern "C" {
@@ -28,7 +33,8 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
                          int act, float slope, int parts, tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 3) || !A1 || !H || !heads || !Wh ||
-        !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))))
+        !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))) ||
+        !et_ld_ok(N, lda, ldh, ldo))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
     const size_t lds = (size_t)parts * 16 * ET_C * 16;
@@ -53,7 +59,7 @@ int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads
                            tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3p) || !aligned16(wh3) || !aligned16(bits_h) || !aligned16(bits_a) ||
-        (parts != 1 && parts != 3) || !dheads || !bits_h || !bits_a || !dA1)
+        (parts != 1 && parts != 3) || !dheads || !bits_h || !bits_a || !dA1 || !et_ld_ok(N, ldd, lda, 0))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
     const size_t lds = (size_t)parts * 18 * ET_C * 16;

@@ -40,25 +40,50 @@ def broadcast_buffers(*modules, src: int = 0, group=None):
 
 
 class GradReducer:
-    """Sum all-reduce of the flat gradient buffer; returns the scale Adam applies (1/world for equal shards).
+    """Sum all-reduce of the flat gradient buffer in (up to) two buckets; returns the scale Adam applies (1/world for
+    equal shards).
+
+    `begin(segment)` posts the all-reduce of a leading segment of the buffer asynchronously (the decoder's
+    gradients are ready first, section 3.2): over RCCL the collective runs on the process group's own stream behind the
+    kernels already queued on the compute stream, so it overlaps the encoder backward that follows; `__call__(flat_g,
+    start)` reduces the rest and waits for the posted bucket.  Every rank issues the same two collectives in the same
+    order (a rank with an empty shard issues both from the optimizer step), so the buckets always match up.
 
     `weight` handles a ragged last minibatch: rank r holds b_r images and its loss is a mean over b_r, so the
     global-batch gradient is sum_r (b_r / b_global) g_r; ranks pre-scale by b_r * world / b_global."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # `always`: issue the collectives even in a one-rank group (they are identities there) -- lets a 1-GPU box
+        # execute the RCCL path end to end (tests/test_dp_gpu.py)
+        self.active = self.world > 1 or (bool(always) and dist.is_initialized())
         self.weight = 1.0
+        self._pending = []
+        self.posted_early = 0          # diagnostics: how many early buckets were posted from a backward
 
     def set_local_fraction(self, local_b: int, global_b: int):
         self.weight = float(local_b) * self.world / float(global_b)
 
-    def __call__(self, flat_g: torch.Tensor) -> float:
-        if self.world == 1:
-            return 1.0
+    def begin(self, segment: torch.Tensor) -> None:
+        if not self.active:
+            return
         if self.weight != 1.0:
-            flat_g.mul_(self.weight)
-        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            segment.mul_(self.weight)
+        self._pending.append(dist.all_reduce(segment, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.posted_early += 1
+
+    def __call__(self, flat_g: torch.Tensor, start: int = 0) -> float:
+        if not self.active:
+            return 1.0
+        rest = flat_g[start:] if start else flat_g
+        if rest.numel() > 0:
+            if self.weight != 1.0:
+                rest.mul_(self.weight)
+            dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
         return 1.0 / self.world
 
 
@@ -127,12 +152,28 @@ def shard_bounds(n_items: int, rank: int, world: int):
 
 def shard_plan(n_items: int, global_batch: int, world: int):
     """Batch plan of the shard-resident loop, identical on every rank without communication: counts[i][r] images of
-    rank r's shard go into global minibatch i.  Rank r contributes its even share of the global batch (shard_slices'
-    split) until its shard is exhausted; the number of minibatches is what the largest shard needs."""
-    quota = [hi - lo for lo, hi, _ in (next(shard_slices(global_batch, global_batch, r, world)) for r in range(world))]
-    sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
-    nb = max((sizes[r] + quota[r] - 1) // quota[r] if quota[r] > 0 else 0 for r in range(world)) if n_items > 0 else 0
-    return [[max(0, min(quota[r], sizes[r] - i * quota[r])) for r in range(world)] for i in range(nb)]
+    rank r's shard go into global minibatch i.
+
+    The N images are laid out as one round-robin sequence of "slots" (round j holds one image of every rank whose
+    shard has more than j rows: rank 0, 1, ..., world-1, then the next round) and global minibatch i takes slots
+    [i*gb, min((i+1)*gb, N)).  So there are exactly ceil(N / gb) minibatches, minibatch i holds exactly
+    g_i = min(gb, N - i*gb) images (the reference's loop, train_mnist.py:586-587), every rank's share of a minibatch
+    is within one image of g_i / world, the ranks that get the extra image rotate from batch to batch when
+    gb % world != 0, and every row of every shard is visited once per epoch (also when gb < world)."""
+    if global_batch <= 0:
+        raise ValueError('global_batch must be positive')
+    base, extra = divmod(n_items, world)
+
+    def taken(t, r):            # slots < t that belong to rank r
+        if t <= base * world:
+            return t // world + (1 if t % world > r else 0)
+        return base + (1 if t - base * world > r else 0)
+
+    plan = []
+    for a in range(0, n_items, global_batch):
+        b = min(a + global_batch, n_items)
+        plan.append([taken(b, r) - taken(a, r) for r in range(world)])
+    return plan
 
 
 def local_permutation(n_local: int, seed: int, epoch: int, rank: int, shuffle: bool = True) -> torch.Tensor:
@@ -164,8 +205,9 @@ def resident_global_batches(n_items: int, global_batch: int, world: int, seed: i
 class ResidentShardBatches:
     """Iterator of (y,) minibatch shards over THIS RANK'S slice of the dataset only (`shard` = rows shard_bounds(..) of
     the full set, already on the device): nothing but the gradient all-reduce crosses ranks, and a GPU holds 1/world of
-    the data.  With world = 1 this is the plain shuffled loop of the reference.  Empty contributions (a shard that ran
-    out one minibatch early) are yielded with reducer weight 0, as in ShardedBatches."""
+    the data.  With world = 1 this is the plain shuffled loop of the reference.  The plan (shard_plan) has the
+    reference's ceil(N / gb) minibatches of gb images (last one ragged); a rank whose share of a minibatch is empty
+    (gb < world, or the tail) still yields it, with reducer weight 0, as in ShardedBatches."""
 
     def __init__(self, shard, n_items: int, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
                  seed: int = 0, reducer: GradReducer = None):

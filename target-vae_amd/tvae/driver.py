@@ -276,7 +276,8 @@ def run(kind: str, argv=None):
 
     params = list(generator_model.parameters()) + list(encoder_model.parameters())
     reducer = dp.GradReducer() if world > 1 else None
-    optimizer = optim.FlatAdam(params, lr=args.learning_rate, reducer=reducer)
+    optimizer = optim.FlatAdam(params, lr=args.learning_rate, reducer=reducer,
+                               early_params=len(list(generator_model.parameters())))   # decoder gradients: first bucket
     if world > 1:
         torch.distributed.broadcast(optimizer.flat_p, src=0)       # identical replicas: parameters ...
         dp.broadcast_buffers(generator_model, encoder_model)       # ... and the random Fourier buffers

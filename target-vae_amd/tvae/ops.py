@@ -344,9 +344,13 @@ def _enc_tail_perm(device) -> torch.Tensor:
     return _dev_table(('enc_tail_perm',), device, build)[0]
 
 
-def _enc_tail_fused(C: int, C2: int, nh: int) -> bool:
-    """Fused encoder tail (enc_tail_x6_kernels.hpp): the reference's default 128 channels, <= 7 head rows, split pipe."""
-    return FUSE_ENC_TAIL and split_pipe() and C == 128 and C2 == 128 and nh <= 7
+ENC_TAIL_MAX_COLS = 1 << 25      # the fused kernels index 32 rows with 32-bit byte offsets (abi_enc_tail_x6.hip: ET_MAX_LD)
+
+
+def _enc_tail_fused(C: int, C2: int, nh: int, N: int = 0) -> bool:
+    """Fused encoder tail (enc_tail_x6_kernels.hpp): the reference's default 128 channels, <= 7 head rows, split pipe,
+    fewer than 2^25 columns (beyond that the unfused path with 64-bit indexing takes over)."""
+    return FUSE_ENC_TAIL and split_pipe() and C == 128 and C2 == 128 and nh <= 7 and N < ENC_TAIL_MAX_COLS
 
 
 class EncoderFn(torch.autograd.Function):
@@ -375,7 +379,7 @@ class EncoderFn(torch.autograd.Function):
         H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
         bits = None
-        if _enc_tail_fused(C, C2, nh):
+        if _enc_tail_fused(C, C2, nh, N):
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
             w3 = _split_weight(W2, C2, C, False, 'enc_w2')
             _note('enc.tail_fwd_x6')

@@ -17,7 +17,7 @@ ALIGN = 64      # floats
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, update_fn=None):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, update_fn=None, early_params=None):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._ps = [p for g in self.param_groups for p in g['params']]
@@ -45,8 +45,31 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = gv
                 self._gviews.append(gv)
         self.steps = 0
-        self.reducer = reducer            # callable(flat_g) -> grad_scale  (data-parallel all-reduce)
+        self.reducer = reducer            # callable(flat_g, start) -> grad_scale  (data-parallel all-reduce)
         self._update = update_fn or ops.adam_flat
+        # Two gradient buckets: the first `early_params` parameters (the drivers pass the generator's --
+        # the decoder backward runs first, section 3.2) form a leading segment of the flat buffer whose all-reduce is
+        # posted from inside the backward, as soon as the last of them has accumulated its gradient; the rest follows at
+        # step().  Only with a reducer that can post (`begin`) and more than one rank.
+        self._early_n = 0
+        self._early_end = 0
+        self._early_seen = 0
+        self._early_posted = False
+        if early_params and reducer is not None and hasattr(reducer, 'begin') and getattr(reducer, 'active', False):
+            self._early_n = min(int(early_params), len(self._ps))
+            self._early_end = self._offsets[self._early_n] if self._early_n < len(self._ps) else total
+            for p in self._ps[:self._early_n]:
+                p.register_post_accumulate_grad_hook(self._early_hook)
+
+    def _early_hook(self, _p):
+        self._early_seen += 1
+        if self._early_seen != self._early_n or self._early_posted:
+            return
+        for p, gv in zip(self._ps[:self._early_n], self._gviews[:self._early_n]):
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                return                      # a gradient was not accumulated in place: step() reduces everything
+        self._early_posted = True
+        self.reducer.begin(self.flat_g[:self._early_end])
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
@@ -63,7 +86,11 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = gv
         scale = 1.0
         if self.reducer is not None:
-            scale = self.reducer(self.flat_g)
+            if self._early_n and not self._early_posted:
+                self.reducer.begin(self.flat_g[:self._early_end])      # no backward ran here (empty shard): same order
+                self._early_posted = True
+            scale = self.reducer(self.flat_g, self._early_end) if self._early_posted else self.reducer(self.flat_g)
+            self._early_seen, self._early_posted = 0, False
         g = self.param_groups[0]
         self.steps += 1
         self._update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.steps, g['lr'], g['betas'][0],

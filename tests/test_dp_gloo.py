@@ -49,7 +49,8 @@ def _train(rank, world, epochs=2):
     gen, enc = _make_params()
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
-    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam,
+                          early_params=len(list(gen.parameters())))
     data, E, ez, et = _data_and_noise()
     x = O.image_coords(NPIX)
     batches = dp.ShardedBatches(data, GB, rank, world, shuffle=True, seed=5, reducer=reducer)
@@ -69,6 +70,8 @@ def _train(rank, world, epochs=2):
             opt.zero_grad()
             stats[0] += float(elbo) * (hi - lo)
             stats[1] += hi - lo
+    if world > 1:           # two buckets: the decoder segment was posted from inside every backward (tvae/optim.py)
+        assert reducer.posted_early == epochs * len(batches) and not reducer._pending
     stats = dp.allreduce_stats(stats, torch.device('cpu'))
     named = {'d.' + k_: v.detach().clone() for k_, v in gen.named_parameters()}
     named.update({'e.' + k_: v.detach().clone() for k_, v in enc.named_parameters()})
@@ -117,13 +120,14 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
 # ----------------------------------------------------------------------------------------------------------------
 # shard-RESIDENT loop (what the drivers use): a rank holds only its contiguous slice of the dataset; the global
 # minibatches are a shuffle stratified by shard.  Two gloo ranks == one process walking dp.resident_global_batches.
-def _train_resident(rank, world, emulate=2, epochs=2):
+def _train_resident(rank, world, emulate=2, epochs=2, GB=GB):
     from oracle import tvae_oracle as O
     from tvae import dp, optim
     gen, enc = _make_params()
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
-    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam,
+                          early_params=len(list(gen.parameters())))
     data, E, ez, et = _data_and_noise()
     x = O.image_coords(NPIX)
     n_img = N_IMG - 3                                   # 8 images, global minibatches of 6: ragged tail, quota 3 per rank
@@ -163,7 +167,7 @@ def _train_resident(rank, world, emulate=2, epochs=2):
     return named, stats
 
 
-def _worker_resident(rank, world, port, out_dir):
+def _worker_resident(rank, world, port, out_dir, gb=GB):
     for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -172,16 +176,19 @@ def _worker_resident(rank, world, port, out_dir):
     torch.set_num_threads(2)
     from tvae import dp
     dp.init_from_env(backend='gloo')
-    flat, stats = _train_resident(rank, world)
+    flat, stats = _train_resident(rank, world, GB=gb)
     torch.save(dict(flat=flat, stats=stats), os.path.join(out_dir, f'res_rank{rank}.pt'))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_resident_shards_match_single_process(tmp_path):
+@pytest.mark.parametrize('gb', [6, 5])       # 5: global minibatch not divisible by the ranks (3+2, then 1+2 of 8 images)
+def test_two_rank_resident_shards_match_single_process(tmp_path, gb):
     torch.set_num_threads(4)
-    flat1, stats1 = _train_resident(0, 1)
-    mp.spawn(_worker_resident, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    from tvae import dp
+    assert [sum(c) for c in dp.shard_plan(N_IMG - 3, gb, 2)] == [gb, N_IMG - 3 - gb]
+    flat1, stats1 = _train_resident(0, 1, GB=gb)
+    mp.spawn(_worker_resident, args=(2, _free_port(), str(tmp_path), gb), nprocs=2, join=True)
     r0 = torch.load(tmp_path / 'res_rank0.pt')
     r1 = torch.load(tmp_path / 'res_rank1.pt')
     for k_ in flat1:
@@ -211,7 +218,8 @@ def _train_epoch_product(rank, world):
         theta_prior=np.pi, normal_prior_over_r=False)
     params = list(gen.parameters()) + list(enc.parameters())
     reducer = dp.GradReducer() if world > 1 else None
-    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam)
+    opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam,
+                          early_params=len(list(gen.parameters())))
     if world > 1:
         dist.broadcast(opt.flat_p, src=0)
         dp.broadcast_buffers(gen, enc)

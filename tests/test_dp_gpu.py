@@ -31,14 +31,14 @@ def _models(dev):
     return gen.to(dev), enc.to(dev)
 
 
-def _train(rank, world, dev_index=0):
+def _train(rank, world, dev_index=0, always=False):
     from tvae import dp, optim, step, tables
     dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
     gen, enc = _models(dev)
     params = list(gen.parameters()) + list(enc.parameters())
-    reducer = dp.GradReducer() if world > 1 else None
-    opt = optim.FlatAdam(params, lr=1e-3, reducer=reducer)
+    reducer = dp.GradReducer(always=always) if (world > 1 or always) else None
+    opt = optim.FlatAdam(params, lr=1e-3, reducer=reducer, early_params=len(list(gen.parameters())))
     if world > 1:
         dist.broadcast(opt.flat_p, src=0)
     g = torch.Generator().manual_seed(11)
@@ -59,6 +59,8 @@ def _train(rank, world, dev_index=0):
             opt.zero_grad()
             tot[0] += float(elbo) * (hi - lo)
             tot[1] += hi - lo
+    if reducer is not None:   # two buckets: the decoder segment went out from inside every backward
+        assert reducer.posted_early == 2 * len(batches) and not reducer._pending
     tot = dp.allreduce_stats(tot, dev)
     named = {'d.' + k_: v.detach().cpu().clone() for k_, v in gen.named_parameters()}
     named.update({'e.' + k_: v.detach().cpu().clone() for k_, v in enc.named_parameters()})
@@ -95,6 +97,38 @@ def test_two_ranks_on_gpu_match_single_process(tmp_path):
         assert rel_err(r0['named'][k_], named1[k_]) < 2e-4, k_
     assert r0['tot'][1] == tot1[1] == 2 * N_IMG
     assert abs(r0['tot'][0] - tot1[0]) / abs(tot1[0]) < 1e-5
+
+
+def _worker_rccl_one(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)       # "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == 'nccl'
+    named, tot = _train(0, 1, always=True)
+    torch.save(dict(named=named, tot=tot), os.path.join(out_dir, 'rccl_one.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_group_runs_the_collective_path(tmp_path):
+    """What a 1-GPU box can execute of the RCCL path: a ONE-rank `nccl` process group, the reducer forced to issue its
+    collectives (GradReducer(always=True)): communicator creation, the early decoder bucket posted asynchronously from the
+    backward hook on RCCL's stream, the second bucket and the wait at the optimizer step, the statistics all-reduce.
+    With one rank every collective is an identity, so the result must equal the plain single-process run BITWISE."""
+    named1, tot1 = _train(0, 1)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.start_processes(_worker_rccl_one, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method='spawn')
+    r = torch.load(tmp_path / 'rccl_one.pt')
+    for k_ in named1:
+        assert torch.equal(r['named'][k_], named1[k_]), k_
+    assert r['tot'] == tot1
 
 
 def _worker_rccl(rank, world, port, out_dir):

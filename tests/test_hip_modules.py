@@ -251,9 +251,11 @@ def test_step_hot_widths_golden(name, gemm_mode):
 def test_step_does_not_read_out_of_bounds(cfg):
     """Out-of-bounds READ detector.  Every float tensor the step allocates (torch.empty / torch.zeros, workspaces
     included) becomes a view into the middle of a larger allocation; ELBO and every gradient must be bitwise independent
-    of what the guard bands hold (0, 1e4, NaN) -- a kernel that reads past a row end, a padded tile or an unwritten
-    workspace slab, and lets it into a result with any weight, fails here.  Full kernel widths (C = 128, hidden 512) at
-    small batches."""
+    of what the guard bands hold (0, 1e4, NaN) -- a kernel that reads past a row end or a padded tile and lets it into
+    a result with any weight fails here.  The INTERIOR of every torch.empty allocation (scratch / workspace tensors
+    included) starts out with the same fill value, so an element that is consumed before any kernel wrote it (an
+    unwritten workspace slab, an accumulate-into-uninitialised launch) changes the result between the three runs too.
+    Full kernel widths (C = 128, hidden 512) at small batches."""
     import src.models as M
     from tvae import ops, step, tables
     n, zd, R, B, C, hid, k, pad, four = {'small': (20, 2, 8, 8, 8, 32, 20, 4, False),
@@ -284,6 +286,8 @@ def test_step_does_not_read_out_of_bounds(cfg):
             v = big[guard:guard + t.numel()].view(t.shape)
             if real is real_zeros:
                 v.zero_()
+            else:
+                v.fill_(fill[0])      # torch.empty interior: an element consumed before any kernel wrote it shows too
             return v
         return f
 

@@ -196,13 +196,24 @@ def test_resident_shard_plan_visits_every_image_once():
     """Shard-resident batches: every image exactly once per epoch, each rank only its own rows, global minibatch sizes
     known to every rank without communication."""
     from tvae import dp
-    for n, gb, world in ((37, 16, 2), (100, 32, 8), (5, 6, 4), (64, 16, 1), (13, 6, 2)):
+    for n, gb, world in ((37, 16, 2), (100, 32, 8), (5, 6, 4), (64, 16, 1), (13, 6, 2), (60000, 100, 8),
+                         (60000, 100, 3), (7, 2, 4), (1003, 100, 8), (9, 1, 4), (0, 4, 2)):
         plan = dp.shard_plan(n, gb, world)
         assert sum(sum(c) for c in plan) == n
+        # the reference's loop: ceil(N / gb) minibatches, batch i holds min(gb, N - i*gb) images (train_mnist.py:586);
+        # also when gb % world != 0 (driver default 100 over 8 ranks) and when gb < world
+        assert len(plan) == (n + gb - 1) // gb
+        for i, c in enumerate(plan):
+            g = min(gb, n - i * gb)
+            assert sum(c) == g
+            assert max(c) - min(c) <= 1 or n - i * gb < gb + world      # even shares (the very tail may be ragged)
         for r in range(world):
             r0, r1 = dp.shard_bounds(n, r, world)
             assert sum(c[r] for c in plan) == r1 - r0
         glob = dp.resident_global_batches(n, gb, world, 3, 1)
+        if n == 0:
+            assert glob == []
+            continue
         assert sorted(torch.cat(glob).tolist()) == list(range(n))
         assert [len(g) for g in glob] == [sum(c) for c in plan]
         assert all(len(g) <= gb for g in glob)
