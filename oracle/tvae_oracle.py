@@ -203,6 +203,21 @@ def encoder_forward(p: Dict[str, Tensor], y: Tensor, E: Tensor, R: int, padding:
     return attn, q_t_r, p_r, a_sampled, offsets, theta, z
 
 
+def encoder_heads(p: Dict[str, Tensor], y: Tensor, R: int, padding: int):
+    """The deterministic part of the encoder forward up to the three 1x1x1 heads (models.py:355-358,390,392), for
+    tests that need the pre-activations: returns (heads, pre1, pre2) with heads (B, 3+2z, R, Ho, Ho) stacked as
+    (conv_a | conv_r (2) | conv_z (2z)) BEFORE the prior / offsets are added, pre1 = conv1 output + bias (input of the
+    first LeakyReLU, :355) and pre2 = conv2 output (input of the second, :356)."""
+    def pw(t, w, b):
+        return torch.einsum('oc,bcrhw->borhw', w.view(w.shape[0], -1), t) + b.view(1, -1, 1, 1, 1)
+    pre1 = groupconv_forward(y, p['conv1.weight'], p['conv1.bias'], R, padding)
+    pre2 = pw(lrelu(pre1), p['conv2.weight'], p['conv2.bias'])
+    h = lrelu(pre2)
+    heads = torch.cat([pw(h, p['conv_a.weight'], p['conv_a.bias']), pw(h, p['conv_r.weight'], p['conv_r.bias']),
+                       pw(h, p['conv_z.weight'], p['conv_z.bias'])], dim=1)
+    return heads, pre1, pre2
+
+
 # --------------------------------------------------------------------------------------
 # SpatialGenerator  (models.py:65-123)
 # --------------------------------------------------------------------------------------

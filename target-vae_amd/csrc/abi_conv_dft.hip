@@ -6,10 +6,18 @@
 
 using namespace tvae;
 
+static int dev_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
 // Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
 struct DftPlan {
     int L, Lh, Ho, M, K2, Cin; // frame, half spectrum, output size, rows C*R, reduction 2*L*Cin
     bool gen;                  // generic transforms along w (Lh > 64 or Ho > 64: no specialised instance)
+    int ring;                  // ring (LDS-DMA) transforms along w: 0 = none, 1 / 2 / 3 = the 44- / 96- / 66-wide frame
     int LHP, NT, REM1;         // forward w-transform: frequencies processed, 32-row output tiles, extra row
     int NS, NRT;               // backward w-transform: k2-steps (pairs of w), 32-row tiles of (fx, ri)
     int FXB, nblk;             // spectra: frequencies per workgroup, blocks per plane
@@ -46,7 +54,14 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.w3_floats = dense_x6_bytes(q.Lh * q.Mb, q.K2) / 4;
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
     q.gen = q.Lh > 64 || q.Ho > DFT_WROWS;
-    if (q.gen) {                                               // whole 32-row tiles, zero rows beyond Ho
+    // frames of the reference configurations (28x28 k28 p8; 64x64 k64 p16; the 50x50 MNIST-U geometry k28 p8) take the
+    // ring kernels (conv_dft_kernels.hpp); TVAE_DFT_RING=0 keeps the register-staged ones (A/B measurements)
+    static const bool ring_on = [] { const char* e = getenv("TVAE_DFT_RING"); return !(e && e[0] == '0'); }();
+    q.ring = !ring_on ? 0 : (q.L == 44 && q.Ho == 17) ? 1 : (q.L == 96 && q.Ho == 33) ? 2 : (q.L == 66 && q.Ho == 39) ? 3 : 0;
+    if (q.ring) {              // (LHP, NT, REM1) / (NS, NRT) of the instances: tables sized to match
+        q.LHP = q.Lh; q.NT = q.ring == 3 ? 2 : 1; q.REM1 = q.ring == 2 ? 1 : 0;
+        q.NS = (q.Ho + 1) / 2; q.NRT = q.ring == 1 ? 2 : 3;
+    } else if (q.gen) {                                               // whole 32-row tiles, zero rows beyond Ho
         q.LHP = q.Lh; q.NT = (q.Ho + 31) / 32; q.REM1 = 0;
         q.NS = (q.Ho + 1) / 2; q.NRT = (2 * q.Lh + 31) / 32;
     } else {
@@ -79,7 +94,7 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.lds_db = lds_db(q.FXBd);
     q.ok = Cin >= 1 && q.Ho >= 1 && q.NT <= 5 && q.lds_sp <= 152 * 1024 && q.lds_db <= 152 * 1024 &&
            (long)q.Lh * q.Mb < 2000000000L && (size_t)4 * 32 * ((2 * q.NS) | 1) * 4 <= 150 * 1024 &&
-           (long)B * Cin * q.nblk + (long)q.M * Cin * q.nblk < 2000000000L;
+           (long)B * Cin * q.nblk + (long)q.M * Cin * q.nblk < 2000000000L && (long)q.M * (q.NBpad / 32) < 2000000000L;
     return q;
 }
 
@@ -152,6 +167,25 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
                            q.NRT);
         TVAE_CHECK_LAUNCH();
         const long ntiles = (long)q.M * (q.NBpad / 32);
+        if (q.ring) {
+            const long vt = (long)q.M * ((q.NB + 31) / 32);           // tiles with at least one real column
+            const int cus = dev_cu_count();
+            const int grid = (int)((vt + 3) / 4 < cus ? (vt + 3) / 4 : cus);
+#define TVAE_OUT_RING(L_, N_, R_, H_)                                                                               \
+    do {                                                                                                            \
+        const size_t lds_r = (size_t)4 * 3 * ((L_ + 3) / 4) * 1024;                                                 \
+        e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_>, lds_r);                                              \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_>), dim3(grid), dim3(256), lds_r, st, (const float*)T, \
+                           (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);                               \
+    } while (0)
+            if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);
+            else if (q.ring == 2) TVAE_OUT_RING(49, 1, true, 33);
+            else TVAE_OUT_RING(34, 2, false, 39);
+#undef TVAE_OUT_RING
+            TVAE_CHECK_LAUNCH();
+            return 0;
+        }
         if (q.gen) {
             const int grid = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
 #define TVAE_OUT_GEN(N_)                                                                                            \
@@ -206,7 +240,24 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
                            q.NT + q.REM1, q.NS, q.NRT);
         TVAE_CHECK_LAUNCH();
         const long ntiles = (long)q.M * (q.NBpad / 32);
-        if (q.gen) {
+        if (q.ring) {
+            const int cus = dev_cu_count();
+            const int grid = (int)((ntiles + 3) / 4 < 2 * cus ? (ntiles + 3) / 4 : 2 * cus);
+            hipError_t er = hipSuccess;
+#define TVAE_DY_RING(S_, T_, L2_, H_, Q_)                                                                           \
+    do {                                                                                                            \
+        const size_t lds_r = (size_t)4 * 2 * ((32 * H_ + 63) / 64) * 256;                                           \
+        er = allow_big_lds(dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>, lds_r);                                         \
+        if (er != hipSuccess) return (int)er;                                                                       \
+        hipLaunchKernelGGL((dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>), dim3(grid), dim3(256), lds_r, st, dpre,       \
+                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad);                                         \
+    } while (0)
+            if (q.ring == 1) TVAE_DY_RING(9, 2, 46, 17, false);
+            else if (q.ring == 2) TVAE_DY_RING(17, 3, 98, 33, true);
+            else TVAE_DY_RING(20, 3, 68, 39, false);
+#undef TVAE_DY_RING
+            TVAE_CHECK_LAUNCH();
+        } else if (q.gen) {
             const size_t lds_g = (size_t)4 * 32 * ((2 * q.NS) | 1) * 4;
             hipError_t eg = allow_big_lds(dft_dy_gen_kernel, lds_g);
             if (eg != hipSuccess) return (int)eg;

@@ -424,6 +424,292 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
     }
 }
 
+// ==========================================================================================
+// Ring forms of the two transforms along w for the frames of the reference configurations (28x28: L = 44, Ho = 17;
+// 64x64: L = 96, Ho = 33; the 50x50 MNIST-U / MNIST-N geometry: L = 66, Ho = 39).
+//
+// What bounded the register-staged kernels above was not the memory system but the compiler's in-order vmcnt
+// bookkeeping (round-3 ISA reading): its loads of the NEXT tile and its stores of the CURRENT one share one counter,
+// and the wait it places in front of the next tile's first use (a loop-header merge of "16 younger operations")
+// makes every wave wait, once per tile, until most of its own output stores have been ACKNOWLEDGED (dft_dy_mf), or
+// drains the whole queue right before the MFMA chain (dft_out_mf: `s_waitcnt vmcnt(0)` in front of the first MFMA,
+// the next tile's loads sunk behind the chain).  Here every streamed operand arrives by `global_load_lds` DMAs that
+// the compiler does not see, into a per-wave ring in LDS, with hand-counted `s_waitcnt vmcnt(N)` (N = the exact number
+// of younger DMAs and stores, all issued unconditionally so that the count is uniform); there is no ordinary vector
+// load in the loops, so the compiler places no vmcnt wait of its own, and the MFMA B operand is read straight from
+// the ring (lane-linear: conflict free).  The constant operand lives in registers.
+// ==========================================================================================
+#define TVAE_DFT_DMA_X4(dst, src) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory")
+#define TVAE_DFT_DMA_X1(dst, src) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory")
+#define TVAE_DFT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]) -- the contraction over fx.  One wave owns a tile
+// (filter row m, 32 columns n): its 2 * LHP frequency rows x 32 columns arrive as ND = ceil(LHP / 4) 1-KB DMAs (lane ->
+// (fx & 3, re | im, 4 columns); the LDS image is [fx][re | im][32 columns] = the B-operand order of the K = 2 MFMA).
+// Three slots per wave: while tile `it` is on the matrix pipe, tile it+1 is in flight and the pieces of tile it+2 are
+// issued between the MFMAs into the slot tile it-1 has left; the consumed slot doubles as the transposition patch of the
+// epilogue.  One 4-wave workgroup per CU (3 x 13 KB per wave at the 96-wide frame).  Per tile: ND DMAs, then SN stores;
+// at the top of iteration it >= 2 the operations younger than tile it's DMAs are stores(it-2), DMAs(it+1), stores(it-1).
+template <int LHP, int NT, bool REM1, int HO>
+static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float* __restrict__ T, const float* __restrict__ EO,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int M, int R, int B, int Lh, int act, float slope) {
+    constexpr int NTT = NT + (REM1 ? 1 : 0), ND = (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
+    constexpr int SN = (32 * HO + 63) / 64, SWO = HO | 1, P = HO * HO;
+    static_assert(32 * SWO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
+    static_assert(ND + 2 * SN <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* ring = sm_w + wave * (3 * SLOTF);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm_w + (unsigned)(wave * 3 * SLOTB);
+    float eo[LHP][NTT];
+#pragma unroll
+    for (int fx = 0; fx < LHP; ++fx)
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) eo[fx][t] = EO[(fx * NTT + t) * 64 + lane];
+    const long NB = (long)B * HO;
+    const int tiles_n = (int)((NB + 31) / 32);           // n-tiles with at least one real column
+    const long ntiles = (long)M * tiles_n, stride = (long)gridDim.x * 4;
+    const long first = (long)blockIdx.x * 4 + wave;
+    if (first >= ntiles) return;                         // (no workgroup barrier anywhere in this kernel)
+    const int my = (int)((ntiles - first + stride - 1) / stride);
+    const int fxl = lane >> 4, rid = (lane >> 3) & 1, c4 = (lane & 7) * 4;
+    auto tile_mn = [&](int it, int& m, long& n0) {
+        const int tl = (int)(first + (long)(it < my ? it : my - 1) * stride);   // past the end: the last tile again
+        m = tl / tiles_n;                                // (host: fewer than 2^31 tiles)
+        n0 = (long)(tl - m * tiles_n) * 32;
+    };
+    auto dma_base = [&](int it) -> const float* {
+        int m;
+        long n0;
+        tile_mn(it, m, n0);
+        return T + dft_t_off(n0 + c4, rid * M + m, 2 * M, Lh);
+    };
+    auto dma_piece = [&](const float* tp, int slot, int g) {
+        const int fx = min(4 * g + fxl, Lh - 1);         // rows beyond Lh (last piece) re-read the last row; never used
+        const float* src = tp + (long)fx * 128;
+        const unsigned dst = ring_lds + (unsigned)(slot * SLOTB + g * 1024);
+        TVAE_DFT_DMA_X4(dst, src);
+    };
+    {
+        const float* t0 = dma_base(0);
+#pragma unroll
+        for (int g = 0; g < ND; ++g) dma_piece(t0, 0, g);
+        const float* t1 = dma_base(1);
+#pragma unroll
+        for (int g = 0; g < ND; ++g) dma_piece(t1, 1, g);
+    }
+    int slot = 0;
+    for (int it = 0; it < my; ++it) {
+        if (it == 0) TVAE_DFT_VMCNT(ND);
+        else if (it == 1) TVAE_DFT_VMCNT(ND + SN);
+        else TVAE_DFT_VMCNT(ND + 2 * SN);
+        const float* tpn = dma_base(it + 2);
+        const int slot2 = slot == 0 ? 2 : slot - 1;      // (it + 2) % 3: the slot tile it-1 has left
+        const float* vs = ring + slot * SLOTF + lane;
+        f32x16 acc[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
+        float racc = 0.f;
+#pragma unroll
+        for (int fx = 0; fx < LHP; ++fx) {
+            const float v = vs[fx * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t][fx & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx][t], v, acc[t][fx & 1], 0, 0, 0);
+            if (REM1) racc = __fmaf_rn(eo[fx][NTT - 1], v, racc);
+            if ((fx & 3) == 1) dma_piece(tpn, slot2, fx >> 2);               // tile it+2, one piece per four MFMA steps
+        }
+#pragma unroll
+        for (int g = 0; g < ND; ++g)
+            if (4 * g + 1 >= LHP) dma_piece(tpn, slot2, g);                  // pieces the unrolled loop did not reach
+        int m;
+        long n0;
+        tile_mn(it, m, n0);
+        const int c = m / R, r_ = m - c * R;
+        const float bv = bias ? bias[c] : 0.f;
+        float* stg = ring + slot * SLOTF;                // the slot just consumed: [32 columns][SWO]
+        const float sl = act == ACT_LRELU ? slope : 1.f;     // ACT_NONE: slope 1
+        float rtot = 0.f;
+        if (REM1) rtot = racc + __shfl_xor(racc, 32, 64) + bv;
+        if (act == ACT_TANH) {                           // (one uniform branch around the whole block, not one per element)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][0][r] = tanhf(acc[t][0][r] + acc[t][1][r] + bv);
+            rtot = tanhf(rtot);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[t][0][r] + acc[t][1][r] + bv;
+                    acc[t][0][r] = x > 0.f ? x : x * sl;
+                }
+            rtot = rtot > 0.f ? rtot : rtot * sl;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * ri;
+                if (32 * t + 31 < HO || w < HO) stg[j * SWO + w] = acc[t][0][r];
+            }
+        if (REM1) {
+            if (ri == 0) stg[j * SWO + 32 * NT] = rtot;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the 32 output rows of the tile are 32*HO consecutive floats of out, plus (R-1)*P for every image boundary
+        // before the row.  Exactly SN store instructions per tile: lanes past the end repeat the last element.
+        const int b0 = (int)(n0 / HO), h0 = (int)(n0 - (long)b0 * HO);
+        float* obase = out + (((long)c * B + b0) * R + r_) * P + (long)h0 * HO;
+        const int jump = (R - 1) * P;
+        const int cnt = (int)(NB - n0 < 32 ? NB - n0 : 32) * HO;
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+            const int e = min(i * 64 + lane, cnt - 1);
+            const int t = e / HO, w = e - t * HO;
+            const int k = (h0 + t) / HO;
+            obase[e + k * jump] = stg[t * SWO + w];
+        }
+        __builtin_amdgcn_wave_barrier();
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    TVAE_DFT_VMCNT(0);                                   // the clamped tail DMAs still target this wave's ring
+}
+
+// number of store instructions dft_dy_ring_kernel issues per tile (rows 32 rt + (r & 3) + 8 (r >> 2) [+ 4] below LH2)
+constexpr int dft_dy_ring_stores(int NRT, int LH2, bool NYQ) {
+    int n = NYQ ? 1 : 0;
+    for (int rt = 0; rt < NRT; ++rt)
+        for (int r = 0; r < 16; ++r)
+            if (32 * rt + (r & 3) + 8 * (r >> 2) < LH2) ++n;
+    return n;
+}
+
+// S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w] -- the DFT over w of the output gradient.  The 32 x HO values
+// of a tile are (mostly) one contiguous run of dY: NL = ceil(32 HO / 64) dword DMAs bring it into the wave's slot in
+// exactly that order ([column][w], row pitch HO: odd, so the B-operand reads column (lane & 31), w = 2s + (lane >> 5)
+// are conflict free) -- no register staging, no transposition.  Two slots per wave; the DMAs of tile it+1 are issued
+// between the MFMAs of tile it, and the only operations younger than them at the next wait are this tile's ST stores.
+// NYQ (2 Lh = 32 NRT + 2, even frame): the Nyquist row is an alternating sum on the vector ALU (its sine row is zero),
+// one store for both; without it those two rows would cost a whole fourth tile of MFMAs (17 of 68 at the 96-wide frame).
+template <int NS, int NRT, int LH2, int HO, bool NYQ>
+static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+                                                                    float* __restrict__ Sp, int M, int R, int B, int Lh,
+                                                                    long NBpad) {
+    constexpr int NL = (32 * HO + 63) / 64, SLOTB = NL * 256, SLOTF = NL * 64, P = HO * HO;
+    constexpr int ST = dft_dy_ring_stores(NRT, LH2, NYQ);
+    static_assert((HO & 1) == 1 && 2 * NS <= HO + 1 && 2 * NS >= HO, "odd output width, NS = ceil(HO / 2)");
+    static_assert(ST <= 63, "vmcnt is a 6-bit counter");
+    static_assert(!NYQ || LH2 == 32 * NRT + 2, "Nyquist rows on the vector ALU");
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    const int lane = threadIdx.x & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* ring = sm_w + wave * (2 * SLOTF);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm_w + (unsigned)(wave * 2 * SLOTB);
+    float areg[NS][NRT];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) areg[s_][rt] = ED[(s_ * NRT + rt) * 64 + lane];
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * HO;
+    const long stride = (long)gridDim.x * 4;
+    const long first = (long)blockIdx.x * 4 + wave;
+    if (first >= ntiles) return;
+    const int my = (int)((ntiles - first + stride - 1) / stride);
+    const int jump = (R - 1) * P;
+    auto tile_mn = [&](int it, int& m, long& n0) {
+        const int tl = (int)(first + (long)(it < my ? it : my - 1) * stride);
+        m = tl / (int)tiles_n;
+        n0 = (long)(tl - m * (int)tiles_n) * 32;
+    };
+    // source of the NL DMAs of a tile: element e = 64 i + lane is (column t = e / HO, w = e % HO).  Columns past the end
+    // of the batch re-read the last valid column (finite values; those columns of S' only ever meet zero columns of A^T).
+    struct Src { const float* base; int h0, tlast; };
+    auto dma_src = [&](int it) {
+        int m;
+        long n0;
+        tile_mn(it, m, n0);
+        if (n0 >= NB) n0 = 0;
+        const int c = m / R, r_ = m - c * R;
+        const int b0 = (int)(n0 / HO), h0 = (int)(n0 - (long)b0 * HO);
+        Src s;
+        s.base = dY + (((long)c * B + b0) * R + r_) * P + (long)h0 * HO;
+        s.h0 = h0;
+        s.tlast = (int)(NB - n0 < 32 ? NB - n0 : 32) - 1;
+        return s;
+    };
+    auto dma_piece = [&](const Src& s, int slot, int i) {
+        const int e = i * 64 + lane;
+        const int t = e / HO;
+        const int tc = t < s.tlast ? t : s.tlast;
+        const int k = (s.h0 + tc) / HO;
+        const float* src = s.base + (e + (tc - t) * HO + k * jump);
+        const unsigned dst = ring_lds + (unsigned)(slot * SLOTB + i * 256);
+        TVAE_DFT_DMA_X1(dst, src);
+    };
+    {
+        const Src s0 = dma_src(0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) dma_piece(s0, 0, i);
+    }
+    for (int it = 0; it < my; ++it) {
+        const int slot = it & 1;
+        if (it == 0) TVAE_DFT_VMCNT(0);
+        else TVAE_DFT_VMCNT(ST);
+        const Src sn = dma_src(it + 1);
+        const float* bs = ring + slot * SLOTF + j * HO + kh;
+        f32x16 acc[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+        float racc = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float bq = bs[2 * s_];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_][rt], bq, acc[rt], 0, 0, 0);
+            if (NYQ) {                                   // (-1)^w, w = 2 s + kh; the last step's kh = 1 half is w = HO: outside
+                if (2 * s_ + 1 < HO) racc += kh ? -bq : bq;
+                else racc += kh ? 0.f : bq;
+            }
+            if (s_ < NL) dma_piece(sn, slot ^ 1, s_);    // tile it+1, one piece per k-step
+        }
+#pragma unroll
+        for (int i = NS; i < NL; ++i) dma_piece(sn, slot ^ 1, i);
+        int m;
+        long n0;
+        tile_mn(it, m, n0);
+        // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh: ri is a compile-time property of (rt, r)
+        float* q0 = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);
+        float* q1 = Sp + dft_t_off(n0 + j, M + m, 2 * M, Lh);
+        float* p0 = q0 + 2 * kh * 128;                   // real rows, fx = fx0 + 2 kh
+        float* p1 = q1 + 2 * kh * 128;                   // imaginary rows
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);             // kh = 0; kh = 1 adds 4
+                float* p = (kk0 & 1) ? p1 : p0;
+                const int fx0 = kk0 >> 1;
+                if (kk0 + 4 < LH2) p[fx0 * 128] = acc[rt][r];
+                else if (kk0 < LH2) { if (kh == 0) p[fx0 * 128] = acc[rt][r]; }
+            }
+        if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
+            const float tot = racc + __shfl_xor(racc, 32, 64);
+            (kh ? q1 : q0)[(LH2 / 2 - 1) * 128] = kh ? 0.f : tot;
+        }
+    }
+    TVAE_DFT_VMCNT(0);
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic forms of the two transforms along w for frames the specialised instances above do not cover (Lh > 64 or
 // Ho > 64: the 192-wide frame of the galaxy configuration has Lh = 97, Ho = 129).  Same tile walk (one wave owns 32

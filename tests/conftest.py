@@ -93,6 +93,28 @@ def assert_encoder_grads(enc, fx, tol, prefix='ge.', kink_prefix=None, name='enc
         assert_grad_close(t.grad, want, tol=tol_k, floor=1e-3 * gmax, name=name + k_)
 
 
+def assert_trajectory_update_close(enc, gen, fx, tol, cos_min=0.999):
+    """Final state of a multi-step run (dicts / state_dicts `enc`, `gen`) against fixture entries eT.* / dT.* with the
+    initial state e.* / d.*: relative L2 error and cosine of the total update p_T - p_0, per tensor.  conv_a.bias has an
+    analytically zero gradient (softmax shift invariance): Adam follows rounding noise at up to lr per step, so it is only
+    bounded by lr * T."""
+    T = fx['curve'].shape[0]
+    for pre, d in (('e', enc), ('d', gen)):
+        for k_, v in d.items():
+            if (pre + 'T.' + k_) not in fx:
+                continue                                   # buffers
+            w = torch.from_numpy(fx[pre + 'T.' + k_]).double()
+            w0 = torch.from_numpy(fx[pre + '.' + k_]).double()
+            got = torch.as_tensor(v).detach().double().cpu()
+            if pre + '.' + k_ == 'e.conv_a.bias':
+                assert (got - w).abs().max() <= 2 * float(fx['lr']) * T + 1e-7
+                continue
+            du, dr = (got - w0).reshape(-1), (w - w0).reshape(-1)
+            rel = float((du - dr).norm() / dr.norm())
+            cos = float(torch.dot(du, dr) / (du.norm() * dr.norm()))
+            assert rel < tol and cos > cos_min, (pre + '.' + k_, rel, cos)
+
+
 def seeded_models(fx):
     """Models of a seed-based fixture (tests/golden/make_goldens.py:gen_hotpath): default init of the drop-in
     src.models classes under fx['seed'] (generator first, then encoder, head weights scaled), verified entry by entry

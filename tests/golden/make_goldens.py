@@ -452,6 +452,127 @@ def gen_epoch():
     print('    epoch', elbo, err, kl)
 
 
+def gen_trajectory():
+    """20 consecutive reference Adam steps (train_mnist.py:300-346 called once per minibatch so that the per-step ELBO is
+    observable): 28x28, P8, C = 16, hidden 64, 4 images per step, lr 2e-3 so that the parameters really move.  Stores the
+    data, the initial state, the noise of every step, the ELBO / Error / KL curve and the final parameters."""
+    torch.manual_seed(0)
+    n, zd, C, R, p, k, B, T = 28, 2, 16, 8, 8, 28, 4, 20
+    gen = models.SpatialGenerator(zd, 64, num_layers=2)
+    enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 1, zd, kernels_num=C, kernels_size=k, padding=p, groupconv=R, rot_refinement=True,
+        theta_prior=np.pi, normal_prior_over_r=False)
+    with torch.no_grad():
+        for nm in ('conv_a', 'conv_r', 'conv_z'):
+            getattr(enc, nm).weight.mul_(10.0)
+    torch.manual_seed(1)
+    data = torch.rand(B * T, 1, n, n)
+    x_coord = coords(n)
+    params = list(gen.parameters()) + list(enc.parameters())
+    lr = 2e-3
+    optim = torch.optim.Adam(params, lr=lr)
+    Ho = n + 2 * p - k + 1
+    P = R * Ho * Ho
+    out = dict(data=data, lr=np.float64(lr), cfg=np.array([n, 1, zd, C, k, p, R, 1, 0, 64, 2, 1, 0, 0]),
+               theta_prior=np.float64(np.pi), sigma=np.float64(2.0 / (n - 1)))
+    out.update({('e.' + k_): v.clone() for k_, v in enc.state_dict().items()})
+    out.update({('d.' + k_): v.clone() for k_, v in gen.state_dict().items()})
+    torch.manual_seed(555)                       # pre-draw the noise of all steps from one stream, in the reference's order
+    Es, ezs, ets = [], [], []
+    for _ in range(T):
+        Es.append(torch.empty(B, P).exponential_())
+        ezs.append(torch.normal(torch.zeros(B, zd, 1), torch.ones(B, zd, 1)).view(B, zd))
+        ets.append(torch.normal(torch.zeros(B, 1, 1), torch.ones(B, 1, 1)).view(B))
+    torch.manual_seed(555)
+    curve = []
+    for t in range(T):
+        e, err, kl = train_mnist.train_epoch([(data[t * B:(t + 1) * B],)], x_coord, gen, enc, optim, 'attention',
+                                             'attention+offsets', 0, 1, B, 'cpu', params, np.pi, R, n)
+        curve.append((e, err, kl))
+    out['E'], out['eps_z'], out['eps_theta'] = torch.stack(Es), torch.stack(ezs), torch.stack(ets)
+    out['curve'] = np.array(curve, dtype=np.float64)
+    for k_, v in enc.state_dict().items():
+        out['eT.' + k_] = v
+    for k_, v in gen.state_dict().items():
+        out['dT.' + k_] = v
+    save('trajectory_20steps', **out)
+    print('    trajectory ELBO', [round(c_[0], 2) for c_ in curve])
+
+
+def gen_wide():
+    """Secondary encoder (translation attention, rotation pooled by fc_r; src/models.py:268-319) and the particle CTF + mask
+    tail (train_particles.py:298-338) at the reference's DEFAULT widths (128 kernels, hidden 512), seed-based like the
+    hot-path fixtures: parameters are re-created from the seed by the drop-in classes and checked against digests."""
+    # (a) attention / unimodal, groupconv 4, C = 128, hidden 512 (train_mnist.py:86-185)
+    n, zd, B, gc, seed = 20, 2, 3, 4, 51
+    torch.manual_seed(seed)
+    gen = models.SpatialGenerator(zd, 512, num_layers=2)
+    enc = models.InferenceNetwork_AttentionTranslation_UnimodalRotation(n, 1, zd, kernels_num=128, groupconv=gc)
+    with torch.no_grad():
+        for nm in ('conv_a', 'conv_r', 'conv_z'):
+            getattr(enc, nm).weight.mul_(10.0)
+    torch.manual_seed(seed + 1000)
+    y = torch.rand(B, 1, n, n)
+    torch.manual_seed(77)
+    elbo, logp, kl = train_mnist.eval_minibatch(coords(n), y, gen, enc, 'attention', 'unimodal', 0, 'cpu', np.pi, gc, n)
+    (-elbo).backward()
+    out = dict(y=y, elbo=elbo, log_p=logp, kl=kl, cfg=np.array([n, zd, gc, 128, 512]), seed=np.int64(seed),
+               scale_heads=np.float64(10.0))
+    torch.manual_seed(77)
+    Ho = n + 2 * (n // 2) - n + 1
+    out['E'] = torch.empty(B, Ho * Ho).exponential_()
+    out['eps_z'] = torch.normal(torch.zeros(B, zd, 1), torch.ones(B, zd, 1)).view(B, zd)
+    out['eps_theta'] = torch.normal(torch.zeros(B, 1, 1), torch.ones(B, 1, 1)).view(B)
+    for pre, mod in (('e.', enc), ('d.', gen)):
+        for k_, v in mod.state_dict().items():
+            out['s' + pre + k_] = param_digest(v)
+        for k_, v in mod.named_parameters():
+            out['g' + pre + k_] = v.grad.clone()
+    save('wide_attention_unimodal_gc4', **out)
+    print('    wide_attention_unimodal_gc4', float(elbo), float(logp), float(kl))
+
+    # (b) particle tail with CTF + circular mask, C = 128, hidden 512, 32x32
+    import pandas as pd
+    sys.path.insert(0, REF)
+    import src.ctf as Cm
+    sys.path.pop(0)
+    rng = np.random.RandomState(1)
+    nrow, n = 3, 32
+    prm = pd.DataFrame(dict(defocus=rng.uniform(1.0, 3.0, nrow), cs=np.full(nrow, 2.7), voltage=np.full(nrow, 300.0),
+                            apix=np.full(nrow, 1.2), bfactor=rng.uniform(50, 150, nrow), ampcont=np.full(nrow, 7.0),
+                            dfdiff=np.zeros(nrow), dfang=rng.uniform(0, 180, nrow)))
+    filt = Cm.ctf_filter(prm, n - 1, n - 1, scale=1)
+    zd, k, p, R, B, seed, radius = 2, 32, 8, 8, 3, 52, 11
+    torch.manual_seed(seed)
+    gen = models.SpatialGenerator(zd, 512, n_out=1, num_layers=2)
+    enc = models.InferenceNetwork_AttentionTranslation_AttentionRotation(
+        n, 1, zd, kernels_num=128, kernels_size=k, padding=p, groupconv=R, rot_refinement=True, theta_prior=np.pi,
+        normal_prior_over_r=False)
+    with torch.no_grad():
+        for nm in ('conv_a', 'conv_r', 'conv_z'):
+            getattr(enc, nm).weight.mul_(10.0)
+    torch.manual_seed(seed + 1000)
+    y = torch.randn(B, 1, n, n)
+    ctf = torch.from_numpy(filt[:B]).float().unsqueeze(1)
+    Ho = n + 2 * p - k + 1
+    E, eps_z, eps_t = draw_noise(123, B, R * Ho * Ho, zd)
+    torch.manual_seed(123)
+    elbo, logp, kl = train_particles.eval_minibatch(coords(n), y, ctf, gen, enc, 'attention', 'attention+offsets', 0,
+                                                    'cpu', np.pi, R, p, radius)
+    (-elbo).backward()
+    out = dict(y=y, ctf=ctf, E=E, eps_z=eps_z, eps_theta=eps_t, elbo=elbo, log_p=logp, kl=kl,
+               cfg=np.array([n, 1, zd, 128, k, p, R, 1, 0, 512, 2, 1, 0, 0]), theta_prior=np.float64(np.pi),
+               sigma=np.float64(2.0 / (n - 1)), mask_radius=np.int64(radius), seed=np.int64(seed),
+               scale_heads=np.float64(10.0))
+    for pre, mod in (('e.', enc), ('d.', gen)):
+        for k_, v in mod.state_dict().items():
+            out['s' + pre + k_] = param_digest(v)
+        for k_, v in mod.named_parameters():
+            out['g' + pre + k_] = v.grad.clone()
+    save('wide_particles32_ctf_mask', **out)
+    print('    wide_particles32_ctf_mask', float(elbo), float(logp), float(kl))
+
+
 def param_digest(t):
     """(sum, abs-sum, first, last) in float64: enough to detect any difference in seeded construction."""
     t = t.detach().double().reshape(-1)
@@ -471,7 +592,14 @@ def gen_hotpath():
                                              fourier=False), 2, 'randn', 10.0, True, 31),
         ('hot_S28F_B8', train_mnist, dict(n=28, cin=1, zd=2, C=128, k=28, p=8, R=16, hidden=512, layers=2, n_out=1,
                                           fourier=True), 8, 'rand', 10.0, False, 32),
+        # the reference's REAL MNIST-U / MNIST-N geometry: 50x50 images with the default 28-tap kernel and padding 8
+        # (train_mnist.py:413-417) -> 39x39 outputs per rotation on a 66-wide frame
+        ('hot_M50_B2', train_mnist, dict(n=50, cin=1, zd=2, C=128, k=28, p=8, R=8, hidden=512, layers=2, n_out=1,
+                                         fourier=False), 2, 'rand', 10.0, False, 33),
     ]
+    only = [a for a in sys.argv[2:] if a.startswith('hot_')]
+    if only:
+        cases = [c_ for c_ in cases if c_[0] in only]
     for name, tm, c, B, data, scale, particles, seed in cases:
         n, R, zd, p = c['n'], c['R'], c['zd'], c['p']
         sigma = 2.0 / (n - 1)
@@ -579,7 +707,8 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc', 'secondary', 'hotpath']
+    which = sys.argv[1:] or ['bank', 'groupconv', 'encoder', 'decoder', 'steps', 'epoch', 'cli', 'particles_tail', 'get_latent', 'mrc', 'secondary', 'hotpath', 'trajectory', 'wide']
+    which = [w for w in which if not w.startswith('hot_')]
     for w in which:
         {'bank': gen_bank, 'groupconv': gen_groupconv, 'encoder': gen_encoder, 'decoder': gen_decoder,
-         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc, 'secondary': gen_secondary, 'hotpath': gen_hotpath}[w]()
+         'steps': gen_steps, 'epoch': gen_epoch, 'cli': gen_cli, 'particles_tail': gen_particles_tail, 'get_latent': gen_get_latent, 'mrc': gen_mrc, 'secondary': gen_secondary, 'hotpath': gen_hotpath, 'trajectory': gen_trajectory, 'wide': gen_wide}[w]()

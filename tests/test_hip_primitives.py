@@ -244,6 +244,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
 @pytest.mark.parametrize('B,n,k,pad,C,R,act,Cin', [
     (2, 28, 28, 8, 32, 8, 1, 1), (3, 64, 64, 16, 32, 8, 1, 1), (5, 40, 32, 6, 64, 4, 0, 1), (17, 64, 64, 16, 64, 8, 1, 1),
     (4, 32, 32, 8, 16, 8, 1, 1), (3, 20, 9, 2, 5, 4, 0, 1),
+    # the three frames of the ring (LDS-DMA) transforms along w, with several tiles per wave (steady-state vmcnt
+    # bookkeeping: iterations 0, 1 and >= 2 differ), ragged last column tiles, tanh; and the real 50x50 MNIST-U geometry
+    (40, 28, 28, 8, 32, 8, 1, 1), (24, 64, 64, 16, 16, 8, 1, 1), (12, 50, 28, 8, 32, 8, 1, 1), (2, 50, 28, 8, 8, 4, 2, 1),
+    (3, 28, 28, 8, 16, 8, 2, 1),
     # several input channels (they join the reduction of the spectral GEMM)
     (3, 28, 28, 8, 16, 8, 1, 3), (2, 20, 9, 2, 5, 4, 0, 2),
     # frames beyond the specialised transforms along w (Lh > 64 or Ho > 64): spectra in frequency blocks, generic
