@@ -174,10 +174,17 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
 #define TVAE_OUT_RING(L_, N_, R_, H_)                                                                               \
     do {                                                                                                            \
         const size_t lds_r = (size_t)4 * 3 * ((L_ + 3) / 4) * 1024;                                                 \
-        e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_>, lds_r);                                              \
-        if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_>), dim3(grid), dim3(256), lds_r, st, (const float*)T, \
-                           (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);                               \
+        if (act == ACT_TANH) {                                                                                      \
+            e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, true>, lds_r);                                    \
+            if (e != hipSuccess) return (int)e;                                                                     \
+            hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, true>), dim3(grid), dim3(256), lds_r, st,       \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);          \
+        } else {                                                                                                    \
+            e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, false>, lds_r);                                   \
+            if (e != hipSuccess) return (int)e;                                                                     \
+            hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, false>), dim3(grid), dim3(256), lds_r, st,      \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);          \
+        }                                                                                                           \
     } while (0)
             if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);
             else if (q.ring == 2) TVAE_OUT_RING(49, 1, true, 33);

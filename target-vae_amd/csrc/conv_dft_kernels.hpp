@@ -439,10 +439,12 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // load in the loops, so the compiler places no vmcnt wait of its own, and the MFMA B operand is read straight from
 // the ring (lane-linear: conflict free).  The constant operand lives in registers.
 // ==========================================================================================
-#define TVAE_DFT_DMA_X4(dst, src) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory")
-#define TVAE_DFT_DMA_X1(dst, src) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory")
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane BYTE offset (global "saddr" addressing): the
+// per-lane offsets are loop invariants kept in registers, so issuing a piece costs no vector-ALU work at all.
+#define TVAE_DFT_DMA_X4(dst, off, base) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory")
+#define TVAE_DFT_DMA_X1(dst, off, base) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory")
 #define TVAE_DFT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]) -- the contraction over fx.  One wave owns a tile
@@ -450,15 +452,17 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // (fx & 3, re | im, 4 columns); the LDS image is [fx][re | im][32 columns] = the B-operand order of the K = 2 MFMA).
 // Three slots per wave: while tile `it` is on the matrix pipe, tile it+1 is in flight and the pieces of tile it+2 are
 // issued between the MFMAs into the slot tile it-1 has left; the consumed slot doubles as the transposition patch of the
-// epilogue.  One 4-wave workgroup per CU (3 x 13 KB per wave at the 96-wide frame).  Per tile: ND DMAs, then SN stores;
-// at the top of iteration it >= 2 the operations younger than tile it's DMAs are stores(it-2), DMAs(it+1), stores(it-1).
-template <int LHP, int NT, bool REM1, int HO>
+// epilogue ([32 columns][HO], HO odd: its linear order IS the order of the tile's outputs in memory).  One 4-wave
+// workgroup per CU (3 x 13 KB per wave at the 96-wide frame).  Per tile: ND DMAs, then SN stores; at the top of
+// iteration it >= 2 the operations younger than tile it's DMAs are stores(it-2), DMAs(it+1), stores(it-1).
+template <int LHP, int NT, bool REM1, int HO, bool TANH>
 static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int M, int R, int B, int Lh, int act, float slope) {
     constexpr int NTT = NT + (REM1 ? 1 : 0), ND = (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
-    constexpr int SN = (32 * HO + 63) / 64, SWO = HO | 1, P = HO * HO;
-    static_assert(32 * SWO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
+    constexpr int SN = (32 * HO + 63) / 64, P = HO * HO;
+    static_assert((HO & 1) == 1, "odd output width: the [column][HO] patch is conflict free and linear in memory order");
+    static_assert(32 * HO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
     static_assert(ND + 2 * SN <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
@@ -476,23 +480,28 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     const long first = (long)blockIdx.x * 4 + wave;
     if (first >= ntiles) return;                         // (no workgroup barrier anywhere in this kernel)
     const int my = (int)((ntiles - first + stride - 1) / stride);
-    const int fxl = lane >> 4, rid = (lane >> 3) & 1, c4 = (lane & 7) * 4;
-    auto tile_mn = [&](int it, int& m, long& n0) {
+    // DMA piece g, lane -> (fx = 4 g + (lane >> 4), re | im = (lane >> 3) & 1, columns 4 (lane & 7) ..): byte offset of the
+    // lane's 16 bytes from the tile's (wave-uniform) base; rows beyond Lh (last piece) re-read the last row, never used
+    unsigned doff[ND];
+    {
+        const int fxl = lane >> 4, rid = (lane >> 3) & 1, c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int g = 0; g < ND; ++g)
+            doff[g] = (unsigned)(((long)rid * M * Lh + min(4 * g + fxl, Lh - 1)) * 128 + c4) * 4u;
+    }
+    auto tile_mn = [&](int it, int& m, int& n0) {
         const int tl = (int)(first + (long)(it < my ? it : my - 1) * stride);   // past the end: the last tile again
-        m = tl / tiles_n;                                // (host: fewer than 2^31 tiles)
-        n0 = (long)(tl - m * tiles_n) * 32;
+        m = tl / tiles_n;                                // (host: fewer than 2^31 tiles, B * HO < 2^31)
+        n0 = (tl - m * tiles_n) * 32;
     };
-    auto dma_base = [&](int it) -> const float* {
-        int m;
-        long n0;
+    auto dma_base = [&](int it) -> const float* {        // wave uniform: T + dft_t_off(n0, m, 2M, Lh)
+        int m, n0;
         tile_mn(it, m, n0);
-        return T + dft_t_off(n0 + c4, rid * M + m, 2 * M, Lh);
+        return T + ((((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127));
     };
-    auto dma_piece = [&](const float* tp, int slot, int g) {
-        const int fx = min(4 * g + fxl, Lh - 1);         // rows beyond Lh (last piece) re-read the last row; never used
-        const float* src = tp + (long)fx * 128;
+    auto dma_piece = [&](const float* tb, int slot, int g) {
         const unsigned dst = ring_lds + (unsigned)(slot * SLOTB + g * 1024);
-        TVAE_DFT_DMA_X4(dst, src);
+        TVAE_DFT_DMA_X4(dst, doff[g], tb);
     };
     {
         const float* t0 = dma_base(0);
@@ -502,12 +511,14 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
 #pragma unroll
         for (int g = 0; g < ND; ++g) dma_piece(t1, 1, g);
     }
+    const float sl = act == ACT_LRELU ? slope : 1.f;     // ACT_NONE: slope 1
+    const int jump = (R - 1) * P;
     int slot = 0;
     for (int it = 0; it < my; ++it) {
         if (it == 0) TVAE_DFT_VMCNT(ND);
         else if (it == 1) TVAE_DFT_VMCNT(ND + SN);
         else TVAE_DFT_VMCNT(ND + 2 * SN);
-        const float* tpn = dma_base(it + 2);
+        const float* tbn = dma_base(it + 2);
         const int slot2 = slot == 0 ? 2 : slot - 1;      // (it + 2) % 3: the slot tile it-1 has left
         const float* vs = ring + slot * SLOTF + lane;
         f32x16 acc[NT][2];
@@ -523,21 +534,19 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
             for (int t = 0; t < NT; ++t)
                 acc[t][fx & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx][t], v, acc[t][fx & 1], 0, 0, 0);
             if (REM1) racc = __fmaf_rn(eo[fx][NTT - 1], v, racc);
-            if ((fx & 3) == 1) dma_piece(tpn, slot2, fx >> 2);               // tile it+2, one piece per four MFMA steps
+            if ((fx & 3) == 1) dma_piece(tbn, slot2, fx >> 2);               // tile it+2, one piece per four MFMA steps
         }
 #pragma unroll
         for (int g = 0; g < ND; ++g)
-            if (4 * g + 1 >= LHP) dma_piece(tpn, slot2, g);                  // pieces the unrolled loop did not reach
-        int m;
-        long n0;
+            if (4 * g + 1 >= LHP) dma_piece(tbn, slot2, g);                  // pieces the unrolled loop did not reach
+        int m, n0;
         tile_mn(it, m, n0);
         const int c = m / R, r_ = m - c * R;
         const float bv = bias ? bias[c] : 0.f;
-        float* stg = ring + slot * SLOTF;                // the slot just consumed: [32 columns][SWO]
-        const float sl = act == ACT_LRELU ? slope : 1.f;     // ACT_NONE: slope 1
+        float* stg = ring + slot * SLOTF;                // the slot just consumed: [32 columns][HO]
         float rtot = 0.f;
         if (REM1) rtot = racc + __shfl_xor(racc, 32, 64) + bv;
-        if (act == ACT_TANH) {                           // (one uniform branch around the whole block, not one per element)
+        if (TANH) {                                      // compile time: a run-time test is if-converted into BOTH forms per element
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -558,24 +567,25 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int w = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * ri;
-                if (32 * t + 31 < HO || w < HO) stg[j * SWO + w] = acc[t][0][r];
+                if (32 * t + 31 < HO || w < HO) stg[j * HO + w] = acc[t][0][r];
             }
         if (REM1) {
-            if (ri == 0) stg[j * SWO + 32 * NT] = rtot;
+            if (ri == 0) stg[j * HO + 32 * NT] = rtot;
         }
         __builtin_amdgcn_wave_barrier();
         // the 32 output rows of the tile are 32*HO consecutive floats of out, plus (R-1)*P for every image boundary
-        // before the row.  Exactly SN store instructions per tile: lanes past the end repeat the last element.
-        const int b0 = (int)(n0 / HO), h0 = (int)(n0 - (long)b0 * HO);
-        float* obase = out + (((long)c * B + b0) * R + r_) * P + (long)h0 * HO;
-        const int jump = (R - 1) * P;
+        // before the row: element e belongs to the next image iff e >= (HO - h0) * HO (a second boundary, HO rows on, only
+        // when HO < 32).  Exactly SN store instructions per tile: lanes past the end repeat the last element.
+        const int b0 = n0 / HO, h0 = n0 - b0 * HO;
+        float* obase = out + ((((long)c * B + b0) * R + r_) * P + (long)h0 * HO);      // wave uniform
         const int cnt = (int)(NB - n0 < 32 ? NB - n0 : 32) * HO;
+        const int thr = (HO - h0) * HO;
 #pragma unroll
         for (int i = 0; i < SN; ++i) {
             const int e = min(i * 64 + lane, cnt - 1);
-            const int t = e / HO, w = e - t * HO;
-            const int k = (h0 + t) / HO;
-            obase[e + k * jump] = stg[t * SWO + w];
+            int o = e + (e >= thr ? jump : 0);
+            if (HO < 32) o += e >= thr + P ? jump : 0;   // narrow outputs: 32 rows can span three images
+            obase[(unsigned)o] = stg[e];
         }
         __builtin_amdgcn_wave_barrier();
         slot = slot == 2 ? 0 : slot + 1;
@@ -618,52 +628,60 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) areg[s_][rt] = ED[(s_ * NRT + rt) * 64 + lane];
-    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * HO;
+    const int tiles_n = (int)(NBpad / 32);
+    const long ntiles = (long)M * tiles_n, NB = (long)B * HO;
     const long stride = (long)gridDim.x * 4;
     const long first = (long)blockIdx.x * 4 + wave;
     if (first >= ntiles) return;
     const int my = (int)((ntiles - first + stride - 1) / stride);
     const int jump = (R - 1) * P;
-    auto tile_mn = [&](int it, int& m, long& n0) {
+    auto tile_mn = [&](int it, int& m, int& n0) {
         const int tl = (int)(first + (long)(it < my ? it : my - 1) * stride);
-        m = tl / (int)tiles_n;
-        n0 = (long)(tl - m * (int)tiles_n) * 32;
+        m = tl / tiles_n;
+        n0 = (tl - m * tiles_n) * 32;
     };
-    // source of the NL DMAs of a tile: element e = 64 i + lane is (column t = e / HO, w = e % HO).  Columns past the end
-    // of the batch re-read the last valid column (finite values; those columns of S' only ever meet zero columns of A^T).
-    struct Src { const float* base; int h0, tlast; };
+    // The NL DMAs of a tile: element e = 64 i + lane is (column t = e / HO, w = e % HO) and sits e floats behind the
+    // tile's first element, plus (R-1)*P once the column belongs to the next image (e >= (HO - h0) HO).  A ragged last
+    // tile re-reads its last valid column for the columns past the end of the batch (finite values; those columns of S'
+    // only ever meet zero columns of A^T); a tile of pure padding columns reads tile 0 of its row.
+    struct Src { const float* base; int tlast, thr; };
     auto dma_src = [&](int it) {
-        int m;
-        long n0;
+        int m, n0;
         tile_mn(it, m, n0);
         if (n0 >= NB) n0 = 0;
         const int c = m / R, r_ = m - c * R;
-        const int b0 = (int)(n0 / HO), h0 = (int)(n0 - (long)b0 * HO);
-        Src s;
-        s.base = dY + (((long)c * B + b0) * R + r_) * P + (long)h0 * HO;
-        s.h0 = h0;
-        s.tlast = (int)(NB - n0 < 32 ? NB - n0 : 32) - 1;
-        return s;
+        const int b0 = n0 / HO, h0 = n0 - b0 * HO;
+        Src q;
+        q.base = dY + ((((long)c * B + b0) * R + r_) * P + (long)h0 * HO);              // wave uniform
+        q.tlast = (int)(NB - n0 < 32 ? NB - n0 : 32) - 1;
+        q.thr = (HO - h0) * HO;
+        return q;
     };
-    auto dma_piece = [&](const Src& s, int slot, int i) {
-        const int e = i * 64 + lane;
-        const int t = e / HO;
-        const int tc = t < s.tlast ? t : s.tlast;
-        const int k = (s.h0 + tc) / HO;
-        const float* src = s.base + (e + (tc - t) * HO + k * jump);
+    auto dma_piece = [&](const Src& q, int slot, int i) {
+        int e = i * 64 + lane;
+        if (q.tlast < 31) {                              // wave uniform, rare
+            const int t = e / HO;
+            if (t > q.tlast) e -= (t - q.tlast) * HO;
+        }
+        int o = e + (e >= q.thr ? jump : 0);
+        if (HO < 32) o += e >= q.thr + P ? jump : 0;     // narrow outputs: 32 columns can span three images
+        const unsigned off = (unsigned)o * 4u;
         const unsigned dst = ring_lds + (unsigned)(slot * SLOTB + i * 256);
-        TVAE_DFT_DMA_X1(dst, src);
+        TVAE_DFT_DMA_X1(dst, off, q.base);
     };
     {
-        const Src s0 = dma_src(0);
+        const Src q0 = dma_src(0);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) dma_piece(s0, 0, i);
+        for (int i = 0; i < NL; ++i) dma_piece(q0, 0, i);
     }
+    // store offsets (floats from Sp + dft_t_off(n0, m, 2M, Lh), wave uniform): real rows at j + 2 kh 128, imaginary rows
+    // M * Lh * 128 further on
+    const unsigned lre = (unsigned)(j + 2 * kh * 128), lim = lre + (unsigned)((long)M * Lh * 128);
     for (int it = 0; it < my; ++it) {
         const int slot = it & 1;
         if (it == 0) TVAE_DFT_VMCNT(0);
         else TVAE_DFT_VMCNT(ST);
-        const Src sn = dma_src(it + 1);
+        const Src qn = dma_src(it + 1);
         const float* bs = ring + slot * SLOTF + j * HO + kh;
         f32x16 acc[NRT];
 #pragma unroll
@@ -680,31 +698,27 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
                 if (2 * s_ + 1 < HO) racc += kh ? -bq : bq;
                 else racc += kh ? 0.f : bq;
             }
-            if (s_ < NL) dma_piece(sn, slot ^ 1, s_);    // tile it+1, one piece per k-step
+            if (s_ < NL) dma_piece(qn, slot ^ 1, s_);    // tile it+1, one piece per k-step
         }
 #pragma unroll
-        for (int i = NS; i < NL; ++i) dma_piece(sn, slot ^ 1, i);
-        int m;
-        long n0;
+        for (int i = NS; i < NL; ++i) dma_piece(qn, slot ^ 1, i);
+        int m, n0;
         tile_mn(it, m, n0);
+        float* sb = Sp + ((((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127));   // wave uniform
         // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh: ri is a compile-time property of (rt, r)
-        float* q0 = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);
-        float* q1 = Sp + dft_t_off(n0 + j, M + m, 2 * M, Lh);
-        float* p0 = q0 + 2 * kh * 128;                   // real rows, fx = fx0 + 2 kh
-        float* p1 = q1 + 2 * kh * 128;                   // imaginary rows
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);             // kh = 0; kh = 1 adds 4
-                float* p = (kk0 & 1) ? p1 : p0;
-                const int fx0 = kk0 >> 1;
-                if (kk0 + 4 < LH2) p[fx0 * 128] = acc[rt][r];
-                else if (kk0 < LH2) { if (kh == 0) p[fx0 * 128] = acc[rt][r]; }
+                const unsigned o = ((kk0 & 1) ? lim : lre) + (unsigned)((kk0 >> 1) * 128);
+                if (kk0 + 4 < LH2) sb[o] = acc[rt][r];
+                else if (kk0 < LH2) { if (kh == 0) sb[o] = acc[rt][r]; }
             }
         if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
             const float tot = racc + __shfl_xor(racc, 32, 64);
-            (kh ? q1 : q0)[(LH2 / 2 - 1) * 128] = kh ? 0.f : tot;
+            const unsigned o = (kh ? lim : lre) - (unsigned)(2 * kh * 128) + (unsigned)((LH2 / 2 - 1) * 128);
+            sb[o] = kh ? 0.f : tot;
         }
     }
     TVAE_DFT_VMCNT(0);
