@@ -23,7 +23,7 @@ int tvae_abi_version(void);
 /* The library keeps NO process-wide state.  The arithmetic of a matrix product is chosen per call by the entry point:
  * tvae_conv1_fwd / tvae_conv1_wgrad / tvae_linear_* compute exact fp32 products (v_mfma_f32_32x32x2_f32); the *_x6 and
  * *_dft entry points compute in the "x6" arithmetic (every fp32 operand split EXACTLY into three bf16 numbers, six
- * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results).  tvae_abi_version() == 2. */
+ * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results).  tvae_abi_version() == 3. */
 
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
@@ -135,8 +135,14 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
-                         int parts, tvae_stream_t stream);
-/* tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
+                         float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
+                         float* rs_dwo, int parts, tvae_stream_t stream);
+/* Row sums of the streamed activation (ABI 3; two-valued form only, i.e. vg_csum given; M <= 512): with rs_part
+ * [N/128][M][2] (workspace), rs_wo [M] (the single-output Linear's weight, src/models.py:121-123), rs_gysum [1] = sum_n
+ * vg_gy[n], the launch also returns rs_db [M] = wo[m] sum_n gy[n] act'(H[m][n]) (bias gradient of the layer that produced
+ * H = dpre) and rs_dwo [M] = sum_n gy[n] H[m][n] (weight gradient of that Linear) -- what tvae_dec_out_bwd would otherwise
+ * compute in a 2 GB pass of its own over H.  rs_part = NULL: off.
+ * tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
  * (never materialised).  tvae_dec_in_total turns the panels into Simg [B][F], dbc [F], dWc [F][2] (cpi panels per image). */

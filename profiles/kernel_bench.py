@@ -85,8 +85,8 @@ call('tvae_dense_split3', W, F_, w3, w3.numel() * 4, F_, F_, 0, None, None)
 w3t = torch.empty_like(w3)
 call('tvae_dense_split3', W, F_, w3t, w3t.numel() * 4, F_, F_, 1, None, None)
 timeit('x6_dec_fwd', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, None, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
-timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
-timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
+timeit('x6_dec_dgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, PARTS))
+timeit('x6_dec_dgrad_nomask', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, h2, F_, Nt, F_, Nt, Nt, 0, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, PARTS))
 timeit('x6_dec_fwd_res', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_fwd_x6', w3, h1, bb, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, None, None, None, 0, None, PARTS))
 timeit('x6_dec_wgrad', 2.0 * F_ * F_ * Nt, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, None, PARTS))
 if query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
@@ -111,10 +111,10 @@ if only and 'tail' in only:
     gxr = torch.empty(Nt, 2, device=dev); partf = torch.empty((Nt // 128) * F_ * 3, device=dev)
     wo1 = torch.randn(F_, device=dev); gy1 = torch.randn(Nt, device=dev)
     fl = 2.0 * F_ * F_ * Nt
-    timeit('tail_dgrad_plain', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, PARTS))
-    timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None, None, None, None, 0, PARTS))
-    timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, None, 0, PARTS))
-    timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, None, 0, PARTS))
+    timeit('tail_dgrad_plain', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, PARTS))
+    timeit('tail_dgrad_intail', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, None, None, None, None, 0, None, 0, None, None, None, None, PARTS))
+    timeit('tail_dgrad_virt', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, h2, F_, Nt, F_, Nt, Nt, 1, 0.01, None, None, None, None, 0, wo1, gy1, None, None, None, 0, None, 0, None, None, None, None, PARTS))
+    timeit('tail_dgrad_both', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, h3, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, None, None, 0, None, 0, None, None, None, None, PARTS))
     timeit('tail_wgrad_plain', fl, lambda: call('tvae_linear_wgrad_x6', h1, h3, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, None, None, 0, 0.01, None, None, None, None, 0, None, PARTS))
     Np_ = n * n
     bc2 = torch.randn(F_, device=dev); lb2 = torch.randn(B, F_, device=dev)
@@ -130,8 +130,8 @@ if only and 'tail' in only:
     csum2 = torch.empty(F_, device=dev)
     w3s = torch.empty_like(w3)
     call('tvae_dense_split3', W, F_, w3s, w3s.numel() * 4, F_, F_, 1, wo1, csum2)
-    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3s, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, gy1, csum2, bc2, lb2, Np_, PARTS))
-    timeit('tail_dgrad_generic', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, PARTS))
+    timeit('tail_dgrad_step', fl, lambda: call('tvae_linear_dgrad_x6', w3s, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), None, gy1, csum2, bc2, lb2, Np_, None, 0, None, None, None, None, PARTS))
+    timeit('tail_dgrad_generic', fl, lambda: call('tvae_linear_dgrad_x6', w3t, h1, None, None, None, F_, Nt, F_, Nt, Nt, 1, 0.01, xr2, wc2, gxr, partf, partf.numel(), wo1, gy1, None, bc2, lb2, Np_, None, 0, None, None, None, None, PARTS))
     hbits = torch.zeros(F_, Nt // 32, dtype=torch.int32, device=dev).random_(-2 ** 31, 2 ** 31 - 1)
     timeit('tail_wgrad_step', fl, lambda: call('tvae_linear_wgrad_x6', None, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, hbits, PARTS))
     timeit('tail_wgrad_from_H', fl, lambda: call('tvae_linear_wgrad_x6', h1, None, dW, ws, ws.numel(), F_, Nt, F_, Nt, Nt, 0, wo1, gy1, 1, 0.01, *va, None, PARTS))

@@ -6,6 +6,26 @@
 
 using namespace tvae;
 
+// Zero fill as an ordinary kernel on the caller's stream.  hipMemsetAsync is NOT used: under GPU sharing (two processes
+// time-slicing the device) its fill was observed to land late relative to the kernels queued behind it on the same
+// stream -- rows of the spectral weight zeroed after dft_spectra had written them, and zeros appearing in blocks the
+// caching allocator had already handed to other tensors (profiles/tools/stress_determinism.py; profiles/README.md).
+static __global__ void dft_zero_kernel(float4* __restrict__ p, long n4, float* __restrict__ tail, int ntail) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+static hipError_t dft_zero(float* p, long floats, hipStream_t st) {     // p is 16-byte aligned
+    const long n4 = floats / 4;
+    const int ntail = (int)(floats - 4 * n4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dft_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4, p + 4 * n4,
+                       ntail);
+    return hipGetLastError();
+}
+
 static int dev_cu_count() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -127,7 +147,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     float* T = W3 + ((q.w3_floats + 3) & ~3L);
     float* tab = T + ((q.t_floats + 3) & ~3L);
     if (q.NBpad != q.NB) {
-        hipError_t e = hipMemsetAsync(at, 0, (size_t)q.at_floats * 4, st);
+        hipError_t e = dft_zero(at, q.at_floats, st);
         if (e != hipSuccess) return (int)e;
     }
     float* EO = tab;
@@ -135,7 +155,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     hipError_t e = allow_big_lds(dft_spectra_kernel, q.lds_sp);
     if (e != hipSuccess) return (int)e;
     if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
-        e = hipMemsetAsync(W, 0, (size_t)q.w_floats * 4, st);
+        e = dft_zero(W, q.w_floats, st);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,

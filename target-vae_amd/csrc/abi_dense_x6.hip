@@ -30,6 +30,31 @@ int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& 
 }
 }  // namespace tvae
 
+namespace {
+// Totals of the per-tile row sums of dense_x6_kernel<4> (VirtGrad.rpart) and the algebra of the two-valued gradient: with
+// S0[m] = sum_n gy[n] [H[m][n] > 0], S1[m] = sum_n gy[n] H[m][n] (tiles added in order: deterministic),
+//   db[m]  = wo[m] * (slope * sum_n gy[n] + (1 - slope) * S0[m])     bias gradient of the layer that produced H
+//   dwo[m] = S1[m]                                                   weight gradient of the single-output Linear
+// One workgroup per row m.
+__global__ void dgrad_rowsum_total_kernel(const float* __restrict__ part, int ntiles, int K, const float* __restrict__ wo,
+                                          const float* __restrict__ gysum, float slope, float* __restrict__ db,
+                                          float* __restrict__ dwo) {
+    __shared__ float sm[2 * 16];
+    const int m = blockIdx.x;
+    float s[2] = {0.f, 0.f};
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((long)t * K + m) * 2);
+        s[0] += v.x;
+        s[1] += v.y;
+    }
+    block_sum<2>(s, sm);
+    if (threadIdx.x == 0) {
+        db[m] = wo[m] * __fmaf_rn(1.f - slope, s[0], slope * gysum[0]);
+        dwo[m] = s[1];
+    }
+}
+}  // namespace
+
 extern "C" {
 
 // ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
@@ -64,6 +89,10 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
         return (int)hipErrorInvalidValue;
     const DenseBatch nb{0, 0, 0};
+    if (vg.csum && vg.rpart) {
+        if (K > DX6_ROWS) return (int)hipErrorInvalidValue;              // the row sums live in one 512-row LDS table
+        return TVAE_DX6_DISPATCH(4, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    }
     if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
     if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
     if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
@@ -87,7 +116,8 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
-                         int parts, tvae_stream_t stream) {
+                         float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
+                         float* rs_dwo, int parts, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -100,9 +130,19 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     } else if (!dX) {
         return (int)hipErrorInvalidValue;
     }
-    return launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
-                           InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
-                           VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, nullptr});
+    if (rs_part) {       // row sums of the streamed activation (two-valued form only; M = rows of H <= 512)
+        if (!vg_csum || !vg_gy || !rs_wo || !rs_gysum || !rs_db || !rs_dwo || M > DX6_ROWS || N % 128 != 0 ||
+            rs_part_floats < (long)(N / 128) * M * 2 || (reinterpret_cast<size_t>(rs_part) & 7))
+            return (int)hipErrorInvalidValue;
+    }
+    int rc = launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
+                             InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
+                             VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, nullptr, rs_part});
+    if (rc || !rs_part || N <= 0 || K <= 0) return rc;
+    hipLaunchKernelGGL(dgrad_rowsum_total_kernel, dim3(M), dim3(256), 0, S(stream), (const float*)rs_part, N / 128, M, rs_wo,
+                       rs_gysum, slope, rs_db, rs_dwo);
+    TVAE_CHECK_LAUNCH();
+    return 0;
 }
 
 

@@ -23,7 +23,7 @@ static inline long dense_x6_bytes(int rows, int K) {
 #define TVAE_DX6_DECL(XV_)                                              \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p3(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p1(TVAE_DX6_LAUNCH_ARGS);
-TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3)
+TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DECL(4)
 #define TVAE_DX6_LAUNCH_DEF(XV_, NP_)                                                                                 \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                       \

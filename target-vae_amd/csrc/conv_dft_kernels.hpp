@@ -87,26 +87,39 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
         const int Lq = L >> 2;
         for (int i = threadIdx.x; i < Lq * nfx; i += blockDim.x) {
             const int fy = i / nfx, f = i - fy * nfx;
-            float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            // the four partial sums are NAMED registers and a term with a run-time residue is added through selects: an
+            // array / by-reference capture here ended up in scratch memory (40 bytes per lane), and scratch is not
+            // dependable when several processes time-slice the GPU (profiles/README.md, round 3: the filter spectra of
+            // one workgroup in ~10^-4 came out wrong under sharing, and nothing else in that configuration used scratch)
+            float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f, a3x = 0.f, a3y = 0.f;
             int ph = (fy * pad) % L;
             int yy = 0;
-            auto term = [&](int r) {                     // r = (yy + pad) & 3 (a compile-time constant in the main loop)
-                const float2 p = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));
-                if (r == 0) { a0.x += p.x; a0.y += p.y; }
-                else if (r == 1) { a1.x += p.x; a1.y += p.y; }
-                else if (r == 2) { a2.x += p.x; a2.y += p.y; }
-                else { a3.x += p.x; a3.y += p.y; }
-                ph += fy;
-                if (ph >= L) ph -= L;
-                ++yy;
-            };
+#define TVAE_DFT_TERM_P(P_)                                                                      \
+    const float2 P_ = cmul(Rw[yy * FXB + f], make_float2(tw[ph].x, -tw[ph].y));                  \
+    ph += fy;                                                                                    \
+    if (ph >= L) ph -= L;                                                                        \
+    ++yy;
+#define TVAE_DFT_TERM_C(AX_, AY_) { TVAE_DFT_TERM_P(p_) AX_ += p_.x; AY_ += p_.y; }
+#define TVAE_DFT_TERM_R(R_)                                                                      \
+    {                                                                                            \
+        TVAE_DFT_TERM_P(p_)                                                                      \
+        a0x += (R_) == 0 ? p_.x : 0.f; a0y += (R_) == 0 ? p_.y : 0.f;                            \
+        a1x += (R_) == 1 ? p_.x : 0.f; a1y += (R_) == 1 ? p_.y : 0.f;                            \
+        a2x += (R_) == 2 ? p_.x : 0.f; a2y += (R_) == 2 ? p_.y : 0.f;                            \
+        a3x += (R_) == 3 ? p_.x : 0.f; a3y += (R_) == 3 ? p_.y : 0.f;                            \
+    }
             // bring (yy + pad) to a multiple of 4 first: the residue of every later term is then known at compile time
             int r0 = pad & 3;
-            while (r0 != 0 && r0 < 4 && yy < S) term(r0++);
-            while (yy + 3 < S) { term(0); term(1); term(2); term(3); }
+            while (r0 != 0 && r0 < 4 && yy < S) { TVAE_DFT_TERM_R(r0) ++r0; }
+            while (yy + 3 < S) {
+                TVAE_DFT_TERM_C(a0x, a0y) TVAE_DFT_TERM_C(a1x, a1y) TVAE_DFT_TERM_C(a2x, a2y) TVAE_DFT_TERM_C(a3x, a3y)
+            }
             r0 = 0;
-            while (yy < S) term(r0++);
-            const float2 a[4] = {a0, a1, a2, a3};
+            while (yy < S) { TVAE_DFT_TERM_R(r0) ++r0; }
+#undef TVAE_DFT_TERM_R
+#undef TVAE_DFT_TERM_C
+#undef TVAE_DFT_TERM_P
+            const float2 a[4] = {make_float2(a0x, a0y), make_float2(a1x, a1y), make_float2(a2x, a2y), make_float2(a3x, a3y)};
             // Y[fy + q Lq] = sum_r a[r] (-i)^(q r):   (-i)^0 = 1, (-i)^1 = -i, (-i)^2 = -1, (-i)^3 = i
             const float2 s02 = make_float2(a[0].x + a[2].x, a[0].y + a[2].y), d02 = make_float2(a[0].x - a[2].x, a[0].y - a[2].y);
             const float2 s13 = make_float2(a[1].x + a[3].x, a[1].y + a[3].y), d13 = make_float2(a[1].x - a[3].x, a[1].y - a[3].y);

@@ -104,6 +104,11 @@ struct VirtGrad {          // the streamed gradient operand given implicitly (ba
     // bits[m * (N/32) + n/32]; the saved activation itself is then not read.  (The data gradient keeps reading H: its
     // operand loads are one instruction per k-row either way, and the bit form measured 0.2 ms slower.)
     const unsigned* bits;
+    // data gradient only (dense_x6_kernel<4>): the launch that streams H for the two-valued operand also produces, per
+    // 128-column tile, the two row sums the backward of the single-output Linear needs of H (tvae_dec_out_bwd's whole job):
+    //   rpart[(tile_n * K + m) * 2 + 0] = sum_{n in tile} gy[n] [H[m][n] > 0]   -> bias gradient of the layer producing H
+    //   rpart[(tile_n * K + m) * 2 + 1] = sum_{n in tile} gy[n] H[m][n]         -> dWo[m]
+    float* rpart;
 };
 __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
     const float dv = vg.act == ACT_LRELU ? (h > 0.f ? 1.f : vg.slope) : (vg.act == ACT_TANH ? 1.f - h * h : 1.f);
@@ -153,6 +158,28 @@ __device__ __forceinline__ float half_wave_sum(float x) {
     x = dpp_add<0x141>(x);                               // row_half_mirror: the other quad of each 8
     x = dpp_add<0x140>(x);                               // row_mirror: the other 8 of each 16
     return x + __shfl_xor(x, 16, 64);                    // the other row of the half wave
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// Sums EIGHT values over the 64 lanes of a wave in 4 + 2 + 1 + 3 exchange steps (a butterfly that halves the number of
+// live values at each of the first three steps) instead of 8 x 6: lane l returns the total of value (l & 7).
+__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)      // lane keeps index 2i + b0, its partner (lane ^ 1) sends exactly that one
+        b[i] = (b0 ? a[2 * i + 1] : a[2 * i]) + dpp_get<0xB1>(b0 ? a[2 * i] : a[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)      // b index 2i + b1 -> original index 4i + 2 b1 + b0
+        c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + dpp_get<0x4E>(b1 ? b[2 * i] : b[2 * i + 1]);
+    float d = (b2 ? c[1] : c[0]) + __shfl_xor(b2 ? c[0] : c[1], 4, 64);     // original index 4 b2 + 2 b1 + b0 = lane & 7
+    d += __shfl_xor(d, 8, 64);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    return d;
 }
 
 template <int ACT, int MASK, bool RES, bool AV, bool MB>
@@ -268,17 +295,21 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 };
 
 // XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct),
-//     3 = two-valued implicit gradient (VirtGrad.csum: X is the saved activation H, the operand is [H > 0])
+//     3 = two-valued implicit gradient (VirtGrad.csum: X is the saved activation H, the operand is [H > 0]),
+//     4 = 3 + the row sums of H against gy per column tile (VirtGrad.rpart): the threads that load H for the operand
+//         also form gy[n] [H > 0] and gy[n] H, reduce them over their wave's 64 columns (wave_sum8: 8 values per step)
+//         and leave them in LDS; a 2.1 GB pass of its own over H (tvae_dec_out_bwd) is then not needed
 template <int XV, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                      int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
-    constexpr bool VIRT = XV == 1, MASKB = XV == 3;
+    constexpr bool VIRT = XV == 1, MASKB = XV == 3 || XV == 4, RSUM = XV == 4;
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
     __shared__ float wsm_[2 * DX6_ROWS];
     __shared__ float vwo_[XV == 1 ? 512 : (XV == 2 ? 2048 : 1)];   // tables of the implicit operand (K <= 512)
     __shared__ float cbm_[2 * DX6_ROWS];                 // (bc, lb) rows of the recomputed mask operand (InTail.bc)
+    __shared__ float rsm_[RSUM ? 2 * 2 * DX6_ROWS + 8 : 1];   // [column half of the tile][row of H][2]: row sums (VirtGrad.rpart) + a dump slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split_unused;
@@ -326,7 +357,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const float* x_col = X + n0 + nb;
     // VIRT (compile time, so that the plain instance keeps its straight-line load stream): the operand is the saved
     // activation and the gradient wo[k] * gy[n] * act'(h) is formed when the cells are built (store_b)
-    const float vg_g = VIRT ? vg.gy[n0 + nb] : 0.f;
+    const float vg_g = (VIRT || RSUM) ? vg.gy[n0 + nb] : 0.f;
     if (VIRT) {
         if (tid < K && tid < 512) vwo_[tid] = vg.wo[tid];
     }
@@ -392,6 +423,24 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         dst[2 * 512] = make_uint2(lw[0], lw[1]);
     };
 
+    // RSUM: this thread holds H[16 t + 4 kq + j][n0 + nb], j < 4, for step t; the two waves with the same kq cover the
+    // tile's 128 columns.  Lane v < 8 of each wave stores the wave's total of value v = 2 j + (0: gy [H > 0], 1: gy H);
+    // every (t, kq, j) row is visited once, so the slots are plain stores (rows >= K are never read back).
+    auto row_sums = [&](int t, bool real, const float (&x)[4]) {
+        if (!RSUM) return;
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[2 * j] = x[j] > 0.f ? vg_g : 0.f;
+            a[2 * j + 1] = vg_g * x[j];
+        }
+        const float tot = wave_sum8(a, lane);
+        // `real` = false: the register set holds a step that does not exist (the loop's clamped prefetch past the end
+        // re-reads an EARLIER step): its sums go to the dump slot -- branch free, like the rest of the operand path
+        const int slot = real ? ((wave & 1) * DX6_ROWS + ((16 * t + 4 * kq) & (DX6_ROWS - 1))) * 2 : 2 * 2 * DX6_ROWS;
+        if (lane < 8) rsm_[slot + lane] = tot;
+    };
+
     f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -415,6 +464,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         load_x(nk > 2 ? 2 : 0, xA);
         virt_x(0, x0);
         store_b(0, x0);
+        row_sums(0, true, x0);
     }
     __syncthreads();
     auto step = [&](int t, Cell16 (&afc)[2][3], Cell16 (&afn)[2][3], float (&xn)[4]) {
@@ -441,6 +491,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             if (j == 1) {                                // cells of step t+1, then its buffer takes the values of step t+3
                 virt_x(t + 1 < nk ? t + 1 : t, xn);
                 store_b(cur ^ 1, xn);
+                row_sums(t + 1, t + 1 < nk, xn);
                 load_x(t + 3 < nk ? t + 3 : t, xn);
             }
         }
@@ -455,6 +506,13 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
+    if (RSUM) {                                          // (the loop's last barrier made every slot visible)
+        if (tid < K) {
+            float* rp = vg.rpart + ((long)tile_n * K + tid) * 2;
+            rp[0] = rsm_[tid * 2] + rsm_[(DX6_ROWS + tid) * 2];
+            rp[1] = rsm_[tid * 2 + 1] + rsm_[(DX6_ROWS + tid) * 2 + 1];
+        }
+    }
     // epilogue specialised on (activation, mask, residual): no per-element branches
     const bool res = ep.res != nullptr;
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};

@@ -28,7 +28,7 @@ SIGNATURES = {
     'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
     'tvae_linear_fwd_x6': 'pppppiiillifpppppppipi',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppii',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppi',
     'tvae_dec_in_total': 'piiippp',
     'tvae_linear_wgrad_x6': 'ppppliiillippifppppipi',
     'tvae_linear_fwd': 'ppppippiiillif',
@@ -108,7 +108,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
 # entry points tvae.ops calls ('x6': *_x6 / *_dft, split-bf16 products with fp32-equivalent results; 'f32': the exact
 # fp32-MFMA entry points; 'bf16': the *_x6 / *_dft entry points with parts = 1 -- operands rounded to one bf16 number, the

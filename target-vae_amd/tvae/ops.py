@@ -221,6 +221,7 @@ FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
 FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
 FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
 FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
+FUSE_ROW_SUMS = os.environ.get('TVAE_FUSE_ROW_SUMS', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -792,10 +793,16 @@ class DecoderFn(torch.autograd.Function):
         virt = (FUSE_VIRT_GRAD and n_out == 1 and n_hidden >= 1 and not resid and _dense_x6_ok(F_, Nt) and F_ >= 256
                 and Nt % 16 == 0)
         d = None if virt else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
-        part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
         tot = torch.empty(1 + n_out, F_, dtype=torch.float32, device=dev)
-        call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
-             part.numel(), tot)
+        # two-valued implicit gradient: the data-gradient launch of the last hidden layer streams H anyway and returns the
+        # two row sums this layer's backward needs of it (tot[0] = bias gradient below, tot[1] = dWo): no pass of its own
+        fuse_rs = (FUSE_ROW_SUMS and virt and act == ACT_LRELU and F_ <= 512 and Nt % 128 == 0)
+        if not fuse_rs:
+            part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
+            call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
+                 part.numel(), tot)
+        else:
+            _note('dec.row_sums_in_dgrad')
         vg = (Wo.contiguous().view(-1), gy.view(-1), act) if virt else None
         if virt:
             _note('dec.virt_grad')
@@ -828,12 +835,16 @@ class DecoderFn(torch.autograd.Function):
                 if fuse_in:
                     gxr_f = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
                     part_f = workspace(dev, (Nt // 128) * F_ * 3)
+                rs = two_val and fuse_rs
+                rs_part = _scratch(dev, 'dec_rs_part', (Nt // 128) * F_ * 2) if rs else None
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
-                         bc if va else None, LB if va else None, Np if va else 0, parts())
+                         bc if va else None, LB if va else None, Np if va else 0,
+                         rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
+                         tot[0] if rs else None, tot[1] if rs else None, parts())
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
@@ -873,7 +884,7 @@ class DecoderFn(torch.autograd.Function):
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
-                         None, None, None, None, 0, None, None, None, None, None, 0, parts())
+                         None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, parts())
             else:
                 call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)

@@ -8,6 +8,8 @@ It subclasses torch.optim.Optimizer so that ReduceLROnPlateau (train_mnist.py:58
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -55,7 +57,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._early_end = 0
         self._early_seen = 0
         self._early_posted = False
-        if early_params and reducer is not None and hasattr(reducer, 'begin') and getattr(reducer, 'active', False):
+        if (early_params and reducer is not None and hasattr(reducer, 'begin') and getattr(reducer, 'active', False)
+                and os.environ.get('TVAE_DP_EARLY', '1') != '0'):
             self._early_n = min(int(early_params), len(self._ps))
             self._early_end = self._offsets[self._early_n] if self._early_n < len(self._ps) else total
             for p in self._ps[:self._early_n]:

@@ -205,9 +205,9 @@ def test_step_golden(name):
 
 
 HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
-                                'dec.sign_bits', 'dec.fuse_in', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
+                                'dec.sign_bits', 'dec.fuse_in', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
        'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
-                               'dec.sign_bits', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'})}
+                               'dec.sign_bits', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'})}
 
 
 @pytest.mark.parametrize('name', sorted(HOT))

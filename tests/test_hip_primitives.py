@@ -222,7 +222,7 @@ def test_linear_fwd_dgrad_x6(M, N, K, act, use_res):
     call('tvae_dense_split3', Wd, K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), add.to(dev()) if use_res else None, aux.to(dev()) if act else None,
-         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0, 3)
+         dX, M, N, K, N, N, act, SLOPE, None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, 3)
     assert rel_err(dX, refg) < GEMM_TOL['f32']
     with pytest.raises(Exception):
         call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N - 1, K, N, N, act, SLOPE, None, None, None, None, None, None, None, 0, None, 3)
@@ -296,7 +296,7 @@ def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     gxr = torch.empty(Nt, 2, device=dev())
     part = torch.empty((Nt // 128) * F_ * 3, device=dev())
     call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), None, M, Nt, F_, Nt, Nt, act, SLOPE, xr.to(dev()),
-         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, None, 0, 3)
+         Wc.to(dev()), gxr, part, part.numel(), None, None, None, None, None, 0, None, 0, None, None, None, None, 3)
     Simg = torch.empty(B, F_, device=dev())
     dbc = torch.empty(F_, device=dev())
     dWc = torch.empty(F_, 2, device=dev())
@@ -319,7 +319,7 @@ def test_linear_x6_implicit_gradient_operand():
     call('tvae_dense_split3', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1, None, None)
     dX = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, wo.to(dev()), gy.to(dev()), None, None, None, 0, 3)
+         None, 0, wo.to(dev()), gy.to(dev()), None, None, None, 0, None, 0, None, None, None, None, 3)
     assert rel_err(dX, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
     # the same product in the two-valued form (LeakyReLU): weights scaled by wo before the split, 0 / 1 streamed operand
     csum = torch.empty(K, device=dev())
@@ -327,8 +327,29 @@ def test_linear_x6_implicit_gradient_operand():
     assert rel_err(csum, (W.double() * wo.double()[:, None]).sum(0)) < TOL
     dX2 = torch.empty(K, N, device=dev())
     call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 1, SLOPE, None, None, None,
-         None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
+         None, 0, None, gy.to(dev()), csum, None, None, 0, None, 0, None, None, None, None, 3)
     assert rel_err(dX2, (W.double().t() @ d) * dact_ref(aux.double(), 1)) < GEMM_TOL['f32']
+    # ... and with the row sums of the streamed activation against gy (ABI 3: what tvae_dec_out_bwd computes in a pass of its
+    # own): the data gradient is bitwise the same launch result, db / dwo agree with fp64
+    for Mr in (512, 384):
+        Hr, wor = H[:Mr].contiguous(), wo[:Mr].contiguous()
+        w3r = torch.empty(query('tvae_dense_x6_bytes', K, Mr) // 4, device=dev())
+        csr = torch.empty(K, device=dev())
+        call('tvae_dense_split3', W[:Mr].contiguous().to(dev()), K, w3r, w3r.numel() * 4, K, Mr, 1, wor.to(dev()), csr)
+        dXa, dXb = torch.empty(K, N, device=dev()), torch.empty(K, N, device=dev())
+        call('tvae_linear_dgrad_x6', w3r, Hr.to(dev()), None, aux.to(dev()), dXa, Mr, N, K, N, N, 1, SLOPE, None, None, None,
+             None, 0, None, gy.to(dev()), csr, None, None, 0, None, 0, None, None, None, None, 3)
+        rs_part = torch.full(((N // 128) * Mr * 2,), float('nan'), device=dev())
+        gys = gy.sum().reshape(1).to(dev())
+        rs_db, rs_dwo = torch.empty(Mr, device=dev()), torch.empty(Mr, device=dev())
+        call('tvae_linear_dgrad_x6', w3r, Hr.to(dev()), None, aux.to(dev()), dXb, Mr, N, K, N, N, 1, SLOPE, None, None, None,
+             None, 0, None, gy.to(dev()), csr, None, None, 0, rs_part, rs_part.numel(), wor.to(dev()), gys, rs_db, rs_dwo, 3)
+        assert torch.equal(dXa, dXb)
+        assert rel_err(rs_db, (wor.double()[:, None] * gy.double()[None, :] * dact_ref(Hr.double(), 1)).sum(1)) < TOL
+        assert rel_err(rs_dwo, Hr.double() @ gy.double()) < TOL
+    with pytest.raises(Exception):         # the row sums need the two-valued form (csum) and a workspace of N/128 * M * 2
+        call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 1, SLOPE, None, None, None,
+             None, 0, None, gy.to(dev()), csum, None, None, 0, rs_part, 16, wo.to(dev()), gys, rs_db, rs_dwo, 3)
     # packed sign bits of the activation (the weight gradient below can read its 0 / 1 operand from them)
     def pack_bits(t):                      # bit (n & 31) of word n / 32 = [t[m][n] > 0]
         b = (t > 0).to(torch.int64).view(t.shape[0], -1, 32)
@@ -337,7 +358,7 @@ def test_linear_x6_implicit_gradient_operand():
     hb = pack_bits(H).to(dev())
     with pytest.raises(Exception):         # the two-valued form exists for LeakyReLU only
         call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 2, SLOPE, None, None, None,
-             None, 0, None, gy.to(dev()), csum, None, None, 0, 3)
+             None, 0, None, gy.to(dev()), csum, None, None, 0, None, 0, None, None, None, None, 3)
     ws = torch.empty(1 << 24, device=dev())
     for vact in (1, 2):                    # LeakyReLU: two-valued weight gradient; tanh: generic implicit operand
         dv = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), vact)
@@ -399,7 +420,7 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
         gxr = torch.empty(Nt, 2, device=dev())
         part = torch.empty((Nt // 128) * F_ * 3, device=dev())
         call('tvae_linear_dgrad_x6', w3t, d, None, None if virt else h0, None, M, Nt, F_, Nt, Nt, act, SLOPE, xr, Wc,
-             gxr, part, part.numel(), None, None, None, bc if virt else None, LB if virt else None, Np if virt else 0, 3)
+             gxr, part, part.numel(), None, None, None, bc if virt else None, LB if virt else None, Np if virt else 0, None, 0, None, None, None, None, 3)
         outs.append((gxr, part))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     d0 = (W.double().t() @ d.double().cpu()) * dact_ref(h0.double().cpu(), act)
