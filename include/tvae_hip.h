@@ -256,6 +256,16 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
 int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads, long ldd, int nh, const void* bits_h,
                            const void* bits_a, float* dA1, long lda, int C, long N, float slope, int parts,
                            tvae_stream_t stream);
+/* tvae_enc_tail_wgrad_x6 (ABI 3): weight gradient of conv2 in ONE pass, dH never stored (autograd of nn.Conv3d(C, C, 1)
+ * behind the 1x1x1 heads, src/models.py:347-358,390-392):  dW2[c2][c] = sum_n dH[c2][n] A1[c][n] with
+ * dH[c2][n] = act'(H[c2][n]) sum_h Wh[h][c2] dheads[h][n] formed on the fly from the head gradients and the sign words
+ * of H (bits_h, as stored by tvae_enc_tail_fwd_x6; LeakyReLU).  C = 128, nh <= 7, N % 32 == 0, 16-byte aligned rows;
+ * ws: tvae_enc_tail_wgrad_x6_ws_floats(N) floats of per-workgroup slabs, added in a fixed order.  (dWh and db2 come from
+ * tvae_heads_bwd with dX = NULL.) */
+long tvae_enc_tail_wgrad_x6_ws_floats(long N);
+int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long ldd, int nh, const void* bits_h,
+                           const float* Wh, float* dW2, float* ws, long ws_floats, int C, long N, float slope, int parts,
+                           tvae_stream_t stream);
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

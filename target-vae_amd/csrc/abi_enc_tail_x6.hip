@@ -81,4 +81,38 @@ int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads
     return 0;
 }
 
+long tvae_enc_tail_wgrad_x6_ws_floats(long N) {
+    const long nchunks = N / EW_NC;
+    const long g = nchunks < cu_count() ? nchunks : cu_count();
+    return (g < 1 ? 1 : g) * (long)ET_C * ET_C;
+}
+
+int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long ldd, int nh, const void* bits_h,
+                           const float* Wh, float* dW2, float* ws, long ws_floats, int C, long N, float slope, int parts,
+                           tvae_stream_t stream) {
+    if (N <= 0) return 0;
+    if (C != ET_C || nh < 1 || nh > ET_MAXH || N % EW_NC != 0 || !aligned16(A1) || !aligned16(dheads) || !aligned16(bits_h) ||
+        lda % 4 != 0 || ldd % 4 != 0 || (parts != 1 && parts != 3) || !A1 || !dheads || !bits_h || !Wh || !dW2 || !ws ||
+        ws_floats < tvae_enc_tail_wgrad_x6_ws_floats(N))
+        return (int)hipErrorInvalidValue;
+    const long nchunks = N / EW_NC;
+    const int grid = (int)(nchunks < cu_count() ? nchunks : cu_count());
+    hipError_t e;
+    if (parts == 3) {
+        e = allow_big_lds(enc_tail_wgrad_x6_kernel<3>, EW_LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_wgrad_x6_kernel<3>), dim3(grid), dim3(ET_THREADS), EW_LDS, S(stream), A1, lda, dheads, ldd,
+                           nh, (const uint4*)bits_h, Wh, ws, N, slope);
+    } else {
+        e = allow_big_lds(enc_tail_wgrad_x6_kernel<1>, EW_LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_wgrad_x6_kernel<1>), dim3(grid), dim3(ET_THREADS), EW_LDS, S(stream), A1, lda, dheads, ldd,
+                           nh, (const uint4*)bits_h, Wh, ws, N, slope);
+    }
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(enc_tail_wgrad_total_kernel, dim3(ET_C * ET_C / 256), dim3(256), 0, S(stream), (const float*)ws, grid, dW2);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // extern "C"

@@ -159,7 +159,7 @@ int tvae_heads_bwd(const float* W, const float* dY, long ldy, const float* X, lo
     if (N <= 0 || C <= 0) return 0;
     const int np = panels_of(N, PANEL8);
     if (nh < 1 || nh > 8 || part_floats < (long)np * C * (nh + 1)) return (int)hipErrorInvalidValue;
-    const int vec = (aligned16(X) && aligned16(dX) && aligned16(dY) && ldx % 4 == 0 && lddx % 4 == 0 && ldy % 4 == 0) ? 1 : 0;
+    const int vec = (aligned16(X) && (!dX || aligned16(dX)) && aligned16(dY) && ldx % 4 == 0 && lddx % 4 == 0 && ldy % 4 == 0) ? 1 : 0;
     switch (nh) {
         case 1: launch_heads_bwd<1>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
         case 2: launch_heads_bwd<2>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;

@@ -348,4 +348,163 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of conv2 in one pass, dH never stored:
+//     dW2[c2][c] = sum_n dH[c2][n] A1[c][n],   dH[c2][n] = act'(H[c2][n]) * sum_h Wh[h][c2] dheads[h][n]
+// (reference: autograd of nn.Conv3d(C, C, 1) behind the three 1x1x1 heads, src/models.py:347-358,390-392) from A1, the
+// head gradients (7 rows) and the sign words of H that the forward launch stored -- 548 B per column instead of the
+// 1 056 B (dH written by tvae_heads_bwd, then dH and A1 read by the fp32-MFMA GEMM) of the unfused pair.
+//
+// The reduction runs over the 2.2 M columns, so both MFMA operands are "row, 8 consecutive columns" fragments -- 32-byte
+// pieces 8.9 MB apart if a lane fetched its own (the per-wave version of round 2 lost to exactly that).  Here the
+// workgroup is cooperative: one persistent 8-wave workgroup per CU walks chunks of EW_NC = 32 columns;
+//   * A1's 128 x 32 chunk arrives by 16 LDS-DMAs of 1 KB (8 rows x 128 contiguous bytes each: whole lines), the 7 head-
+//     gradient rows and the 32 sign-word columns by one more each, one chunk ahead (double buffer, counted per wave);
+//   * thread (row, k-octet) builds ONE cell of each operand per chunk: the 8 A1 values of its row from the raw stage,
+//     and the 8 dH values of its row formed on the spot (7 FMAs per value against broadcast LDS reads of the head
+//     gradients, one mask bit each), split exactly into three bf16 parts, stored as [part][octet][row] cells;
+//   * wave (i, jj) owns the 32 x 64 block (row tile i of dH) x (column tiles 2 jj, 2 jj + 1 of A1^T) of dW2: per 16-column
+//     step one A fragment and two B fragments (conflict-free 16-byte cell reads), twelve MFMAs;
+//   * the 128 x 128 accumulators stay in registers for the workgroup's whole column range; the per-workgroup results go
+//     to a slab and a second launch adds the slabs in workgroup order (deterministic, no atomics).
+// Columns: N % 32 == 0 (else the unfused path).  LDS 84 KB.
+// ------------------------------------------------------------------------------------------
+constexpr int EW_NC = 32;                              // columns per chunk (two 16-column MFMA steps)
+constexpr int EW_RAW = ET_C * EW_NC * 4;               // raw A1 stage of one chunk: [row][32 columns], 16 KB
+constexpr int EW_AUX = 1024;                           // head gradients [<= 8 rows][32 columns] (896 B used)
+constexpr int EW_BITS = 1024;                          // sign words [32 columns][4] (the DMA's 64 lanes fetch every column twice)
+constexpr int EW_STAGE = EW_RAW + EW_AUX + EW_BITS;    // one DMA stage
+constexpr int EW_CELLS = 3 * 4 * ET_C * 16;            // one operand of one chunk as cells [part][octet < 4][row]: 24 KB
+constexpr int EW_LDS = 2 * EW_STAGE + 2 * EW_CELLS;
+
+#define TVAE_EW_DMA_X4(dst, src) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory")
+
+template <int NP>
+static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel(
+    const float* __restrict__ A1, long lda, const float* __restrict__ dheads, long ldd, int nh,
+    const uint4* __restrict__ bitsH, const float* __restrict__ Wh, float* __restrict__ slabs, long N, float slope) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ew_sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ew_sm;
+    uint4* cellsD = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE);              // dH cells   [part][octet][row]
+    uint4* cellsA = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE + EW_CELLS);   // A1 cells
+    // this workgroup's chunks: a contiguous range (chunk = 32 columns)
+    const long nchunks = N / EW_NC;
+    const long per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const long c_beg = (long)blockIdx.x * per;
+    const long c_end = c_beg + per < nchunks ? c_beg + per : nchunks;
+    // cell build role: row (of A1 resp. dH) and k-octet of the chunk
+    const int row = tid & 127, oct = tid >> 7;
+    float wh[ET_MAXH];
+#pragma unroll
+    for (int h = 0; h < ET_MAXH; ++h) wh[h] = h < nh ? Wh[(long)h * ET_C + row] : 0.f;
+    // DMA role (per wave and chunk: two pieces of A1 + one auxiliary piece = 3 instructions, uniform for the counting):
+    //   A1 piece g = 2 wave + q: rows 8 g .. 8 g + 7, lane -> (row 8 g + (lane >> 3), columns 4 (lane & 7) ..)
+    //   aux: wave 1: the sign words (16 bytes) of column (lane & 31); every other wave: head-gradient row (lane >> 3) < nh
+    //        (rows beyond nh re-read row 0; waves 2..7 repeat wave 0's piece into the same place: harmless)
+    const float* a_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a_src[q] = A1 + (long)(8 * (2 * wave + q) + (lane >> 3)) * lda + 4 * (lane & 7);
+    const int hrow = (lane >> 3) < nh ? (lane >> 3) : 0;
+    const float* h_src = dheads + (long)hrow * ldd + 4 * (lane & 7);
+    auto dma_chunk = [&](long ch, int stage) {
+        const long n0 = ch * EW_NC;
+        const unsigned st = lds0 + (unsigned)(stage * EW_STAGE);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* src = a_src[q] + n0;
+            const unsigned dst = st + (unsigned)((2 * wave + q) * 1024);
+            TVAE_EW_DMA_X4(dst, src);
+        }
+        if (wave == 1) {                                 // wave-uniform branch: every wave issues exactly one aux DMA
+            const uint4* src = bitsH + n0 + (lane & 31);
+            const unsigned dst = st + (unsigned)(EW_RAW + EW_AUX);
+            TVAE_EW_DMA_X4(dst, src);
+        } else {
+            const float* src = h_src + n0;
+            const unsigned dst = st + (unsigned)EW_RAW;
+            TVAE_EW_DMA_X4(dst, src);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int ti = wave >> 1, tj = 2 * (wave & 1), kh = lane >> 5, li = lane & 31;
+    if (c_beg < c_end) dma_chunk(c_beg, 0);
+    int stage = 0;
+    for (long ch = c_beg; ch < c_end; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of chunk `ch` have landed
+        __syncthreads();                                                 // ... everybody's; the previous chunk's MFMAs are done
+        dma_chunk(ch + 1 < c_end ? ch + 1 : ch, stage ^ 1);              // (clamped: uniform bookkeeping)
+        const unsigned char* sb = ew_sm + stage * EW_STAGE;
+        {   // A1 cell of (row, oct)
+            const float4* rp = reinterpret_cast<const float4*>(sb + row * (EW_NC * 4) + oct * 32);
+            const float4 v0 = rp[0], v1 = rp[1];
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            Cell16 c3[3];
+            et_split<NP>(x, c3);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) cellsA[(p * 4 + oct) * ET_C + row] = c3[p].u;
+        }
+        {   // dH cell of (row, oct): G = Wh^T dheads (wave-uniform LDS addresses: broadcast reads), masked by the sign bit
+            const float* hs = reinterpret_cast<const float*>(sb + EW_RAW) + oct * 8;
+            const unsigned* bw = reinterpret_cast<const unsigned*>(sb + EW_RAW + EW_AUX) + (row >> 5);
+            float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < ET_MAXH; ++h) {
+                const float4 d0 = *reinterpret_cast<const float4*>(hs + h * EW_NC);
+                const float4 d1 = *reinterpret_cast<const float4*>(hs + h * EW_NC + 4);
+                g[0] = __fmaf_rn(wh[h], d0.x, g[0]); g[1] = __fmaf_rn(wh[h], d0.y, g[1]);
+                g[2] = __fmaf_rn(wh[h], d0.z, g[2]); g[3] = __fmaf_rn(wh[h], d0.w, g[3]);
+                g[4] = __fmaf_rn(wh[h], d1.x, g[4]); g[5] = __fmaf_rn(wh[h], d1.y, g[5]);
+                g[6] = __fmaf_rn(wh[h], d1.z, g[6]); g[7] = __fmaf_rn(wh[h], d1.w, g[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w = bw[(oct * 8 + j) * 4];
+                g[j] *= ((w >> (row & 31)) & 1u) ? 1.f : slope;
+            }
+            Cell16 c3[3];
+            et_split<NP>(g, c3);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) cellsD[(p * 4 + oct) * ET_C + row] = c3[p].u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Cell16 af[3], bf[2][3];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                af[p].u = cellsD[(p * 4 + 2 * ks + kh) * ET_C + 32 * ti + li];
+                bf[0][p].u = cellsA[(p * 4 + 2 * ks + kh) * ET_C + 32 * tj + li];
+                bf[1][p].u = cellsA[(p * 4 + 2 * ks + kh) * ET_C + 32 * (tj + 1) + li];
+            }
+            mfma_np<NP>(acc[0], af, bf[0]);
+            mfma_np<NP>(acc[1], af, bf[1]);
+        }
+        stage ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this workgroup's LDS
+    // slab [workgroup][c2][c]: lane (c = 32 (tj + j) + li), register r -> row c2 = et_row(ti, r, kh)
+    float* slab = slabs + (long)blockIdx.x * ET_C * ET_C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] = acc[j][r];
+}
+
+// dW2[e] = sum over workgroups of slabs[g][e], in workgroup order
+static __global__ void enc_tail_wgrad_total_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dW2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ET_C * ET_C) return;
+    float s = 0.f;
+    for (int g = 0; g < nslab; ++g) s += slabs[(long)g * ET_C * ET_C + e];
+    dW2[e] = s;
+}
+
 }  // namespace tvae

@@ -244,7 +244,7 @@ static __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __re
 }
 
 // Backward of the head projection fused with the activation mask of its input and all row reductions:
-//   dX[c][n]        = act'(X[c][n]) * sum_j W[j*C + c] * dY[j][n]
+//   dX[c][n]        = act'(X[c][n]) * sum_j W[j*C + c] * dY[j][n]            (not stored when dX == NULL: sums only)
 //   part[p][c][j]   = sum_{n in panel p} dY[j][n] * X[c][n]        -> dW[j][c]
 //   part[p][c][NO]  = sum_{n in panel p} dX[c][n]                  -> bias gradient of the layer producing X
 template <int NO>
@@ -290,7 +290,7 @@ static __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __re
                 dv[e] = s * act_deriv_from_out(xe, act, slope);
                 acc[NO] += dv[e];
             }
-            store4(orow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
+            if (dX) store4(orow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
         }
 #pragma unroll
         for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);

@@ -48,6 +48,7 @@ SIGNATURES = {
     'tvae_get_latent': 'plpppiiiifppp',
     'tvae_enc_tail_fwd_x6': 'pplpppiplplppilifi',
     'tvae_enc_tail_dgrad_x6': 'ppplippplilfi',
+    'tvae_enc_tail_wgrad_x6': 'plplipppplilfi',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',
@@ -74,6 +75,7 @@ QUERIES = {
     'tvae_conv1_dft_supported': ('iiiiiii', 'i'),
     'tvae_conv1_dft_at_floats': ('iiiiiii', 'l'),
     'tvae_conv1_dft_ws_floats': ('iiiiiii', 'l'),
+    'tvae_enc_tail_wgrad_x6_ws_floats': ('l', 'l'),
 }
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}

@@ -223,6 +223,7 @@ FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
 FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
 FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
 FUSE_ROW_SUMS = os.environ.get('TVAE_FUSE_ROW_SUMS', '1') != '0'
+FUSE_ENC_WGRAD = os.environ.get('TVAE_FUSE_ENC_WGRAD', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -426,7 +427,10 @@ class EncoderFn(torch.autograd.Function):
             with _timed('tvae_enc_tail_dgrad_x6'):
                 call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, ctx.bits[0], ctx.bits[1], dA1, N, C, N,
                      LRELU_SLOPE, parts())
-        dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        # conv2's weight gradient in one pass from A1, the head gradients and the sign words of H (dH is formed inside the
+        # GEMM's operand build and never written); dWh / db2 from a sums-only pass over H
+        fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0
+        dH = None if fuse_w else torch.empty(C2, N, dtype=torch.float32, device=y.device)
         if nh <= SKINNY_MAX:
             # one pass over H: masked dgrad + dWh + the row sums of dH (= db2)
             npan = (N + 511) // 512
@@ -439,7 +443,15 @@ class EncoderFn(torch.autograd.Function):
             dWh = _wgrad(dheads, H, nh, N, C2)
             call('tvae_linear_dgrad', Wh.contiguous(), dheads, None, H, dH, nh, N, C2, N, N, act, LRELU_SLOPE)
             db2 = _rowsum(dH, C2, N)
-        dW2 = _wgrad(dH, A1, C2, N, C)
+        if fuse_w:
+            _note('enc.tail_wgrad_x6')
+            dW2 = torch.empty(C2, C, dtype=torch.float32, device=y.device)
+            wsw = _scratch(y.device, 'enc_wgrad_slabs', query('tvae_enc_tail_wgrad_x6_ws_floats', N))
+            with _timed('tvae_enc_tail_wgrad_x6'):
+                call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, ctx.bits[0], Wh.contiguous(), dW2, wsw, wsw.numel(), C,
+                     N, LRELU_SLOPE, parts())
+        else:
+            dW2 = _wgrad(dH, A1, C2, N, C)
         if dA1 is None:
             dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
             call('tvae_linear_dgrad', W2.contiguous(), dH, None, A1, dA1, C2, N, C, N, N, act, LRELU_SLOPE)

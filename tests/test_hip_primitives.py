@@ -548,7 +548,8 @@ def _enc_tail_perm():
 
 
 @pytest.mark.parametrize('N,nh,act,parts', [(64 * 40, 7, 1, 3), (64 * 2048 + 37, 7, 1, 3), (1000, 5, 2, 3), (31, 1, 0, 3),
-                                            (64 * 300, 7, 1, 1), (64 * 1024 + 36, 3, 1, 3), (4, 7, 1, 3)])
+                                            (64 * 300, 7, 1, 1), (64 * 1024 + 36, 3, 1, 3), (4, 7, 1, 3), (32 * 9001, 7, 1, 3),
+                                            (32, 2, 1, 3)])
 def test_enc_tail_x6(N, nh, act, parts):
     """Fused conv2 + head projection (reference models.py:356-358, 390-392) and its fused data gradient against fp64."""
     C = 128
@@ -593,6 +594,23 @@ def test_enc_tail_x6(N, nh, act, parts):
     dH = (Wh.double().t() @ dheads.double()) * dact_ref(Hs, 1)
     ref = (W2.double().t() @ dH) * dact_ref(A1.double(), 1)
     assert rel_err(dA1, ref) < tol
+    # conv2's weight gradient in one pass (dH formed from the head gradients and the sign words, never stored), and the
+    # sums-only form of tvae_heads_bwd (dX = NULL) that supplies dWh / db2 beside it
+    if N % 32 == 0:
+        wsl = torch.full((query('tvae_enc_tail_wgrad_x6_ws_floats', N),), float('nan'), device=dev())
+        dW2 = torch.full((C, C), float('nan'), device=dev())
+        call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, dheads.to(dev()), N, nh, bits_h, Wh.to(dev()), dW2, wsl, wsl.numel(), C, N,
+             SLOPE, parts)
+        assert rel_err(dW2, dH @ A1.double().t()) < tol
+        npan = (N + 511) // 512
+        part = torch.empty(npan * C * (nh + 1), device=dev())
+        tot = torch.empty(nh + 1, C, device=dev())
+        call('tvae_heads_bwd', Wh.to(dev()), dheads.to(dev()), N, H, N, None, N, nh, C, N, 1, SLOPE, part, part.numel(), tot)
+        assert rel_err(tot[:nh], dheads.double() @ Hs.t()) < TOL and rel_err(tot[nh], dH.sum(1)) < 1e-4
+    else:
+        with pytest.raises(Exception):                   # whole 32-column chunks only (the unfused path takes the rest)
+            call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, dheads.to(dev()), N, nh, bits_h, Wh.to(dev()), dA1, dA1, dA1.numel(),
+                 C, N, SLOPE, parts)
 
 
 def test_enc_tail_x6_full_size_properties():
@@ -658,6 +676,15 @@ def test_enc_tail_x6_full_size_properties():
     assert rel_err(tot[:nh], dWhr) < TOL
     assert rel_err(tot[nh], dbr) < 1e-4
     assert rel_err(dW2, dHr) < TOL
+    # the one-pass form (dH never stored): same sums, bitwise repeatable
+    wsl = torch.empty(query('tvae_enc_tail_wgrad_x6_ws_floats', N), device=dev())
+    dW2f, dW2g = torch.empty(C, C, device=dev()), torch.empty(C, C, device=dev())
+    call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, bits[0], Wh, dW2f, wsl, wsl.numel(), C, N, SLOPE, 3)
+    call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, bits[0], Wh, dW2g, wsl, wsl.numel(), C, N, SLOPE, 3)
+    assert torch.equal(dW2f, dW2g) and rel_err(dW2f, dHr) < TOL
+    tot2 = torch.empty(nh + 1, C, device=dev())
+    call('tvae_heads_bwd', Wh, dheads, N, H, N, None, N, nh, C, N, 1, SLOPE, part, part.numel(), tot2)
+    assert torch.equal(tot2, tot)
 
 
 @pytest.mark.parametrize('C,B,R,Ho,act', [(8, 3, 4, 9, 1), (128, 5, 8, 29, 1), (16, 2, 16, 7, 2), (5, 1, 8, 3, 0)])
