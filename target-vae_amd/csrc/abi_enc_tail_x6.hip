@@ -110,7 +110,7 @@ int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long 
                            nh, (const uint4*)bits_h, Wh, ws, N, slope);
     }
     TVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(enc_tail_wgrad_total_kernel, dim3(ET_C * ET_C / 256), dim3(256), 0, S(stream), (const float*)ws, grid, dW2);
+    hipLaunchKernelGGL(enc_tail_wgrad_total_kernel, dim3(ET_C * ET_C / 64), dim3(256), 0, S(stream), (const float*)ws, grid, dW2);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

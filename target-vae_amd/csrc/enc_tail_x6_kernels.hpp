@@ -368,7 +368,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
 //     step one A fragment and two B fragments (conflict-free 16-byte cell reads), twelve MFMAs;
 //   * the 128 x 128 accumulators stay in registers for the workgroup's whole column range; the per-workgroup results go
 //     to a slab and a second launch adds the slabs in workgroup order (deterministic, no atomics).
-// Columns: N % 32 == 0 (else the unfused path).  LDS 84 KB.
+// Columns: N % 32 == 0 (else the unfused path).  LDS 132 KB (two DMA stages, two sets of cells).
 // ------------------------------------------------------------------------------------------
 constexpr int EW_NC = 32;                              // columns per chunk (two 16-column MFMA steps)
 constexpr int EW_RAW = ET_C * EW_NC * 4;               // raw A1 stage of one chunk: [row][32 columns], 16 KB
@@ -376,7 +376,7 @@ constexpr int EW_AUX = 1024;                           // head gradients [<= 8 r
 constexpr int EW_BITS = 1024;                          // sign words [32 columns][4] (the DMA's 64 lanes fetch every column twice)
 constexpr int EW_STAGE = EW_RAW + EW_AUX + EW_BITS;    // one DMA stage
 constexpr int EW_CELLS = 3 * 4 * ET_C * 16;            // one operand of one chunk as cells [part][octet < 4][row]: 24 KB
-constexpr int EW_LDS = 2 * EW_STAGE + 2 * EW_CELLS;
+constexpr int EW_LDS = 2 * EW_STAGE + 4 * EW_CELLS;    // two stages, two sets of (dH cells, A1 cells)
 
 #define TVAE_EW_DMA_X4(dst, src) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory")
@@ -389,8 +389,8 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ew_sm;
-    uint4* cellsD = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE);              // dH cells   [part][octet][row]
-    uint4* cellsA = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE + EW_CELLS);   // A1 cells
+    uint4* cellsD = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE);              // dH cells [set][part][octet][row]: set stride 2 EW_CELLS
+    uint4* cellsA = reinterpret_cast<uint4*>(ew_sm + 2 * EW_STAGE + EW_CELLS);   // A1 cells, likewise
     // this workgroup's chunks: a contiguous range (chunk = 32 columns)
     const long nchunks = N / EW_NC;
     const long per = (nchunks + gridDim.x - 1) / gridDim.x;
@@ -402,12 +402,15 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
 #pragma unroll
     for (int h = 0; h < ET_MAXH; ++h) wh[h] = h < nh ? Wh[(long)h * ET_C + row] : 0.f;
     // DMA role (per wave and chunk: two pieces of A1 + one auxiliary piece = 3 instructions, uniform for the counting):
-    //   A1 piece g = 2 wave + q: rows 8 g .. 8 g + 7, lane -> (row 8 g + (lane >> 3), columns 4 (lane & 7) ..)
+    //   A1 piece g = 2 wave + q: rows 8 g .. 8 g + 7, lane -> (row 8 g + (lane >> 3), 16-byte piece (lane & 7) of the stage row)
     //   aux: wave 1: the sign words (16 bytes) of column (lane & 31); every other wave: head-gradient row (lane >> 3) < nh
     //        (rows beyond nh re-read row 0; waves 2..7 repeat wave 0's piece into the same place: harmless)
     const float* a_src[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) a_src[q] = A1 + (long)(8 * (2 * wave + q) + (lane >> 3)) * lda + 4 * (lane & 7);
+    for (int q = 0; q < 2; ++q) {                        // 16-byte pieces of a row are stored XOR-swizzled by (row >> 1) & 7:
+        const int r_ = 8 * (2 * wave + q) + (lane >> 3);     // the cell build's two 16-byte reads per row are then conflict free
+        a_src[q] = A1 + (long)r_ * lda + 4 * ((lane & 7) ^ ((r_ >> 1) & 7));
+    }
     const int hrow = (lane >> 3) < nh ? (lane >> 3) : 0;
     const float* h_src = dheads + (long)hrow * ldd + 4 * (lane & 7);
     auto dma_chunk = [&](long ch, int stage) {
@@ -435,23 +438,22 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int ti = wave >> 1, tj = 2 * (wave & 1), kh = lane >> 5, li = lane & 31;
-    if (c_beg < c_end) dma_chunk(c_beg, 0);
-    int stage = 0;
-    for (long ch = c_beg; ch < c_end; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of chunk `ch` have landed
-        __syncthreads();                                                 // ... everybody's; the previous chunk's MFMAs are done
-        dma_chunk(ch + 1 < c_end ? ch + 1 : ch, stage ^ 1);              // (clamped: uniform bookkeeping)
+    // cells of one chunk from its raw stage: the A1 cell and the dH cell of (row, oct)
+    auto build = [&](int stage, int cb) {
         const unsigned char* sb = ew_sm + stage * EW_STAGE;
-        {   // A1 cell of (row, oct)
-            const float4* rp = reinterpret_cast<const float4*>(sb + row * (EW_NC * 4) + oct * 32);
-            const float4 v0 = rp[0], v1 = rp[1];
+        uint4* cD = cellsD + cb * (2 * EW_CELLS / 16);
+        uint4* cA = cellsA + cb * (2 * EW_CELLS / 16);
+        {
+            const float4* rp = reinterpret_cast<const float4*>(sb + row * (EW_NC * 4));
+            const int sw = (row >> 1) & 7;
+            const float4 v0 = rp[(2 * oct) ^ sw], v1 = rp[(2 * oct + 1) ^ sw];
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             Cell16 c3[3];
             et_split<NP>(x, c3);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) cellsA[(p * 4 + oct) * ET_C + row] = c3[p].u;
+            for (int p = 0; p < NP; ++p) cA[(p * 4 + oct) * ET_C + row] = c3[p].u;
         }
-        {   // dH cell of (row, oct): G = Wh^T dheads (wave-uniform LDS addresses: broadcast reads), masked by the sign bit
+        {   // G = Wh^T dheads (wave-uniform LDS addresses: broadcast reads), masked by the sign bit of H
             const float* hs = reinterpret_cast<const float*>(sb + EW_RAW) + oct * 8;
             const unsigned* bw = reinterpret_cast<const unsigned*>(sb + EW_RAW + EW_AUX) + (row >> 5);
             float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -472,22 +474,39 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
             Cell16 c3[3];
             et_split<NP>(g, c3);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) cellsD[(p * 4 + oct) * ET_C + row] = c3[p].u;
+            for (int p = 0; p < NP; ++p) cD[(p * 4 + oct) * ET_C + row] = c3[p].u;
         }
+    };
+    // Software pipeline, ONE barrier per chunk: iteration ch runs the MFMAs of chunk ch (cells built during iteration
+    // ch - 1) while the same threads build the cells of chunk ch + 1 from the stage that landed meanwhile, and the DMAs of
+    // chunk ch + 2 are in flight into the stage chunk ch has left.  Cells and stages are double buffered.
+    if (c_beg < c_end) {
+        dma_chunk(c_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        dma_chunk(c_beg + 1 < c_end ? c_beg + 1 : c_beg, 1);
+        build(0, 0);
+    }
+    for (long ch = c_beg; ch < c_end; ++ch) {
+        const int cb = (int)((ch - c_beg) & 1);          // cells (and stage) of chunk ch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of chunk ch + 1 have landed
+        __syncthreads();                                                 // cells of chunk ch complete; stage cb is free again
+        dma_chunk(ch + 2 < c_end ? ch + 2 : c_end - 1, cb);              // (clamped: uniform bookkeeping)
+        const uint4* cD = cellsD + cb * (2 * EW_CELLS / 16);
+        const uint4* cA = cellsA + cb * (2 * EW_CELLS / 16);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Cell16 af[3], bf[2][3];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                af[p].u = cellsD[(p * 4 + 2 * ks + kh) * ET_C + 32 * ti + li];
-                bf[0][p].u = cellsA[(p * 4 + 2 * ks + kh) * ET_C + 32 * tj + li];
-                bf[1][p].u = cellsA[(p * 4 + 2 * ks + kh) * ET_C + 32 * (tj + 1) + li];
+                af[p].u = cD[(p * 4 + 2 * ks + kh) * ET_C + 32 * ti + li];
+                bf[0][p].u = cA[(p * 4 + 2 * ks + kh) * ET_C + 32 * tj + li];
+                bf[1][p].u = cA[(p * 4 + 2 * ks + kh) * ET_C + 32 * (tj + 1) + li];
             }
             mfma_np<NP>(acc[0], af, bf[0]);
             mfma_np<NP>(acc[1], af, bf[1]);
         }
-        stage ^= 1;
+        if (ch + 1 < c_end) build(cb ^ 1, cb ^ 1);       // (the MFMAs above are independent of it: they overlap)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this workgroup's LDS
     // slab [workgroup][c2][c]: lane (c = 32 (tj + j) + li), register r -> row c2 = et_row(ti, r, kh)
@@ -500,11 +519,18 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
 
 // dW2[e] = sum over workgroups of slabs[g][e], in workgroup order
 static __global__ void enc_tail_wgrad_total_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dW2) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ET_C * ET_C) return;
-    float s = 0.f;
-    for (int g = 0; g < nslab; ++g) s += slabs[(long)g * ET_C * ET_C + e];
-    dW2[e] = s;
+    // thread (element e, slab group q < 4): eight loads in flight per thread, fixed summation order
+    __shared__ float sm[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 8 * q; g0 < nslab; g0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (g0 + u < nslab) s[u] += slabs[(long)(g0 + u) * ET_C * ET_C + e];
+    }
+    sm[q][threadIdx.x & 63] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (q == 0) dW2[e] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 }  // namespace tvae

@@ -292,11 +292,19 @@ static __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __re
             }
             if (dX) store4(orow, c0 + q * 256 + lane * 4, cend, vec, make_float4(dv[0], dv[1], dv[2], dv[3]));
         }
+        if (NO == 7) {                                   // eight sums: one butterfly (10 exchange steps instead of 48)
+            float a8[8];
 #pragma unroll
-        for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);
-        if (lane == 0) {
+            for (int v = 0; v < 8; ++v) a8[v] = acc[v < NO + 1 ? v : 0];
+            const float tot = wave_sum8(a8, lane);
+            if (lane < 8) part[((long)blockIdx.x * C + c) * (NO + 1) + lane] = tot;
+        } else {
 #pragma unroll
-            for (int v = 0; v <= NO; ++v) part[((long)blockIdx.x * C + c) * (NO + 1) + v] = acc[v];
+            for (int v = 0; v <= NO; ++v) acc[v] = wave_sum(acc[v]);
+            if (lane == 0) {
+#pragma unroll
+                for (int v = 0; v <= NO; ++v) part[((long)blockIdx.x * C + c) * (NO + 1) + v] = acc[v];
+            }
         }
     }
 }

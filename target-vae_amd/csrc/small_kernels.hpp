@@ -25,6 +25,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// Sums EIGHT values over the 64 lanes of a wave in 4 + 2 + 1 + 3 exchange steps (a butterfly that halves the number of
+// live values at each of the first three steps) instead of 8 x 6: lane l returns the total of value (l & 7).
+__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)      // lane keeps index 2i + b0, its partner (lane ^ 1) sends exactly that one
+        b[i] = (b0 ? a[2 * i + 1] : a[2 * i]) + dpp_get<0xB1>(b0 ? a[2 * i] : a[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)      // b index 2i + b1 -> original index 4i + 2 b1 + b0
+        c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + dpp_get<0x4E>(b1 ? b[2 * i] : b[2 * i + 1]);
+    float d = (b2 ? c[1] : c[0]) + __shfl_xor(b2 ? c[0] : c[1], 4, 64);     // original index 4 b2 + 2 b1 + b0 = lane & 7
+    d += __shfl_xor(d, 8, 64);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    return d;
+}
+
 // Sum NV values over the workgroup; every thread returns with the totals.  sm: >= NV*16 floats.
 template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* sm) {
