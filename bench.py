@@ -441,8 +441,10 @@ def main():
         tail_flops = 2.0 * c['C'] * (c['C'] + nh_) * ncol
         entries['tvae_enc_tail_fwd_x6'] = (tail_flops, 'enc_tail_fwd_x6_kernel')
         entries['tvae_enc_tail_dgrad_x6'] = (tail_flops, 'enc_tail_dgrad_x6_kernel')
+        entries['tvae_enc_tail_wgrad_x6'] = (2.0 * c['C'] * c['C'] * ncol, 'enc_tail_wgrad_x6_kernel')
         tail_bytes = {'tvae_enc_tail_fwd_x6': (2 * 4 * c['C'] + 4 * nh_ + 32) * ncol,       # A1 in, H out, heads, sign words
-                      'tvae_enc_tail_dgrad_x6': (4 * c['C'] + 4 * nh_ + 32) * ncol}         # dA1 out, head gradients, sign words
+                      'tvae_enc_tail_dgrad_x6': (4 * c['C'] + 4 * nh_ + 32) * ncol,         # dA1 out, head gradients, sign words
+                      'tvae_enc_tail_wgrad_x6': (4 * c['C'] + 4 * nh_ + 16) * ncol}         # A1 in, head gradients, sign words of H
         timed = {k_: v for k_, v in kev.items() if k_ in entries}
         enc_tail = {k_: {'ms': round(kev[k_]['mean_ms'], 3), 'bound': 'hbm',
                          'algorithmic_bytes_per_launch': float(tail_bytes[k_]),
