@@ -149,7 +149,9 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
 int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
                       tvae_stream_t stream);
 /* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned
- * rows and a workspace of at least M*K floats (hipErrorInvalidValue otherwise: use the fp32 entry). */
+ * rows and a workspace of tvae_linear_wgrad_x6_ws_floats(M, N, K) floats (hipErrorInvalidValue otherwise: use the fp32
+ * entry).  The number of reduction slices -- i.e. the summation order -- depends on the shape only. */
+long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K);
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,

@@ -20,6 +20,22 @@ int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, 
 
 extern "C" {
 
+// reduction slices of tvae_linear_wgrad_x6: a function of the SHAPE only -- never of the workspace the caller happens to
+// pass (a cap by ws_floats made the first step of a process, whose shared workspace was still small, sum in a different
+// order than every later step: 2.4e-7 relative on one tensor; round 3, profiles/tools/graph_replay_probe.py)
+static int wgrad_x6_splits(int M, int N, int K) {
+    const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
+    int splits = (2 * 256 + tilesM * tilesK - 1) / (tilesM * tilesK);     // ~2 workgroups per CU
+    if (splits > N / 16) splits = N / 16;
+    if (splits < 2) splits = 2;                        // TileMap groups by reduction slice only when there are >= 2
+    const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
+    return cdiv(N, nchunk);
+}
+long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K) {
+    if (M <= 0 || K <= 0 || N < 32) return 0;
+    return (long)wgrad_x6_splits(M, N, K) * M * K;
+}
+
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
@@ -38,14 +54,9 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     const VirtAct vas{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, vg_act, vg_slope};
     const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
     const long per = (long)M * K;
-    const long cap = ws_floats / per;
-    if (cap < 2 || N < 32) return (int)hipErrorInvalidValue;
-    int splits = (2 * 256 + tilesM * tilesK - 1) / (tilesM * tilesK);     // ~2 workgroups per CU
-    if (splits > cap) splits = (int)cap;
-    if (splits > N / 16) splits = N / 16;
-    if (splits < 2) splits = 2;                        // TileMap groups by reduction slice only when there are >= 2
+    if (N < 32 || ws_floats < tvae_linear_wgrad_x6_ws_floats(M, N, K)) return (int)hipErrorInvalidValue;
+    const int splits = wgrad_x6_splits(M, N, K);
     const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
-    splits = cdiv(N, nchunk);
     if (splits < 2) return (int)hipErrorInvalidValue;
     const TileMap tmk{tilesM, tilesK, splits};
     // the implicit LeakyReLU gradient runs in its two-valued form (0 / 1 streamed operand, see the kernel)

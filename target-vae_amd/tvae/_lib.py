@@ -76,6 +76,7 @@ QUERIES = {
     'tvae_conv1_dft_at_floats': ('iiiiiii', 'l'),
     'tvae_conv1_dft_ws_floats': ('iiiiiii', 'l'),
     'tvae_enc_tail_wgrad_x6_ws_floats': ('l', 'l'),
+    'tvae_linear_wgrad_x6_ws_floats': ('iii', 'l'),
 }
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}

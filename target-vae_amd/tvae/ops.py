@@ -100,13 +100,16 @@ _TABLES = {}
 
 
 def workspace(device, floats: int) -> torch.Tensor:
-    """Split-K scratch (grown on demand, reused across calls on the same stream)."""
+    """Split-K scratch (grown on demand, reused across calls on the same stream).  The caller gets a view of EXACTLY the
+    size it asked for: several entry points cap their number of reduction slices by the workspace they are handed, so
+    passing "whatever the shared buffer has grown to" would make the summation order of a step depend on which other call
+    had run before it (the first step of a process differed from every later one by 2e-7 on one tensor: round 3)."""
     key = (device.type, device.index)
     t = _WS.get(key)
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
         _WS[key] = t
-    return t
+    return t[:int(floats)]
 
 
 def _dev_table(key, device, builder):
@@ -166,14 +169,15 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None) -> torch.Tens
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only)."""
     dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
     need = 64 * max(M, 128) * max(K, 128)
-    ws = workspace(dpre.device, max(need, 1 << 24))
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
+        ws = workspace(dpre.device, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
         with _timed('tvae_linear_wgrad_x6'):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
                  *(va if va else (None, None, None, None, 0)), bits, parts())
         return dW
     _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
+    ws = workspace(dpre.device, max(need, 1 << 24))
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
 

@@ -234,9 +234,17 @@ def test_linear_wgrad_x6(M, N, K, acc):
     init = rnd(M, K, seed=3)
     ref = d.double() @ X.double().t() + (init.double() if acc else 0)
     dW = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
-    ws = torch.empty(1 << 24, device=dev())
+    ws = torch.empty(1 << 26, device=dev())       # >= tvae_linear_wgrad_x6_ws_floats(M, N, K): slices x M x K
+    from tvae._lib import query
+    need = query('tvae_linear_wgrad_x6_ws_floats', M, N, K)
+    assert 2 * M * K <= need <= ws.numel()
     call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
     assert rel_err(dW, ref) < GEMM_TOL['f32']
+    dW2 = init.clone().to(dev()) if acc else torch.empty(M, K, device=dev())
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW2, ws, need, M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
+    assert torch.equal(dW, dW2)          # the summation order does not depend on how much workspace is offered
+    with pytest.raises(Exception):
+        call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW2, ws, need - 1, M, N, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
     with pytest.raises(Exception):
         call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N - 8, K, N, N, acc, None, None, 0, SLOPE, None, None, None, None, 0, None, 3)
 
@@ -359,7 +367,7 @@ def test_linear_x6_implicit_gradient_operand():
     with pytest.raises(Exception):         # the two-valued form exists for LeakyReLU only
         call('tvae_linear_dgrad_x6', w3t, H.to(dev()), None, aux.to(dev()), dX2, M, N, K, N, N, 2, SLOPE, None, None, None,
              None, 0, None, gy.to(dev()), csum, None, None, 0, None, 0, None, None, None, None, 3)
-    ws = torch.empty(1 << 24, device=dev())
+    ws = torch.empty(1 << 26, device=dev())       # >= tvae_linear_wgrad_x6_ws_floats(M, N, K): slices x M x K
     for vact in (1, 2):                    # LeakyReLU: two-valued weight gradient; tanh: generic implicit operand
         dv = wo.double()[:, None] * gy.double()[None, :] * dact_ref(H.double(), vact)
         dW = torch.empty(M, K, device=dev())
@@ -426,7 +434,7 @@ def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     d0 = (W.double().t() @ d.double().cpu()) * dact_ref(h0.double().cpu(), act)
     assert rel_err(outs[1][0], d0.t() @ Wc.double().cpu()) < GEMM_TOL['f32']
     # weight gradient
-    ws = torch.empty(1 << 24, device=dev())
+    ws = torch.empty(1 << 26, device=dev())       # >= tvae_linear_wgrad_x6_ws_floats(M, N, K): slices x M x K
     dW = [torch.empty(M, F_, device=dev()) for _ in range(2)]
     call('tvae_linear_wgrad_x6', d, h0, dW[0], ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, None, None, act, SLOPE,
          None, None, None, None, 0, None, 3)
@@ -873,7 +881,7 @@ def test_implicit_wgrad_and_multi_tile_dft_fp64():
     M, N, K = 512, 20000 // 16 * 16, 384
     H = torch.randn(M, N, generator=g).clamp(-0.9, 0.9); X = torch.randn(K, N, generator=g)
     wo = torch.randn(M, generator=g); gy = torch.randn(N, generator=g)
-    dW = torch.empty(M, K, device=dev()); ws = torch.empty(1 << 24, device=dev())
+    dW = torch.empty(M, K, device=dev()); ws = torch.empty(1 << 26, device=dev())       # >= tvae_linear_wgrad_x6_ws_floats(M, N, K): slices x M x K
     call('tvae_linear_wgrad_x6', H.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, wo.to(dev()), gy.to(dev()), 1, 0.01,
          None, None, None, None, 0, None, 3)
     d = wo.double()[:, None] * gy.double()[None, :] * torch.where(H.double() > 0, 1.0, 0.01)
