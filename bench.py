@@ -113,6 +113,9 @@ def parse_args():
                          "the opt-in bf16 throughput mode")
     ap.add_argument('--no-strong', action='store_true',
                     help='N > 1: skip the extra strong-scaling measurement (global batch fixed at the per-GPU batch)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay a captured hipGraph of forward + backward (tvae/graph.py: bitwise the eager result) in the '
+                         'timed loop; without the flag the 28x28 workloads report it as a companion measurement')
     ap.add_argument('--workload', choices=['S128G', 'S28', 'S28F', 'S64'], default='S64',
                     help='S64 = the BASELINE.json metric configuration (default); others are extra measurements')
     return ap.parse_args()
@@ -282,10 +285,21 @@ def main():
     x = torch.from_numpy(__import__('tvae.tables', fromlist=['x']).image_coords(c['n'])).to(dev)
     step.pixel_spacing(x)                           # cached once (the reference syncs for it every step)
 
+    gs_box = [None]
+    if args.graph:
+        from tvae import graph as _graph
+        gs_box[0] = _graph.GraphedStep(x, gen, enc, opt, c['lik'], B, (c['cin'], c['n'], c['n']), dev)
+
     def one_step(i, b=None):
         b = B if b is None else b
         lo = (i % (n_img // B)) * B
         y = data[lo:lo + b]
+        if gs_box[0] is not None and b == gs_box[0].B:      # captured forward + backward; noise, all-reduce, Adam outside
+            terms = gs_box[0].run(y)
+            opt.step()
+            e_ = terms[0].clone()
+            opt.zero_grad()
+            return e_
         elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, c['lik'])
         (-elbo).backward()
         opt.step()
@@ -377,6 +391,24 @@ def main():
                           'elbo': float(lastb),
                           'entry_points_ms': {k_: round(v['mean_ms'], 3) for k_, v in sorted(kev2.items())
                                               if k_.startswith('tvae_linear') or k_.startswith('tvae_conv1')}}
+    # third companion (28x28 workloads, where ~70 launches per 4 ms step make the host's launch cost visible): the same steps
+    # with forward + backward replayed from a hipGraph (tvae/graph.py; bitwise the eager result)
+    companion_graph = None
+    if world == 1 and mode == 'x6' and not args.graph and not args.no_f32_companion and args.workload in ('S28', 'S28F'):
+        from tvae import graph as _graph
+        gs_box[0] = _graph.GraphedStep(x, gen, enc, opt, c['lik'], B, (c['cin'], c['n'], c['n']), dev)
+        for i in range(2):
+            one_step(i)
+        barrier()
+        t3 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        barrier()
+        dt3 = time.perf_counter() - t3
+        gs_box[0] = None
+        companion_graph = {'value': B * args.steps / dt3, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt3 / args.steps,
+                           'what': 'forward + backward replayed from a captured hipGraph (--graph); noise draws, Adam and the '
+                                   'minibatch copy stay eager'}
     # encoder forward only (SURVEY 8d "Metric"; BASELINE north_star states its roofline target on it): the same 256
     # images through conv1 -> conv2 -> heads -> attention head in training mode (the two activations a backward needs are
     # written), timed with events on the launch stream
@@ -486,7 +518,7 @@ def main():
                                        'buckets': 'decoder segment posted from the backward, encoder segment at the '
                                                   'optimizer step (tvae/optim.py)'}
                                       if world > 1 else None),
-                       'arithmetic_mode': mode,
+                       'arithmetic_mode': mode, 'graph_replay': bool(args.graph),
                        'lifting_conv': ('frequency domain: DFT + batched split-pipe GEMM (326 GFLOP of matrix work per '
                                         'launch instead of 2339)' if conv_dft else 'direct implicit GEMM')},
             'roofline': {'kernel': dom + ' (' + entries[dom][1] + ', ' + info['insn'] + ')', 'bound': 'mfma',
@@ -537,6 +569,8 @@ def main():
             out['exact_f32_mode'] = companion
         if companion_bf16 is not None:
             out['bf16_throughput_mode'] = companion_bf16
+        if companion_graph is not None:
+            out['graph_replay_mode'] = companion_graph
         if world == 1 and not args.no_cpu_baseline and args.workload == 'S64':
             out['cpu_baseline'] = cpu_baseline()
         else:

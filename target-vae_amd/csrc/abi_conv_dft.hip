@@ -75,9 +75,8 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.t_floats = (long)q.Lh * 2 * q.M * q.NBpad;
     q.gen = q.Lh > 64 || q.Ho > DFT_WROWS;
     // frames of the reference configurations (28x28 k28 p8; 64x64 k64 p16; the 50x50 MNIST-U geometry k28 p8) take the
-    // ring kernels (conv_dft_kernels.hpp); TVAE_DFT_RING=0 keeps the register-staged ones (A/B measurements)
-    static const bool ring_on = [] { const char* e = getenv("TVAE_DFT_RING"); return !(e && e[0] == '0'); }();
-    q.ring = !ring_on ? 0 : (q.L == 44 && q.Ho == 17) ? 1 : (q.L == 96 && q.Ho == 33) ? 2 : (q.L == 66 && q.Ho == 39) ? 3 : 0;
+    // ring kernels (conv_dft_kernels.hpp); every other frame the register-staged / generic ones
+    q.ring = (q.L == 44 && q.Ho == 17) ? 1 : (q.L == 96 && q.Ho == 33) ? 2 : (q.L == 66 && q.Ho == 39) ? 3 : 0;
     if (q.ring) {              // (LHP, NT, REM1) / (NS, NRT) of the instances: tables sized to match
         q.LHP = q.Lh; q.NT = q.ring == 3 ? 2 : 1; q.REM1 = q.ring == 2 ? 1 : 0;
         q.NS = (q.Ho + 1) / 2; q.NRT = q.ring == 1 ? 2 : 3;

@@ -82,6 +82,9 @@ def build_parser(kind: str) -> argparse.ArgumentParser:
     p.add_argument('--seed', type=int, default=None, help='seed for init / shuffling / noise (reference: unseeded)')
     p.add_argument('--synthetic', type=int, default=0, metavar='N',
                    help='train on N synthetic images of the dataset shape instead of loading files')
+    p.add_argument('--graph', action='store_true',
+                   help='replay a captured hipGraph of forward + backward for full-size minibatches (tvae/graph.py; '
+                        'bitwise the eager result, fewer launches: pays on the 28x28 workloads)')
     return p
 
 
@@ -306,6 +309,15 @@ def run(kind: str, argv=None):
         raise SystemExit('--fit-noise together with CTF filters or --mask-radius does not broadcast in the reference '
                          '(train_particles.py:303-307,330-333) and is not built')
     step_dim = args.encoder_padding if kind == 'particles' else image_dim   # reference positional argument
+    graphed = None
+    if args.graph:
+        if not (t_inf == 'attention' and r_inf != 'unimodal') or isinstance(train_src, tuple) or (mask_radius or 0) > 0:
+            raise SystemExit('--graph captures the TARGET-VAE attention branch without CTF filters / mask')
+        from . import graph as _graph
+        b_cap = train_it.plan[0][rank] if train_it.plan else 0
+        if b_cap > 0:
+            graphed = _graph.GraphedStep(x_coord, generator_model, encoder_model, optimizer, likelihood, b_cap,
+                                         tuple(train_it.data.shape[1:]), device)
 
     output = sys.stdout
     log_file = None
@@ -353,7 +365,7 @@ def run(kind: str, argv=None):
         n_local = train_it.local_count()
         e, err, kl = step.train_epoch(train_it, x_coord, generator_model, encoder_model, optimizer, t_inf, r_inf, epoch,
                                       num_epochs, max(n_local, 1), device, params, theta_prior, group_conv, step_dim,
-                                      likelihood=likelihood, progress=is_main, mask_radius=mask_radius)
+                                      likelihood=likelihood, progress=is_main, mask_radius=mask_radius, graphed=graphed)
         e, err, kl = global_means(e, err, kl, n_local)
         emit('\t'.join([str(epoch + 1), 'train', str(e), str(err), str(kl)]))
         n_test = test_it.local_count()

@@ -250,7 +250,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
                          device=y.device)
         ws = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
         _note('conv1.dft')
-        if (n + 2 * pad, n + 2 * pad - k + 1) in DFT_RING_FRAMES and os.environ.get('TVAE_DFT_RING', '1') != '0':
+        if (n + 2 * pad, n + 2 * pad - k + 1) in DFT_RING_FRAMES:
             _note('conv1.dft_ring')      # ring (LDS-DMA) transforms along w: abi_conv_dft.hip dft_plan
         with _timed('tvae_conv1_fwd'):
             call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,

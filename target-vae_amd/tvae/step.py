@@ -131,10 +131,11 @@ def eval_minibatch_particles(x, y, ctf, generator_model, encoder_model, t_inf, r
 
 def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf, r_inf, epoch, num_epochs, N, device,
                 params, theta_prior, groupconv, image_dim, likelihood='bce', progress=True, noise_iter=None,
-                mask_radius=None):
+                mask_radius=None, graphed=None):
     """Reference train_mnist.py:300-346: loss = -elbo; backward; step; batch-weighted running means.
     With `mask_radius` not None it is the particles variant (train_particles.py:350-410): minibatches are (y,) or
-    (y, ctf) and `image_dim` carries the encoder padding like the reference's positional argument."""
+    (y, ctf) and `image_dim` carries the encoder padding like the reference's positional argument.
+    `graphed` (tvae.graph.GraphedStep, opt-in): minibatches of its captured size replay a hipGraph of forward + backward."""
     generator_model.train()
     encoder_model.train()
     c = 0
@@ -149,17 +150,24 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
             optim.step()
             optim.zero_grad()
             continue
-        if mask_radius is not None:
-            elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None, generator_model,
-                                                       encoder_model, t_inf, r_inf, epoch, device, theta_prior,
-                                                       groupconv, image_dim, mask_radius, noise)
+        if graphed is not None and b == graphed.B and len(mb) == 1 and mask_radius in (None, 0):
+            # captured forward + backward (tvae/graph.py): a replay instead of ~70 launches; bitwise the eager result
+            stats_t = graphed.run(y, noise)
+            optim.step()
+            stats = stats_t.tolist()
+            optim.zero_grad()
         else:
-            elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch, device,
-                                             theta_prior, groupconv, image_dim, likelihood, noise)
-        (-elbo).backward()
-        optim.step()
-        optim.zero_grad()
-        stats = torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()]).tolist()
+            if mask_radius is not None:
+                elbo, log_p, kl = eval_minibatch_particles(x_coord, y, mb[1] if len(mb) > 1 else None, generator_model,
+                                                           encoder_model, t_inf, r_inf, epoch, device, theta_prior,
+                                                           groupconv, image_dim, mask_radius, noise)
+            else:
+                elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch, device,
+                                                 theta_prior, groupconv, image_dim, likelihood, noise)
+            (-elbo).backward()
+            optim.step()
+            optim.zero_grad()
+            stats = torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()]).tolist()
         elbo_v, gen_loss, kl_loss = stats[0], -stats[1], stats[2]   # one sync instead of three .item()
         c += b
         gen_loss_accum += b * (gen_loss - gen_loss_accum) / c

@@ -143,3 +143,77 @@ def test_eval_model_matches_oracle():
     assert not enc.training and not gen.training
     for t, b in zip(list(enc.parameters()) + list(gen.parameters()), before):
         assert t.grad is None and torch.equal(t.detach(), b)
+
+
+def test_graphed_step_bitwise_equals_eager():
+    """tvae.graph.GraphedStep (opt-in `--graph`): replaying the captured forward + backward gives BIT FOR BIT the eager
+    gradients and ELBO terms over several optimizer steps -- also with the two triggers under which round 2 saw corrupted
+    replays (a host synchronize between a replay and the next launch; deepcopy(model).cpu() between replays)."""
+    import copy
+    sys.path.insert(0, PKG)
+    import src.models as M
+    from tvae import graph, optim, step, tables
+    dev = torch.device('cuda:0')
+    n, R, B = 28, 8, 32
+
+    def models():
+        torch.manual_seed(5)
+        gen = M.SpatialGenerator(2, 512, num_layers=2).to(dev)
+        enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
+            n, 1, 2, kernels_num=128, kernels_size=28, padding=8, groupconv=R, rot_refinement=True, theta_prior=np.pi,
+            normal_prior_over_r=False).to(dev)
+        params = list(gen.parameters()) + list(enc.parameters())
+        return gen, enc, params, optim.FlatAdam(params, lr=1e-3)
+    x = torch.from_numpy(tables.image_coords(n)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    ys = [torch.rand(B, 1, n, n, device=dev, generator=g) for _ in range(4)]
+    noises = [step.draw_noise(B, R * 17 * 17, 2, dev, generator=g) for _ in range(4)]
+    # eager trajectory
+    gen, enc, params, opt = models()
+    eager = []
+    for y, nz in zip(ys, noises):
+        e, lp, kl = step.elbo_terms(x, y, gen, enc, 'bce', nz)
+        (-e).backward()
+        eager.append((opt.flat_g.clone(), torch.stack([e.detach().double(), lp.detach().double(), kl.detach().double()])))
+        opt.step()
+        opt.zero_grad()
+    p_eager = opt.flat_p.clone()
+    # the same trajectory through the graph
+    gen, enc, params, opt = models()
+    gs = graph.GraphedStep(x, gen, enc, opt, 'bce', B, (1, n, n), dev)
+    for i, (y, nz) in enumerate(zip(ys, noises)):
+        terms = gs.run(y, nz)
+        if i == 1:
+            torch.cuda.synchronize()
+        if i == 2:
+            copy.deepcopy(gen).cpu()
+        assert torch.equal(opt.flat_g.view(torch.int32), eager[i][0].view(torch.int32)), i
+        assert torch.equal(terms, eager[i][1]), i
+        opt.step()
+        opt.zero_grad()
+    assert torch.equal(opt.flat_p, p_eager)
+    # train_epoch takes the replay for minibatches of the captured size and the eager path for a ragged tail
+    data = torch.cat(ys + [ys[0][:5]])
+    it = [(data[i:i + B],) for i in range(0, data.shape[0], B)]
+    gen, enc, params, opt = models()
+    gs = graph.GraphedStep(x, gen, enc, opt, 'bce', B, (1, n, n), dev)
+    nz_all = noises + [tuple(t[:5] for t in noises[0])]
+    r1 = step.train_epoch(it, x, gen, enc, opt, 'attention', 'attention+offsets', 0, 1, data.shape[0], dev, params, np.pi, R, n,
+                          progress=False, noise_iter=iter(nz_all), graphed=gs)
+    p1 = opt.flat_p.clone()
+    gen, enc, params, opt = models()
+    r0 = step.train_epoch(it, x, gen, enc, opt, 'attention', 'attention+offsets', 0, 1, data.shape[0], dev, params, np.pi, R, n,
+                          progress=False, noise_iter=iter(nz_all))
+    assert r0 == r1 and torch.equal(opt.flat_p, p1)
+
+
+def test_cli_graph_flag_same_log_as_eager(tmp_path):
+    """`train_mnist.py --graph` prints the same TSV lines as the eager run under the same seed."""
+    outs = []
+    for extra in ([], ['--graph']):
+        cmd = [sys.executable, os.path.join(PKG, 'train_mnist.py')] + SMALL + CASES['train_mnist'][0] + extra + \
+            ['--seed', '7', '--log-root', str(tmp_path / ('logs' + ''.join(extra)))]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if '\t' in ln])
+    assert outs[0] == outs[1] and len(outs[0]) == 5
