@@ -138,7 +138,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
                          float* rs_dwo, int parts, tvae_stream_t stream);
 /* Row sums of the streamed activation (ABI 3; two-valued form only, i.e. vg_csum given; M <= 512): with rs_part
- * [N/128][M][2] (workspace), rs_wo [M] (the single-output Linear's weight, src/models.py:121-123), rs_gysum [1] = sum_n
+ * [M][N/128][2] (workspace), rs_wo [M] (the single-output Linear's weight, src/models.py:121-123), rs_gysum [1] = sum_n
  * vg_gy[n], the launch also returns rs_db [M] = wo[m] sum_n gy[n] act'(H[m][n]) (bias gradient of the layer that produced
  * H = dpre) and rs_dwo [M] = sum_n gy[n] H[m][n] (weight gradient of that Linear) -- what tvae_dec_out_bwd would otherwise
  * compute in a 2 GB pass of its own over H.  rs_part = NULL: off.

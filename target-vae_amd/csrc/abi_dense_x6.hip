@@ -43,7 +43,7 @@ __global__ void dgrad_rowsum_total_kernel(const float* __restrict__ part, int nt
     const int m = blockIdx.x;
     float s[2] = {0.f, 0.f};
     for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((long)t * K + m) * 2);
+        const float2 v = *reinterpret_cast<const float2*>(part + ((long)m * ntiles + t) * 2);
         s[0] += v.x;
         s[1] += v.y;
     }

@@ -106,8 +106,8 @@ struct VirtGrad {          // the streamed gradient operand given implicitly (ba
     const unsigned* bits;
     // data gradient only (dense_x6_kernel<4>): the launch that streams H for the two-valued operand also produces, per
     // 128-column tile, the two row sums the backward of the single-output Linear needs of H (tvae_dec_out_bwd's whole job):
-    //   rpart[(tile_n * K + m) * 2 + 0] = sum_{n in tile} gy[n] [H[m][n] > 0]   -> bias gradient of the layer producing H
-    //   rpart[(tile_n * K + m) * 2 + 1] = sum_{n in tile} gy[n] H[m][n]         -> dWo[m]
+    //   rpart[(m * (N/128) + tile_n) * 2 + 0] = sum_{n in tile} gy[n] [H[m][n] > 0]   -> bias gradient of the layer producing H
+    //   rpart[(m * (N/128) + tile_n) * 2 + 1] = sum_{n in tile} gy[n] H[m][n]         -> dWo[m]
     float* rpart;
 };
 __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
@@ -486,7 +486,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     if (nk & 1) step(nk - 1, afA, afB, xB);
     if (RSUM) {                                          // (the loop's last barrier made every slot visible)
         if (tid < K) {
-            float* rp = vg.rpart + ((long)tile_n * K + tid) * 2;
+            float* rp = vg.rpart + ((long)tid * (N >> 7) + tile_n) * 2;   // [row][tile][2]: a row's partials are contiguous
             rp[0] = rsm_[tid * 2] + rsm_[(DX6_ROWS + tid) * 2];
             rp[1] = rsm_[tid * 2 + 1] + rsm_[(DX6_ROWS + tid) * 2 + 1];
         }
