@@ -22,6 +22,11 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          # with the implicit gradient operand (generic / two-valued); the bench line looks its launch up by grid size
          'dense_x6_kernel<0, 3>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2, 3>': 'tvae_linear_fwd_x6',
          'dense_x6_kernel<1, 3>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<3, 3>': 'tvae_linear_dgrad_x6',
+         'dense_x6_kernel<4, 3>': 'tvae_linear_dgrad_x6',        # round 3: two-valued + row sums of H (no dec_out_bwd pass)
+         'dense_x6_plain4_kernel': 'tvae_spectral_fwd',
+         'dft_out_ring_kernel': 'tvae_dft_out', 'dft_dy_ring_kernel': 'tvae_dft_dy',
+         'enc_tail_wgrad_x6_kernel': 'tvae_enc_tail_wgrad_x6', 'dft_dbank_kernel': 'tvae_dft_dbank',
+         'dft_spectra_kernel': 'tvae_dft_spectra',
          'dense_wgrad_x6_dma_kernel<true': 'tvae_linear_wgrad_x6', 'dense_wgrad_x6_dma_kernel<false': 'tvae_spectral_wgrad',
          'dft_out_mf_kernel': 'tvae_dft_out', 'dft_dy_mf_kernel': 'tvae_dft_dy',
          'dft_out_gen_kernel': 'tvae_dft_out', 'dft_dy_gen_kernel': 'tvae_dft_dy',
@@ -29,6 +34,9 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          'heads_fwd_kernel': 'tvae_heads_fwd', 'heads_bwd_kernel': 'tvae_heads_bwd',
          'enc_tail_fwd_x6_kernel': 'tvae_enc_tail_fwd_x6', 'enc_tail_dgrad_x6_kernel': 'tvae_enc_tail_dgrad_x6',
          'gemm_f32_kernel<': 'tvae_conv2_wgrad',
+         # calibration kernels with an exactly known read volume: round <= 2 dec_out_bwd_kernel<1> (reads H [512][B*4096] once);
+         # round 3 (that pass is folded into the data-gradient launch): heads_bwd_kernel<7> in its sums-only form reads
+         # H [128][N] + dheads [7][N] = 540 N bytes and writes next to nothing
          'dec_out_bwd_kernel<1>': 'calibration_dec_out_bwd'}
 
 
