@@ -672,7 +672,12 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     };
     auto dma_piece = [&](const Src& q, int slot, int i) {
         int e = i * 64 + lane;
-        if (q.tlast < 31) {                              // wave uniform, rare
+        // the last piece overhangs the tile when 32 HO is not a multiple of 64; element 32 HO IS consumed (column 31 at
+        // the padded step w = HO, against a zero of the constant operand), so it must be finite and inside dY: the
+        // overhang re-reads the last valid column as well (found by the NaN guard bands of
+        // tests/test_hip_modules.py::test_step_does_not_read_out_of_bounds[M28]: the last tile of the last filter read
+        // 128 bytes past the end of dY)
+        if (q.tlast < 31 || (i == NL - 1 && (32 * HO) % 64 != 0)) {      // first: wave uniform, rare; second: static
             const int t = e / HO;
             if (t > q.tlast) e -= (t - q.tlast) * HO;
         }

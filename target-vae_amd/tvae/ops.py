@@ -99,6 +99,12 @@ _WS = {}
 _TABLES = {}
 
 
+# debugging aid (TVAE_POISON_WS=1; off by default, costs a fill per call): every workspace view handed out, and every named
+# scratch buffer when it is (re)allocated, is filled with NaN first -- a kernel that reads what no kernel of the same call
+# wrote then shows up as NaN instead of depending on what an earlier, larger problem left there
+POISON_WS = os.environ.get('TVAE_POISON_WS', '0') == '1'
+
+
 def workspace(device, floats: int) -> torch.Tensor:
     """Split-K scratch (grown on demand, reused across calls on the same stream).  The caller gets a view of EXACTLY the
     size it asked for: several entry points cap their number of reduction slices by the workspace they are handed, so
@@ -109,6 +115,8 @@ def workspace(device, floats: int) -> torch.Tensor:
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
         _WS[key] = t
+    if POISON_WS:
+        t[:int(floats)].fill_(float('nan'))
     return t[:int(floats)]
 
 
@@ -214,6 +222,8 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
     t = _WS.get(k_)
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
+        if POISON_WS:
+            t.fill_(float('nan'))
         _WS[k_] = t
     return t
 

@@ -252,7 +252,7 @@ def test_step_hot_widths_golden(name, gemm_mode):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=max(GRAD_TOL, 2 * float(fx['kd.' + k_])), name='gen.' + k_)
 
 
-@pytest.mark.parametrize('cfg', ['small', 'small_fourier', 'S28', 'S28F', 'S64'])
+@pytest.mark.parametrize('cfg', ['small', 'small_fourier', 'S28', 'S28F', 'S64', 'S64x', 'M28', 'M28r', 'M50', 'M50x'])
 def test_step_does_not_read_out_of_bounds(cfg):
     """Out-of-bounds READ detector.  Every float tensor the step allocates (torch.empty / torch.zeros, workspaces
     included) becomes a view into the middle of a larger allocation; ELBO and every gradient must be bitwise independent
@@ -267,7 +267,15 @@ def test_step_does_not_read_out_of_bounds(cfg):
                                          'small_fourier': (20, 2, 8, 8, 8, 32, 20, 4, True),
                                          'S28': (28, 2, 8, 16, 128, 512, 28, 14, False),
                                          'S28F': (28, 2, 16, 8, 128, 512, 28, 14, True),
-                                         'S64': (64, 2, 8, 4, 128, 512, 64, 16, False)}[cfg]
+                                         'S64': (64, 2, 8, 4, 128, 512, 64, 16, False),
+                                         # B * Ho a multiple of 32 (as at the bench's B = 256): no ragged last tile
+                                         'S64x': (64, 2, 8, 32, 128, 512, 64, 16, False),
+                                         'M50x': (50, 2, 8, 32, 128, 512, 28, 8, False),
+                                         # the reference's MNIST geometries (k = 28, padding 8): the 44- and 66-wide ring
+                                         # transforms; M28r: a batch whose last 32-column tile is ragged
+                                         'M28': (28, 2, 8, 32, 128, 512, 28, 8, False),
+                                         'M28r': (28, 2, 8, 5, 128, 512, 28, 8, False),
+                                         'M50': (50, 2, 8, 4, 128, 512, 28, 8, False)}[cfg]
     torch.manual_seed(0)
     gen = M.SpatialGenerator(zd, hid, num_layers=2, fourier_expansion=four, sigma=2.0 / (n - 1)).to(dev())
     enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
