@@ -123,8 +123,11 @@ extern "C" {
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
 }
+// A^T is followed by four words: the maxima of the h3 arithmetic ([0] max |A^T|, [1] max |W|, [2] max |S'|), written by
+// the kernels that produce those operands and read by the GEMMs that split them
+constexpr int DFT_AT_TRAILER = 4;
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
-    return dft_plan(B, Cin, n, ksz, pad, C, R).at_floats;
+    return ((dft_plan(B, Cin, n, ksz, pad, C, R).at_floats + 3) & ~3L) + DFT_AT_TRAILER;
 }
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
@@ -149,6 +152,14 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         hipError_t e = dft_zero(at, q.at_floats, st);
         if (e != hipSuccess) return (int)e;
     }
+    // h3 arithmetic (two fp16 parts, three products): the 4-wave spectral GEMM has the instance; other shapes stay exact x6
+    const bool h3 = parts == 2 && q.K2 <= 256;
+    if (parts == 2 && !h3) parts = 3;
+    // the maxima are produced in every arithmetic (a 64-thread launch and a few atomics): the weight gradient may run in
+    // h3 after a forward that did not
+    float* amax = at + ((q.at_floats + 3) & ~3L);
+    hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, amax, DFT_AT_TRAILER);
+    TVAE_CHECK_LAUNCH();
     float* EO = tab;
     float* ED = EO + ((q.eo_floats + 3) & ~3L);
     hipError_t e = allow_big_lds(dft_spectra_kernel, q.lds_sp);
@@ -158,11 +169,19 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
-                       n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk);
+                       n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, amax);
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
-    int rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, nullptr, nullptr, stream);
+    int rc = 0;
+    if (h3) {
+        const int Rp = x6_round_up(rows, DX6_ROWS), K8p = dense_k8pad(q.K2);
+        hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d((long)K8p * Rp, 256)), dim3(256), 0, st, (const float*)W,
+                           (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, 0, (const float*)nullptr, (const float*)(amax + 1));
+        TVAE_CHECK_LAUNCH();
+    } else {
+        rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, nullptr, nullptr, stream);
+    }
     if (rc) return rc;
     {
         Epilogue ep;
@@ -175,7 +194,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / TR;                             // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
-        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st)
+        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st,
+                                                H3Scale{amax + 1, amax})
                             : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st);
         if (rc) return rc;
     }
@@ -256,6 +276,14 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
     hipStream_t st = S(stream);
+    // h3 arithmetic: max |A^T| was left behind A^T by the forward, max |S'| comes from the ring transform below
+    const bool h3 = parts == 2 && q.ring && q.K2 <= 256;
+    if (parts == 2 && !h3) parts = 3;
+    float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
+    if (h3) {
+        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, amax + 2, 1);
+        TVAE_CHECK_LAUNCH();
+    }
     float* Sp = ws;
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
     float* tab = slabs + (((long)q.splits * q.g_floats + 3) & ~3L);
@@ -276,7 +304,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         er = allow_big_lds(dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>, lds_r);                                         \
         if (er != hipSuccess) return (int)er;                                                                       \
         hipLaunchKernelGGL((dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>), dim3(grid), dim3(256), lds_r, st, dpre,       \
-                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad);                                         \
+                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad, h3 ? amax + 2 : (float*)nullptr);         \
     } while (0)
             if (q.ring == 1) TVAE_DY_RING(9, 2, 46, 17, false);
             else if (q.ring == 2) TVAE_DY_RING(17, 3, 98, 33, true);
@@ -326,7 +354,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
-                                        128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st);
+                                        128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st,
+                                        H3Scale{amax + 2, amax});
         if (rc) return rc;
     }
     hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);

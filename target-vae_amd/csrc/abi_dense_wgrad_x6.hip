@@ -9,11 +9,13 @@ TVAE_WG_LAUNCH_DEF(3)
 namespace tvae {
 int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M, int Kf, int N,
                            int nchunk, const TileMap& tm, const DenseBatch& bt, long dy_stride, const ATile& atile,
-                           int parts, hipStream_t st) {
+                           int parts, hipStream_t st, H3Scale hs) {
     const VirtGrad vg{nullptr, nullptr, 0, 0.f};
     const VirtAct va{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f};
-    if (parts == 1) return dense_wgrad_x6_launch_p1(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st);
-    if (parts == 3) return dense_wgrad_x6_launch_p3(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st);
+    if (parts == 1) return dense_wgrad_x6_launch_p1(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
+    if (parts == 2 && hs.amax_a && hs.amax_x)
+        return dense_wgrad_x6_launch_p2(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
+    if (parts == 3) return dense_wgrad_x6_launch_p3(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
     return (int)hipErrorInvalidValue;
 }
 }  // namespace tvae
@@ -63,8 +65,8 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     const bool lrf = vg_wo && vg_act == ACT_LRELU;
     const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? (from_bits ? 8 : 4) : 0);
     const int rc = parts == 1
-        ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream))
-        : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream));
+        ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE)
+        : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE);
     if (rc) return rc;
     TVAE_CHECK_LAUNCH();
     Epilogue ep;

@@ -17,15 +17,19 @@ int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& e
                              VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st);
 }
 int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
-                      int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st) {
+                      int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs) {
     const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);     // the cells keep their 512-row padding
-    if (N % 128 != 0 || !aligned16(w3) || (parts != 1 && parts != 3)) return (int)hipErrorInvalidValue;
+    if (N % 128 != 0 || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
+    if (parts == 2 && (!hs.amax_a || !hs.amax_x)) return (int)hipErrorInvalidValue;
     if (parts == 3)
         hipLaunchKernelGGL((dense_x6_plain4_kernel<3>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
-                           rows_per_problem, Rpad, N, K, K8pad, tm, bt);
+                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
+    else if (parts == 2)
+        hipLaunchKernelGGL((dense_x6_plain4_kernel<2>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
+                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
     else
         hipLaunchKernelGGL((dense_x6_plain4_kernel<1>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
-                           rows_per_problem, Rpad, N, K, K8pad, tm, bt);
+                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
     return (int)hipGetLastError();
 }
 }  // namespace tvae

@@ -40,8 +40,9 @@ TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DEC
 #define TVAE_WG_LAUNCH_ARGS                                                                                           \
     int variant, const float *dY, long ldd, const float *X, long ldx, float *ws, int M, int Kf, int N, int nchunk,     \
         const TileMap &tm, const DenseBatch &bt, long dy_stride, const VirtGrad &vg, const VirtAct &va,               \
-        const ATile &atile, hipStream_t st
+        const ATile &atile, hipStream_t st, const H3Scale &hs
 TVAE_INTERNAL int dense_wgrad_x6_launch_p3(TVAE_WG_LAUNCH_ARGS);
+TVAE_INTERNAL int dense_wgrad_x6_launch_p2(TVAE_WG_LAUNCH_ARGS);
 TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
 // variant = VIRT | XVA << 1 | LRF << 2   (LRF: 0 off, 1 two-valued from H, 2 two-valued from sign bits)
 #define TVAE_WG_ONE(V_, X_, L_, NP_)                                                                                  \
@@ -49,7 +50,7 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
         hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<V_, X_, L_, NP_>, WG_RING_BYTES);                     \
         if (e_ != hipSuccess) return (int)e_;                                                                         \
         hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<V_, X_, L_, NP_>), dim3(tm.grid()), dim3(DX6_THREADS),           \
-                           WG_RING_BYTES, st, dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile); \
+                           WG_RING_BYTES, st, dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, hs); \
         return (int)hipGetLastError();                                                                                \
     } while (0)
 #define TVAE_WG_LAUNCH_DEF(NP_)                                                                                       \
@@ -72,7 +73,7 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
 // the same with the 256-row / four-wave tile (dense_x6_plain4_kernel: short reductions); tm / bt count 256-row tiles
 TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                     int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
-                                    hipStream_t st);
+                                    hipStream_t st, H3Scale hs = H3_NONE);
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
@@ -80,6 +81,7 @@ TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, con
 // batched weight-gradient GEMM into split-K slabs (abi_dense_wgrad_x6.hip)
 TVAE_INTERNAL int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M,
                                          int Kf, int N, int nchunk, const TileMap& tm, const DenseBatch& bt,
-                                         long dy_stride, const ATile& atile, int parts, hipStream_t st);
+                                         long dy_stride, const ATile& atile, int parts, hipStream_t st,
+                                         H3Scale hs = H3_NONE);
 
 }  // namespace tvae

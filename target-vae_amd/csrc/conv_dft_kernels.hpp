@@ -149,7 +149,7 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
 
 static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
                                           int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
-                                          int M, int Mb, int L, int Lh, int FXB, int nblk) {
+                                          int M, int Mb, int L, int Lh, int FXB, int nblk, float* __restrict__ amax) {
     extern __shared__ float sm_dft[];
     const int nimg = B * Cin * nblk;
     int id = blockIdx.x;
@@ -160,6 +160,7 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
     const int outer = id / (nblk * Cin);                 // image b or filter m
     const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
     float2 *Yh, *tw;
+    float mx = 0.f;                    // h3 arithmetic: largest magnitude this workgroup writes (amax[0]: A^T, amax[1]: W)
     if (is_img) {
         dft_plane_spectrum(sm_dft, y + ((long)outer * Cin + ci) * n * n, n, pad, L, fx0, nfx, FXB, Yh, tw);
         const int total = nfx * L * Ho;
@@ -171,6 +172,7 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             float* dst = AT + ((long)(fx0 + f) * 2 * L * Cin + (long)(2 * ci) * L + fy) * NBpad + (long)outer * Ho + h;
             dst[0] = v.x;
             dst[(long)L * NBpad] = v.y;
+            mx = fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
     } else {
         const int m = outer;
@@ -185,7 +187,12 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             r0[L + fy] = k.y;
             r1[fy] = -k.y;
             r1[L + fy] = k.x;
+            mx = fmaxf(mx, fmaxf(fabsf(k.x), fabsf(k.y)));
         }
+    }
+    if (amax) {
+        mx = h3_wave_max(mx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax + (is_img ? 0 : 1), mx);
     }
 }
 
@@ -625,7 +632,7 @@ constexpr int dft_dy_ring_stores(int NRT, int LH2, bool NYQ) {
 template <int NS, int NRT, int LH2, int HO, bool NYQ>
 static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                                     float* __restrict__ Sp, int M, int R, int B, int Lh,
-                                                                    long NBpad) {
+                                                                    long NBpad, float* __restrict__ amax) {
     constexpr int NL = (32 * HO + 63) / 64, SLOTB = NL * 256, SLOTF = NL * 64, P = HO * HO;
     constexpr int ST = dft_dy_ring_stores(NRT, LH2, NYQ);
     static_assert((HO & 1) == 1 && 2 * NS <= HO + 1 && 2 * NS >= HO, "odd output width, NS = ceil(HO / 2)");
@@ -695,6 +702,7 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     // store offsets (floats from Sp + dft_t_off(n0, m, 2M, Lh), wave uniform): real rows at j + 2 kh 128, imaginary rows
     // M * Lh * 128 further on
     const unsigned lre = (unsigned)(j + 2 * kh * 128), lim = lre + (unsigned)((long)M * Lh * 128);
+    float mx = 0.f;                                      // h3 arithmetic of the GEMM that follows: max |S'| (amax, optional)
     for (int it = 0; it < my; ++it) {
         const int slot = it & 1;
         if (it == 0) TVAE_DFT_VMCNT(0);
@@ -732,14 +740,20 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
                 const unsigned o = ((kk0 & 1) ? lim : lre) + (unsigned)((kk0 >> 1) * 128);
                 if (kk0 + 4 < LH2) sb[o] = acc[rt][r];
                 else if (kk0 < LH2) { if (kh == 0) sb[o] = acc[rt][r]; }
+                if (kk0 < LH2) mx = fmaxf(mx, fabsf(acc[rt][r]));      // (a few values beyond LH2 in the kh = 1 half: zero table rows)
             }
         if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
             const float tot = racc + __shfl_xor(racc, 32, 64);
             const unsigned o = (kh ? lim : lre) - (unsigned)(2 * kh * 128) + (unsigned)((LH2 / 2 - 1) * 128);
             sb[o] = kh ? 0.f : tot;
+            mx = fmaxf(mx, fabsf(tot));
         }
     }
     TVAE_DFT_VMCNT(0);
+    if (amax) {
+        mx = h3_wave_max(mx);
+        if (lane == 0) h3_atomic_amax(amax, mx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -27,9 +27,11 @@
 namespace tvae {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-union Cell16 {                 // one fragment cell: 8 consecutive-k bf16 of one row (an MFMA operand register quad)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union Cell16 {                 // one fragment cell: 8 consecutive-k bf16 (or fp16) of one row (an MFMA operand register quad)
     uint4 u;
     bf16x8 v;
+    f16x8 h;
     unsigned w[4];
 };
 
@@ -72,6 +74,62 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hw, un
 __device__ __forceinline__ void split3x8(const float (&r)[8], Cell16& h, Cell16& m, Cell16& l) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) split3_pair(r[2 * q], r[2 * q + 1], h.w[q], m.w[q], l.w[q]);
+}
+
+// ------------------------------------------------------------------------------------------
+// "h3" arithmetic (round 3): TWO fp16 parts per operand, THREE partial products.
+// fp16 carries 11 significant bits, so with round-to-nearest parts  h = fp16(x), l = fp16(x - h)
+//   |x - h| <= 2^-12 |x|,   |x - h - l| <= 2^-24 |x|   (as long as l is a normal fp16 number),
+// i.e. two parts represent an fp32 value to half an ulp, and  h k + h k' + l k  leaves out only  l k' <= 2^-24 |x y|.
+// Products of fp16 numbers are exact in the fp32 accumulator (22 bits).  Against fp64 the result is at least as
+// accurate as the fp32 matrix pipe and as the six-product bf16 split for every distribution and reduction length
+// probed (profiles/experiments/f16_split_probe.hip: 2.6e-7 vs 4.1e-7 (fp32 MFMA) vs 3.5e-7 (x6) at K = 512), with
+// HALF the matrix instructions of x6.  The price is fp16's 5-bit exponent: every operand tensor is multiplied by a
+// power of two (exact) that brings its largest magnitude -- or an upper bound of it -- just below 2^15, and the
+// accumulators by the inverse powers in the epilogue.  Elements more than 2^16 below the tensor's maximum lose low
+// part bits to the subnormal range: their absolute error is <= 2^-40 of the maximum, which a sum does not see.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+// the power of two s with 2^14 <= s * amax < 2^15 (amax = 0, or absurdly small / large: clamped, s stays a normal number
+// whose inverse is one too)
+__device__ __forceinline__ float h3_scale(float amax) {
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);        // amax in [2^(e-127), 2^(e-126))
+    if (e == 0) e = 127;                                         // zero (or denormal) maximum: scale 2^14
+    int se = 268 - e;                                            // biased exponent of 2^(14 - (e - 127))
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float h3_inv(float s) {               // 1 / s for a power of two produced by h3_scale
+    return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23);
+}
+// both parts of two (already scaled) values at once, packed (x0 in the low half)
+__device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned& hw, unsigned& lw) {
+    const f32x2v x = {x0, x1};
+    const f16x2v h = __builtin_convertvector(x, f16x2v);
+    hw = __builtin_bit_cast(unsigned, h);
+    const f32x2v hf = __builtin_convertvector(h, f32x2v);
+    const f32x2v r = x - hf;
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+}
+__device__ __forceinline__ void split2hx8(const float (&r)[8], Cell16& h, Cell16& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2h_pair(r[2 * q], r[2 * q + 1], h.w[q], l.w[q]);
+}
+// three partial products; the small ones first is not needed (see mfma6)
+__device__ __forceinline__ void mfma3h(f32x16& acc, const Cell16 (&a)[3], const Cell16 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].h, b[0].h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].h, b[1].h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1].h, b[0].h, acc, 0, 0, 0);
+}
+// max |x| into a device word by atomic max on the bit pattern (non-negative floats order like unsigned integers); NaN
+// / Inf propagate as a huge maximum -> scale clamped, the result is then non-finite as it would be in any arithmetic
+__device__ __forceinline__ void h3_atomic_amax(float* slot, float v) {
+    atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(fabsf(v)));
+}
+__device__ __forceinline__ float h3_wave_max(float v) {          // in every lane
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // six partial products, in the order the A parts arrive from LDS (h, m, l): the first MFMA of a fragment then waits

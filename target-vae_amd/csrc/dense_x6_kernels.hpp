@@ -47,6 +47,50 @@ static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw
     }
 }
 
+// The same pre-pass in the h3 arithmetic: cells [part < 2][octet][row] of fp16 parts of A(row, k) * s, s = h3_scale(*amax);
+// *amax = max |A(row, k)| over the operand (dense_absmax_kernel), kept in the first word behind the two parts
+// (A3[2 * total]: the buffer is sized for three parts) where the GEMM finds it again for its epilogue.
+static __global__ void dense_absmax_kernel(const float* __restrict__ W, long ldw, int Rrows, int K, int transpose,
+                                           const float* __restrict__ scale, float* __restrict__ amax) {
+    const long total = (long)Rrows * K;
+    float mx = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // consecutive threads read consecutive addresses in either orientation
+        const int k = transpose ? (int)(i / Rrows) : (int)(i % K);
+        const int row = transpose ? (int)(i % Rrows) : (int)(i / K);
+        float v = transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k];
+        if (scale) v *= scale[k];
+        mx = fmaxf(mx, fabsf(v));
+    }
+    mx = h3_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, mx);
+}
+static __global__ void h3_zero_slots_kernel(float* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
+                                            int K, int K8pad, int transpose, const float* __restrict__ scale,
+                                            const float* __restrict__ amax) {
+    const long total = (long)K8pad * Rpad;
+    const float s = h3_scale(*amax);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i % Rpad);
+        const int o = (int)(i / Rpad);
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * o + j;
+            r[j] = (row < Rrows && k < K) ? (transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k]) : 0.f;
+            if (scale && k < K) r[j] *= scale[k];
+            r[j] *= s;
+        }
+        Cell16 h, l;
+        split2hx8(r, h, l);
+        A3[i] = h.u;
+        A3[total + i] = l.u;
+    }
+}
+
 // rowsum[row] = sum_k A(row, k) of the (scaled) operand above (VirtGrad.csum).  Block = 64 rows x 16 k-slices; the slice
 // sums are added in slice order (deterministic).
 static __global__ __launch_bounds__(1024) void dense_rowsum_kernel(const float* __restrict__ W, long ldw, int Rrows, int K,
@@ -78,13 +122,37 @@ static __global__ __launch_bounds__(1024) void dense_rowsum_kernel(const float* 
 template <int NP>
 __device__ __forceinline__ void mfma_np(f32x16& acc, const Cell16 (&a)[3], const Cell16 (&b)[3]) {
     if (NP == 3) mfma6(acc, a, b);
+    else if (NP == 2) mfma3h(acc, a, b);                 // two fp16 parts, three products ("h3", conv_x6_kernels.hpp)
     else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, acc, 0, 0, 0);
+}
+// one part of A against one cell of B in the arithmetic of NP (the exact 0 / 1 operands: 1.0 is 0x3f80 as bf16, 0x3c00 as fp16)
+template <int NP>
+__device__ __forceinline__ void mfma_part(f32x16& acc, const Cell16& a, const Cell16& b) {
+    if (NP == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+template <int NP> struct OneBits { static constexpr unsigned lo = NP == 2 ? 0x3c00u : 0x3f80u, hi = lo << 16; };
+// h3 epilogue: the two inverse powers of two, one after the other (their product may leave the fp32 range, each
+// intermediate result does not unless the true value does)
+__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[2][4], float ia, float ix) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * ia) * ix;
 }
 // rounds two values to bf16 (RNE), packed (x0 in the low half): the whole "split" of the one-part mode
 __device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
     const f32x2v x = {x0, x1};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
 }
+
+struct H3Scale {           // h3 arithmetic (NP == 2) only: device words holding max |.| (or an upper bound) of the two
+    const float* amax_a;   // operands -- the pre-split cells were built with h3_scale(*amax_a), the streamed operand is
+    const float* amax_x;   // multiplied by h3_scale(*amax_x) when it is split; the epilogue undoes both (powers of two)
+};
+constexpr H3Scale H3_NONE = {nullptr, nullptr};
 
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
 constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
@@ -565,7 +633,7 @@ constexpr int DX4_ROWS = 256;
 template <int NP>
 static __global__ __launch_bounds__(DX4_THREADS, 2)
 void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                            int N, int K, int K8pad, TileMap tm, DenseBatch bt) {
+                            int N, int K, int K8pad, TileMap tm, DenseBatch bt, H3Scale hs) {
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX4_ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,6 +651,7 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
+    const float sx = NP == 2 ? h3_scale(*hs.amax_x) : 1.f;             // h3: power-of-two scale of the streamed operand
 
     const long part_cells = (long)K8pad * Mpad;
     const uint4* a_ptr = A3 + (long)khalf * Mpad + m0g + 64 * wave + (lane & 31);
@@ -610,6 +679,14 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
             uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + h * 128 + nb) + kq;
             if (NP == 1) {
                 dst[0] = make_uint2(bf16_pair(x[h][0], x[h][1]), bf16_pair(x[h][2], x[h][3]));
+                continue;
+            }
+            if (NP == 2) {
+                unsigned hw[2], lw[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) split2h_pair(x[h][2 * q] * sx, x[h][2 * q + 1] * sx, hw[q], lw[q]);
+                dst[0] = make_uint2(hw[0], hw[1]);
+                dst[2 * 256] = make_uint2(lw[0], lw[1]);
                 continue;
             }
             unsigned hw[2], mw[2], lw[2];
@@ -663,6 +740,7 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
+    if (NP == 2) h3_unscale(acc, h3_inv(h3_scale(*hs.amax_a)), h3_inv(sx));
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float gyv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -732,7 +810,7 @@ template <bool VIRT, bool XVA, int LRF, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
-                               VirtAct va, ATile atile) {
+                               VirtAct va, ATile atile, H3Scale hs) {
     constexpr int NDMA = (LRF == 2 ? 2 : 4) + (XVA ? 2 : 1) + (VIRT ? 1 : 0);   // DMA instructions per wave and step
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_ring[];   // [wave][slot < 3][WG_SLOT_BYTES]
@@ -768,6 +846,9 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         return;
     }
 
+    // h3 arithmetic: power-of-two scales of the two streamed operands (the 0 / 1 operand of the two-valued form has none)
+    const float sa = (NP == 2 && !LRF) ? h3_scale(*hs.amax_a) : 1.f;
+    const float sx = NP == 2 ? h3_scale(*hs.amax_x) : 1.f;
     // ---- DMA sources
     const float* d_ptr[4];                               // A: instruction g, row 16g + lane/4 of this wave, swizzled piece
 #pragma unroll
@@ -890,27 +971,30 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
                 const unsigned b = __float_as_uint(r[i][0].x) >> sh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    a[i][0].w[q] = ((b >> (2 * q)) & 1u) * 0x3f80u | ((b >> (2 * q + 1)) & 1u) * 0x3f800000u;
+                    a[i][0].w[q] = ((b >> (2 * q)) & 1u) * OneBits<NP>::lo | ((b >> (2 * q + 1)) & 1u) * OneBits<NP>::hi;
             }
             return;
         }
-        if (LRF) {                                       // cells of [H > 0]: 1.0 = 0x3f80, a single part
+        if (LRF) {                                       // cells of [H > 0]: 1.0 = 0x3f80 (bf16) / 0x3c00 (fp16), a single part
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float v[8] = {r[i][0].x, r[i][0].y, r[i][0].z, r[i][0].w, r[i][1].x, r[i][1].y, r[i][1].z, r[i][1].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    a[i][0].w[q] = (v[2 * q] > 0.f ? 0x3f80u : 0u) | (v[2 * q + 1] > 0.f ? 0x3f800000u : 0u);
+                    a[i][0].w[q] = (v[2 * q] > 0.f ? OneBits<NP>::lo : 0u) | (v[2 * q + 1] > 0.f ? OneBits<NP>::hi : 0u);
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float v[8] = {r[i][0].x * a_ok[i], r[i][0].y * a_ok[i], r[i][0].z * a_ok[i], r[i][0].w * a_ok[i],
-                                r[i][1].x * a_ok[i], r[i][1].y * a_ok[i], r[i][1].z * a_ok[i], r[i][1].w * a_ok[i]};
+            const float f = NP == 2 ? a_ok[i] * sa : a_ok[i];
+            const float v[8] = {r[i][0].x * f, r[i][0].y * f, r[i][0].z * f, r[i][0].w * f,
+                                r[i][1].x * f, r[i][1].y * f, r[i][1].z * f, r[i][1].w * f};
             if (NP == 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[i][0].w[q] = bf16_pair(v[2 * q], v[2 * q + 1]);
+            } else if (NP == 2) {
+                split2hx8(v, a[i][0], a[i][1]);
             } else {
                 split3x8(v, a[i][0], a[i][1], a[i][2]);
             }
@@ -930,6 +1014,13 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (q4 >> 1) * 128 + kr) + (q4 & 1);
         if (NP == 1) {
             dst[0] = make_uint2(bf16_pair(v[0], v[1]), bf16_pair(v[2], v[3]));
+            return;
+        }
+        if (NP == 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) split2h_pair(v[2 * q] * sx, v[2 * q + 1] * sx, hw[q], lw[q]);
+            dst[0] = make_uint2(hw[0], hw[1]);
+            dst[2 * 256] = make_uint2(lw[0], lw[1]);
             return;
         }
 #pragma unroll
@@ -977,8 +1068,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0].v, bf[p].v, acc[i][j], 0, 0, 0);
+                    for (int p = 0; p < NP; ++p) mfma_part<NP>(acc[i][j], af[i][0], bf[p]);
             } else {
                 mfma_np<NP>(acc[0][j], af[0], bf);
                 mfma_np<NP>(acc[1][j], af[1], bf);
@@ -1001,6 +1091,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's ring
+    if (NP == 2) h3_unscale(acc, h3_inv(sa), h3_inv(sx));
     float sk[4] = {0.f, 0.f, 0.f, 0.f};                  // slope * s[k] of this lane's four columns
     if (LRF) {
         float* ssm = reinterpret_cast<float*>(Bs);       // the B stages are free after the loop's last barrier

@@ -117,7 +117,7 @@ ABI_VERSION = 3
 # fp32-MFMA entry points; 'bf16': the *_x6 / *_dft entry points with parts = 1 -- operands rounded to one bf16 number, the
 # throughput mode of BASELINE.json configs 2 / 5, not fp32-equivalent and never the default).  Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so
 # two models with different arithmetic coexist in one process.
-GEMM_MODES = ('f32', 'x6', 'bf16')
+GEMM_MODES = ('f32', 'x6', 'h3', 'bf16')
 _mode = os.environ.get('TVAE_GEMM', 'x6')
 if _mode not in GEMM_MODES:
     raise TvaeHipError(f'TVAE_GEMM={_mode!r}: choose from {GEMM_MODES}')
@@ -136,12 +136,13 @@ def get_gemm_mode() -> str:
 
 def split_pipe() -> bool:
     """True when matrix products go to the bf16 matrix pipe (*_x6 / *_dft entry points)."""
-    return _mode in ('x6', 'bf16')
+    return _mode in ('x6', 'h3', 'bf16')
 
 
 def parts() -> int:
-    """bf16 parts per operand for the *_x6 / *_dft entry points in the current mode."""
-    return 1 if _mode == 'bf16' else 3
+    """Parts per operand for the *_x6 / *_dft entry points in the current mode: 3 = exact bf16 split (six products), 2 = two
+    fp16 parts (three products, "h3": entry points without an h3 instance run x6), 1 = plain bf16."""
+    return {'bf16': 1, 'h3': 2}.get(_mode, 3)
 
 
 class arithmetic:

@@ -261,8 +261,10 @@ def test_linear_wgrad_x6(M, N, K, acc):
     # frames beyond the specialised transforms along w (Lh > 64 or Ho > 64): spectra in frequency blocks, generic
     # transforms -- the galaxy configuration's shape class (192-wide frame, 3 channels) at a small size
     (2, 96, 32, 16, 4, 4, 1, 2), (2, 128, 64, 32, 2, 16, 1, 3)])
-def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin):
-    """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64."""
+@pytest.mark.parametrize('nparts', [3, 2])
+def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin, nparts):
+    """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64, in the exact
+    bf16 split (3 parts, six products) and in the h3 arithmetic (2 fp16 parts, three products)."""
     from tvae._lib import query
     if not query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R):
         pytest.skip('geometry not handled by the frequency-domain path')
@@ -277,7 +279,7 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin):
     ws = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
     out = torch.empty(C, B * R * Ho * Ho, device=dev())
     call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, ws, ws.numel(), B, Cin, n, k, pad,
-         C, R, act, SLOPE, 3)
+         C, R, act, SLOPE, nparts)
     got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
     assert rel_err(got, ref) < GEMM_TOL['f32']
     g = rnd(B, C, R, Ho, Ho, seed=4)
@@ -285,7 +287,7 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin):
     dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
     dbank = torch.empty(C * R, Cin * k * k, device=dev())
     dbias = torch.empty(C, device=dev())
-    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, 3)
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, nparts)
     assert rel_err(dbias, g.double().sum(dim=(0, 2, 3, 4))) < TOL
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
