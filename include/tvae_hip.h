@@ -127,6 +127,16 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
 long tvae_dense_x6_bytes(int rows, int K);
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                       const float* scale, float* rowsum, tvae_stream_t stream);
+/* The same cells in the h3 arithmetic (parts = 2 of the entry points below: TWO fp16 parts per operand, THREE products per
+ * block instead of six; every operand tensor scaled by a power of two into fp16's range, undone in the epilogue; accuracy
+ * against fp64 at least that of the fp32 matrix pipe, profiles/experiments/f16_split_probe.hip).  Same buffer size; the
+ * operand's maximum is kept behind the two part arrays, and the GEMM entry points use the following 12 bytes as scratch.
+ * Entry points / operand forms with an h3 instance: tvae_conv1_fwd_dft / tvae_conv1_wgrad_dft (reductions 2 L Cin <= 256),
+ * tvae_linear_fwd_x6 with the recomputed first-layer operand (va_xr), tvae_linear_dgrad_x6 in its two-valued form (vg_csum),
+ * tvae_linear_wgrad_x6 from sign bits with the recomputed operand.  Elsewhere parts = 2 is rejected (hipErrorInvalidValue)
+ * or, inside the *_dft entry points, runs the exact three-part split. */
+int tvae_dense_split2h(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                       const float* scale, float* rowsum, tvae_stream_t stream);
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,

@@ -33,9 +33,10 @@ static int wgrad_x6_splits(int M, int N, int K) {
     const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
     return cdiv(N, nchunk);
 }
+constexpr int WG_H3_SLOTS = 8;         // behind the slabs: the operand maxima of the h3 arithmetic
 long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K) {
     if (M <= 0 || K <= 0 || N < 32) return 0;
-    return (long)wgrad_x6_splits(M, N, K) * M * K;
+    return (long)wgrad_x6_splits(M, N, K) * M * K + WG_H3_SLOTS;
 }
 
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
@@ -44,8 +45,10 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                          int va_np, const void* vg_bits, int parts, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
-    if (parts != 1 && parts != 3) return (int)hipErrorInvalidValue;
+    if (parts != 1 && parts != 2 && parts != 3) return (int)hipErrorInvalidValue;
     const bool from_bits = vg_bits && vg_wo && vg_act == ACT_LRELU;        // two-valued form from stored sign bits: dpre unused
+    // h3 instance: sign bits (exact 0 / 1 operand) against gy x the recomputed first-layer activation, whose bound is formed here
+    if (parts == 2 && !(from_bits && va_xr && vg_gy)) return (int)hipErrorInvalidValue;
     if (vg_bits && !from_bits) return (int)hipErrorInvalidValue;
     if (N <= 0 || N % 16 != 0 || !ws || (from_bits ? N % 32 != 0 : (ldd % 4 != 0 || !dpre || !aligned16(dpre))))
         return (int)hipErrorInvalidValue;
@@ -64,9 +67,25 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     // the implicit LeakyReLU gradient runs in its two-valued form (0 / 1 streamed operand, see the kernel)
     const bool lrf = vg_wo && vg_act == ACT_LRELU;
     const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? (from_bits ? 8 : 4) : 0);
-    const int rc = parts == 1
-        ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE)
-        : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE);
+    int rc;
+    if (parts == 2) {
+        float* slots = ws + (long)splits * per;
+        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), slots, 4);
+        TVAE_CHECK_LAUNCH();
+        const long nlb = va_lb ? (long)(N / vas.Np) * K : 0;
+        hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(2L * N, 256, 256)), dim3(256), 0, S(stream), va_xr, 2L * N, va_wc,
+                           va_bc, va_lb, nlb, K, slots);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)N, 256, 256)), dim3(256), 0, S(stream), vg_gy, (long)N, 1, N,
+                           0, (const float*)nullptr, slots + 3);
+        TVAE_CHECK_LAUNCH();
+        rc = dense_wgrad_x6_launch_p2(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas,
+                                      ATILE_PLAIN, S(stream), H3Scale{nullptr, slots});
+    } else {
+        rc = parts == 1
+            ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE)
+            : dense_wgrad_x6_launch_p3(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE);
+    }
     if (rc) return rc;
     TVAE_CHECK_LAUNCH();
     Epilogue ep;

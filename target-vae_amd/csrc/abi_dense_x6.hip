@@ -14,7 +14,8 @@ int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& e
     return TVAE_DX6_DISPATCH(0, parts, (const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
                              ColDot{nullptr, nullptr, nullptr},
                              InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
-                             VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st);
+                             VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st,
+                             H3_NONE);
 }
 int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
                       int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs) {
@@ -63,14 +64,32 @@ extern "C" {
 
 // ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
 long tvae_dense_x6_bytes(int rows, int K) { return dense_x6_bytes(rows, K); }
-int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
-                      const float* scale, float* rowsum, tvae_stream_t stream) {
+// h3 cells (parts == 2) occupy two of the three part arrays the buffer is sized for; the first four floats of the third
+// hold the operand's maximum ([0], read again by the GEMM for its epilogue) and, for launches whose streamed operand is
+// recomputed, the three maxima of dec_l0_bound_kernel ([1..3], written by the GEMM entry point).
+static float* h3_trailer(const void* a3, int rows, int K) {
+    const long total = (long)dense_k8pad(K) * x6_round_up(rows, DX6_ROWS);
+    return reinterpret_cast<float*>(const_cast<void*>(a3)) + 2 * total * 4;
+}
+static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                       const float* scale, float* rowsum, int parts, tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;
     if (a3_bytes < tvae_dense_x6_bytes(rows, K) || !aligned16(a3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const long total = (long)K8pad * Rpad;
-    hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
-                       Rpad, K, K8pad, transpose, scale);
+    if (parts == 2) {
+        float* tr = h3_trailer(a3, rows, K);
+        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), tr, 4);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)rows * K, 256, 256)), dim3(256), 0, S(stream), W, ldw, rows, K,
+                           transpose, scale, tr);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
+                           Rpad, K, K8pad, transpose, scale, (const float*)tr);
+    } else {
+        hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
+                           Rpad, K, K8pad, transpose, scale);
+    }
     TVAE_CHECK_LAUNCH();
     if (rowsum) {
         hipLaunchKernelGGL(dense_rowsum_kernel, dim3((rows + 63) / 64), dim3(1024), 0, S(stream), W, ldw, rows, K, transpose,
@@ -79,6 +98,14 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
     }
     return 0;
 }
+int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                      const float* scale, float* rowsum, tvae_stream_t stream) {
+    return dense_split(W, ldw, a3, a3_bytes, rows, K, transpose, scale, rowsum, 3, stream);
+}
+int tvae_dense_split2h(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
+                       const float* scale, float* rowsum, tvae_stream_t stream) {
+    return dense_split(W, ldw, a3, a3_bytes, rows, K, transpose, scale, rowsum, 2, stream);
+}
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K, int parts,
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
                            InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
@@ -86,21 +113,39 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
                            VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
-    if (N % 128 != 0 || !aligned16(a3) || (parts != 1 && parts != 3)) return (int)hipErrorInvalidValue;
+    if (N % 128 != 0 || !aligned16(a3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
+    H3Scale hs = H3_NONE;
+    if (parts == 2) {
+        // h3 instances: the recomputed first-layer activation (its bound is formed here) and the exact 0 / 1 operand of the
+        // two-valued gradient; an operand streamed from memory would need its maximum from its producer (not wired: x6)
+        float* tr = h3_trailer(a3, rows, K);
+        hs.amax_a = tr;
+        if (va.xr) {
+            hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, tr + 1, 3);
+            TVAE_CHECK_LAUNCH();
+            const long nlb = va.lb ? (long)(N / va.Np) * K : 0;
+            hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(2L * N, 256, 256)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
+                               va.bc, va.lb, nlb, K, tr + 1);
+            TVAE_CHECK_LAUNCH();
+            hs.amax_x = tr + 1;
+        } else if (!vg.csum) {
+            return (int)hipErrorInvalidValue;
+        }
+    }
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
     if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
         return (int)hipErrorInvalidValue;
     const DenseBatch nb{0, 0, 0};
     if (vg.csum && vg.rpart) {
         if (K > DX6_ROWS) return (int)hipErrorInvalidValue;              // the row sums live in one 512-row LDS table
-        return TVAE_DX6_DISPATCH(4, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+        return TVAE_DX6_DISPATCH(4, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     }
-    if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
-    return TVAE_DX6_DISPATCH(0, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st);
+    if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    return TVAE_DX6_DISPATCH(0, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
 }
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,

@@ -19,22 +19,24 @@ static inline long dense_x6_bytes(int rows, int K) {
 #define TVAE_DX6_LAUNCH_ARGS                                                                                          \
     const uint4 *a3, const float *X, long ldx, const Epilogue &ep, int M, int Mpad, int N, int K, int K8pad,          \
         const TileMap &tm, const DenseBatch &bt, const ColDot &cd, const InTail &it, const VirtGrad &vg,              \
-        const VirtAct &va, hipStream_t st
+        const VirtAct &va, hipStream_t st, const H3Scale &hs
 #define TVAE_DX6_DECL(XV_)                                              \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p3(TVAE_DX6_LAUNCH_ARGS); \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##_p2(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p1(TVAE_DX6_LAUNCH_ARGS);
 TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DECL(4)
 #define TVAE_DX6_LAUNCH_DEF(XV_, NP_)                                                                                 \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                       \
         hipLaunchKernelGGL((dense_x6_kernel<XV_, NP_>), dim3(tm.grid()), dim3(DX6_THREADS), 0, st, a3, X, ldx, ep, M, \
-                           Mpad, N, K, K8pad, tm, bt, cd, it, vg, va);                                                \
+                           Mpad, N, K, K8pad, tm, bt, cd, it, vg, va, hs);                                            \
         return (int)hipGetLastError();                                                                                \
     }                                                                                                                 \
     }
-// parts = 3 (exact split) or 1 (bf16 throughput mode); anything else is rejected by the entry points
-#define TVAE_DX6_DISPATCH(XV_, parts_, ...) \
-    ((parts_) == 1 ? dense_x6_launch_v##XV_##_p1(__VA_ARGS__) : dense_x6_launch_v##XV_##_p3(__VA_ARGS__))
+// parts = 3 (exact split), 2 (h3: two fp16 parts) or 1 (bf16 throughput mode); anything else is rejected by the entry points
+#define TVAE_DX6_DISPATCH(XV_, parts_, ...)                            \
+    ((parts_) == 1 ? dense_x6_launch_v##XV_##_p1(__VA_ARGS__)           \
+                   : ((parts_) == 2 ? dense_x6_launch_v##XV_##_p2(__VA_ARGS__) : dense_x6_launch_v##XV_##_p3(__VA_ARGS__)))
 
 // weight-gradient launchers (abi_dense_wgrad_x6.hip: three parts, abi_dense_wgrad_x6_b.hip: one part)
 #define TVAE_WG_LAUNCH_ARGS                                                                                           \

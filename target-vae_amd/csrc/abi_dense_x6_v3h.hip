@@ -1,0 +1,3 @@
+// libtvae_hip.so: dense_x6_kernel<3, 2> -- two-valued implicit LeakyReLU gradient operand; h3 arithmetic (two fp16 parts, three products).
+#include "abi_dense_x6.hpp"
+TVAE_DX6_LAUNCH_DEF(3, 2)

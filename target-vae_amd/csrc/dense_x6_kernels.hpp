@@ -91,6 +91,31 @@ static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ld
     }
 }
 
+// h3 scale of the recomputed first-layer activation (VirtAct): slots[0] = max |xr|, slots[1] = max_k (|wc[k][0]| + |wc[k][1]|),
+// slots[2] = max_{b,k} |bc[k] + lb[b][k]| (atomic maxima into zeroed slots); |act(pre)| <= |pre| <= slots[1] slots[0] + slots[2]
+// for LeakyReLU (slope <= 1), tanh and the identity.
+static __global__ void dec_l0_bound_kernel(const float* __restrict__ xr, long nxr, const float* __restrict__ wc,
+                                           const float* __restrict__ bc, const float* __restrict__ lb, long nlb, int K,
+                                           float* __restrict__ slots) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (long i = gid; i < nxr; i += gsz) m0 = fmaxf(m0, fabsf(xr[i]));
+    for (long i = gid; i < K; i += gsz) m1 = fmaxf(m1, fabsf(wc[2 * i]) + fabsf(wc[2 * i + 1]));
+    if (lb) {
+        for (long i = gid; i < nlb; i += gsz) m2 = fmaxf(m2, fabsf(bc[i % K] + lb[i]));
+    } else {
+        for (long i = gid; i < K; i += gsz) m2 = fmaxf(m2, fabsf(bc[i]));
+    }
+    m0 = h3_wave_max(m0);
+    m1 = h3_wave_max(m1);
+    m2 = h3_wave_max(m2);
+    if ((threadIdx.x & 63) == 0) {
+        h3_atomic_amax(slots, m0);
+        h3_atomic_amax(slots + 1, m1);
+        h3_atomic_amax(slots + 2, m2);
+    }
+}
+
 // rowsum[row] = sum_k A(row, k) of the (scaled) operand above (VirtGrad.csum).  Block = 64 rows x 16 k-slices; the slice
 // sums are added in slice order (deterministic).
 static __global__ __launch_bounds__(1024) void dense_rowsum_kernel(const float* __restrict__ W, long ldw, int Rrows, int K,
@@ -348,7 +373,8 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 template <int XV, int NP>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
-                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va) {
+                     int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va,
+                     H3Scale hs) {
     constexpr bool VIRT = XV == 1, MASKB = XV == 3 || XV == 4, RSUM = XV == 4;
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
     __shared__ float bsm[DX6_ROWS];
@@ -373,6 +399,11 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     const int m0 = m0g - batch * bt.tiles_per_batch * DX6_ROWS, n0 = tile_n * 128;   // row offset inside the problem
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
+    // h3 arithmetic: scale of the streamed operand.  The recomputed first-layer activation (XV == 2) has no producer that
+    // could have measured it: hs.amax_x then holds three maxima {max |x'|, max_k (|wc[k][0]| + |wc[k][1]|), max |bc + lb|}
+    // (dec_l0_bound_kernel) whose combination bounds every |act(pre)| <= |pre|.  The 0 / 1 operand needs none.
+    float sx = 1.f;
+    if (NP == 2 && !MASKB) sx = h3_scale(XV == 2 ? __fmaf_rn(hs.amax_x[1], hs.amax_x[0], hs.amax_x[2]) : hs.amax_x[0]);
     if (MASKB) bsm[tid] = (m0 + tid) < M ? vg.slope * vg.csum[m0 + tid] : 0.f;
     else bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
     if (it.xr) {
@@ -452,13 +483,21 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     };
     auto store_b = [&](int stage, const float (&x)[4]) {
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
-        if (MASKB) {                                     // [H > 0] as bf16: 1.0 = 0x3f80, one part (rows k >= K meet zero weights)
-            dst[0] = make_uint2((x[0] > 0.f ? 0x3f80u : 0u) | (x[1] > 0.f ? 0x3f800000u : 0u),
-                                (x[2] > 0.f ? 0x3f80u : 0u) | (x[3] > 0.f ? 0x3f800000u : 0u));
+        if (MASKB) {                                     // [H > 0]: 1.0 = 0x3f80 (bf16) / 0x3c00 (fp16), one part (rows k >= K meet zero weights)
+            dst[0] = make_uint2((x[0] > 0.f ? OneBits<NP>::lo : 0u) | (x[1] > 0.f ? OneBits<NP>::hi : 0u),
+                                (x[2] > 0.f ? OneBits<NP>::lo : 0u) | (x[3] > 0.f ? OneBits<NP>::hi : 0u));
             return;
         }
         if (NP == 1) {
             dst[0] = make_uint2(bf16_pair(x[0], x[1]), bf16_pair(x[2], x[3]));
+            return;
+        }
+        if (NP == 2) {
+            unsigned hw[2], lw[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) split2h_pair(x[2 * q] * sx, x[2 * q + 1] * sx, hw[q], lw[q]);
+            dst[0] = make_uint2(hw[0], hw[1]);
+            dst[2 * 256] = make_uint2(lw[0], lw[1]);
             return;
         }
         unsigned hw[2], mw[2], lw[2];
@@ -525,8 +564,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[i][p].v, b0.v, acc[i][j], 0, 0, 0);
+                    for (int p = 0; p < NP; ++p) mfma_part<NP>(acc[i][j], afc[i][p], b0);
             } else {
                 Cell16 bf[3];
 #pragma unroll
@@ -552,6 +590,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
+    if (NP == 2) h3_unscale(acc, h3_inv(h3_scale(hs.amax_a[0])), h3_inv(sx));
     if (RSUM) {                                          // (the loop's last barrier made every slot visible)
         if (tid < K) {
             float* rp = vg.rpart + ((long)tid * (N >> 7) + tile_n) * 2;   // [row][tile][2]: a row's partials are contiguous
@@ -847,8 +886,11 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     }
 
     // h3 arithmetic: power-of-two scales of the two streamed operands (the 0 / 1 operand of the two-valued form has none)
+    // The X operand of the two-valued decoder form is gy[n] * (recomputed first-layer activation): hs.amax_x then holds the
+    // three maxima of dec_l0_bound_kernel and max |gy| ({max |x'|, max (|w0| + |w1|), max |bc + lb|, max |gy|}).
     const float sa = (NP == 2 && !LRF) ? h3_scale(*hs.amax_a) : 1.f;
-    const float sx = NP == 2 ? h3_scale(*hs.amax_x) : 1.f;
+    float sx = 1.f;
+    if (NP == 2) sx = h3_scale((XVA && LRF) ? __fmaf_rn(hs.amax_x[1], hs.amax_x[0], hs.amax_x[2]) * hs.amax_x[3] : hs.amax_x[0]);
     // ---- DMA sources
     const float* d_ptr[4];                               // A: instruction g, row 16g + lane/4 of this wave, swizzled piece
 #pragma unroll

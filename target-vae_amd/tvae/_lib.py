@@ -27,6 +27,7 @@ SIGNATURES = {
     'tvae_conv1_fwd_dft': 'ppppppliiiiiiiifi',
     'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
+    'tvae_dense_split2h': 'plpliiipp',
     'tvae_linear_fwd_x6': 'pppppiiillifpppppppipi',
     'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppi',
     'tvae_dec_in_total': 'piiippp',

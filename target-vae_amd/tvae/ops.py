@@ -161,14 +161,22 @@ def _dense_x6_ok(rows: int, N: int) -> bool:
     return split_pipe() and N % 128 == 0 and rows >= 256
 
 
-def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str, scale=None):
-    """W (out, in) -> fragment-ready 3 x bf16 cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad).
+def _p3() -> int:
+    """parts for an entry point / operand form WITHOUT an h3 instance: the h3 mode runs those in the exact x6 arithmetic."""
+    p = parts()
+    return 3 if p == 2 else p
+
+
+def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str, scale=None, nparts: int = 3):
+    """W (out, in) -> fragment-ready cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad): 3 x bf16 parts, or
+    (nparts = 2) the 2 x fp16 parts of the h3 arithmetic.
     scale (K floats): A(row, k) *= scale[k] before the split; then also returns the row sums of the scaled operand
     (the two-valued implicit-gradient form of tvae_linear_dgrad_x6, include/tvae_hip.h)."""
     W = W.contiguous()
     w3 = _scratch(W.device, key, query('tvae_dense_x6_bytes', rows, K) // 4)
     csum = torch.empty(rows, dtype=torch.float32, device=W.device) if scale is not None else None
-    call('tvae_dense_split3', W, W.shape[1], w3, w3.numel() * 4, rows, K, 1 if transpose else 0, scale, csum)
+    call('tvae_dense_split2h' if nparts == 2 else 'tvae_dense_split3', W, W.shape[1], w3, w3.numel() * 4, rows, K,
+         1 if transpose else 0, scale, csum)
     return w3 if scale is None else (w3, csum)
 
 
@@ -179,10 +187,12 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None) -> torch.Tens
     need = 64 * max(M, 128) * max(K, 128)
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
         ws = workspace(dpre.device, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
+        # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
+        p = 2 if (parts() == 2 and bits is not None and va and virt and virt[2] == ACT_LRELU) else _p3()
         with _timed('tvae_linear_wgrad_x6'):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
-                 *(va if va else (None, None, None, None, 0)), bits, parts())
+                 *(va if va else (None, None, None, None, 0)), bits, p)
         return dW
     _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
     ws = workspace(dpre.device, max(need, 1 << 24))
@@ -407,7 +417,7 @@ class EncoderFn(torch.autograd.Function):
             with _timed('tvae_enc_tail_fwd_x6'):
                 call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N,
                      bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act,
-                     LRELU_SLOPE, parts())
+                     LRELU_SLOPE, _p3())
         else:
             call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
             if nh <= SKINNY_MAX:
@@ -440,7 +450,7 @@ class EncoderFn(torch.autograd.Function):
             _note('enc.tail_dgrad_x6')
             with _timed('tvae_enc_tail_dgrad_x6'):
                 call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, ctx.bits[0], ctx.bits[1], dA1, N, C, N,
-                     LRELU_SLOPE, parts())
+                     LRELU_SLOPE, _p3())
         # conv2's weight gradient in one pass from A1, the head gradients and the sign words of H (dH is formed inside the
         # GEMM's operand build and never written); dWh / db2 from a sums-only pass over H
         fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0
@@ -463,7 +473,7 @@ class EncoderFn(torch.autograd.Function):
             wsw = _scratch(y.device, 'enc_wgrad_slabs', query('tvae_enc_tail_wgrad_x6_ws_floats', N))
             with _timed('tvae_enc_tail_wgrad_x6'):
                 call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, ctx.bits[0], Wh.contiguous(), dW2, wsw, wsw.numel(), C,
-                     N, LRELU_SLOPE, parts())
+                     N, LRELU_SLOPE, _p3())
         else:
             dW2 = _wgrad(dH, A1, C2, N, C)
         if dA1 is None:
@@ -755,7 +765,7 @@ class DecoderFn(torch.autograd.Function):
                 w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
                 with _timed('tvae_linear_fwd_x6'):
                     call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
-                         None, None, None, None, None, None, None, 0, None, parts())
+                         None, None, None, None, None, None, None, 0, None, _p3())
             else:
                 call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
         else:
@@ -767,7 +777,9 @@ class DecoderFn(torch.autograd.Function):
         for li, (W, b) in enumerate(hidden):
             hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
-                w3 = _split_weight(W, F_, F_, False, 'x6_dense_w')
+                # h3 instance: the layer whose streamed operand is the recomputed first-layer activation
+                p_l = 2 if (parts() == 2 and va and li == 0) else _p3()
+                w3 = _split_weight(W, F_, F_, False, 'x6_dense_w', nparts=p_l)
                 # the last hidden layer also applies the single-output Linear that follows it (one pass less over h)
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
                 # the backward of the single-output Linear behind the last hidden layer needs only the SIGN of this
@@ -780,7 +792,7 @@ class DecoderFn(torch.autograd.Function):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
-                         parts())
+                         p_l)
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
@@ -856,8 +868,9 @@ class DecoderFn(torch.autograd.Function):
             if _dense_x6_ok(F_, Nt):
                 # LeakyReLU: the implicit gradient in its two-valued form (3 MFMAs per block instead of 6)
                 two_val = use_vg and act == ACT_LRELU
+                p_d = 2 if (parts() == 2 and two_val) else _p3()      # h3 instance: the exact 0 / 1 operand (two products)
                 if two_val:
-                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt', scale=vg[0])
+                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt', scale=vg[0], nparts=p_d)
                     _note('dec.virt_grad_2val')
                 else:
                     w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt'), None
@@ -873,7 +886,7 @@ class DecoderFn(torch.autograd.Function):
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
                          bc if va else None, LB if va else None, Np if va else 0,
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
-                         tot[0] if rs else None, tot[1] if rs else None, parts())
+                         tot[0] if rs else None, tot[1] if rs else None, p_d)
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
@@ -913,7 +926,7 @@ class DecoderFn(torch.autograd.Function):
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
                 with _timed('tvae_linear_dgrad_x6'):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
-                         None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, parts())
+                         None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, _p3())
             else:
                 call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
