@@ -145,6 +145,12 @@ MODE_INFO = {
                dtype='f32 (matrix products: operands split exactly into 3 x bf16, 6 bf16 MFMAs per product, fp32 '
                      'accumulate -- fp32-equivalent, same parity tolerances; the 512-wide decoder layers and the forward / data '
                      'gradient of the 128-wide encoder 1x1x1 layers likewise, their weight gradient on the fp32 MFMA)'),
+    'h3': dict(peak=PEAK_BF16_MFMA_TFLOPS / 3.0, insn='3 x v_mfma_f32_32x32x16_f16 per product block', suffix='_x6',
+               kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
+               dtype='f32 (matrix products: operands as TWO fp16 parts under a power-of-two tensor scale, 3 fp16 MFMAs per '
+                     'product -- 2 where one operand is the exact 0 / 1 matrix -- fp32 accumulate: at least as accurate '
+                     'against fp64 as the fp32 matrix pipe (profiles/experiments/f16_split_probe.hip), same parity '
+                     'tolerances; launches without an h3 instance (encoder 1x1x1 layers) run the exact 3 x bf16 split)'),
     # opt-in throughput mode (TVAE_GEMM=bf16; BASELINE.json configs 2 / 5): NOT the headline, not fp32-equivalent
     'bf16': dict(peak=PEAK_BF16_MFMA_TFLOPS, insn='1 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                  kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
@@ -345,7 +351,7 @@ def main():
                   'steps': args.steps, 'warmup': 2}
     # companion measurement: the same number of steps with every matrix product on the exact fp32 MFMA
     companion = None
-    if world == 1 and mode == 'x6' and not args.no_f32_companion:
+    if world == 1 and mode in ('x6', 'h3') and not args.no_f32_companion:
         _lib.set_gemm_mode('f32')
         for i in range(2):
             one_step(i)
@@ -358,7 +364,7 @@ def main():
         dt1 = time.perf_counter() - t1
         kev1 = ops.kernel_event_ms()
         ops.KERNEL_EVENTS = None
-        _lib.set_gemm_mode('x6')
+        _lib.set_gemm_mode(mode)
         fl1 = conv1_flops_per_image(c) * B
         companion = {'value': B * args.steps / dt1, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt1 / args.steps,
                      'arithmetic': 'TVAE_GEMM=f32: every matrix product on v_mfma_f32_32x32x2_f32',
@@ -367,9 +373,32 @@ def main():
                      'conv1_wgrad_frac_of_f32_peak':
                          fl1 / (kev1['tvae_conv1_wgrad']['mean_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
                          if 'tvae_conv1_wgrad' in kev1 else None}
+    # companion: the exact three-part bf16 split (six products per block; the default arithmetic of rounds 1-2)
+    companion_x6 = None
+    if world == 1 and mode == 'h3' and not args.no_f32_companion:
+        _lib.set_gemm_mode('x6')
+        for i in range(2):
+            one_step(i)
+        barrier()
+        ops.KERNEL_EVENTS = {}
+        t3 = time.perf_counter()
+        lastx = None
+        for i in range(args.steps):
+            lastx = one_step(args.warmup + i)
+        barrier()
+        dt3 = time.perf_counter() - t3
+        kev3 = ops.kernel_event_ms()
+        ops.KERNEL_EVENTS = None
+        _lib.set_gemm_mode(mode)
+        companion_x6 = {'value': B * args.steps / dt3, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt3 / args.steps,
+                        'arithmetic': 'TVAE_GEMM=x6: operands split exactly into 3 x bf16, 6 MFMAs per product block '
+                                      '(3 against the 0 / 1 operand)',
+                        'elbo': float(lastx),
+                        'entry_points_ms': {k_: round(v['mean_ms'], 3) for k_, v in sorted(kev3.items())
+                                            if k_.startswith('tvae_linear') or k_.startswith('tvae_conv1')}}
     # second companion: the opt-in bf16 throughput mode (one bf16 MFMA per product block; never the headline)
     companion_bf16 = None
-    if world == 1 and mode == 'x6' and not args.no_f32_companion:
+    if world == 1 and mode in ('x6', 'h3') and not args.no_f32_companion:
         _lib.set_gemm_mode('bf16')
         for i in range(2):
             one_step(i)
@@ -383,7 +412,7 @@ def main():
         dt2 = time.perf_counter() - t2
         kev2 = ops.kernel_event_ms()
         ops.KERNEL_EVENTS = None
-        _lib.set_gemm_mode('x6')
+        _lib.set_gemm_mode(mode)
         companion_bf16 = {'value': B * args.steps / dt2, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt2 / args.steps,
                           'arithmetic': 'TVAE_GEMM=bf16: operands of the convolution and decoder GEMMs rounded to one bf16 '
                                         'number, fp32 accumulate (tolerance 2e-2 on the ELBO terms, tests/test_hip_modules.py'
@@ -394,7 +423,7 @@ def main():
     # third companion (28x28 workloads, where ~70 launches per 4 ms step make the host's launch cost visible): the same steps
     # with forward + backward replayed from a hipGraph (tvae/graph.py; bitwise the eager result)
     companion_graph = None
-    if world == 1 and mode == 'x6' and not args.graph and not args.no_f32_companion and args.workload in ('S28', 'S28F'):
+    if world == 1 and mode in ('x6', 'h3') and not args.graph and not args.no_f32_companion and args.workload in ('S28', 'S28F'):
         from tvae import graph as _graph
         gs_box[0] = _graph.GraphedStep(x, gen, enc, opt, c['lik'], B, (c['cin'], c['n'], c['n']), dev)
         for i in range(2):
@@ -456,7 +485,7 @@ def main():
         dense_flops = 2.0 * c['hidden'] * c['hidden'] * Nt
         info = MODE_INFO[mode]
         # every timed entry point: (algorithmic FLOPs per launch, kernel, note)
-        conv_dft = mode in ('x6', 'bf16') and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
+        conv_dft = mode in ('x6', 'h3', 'bf16') and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
         entries = {
             'tvae_conv1_fwd': (conv_flops, 'dft_image + dft_bank + batched dense_x6_kernel + dft_out_mf_kernel'
                                if conv_dft else info['kernels']['tvae_conv1_fwd']),
@@ -493,16 +522,19 @@ def main():
         two_val = c['layers'] >= 2 and c['n_out'] == 1          # ops.DecoderFn: virt + LeakyReLU (bench models)
         products = {'tvae_linear_fwd_x6': 6, 'tvae_linear_dgrad_x6': 3 if two_val else 6,
                     'tvae_linear_wgrad_x6': 3 if two_val else 6}
+        if mode == 'h3':        # two fp16 parts: 3 products, 2 against the exact 0 / 1 operand (the general forms stay x6)
+            products = {'tvae_linear_fwd_x6': 3, 'tvae_linear_dgrad_x6': 2 if two_val else 6,
+                        'tvae_linear_wgrad_x6': 2 if two_val else 6}
         if mode == 'bf16':
             products = {k_: 1 for k_ in products}
         dense = [k_ for k_ in products if k_ in timed]
-        if mode in ('x6', 'bf16') and dense:
+        if mode in ('x6', 'h3', 'bf16') and dense:
             dom = max(dense, key=lambda k_: kev[k_]['total_ms'])
         else:
             dom = max(('tvae_conv1_fwd', 'tvae_conv1_wgrad'), key=lambda k_: kev.get(k_, {}).get('total_ms', 0.0))
         flops = entries[dom][0]
         ach = flops / (kev[dom]['mean_ms'] * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS / products[dom] if (mode in ('x6', 'bf16') and dom in products) else info['peak']
+        peak = PEAK_BF16_MFMA_TFLOPS / products[dom] if (mode in ('x6', 'h3', 'bf16') and dom in products) else info['peak']
         out = {
             'metric': ('training images/sec (fwd+bwd+Adam), P8 z=2 64x64 bs=256/GPU' if args.workload == 'S64' else
                        'training images/sec (fwd+bwd+Adam), extra workload ' + args.workload) +
@@ -525,7 +557,7 @@ def main():
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': ach / peak,
                          'peak_note': 'algorithmic (fp32-equivalent) FLOP/s; peak = 2500 TFLOP/s dense bf16 / bf16 MFMAs per '
-                                      'product block of this launch (dense_launches)' if mode in ('x6', 'bf16') else
+                                      'product block of this launch (dense_launches)' if mode in ('x6', 'h3', 'bf16') else
                                       'dense f32 MFMA peak',
                          'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
                          # dense_x6_kernel is launched with several shapes: pick the decoder-layer launch by its grid
@@ -545,7 +577,7 @@ def main():
                                                  (kev[k_]['total_ms'] * 1e-3) / 1e15,
                                                  'frac_of_bf16_peak': products[k_] * dense_flops * kev[k_]['launches'] /
                                                  (kev[k_]['total_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
-                                            for k_ in dense} if mode in ('x6', 'bf16') else None,
+                                            for k_ in dense} if mode in ('x6', 'h3', 'bf16') else None,
                          'dense_aggregate': ({'algorithmic_tflops': sum(dense_flops * kev[k_]['launches'] for k_ in dense) /
                                               (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12,
                                               'executed_bf16_pflops':
@@ -555,7 +587,7 @@ def main():
                                               sum(products[k_] * dense_flops * kev[k_]['launches'] for k_ in dense) /
                                               (sum(kev[k_]['total_ms'] for k_ in dense) * 1e-3) / 1e12 /
                                               PEAK_BF16_MFMA_TFLOPS}
-                                             if (mode in ('x6', 'bf16') and dense) else None),
+                                             if (mode in ('x6', 'h3', 'bf16') and dense) else None),
                          'conv_direct_form_tflops': {k_: conv_flops / (kev[k_]['mean_ms'] * 1e-3) / 1e12
                                                      for k_ in ('tvae_conv1_fwd', 'tvae_conv1_wgrad') if k_ in kev}},
         }
@@ -567,6 +599,8 @@ def main():
             out['encoder_tail'] = enc_tail
         if companion is not None:
             out['exact_f32_mode'] = companion
+        if companion_x6 is not None:
+            out['exact_split_x6_mode'] = companion_x6
         if companion_bf16 is not None:
             out['bf16_throughput_mode'] = companion_bf16
         if companion_graph is not None:

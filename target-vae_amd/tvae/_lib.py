@@ -114,12 +114,19 @@ def lib():
 
 ABI_VERSION = 3
 # Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
-# entry points tvae.ops calls ('x6': *_x6 / *_dft, split-bf16 products with fp32-equivalent results; 'f32': the exact
-# fp32-MFMA entry points; 'bf16': the *_x6 / *_dft entry points with parts = 1 -- operands rounded to one bf16 number, the
-# throughput mode of BASELINE.json configs 2 / 5, not fp32-equivalent and never the default).  Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so
-# two models with different arithmetic coexist in one process.
+# entry points tvae.ops calls and with which `parts`:
+#   'h3'   (default) *_x6 / *_dft entry points with parts = 2: operands as TWO fp16 parts under a power-of-two tensor scale,
+#          three products per block (two against an exact 0 / 1 operand), fp32 accumulate -- fp32-equivalent results (at
+#          least as accurate against fp64 as the fp32 matrix pipe: profiles/experiments/f16_split_probe.hip, the parity
+#          tests run in it at the same tolerances); launches without an h3 instance run 'x6'
+#   'x6'   the same entry points with parts = 3: operands split EXACTLY into three bf16 numbers, six products
+#   'f32'  the exact fp32-MFMA entry points
+#   'bf16' parts = 1: operands rounded to one bf16 number -- the throughput mode of BASELINE.json configs 2 / 5, not
+#          fp32-equivalent and never the default.
+# Default from TVAE_GEMM; `with arithmetic('f32'): ...` scopes a different mode to a block, so two models with different
+# arithmetic coexist in one process.
 GEMM_MODES = ('f32', 'x6', 'h3', 'bf16')
-_mode = os.environ.get('TVAE_GEMM', 'x6')
+_mode = os.environ.get('TVAE_GEMM', 'h3')
 if _mode not in GEMM_MODES:
     raise TvaeHipError(f'TVAE_GEMM={_mode!r}: choose from {GEMM_MODES}')
 

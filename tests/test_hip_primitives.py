@@ -398,6 +398,69 @@ def test_linear_x6_implicit_gradient_operand():
     assert rel_err(tot[0], d.sum(1)) < TOL and rel_err(tot[1], H.double() @ gy.double()) < TOL
 
 
+@pytest.mark.parametrize('sw,sg,sx', [(1.0, 1.0, 1.0), (1e-3, 1e-6, 1.0), (30.0, 1e3, 50.0), (1.0, 0.0, 1.0), (1e-12, 1e-9, 1e-3)])
+def test_h3_decoder_entry_points(sw, sg, sx):
+    """The three decoder launches with an h3 instance (two fp16 parts per operand under a power-of-two tensor scale: three
+    products per block, two against the exact 0 / 1 operand) against fp64 at the fp32 tolerance, and against the exact x6
+    split of the same launch: forward with the recomputed first-layer operand (+ sign bits), two-valued data gradient (+ row
+    sums), weight gradient from sign bits against gy x the recomputed operand.  Operand magnitudes from 1e-12 to 1e3 (the
+    scales must absorb them: fp16 alone spans 6e-8 .. 6.5e4), a zero gradient (maximum 0)."""
+    from tvae._lib import query
+    F_, B, Np, M, act = 512, 2, 256, 512, 1
+    Nt = B * Np
+    xr, Wc, bc = (rnd(Nt, 2, seed=1) * sx).to(dev()), rnd(F_, 2, seed=2).to(dev()), rnd(F_, seed=3).to(dev())
+    LB = rnd(B, F_, seed=4).to(dev())
+    h0 = torch.empty(F_, Nt, device=dev())
+    call('tvae_dec_l0_fwd', xr, Wc, bc, LB, h0, Nt, F_, Nt, Np, act, SLOPE)
+    W, b = rnd(M, F_, seed=5, scale=sw * F_ ** -0.5), rnd(M, seed=6, scale=sw)
+    wo, gy = rnd(M, seed=8), rnd(Nt, seed=9) * sg
+    va = (xr, Wc, bc, LB, Np)
+    H0 = h0.double().cpu()
+    res = {}
+    for nparts, split in ((3, 'tvae_dense_split3'), (2, 'tvae_dense_split2h')):
+        w3 = torch.empty(query('tvae_dense_x6_bytes', M, F_) // 4, device=dev())
+        call(split, W.to(dev()), F_, w3, w3.numel() * 4, M, F_, 0, None, None)
+        Y = torch.empty(M, Nt, device=dev())
+        bits = torch.empty(M, Nt // 32, dtype=torch.int32, device=dev())
+        call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y, M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va, bits,
+             nparts)
+        # two-valued data gradient of THIS layer's input from (wo, gy, Y): weights W^T diag(wo), 0 / 1 operand [Y > 0]
+        w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
+        csum = torch.empty(F_, device=dev())
+        call(split, W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1, wo.to(dev()), csum)
+        dX = torch.empty(F_, Nt, device=dev())
+        rs_part = torch.full(((Nt // 128) * M * 2,), float('nan'), device=dev())
+        gys = gy.sum().reshape(1).to(dev())
+        rs_db, rs_dwo = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+        call('tvae_linear_dgrad_x6', w3t, Y, None, h0, dX, M, Nt, F_, Nt, Nt, 1, SLOPE, None, None, None, None, 0, None,
+             gy.to(dev()), csum, None, None, 0, rs_part, rs_part.numel(), wo.to(dev()), gys, rs_db, rs_dwo, nparts)
+        ws = torch.empty(query('tvae_linear_wgrad_x6_ws_floats', M, Nt, F_), device=dev())
+        dW = torch.empty(M, F_, device=dev())
+        call('tvae_linear_wgrad_x6', None, None, dW, ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, wo.to(dev()), gy.to(dev()), 1, SLOPE,
+             *va, bits, nparts)
+        res[nparts] = (Y, dX, dW, rs_db, rs_dwo, bits)
+        assert torch.isfinite(Y).all() and torch.isfinite(dX).all() and torch.isfinite(dW).all()
+    Yd = res[3][0].double().cpu()                     # masks from the x6 forward (the two forwards may differ in a sign at 0)
+    ref_Y = act_ref(W.double() @ H0 + b.double()[:, None], act)
+    d = wo.double()[:, None] * gy.double()[None, :] * dact_ref(Yd, 1)
+    ref_dX = (W.double().t() @ d) * dact_ref(H0, 1)
+    ref_dW = d @ H0.t()
+    flips = int(((res[2][0] > 0) != (res[3][0] > 0)).sum())
+    assert flips <= 2                                 # elements at zero to rounding
+    for nparts in (3, 2):
+        Y, dX, dW, rs_db, rs_dwo, bits = res[nparts]
+        assert rel_err(Y, ref_Y) < GEMM_TOL['f32'], nparts
+        if sg == 0.0:
+            assert float(dX.abs().max()) == 0.0 and float(dW.abs().max()) == 0.0
+            continue
+        tol = GEMM_TOL['f32'] * (1 if (nparts == 3 or flips == 0) else 50)
+        assert rel_err(dX, ref_dX) < tol, nparts
+        assert rel_err(dW, ref_dW) < tol, nparts
+    # h3 is not less accurate than the exact split by more than rounding (both are dominated by fp32 accumulation)
+    e3, e2 = rel_err(res[3][0], ref_Y), rel_err(res[2][0], ref_Y)
+    assert e2 < 2 * e3 + 1e-7, (e2, e3)
+
+
 @pytest.mark.parametrize('F_,B,Np,act,has_lb', [(512, 3, 256, 1, True), (300, 2, 384, 2, True), (256, 2, 128, 1, False)])
 def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     """The output of the coordinate layer formed inside its three consumers (forward X, data-gradient mask, weight-gradient
