@@ -23,6 +23,10 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          'dense_x6_kernel<0, 3>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2, 3>': 'tvae_linear_fwd_x6',
          'dense_x6_kernel<1, 3>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<3, 3>': 'tvae_linear_dgrad_x6',
          'dense_x6_kernel<4, 3>': 'tvae_linear_dgrad_x6',        # round 3: two-valued + row sums of H (no dec_out_bwd pass)
+         # the same launches in the h3 arithmetic (parts = 2: the default since round 3)
+         'dense_x6_kernel<0, 2>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2, 2>': 'tvae_linear_fwd_x6',
+         'dense_x6_kernel<1, 2>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<3, 2>': 'tvae_linear_dgrad_x6',
+         'dense_x6_kernel<4, 2>': 'tvae_linear_dgrad_x6',
          'dense_x6_plain4_kernel': 'tvae_spectral_fwd',
          'dft_out_ring_kernel': 'tvae_dft_out', 'dft_dy_ring_kernel': 'tvae_dft_dy',
          'enc_tail_wgrad_x6_kernel': 'tvae_enc_tail_wgrad_x6', 'dft_dbank_kernel': 'tvae_dft_dbank',

@@ -81,7 +81,7 @@ static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int ro
         float* tr = h3_trailer(a3, rows, K);
         hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), tr, 4);
         TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)rows * K, 256, 256)), dim3(256), 0, S(stream), W, ldw, rows, K,
+        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)rows * K, 256 * 8, 128)), dim3(256), 0, S(stream), W, ldw, rows, K,
                            transpose, scale, tr);
         TVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
@@ -126,7 +126,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
             hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, tr + 1, 3);
             TVAE_CHECK_LAUNCH();
             const long nlb = va.lb ? (long)(N / va.Np) * K : 0;
-            hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(2L * N, 256, 256)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
+            hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 128)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
                                va.bc, va.lb, nlb, K, tr + 1);
             TVAE_CHECK_LAUNCH();
             hs.amax_x = tr + 1;

@@ -190,10 +190,7 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             mx = fmaxf(mx, fmaxf(fabsf(k.x), fabsf(k.y)));
         }
     }
-    if (amax) {
-        mx = h3_wave_max(mx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax + (is_img ? 0 : 1), mx);
-    }
+    if (amax) h3_block_amax(mx, amax + (is_img ? 0 : 1));            // (uniform: every thread of the workgroup arrives)
 }
 
 // ==========================================================================================

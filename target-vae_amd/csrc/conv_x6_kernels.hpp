@@ -124,12 +124,29 @@ __device__ __forceinline__ void mfma3h(f32x16& acc, const Cell16 (&a)[3], const 
 // max |x| into a device word by atomic max on the bit pattern (non-negative floats order like unsigned integers); NaN
 // / Inf propagate as a huge maximum -> scale clamped, the result is then non-finite as it would be in any arithmetic
 __device__ __forceinline__ void h3_atomic_amax(float* slot, float v) {
-    atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(fabsf(v)));
+    const unsigned b = __float_as_uint(fabsf(v));
+    // most callers arrive with less than what is already there: a plain read spares the L2 their atomic
+    if (b > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(slot))) atomicMax(reinterpret_cast<unsigned*>(slot), b);
 }
 __device__ __forceinline__ float h3_wave_max(float v) {          // in every lane
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// block-wide maximum, then ONE atomic per workgroup (per-wave atomics on a single word serialise at the L2: 12 000 of
+// them made a 5 us reduction take 140).  Every thread of the workgroup must call it.
+__device__ __forceinline__ void h3_block_amax(float v, float* slot) {
+    __shared__ float red_[16];
+    v = h3_wave_max(v);
+    __syncthreads();                                             // red_ may still be read by the previous call
+    if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red_[0];
+        for (int i = 1; i < (int)((blockDim.x + 63) >> 6); ++i) m = fmaxf(m, red_[i]);
+        h3_atomic_amax(slot, m);
+    }
 }
 
 // six partial products, in the order the A parts arrive from LDS (h, m, l): the first MFMA of a fragment then waits

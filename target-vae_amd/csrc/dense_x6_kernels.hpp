@@ -62,8 +62,7 @@ static __global__ void dense_absmax_kernel(const float* __restrict__ W, long ldw
         if (scale) v *= scale[k];
         mx = fmaxf(mx, fabsf(v));
     }
-    mx = h3_wave_max(mx);
-    if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, mx);
+    h3_block_amax(mx, amax);
 }
 static __global__ void h3_zero_slots_kernel(float* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
@@ -99,21 +98,23 @@ static __global__ void dec_l0_bound_kernel(const float* __restrict__ xr, long nx
                                            float* __restrict__ slots) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-    for (long i = gid; i < nxr; i += gsz) m0 = fmaxf(m0, fabsf(xr[i]));
+    const long n4 = (reinterpret_cast<size_t>(xr) & 15) == 0 ? nxr / 4 : 0;        // 16-byte loads, several in flight
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+#pragma unroll 4
+    for (long i = gid; i < n4; i += gsz) {
+        const float4 v = x4[i];
+        m0 = fmaxf(fmaxf(m0, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (long i = 4 * n4 + gid; i < nxr; i += gsz) m0 = fmaxf(m0, fabsf(xr[i]));
     for (long i = gid; i < K; i += gsz) m1 = fmaxf(m1, fabsf(wc[2 * i]) + fabsf(wc[2 * i + 1]));
     if (lb) {
         for (long i = gid; i < nlb; i += gsz) m2 = fmaxf(m2, fabsf(bc[i % K] + lb[i]));
     } else {
         for (long i = gid; i < K; i += gsz) m2 = fmaxf(m2, fabsf(bc[i]));
     }
-    m0 = h3_wave_max(m0);
-    m1 = h3_wave_max(m1);
-    m2 = h3_wave_max(m2);
-    if ((threadIdx.x & 63) == 0) {
-        h3_atomic_amax(slots, m0);
-        h3_atomic_amax(slots + 1, m1);
-        h3_atomic_amax(slots + 2, m2);
-    }
+    h3_block_amax(m0, slots);
+    h3_block_amax(m1, slots + 1);
+    h3_block_amax(m2, slots + 2);
 }
 
 // rowsum[row] = sum_k A(row, k) of the (scaled) operand above (VirtGrad.csum).  Block = 64 rows x 16 k-slices; the slice
