@@ -23,7 +23,12 @@ int tvae_abi_version(void);
 /* The library keeps NO process-wide state.  The arithmetic of a matrix product is chosen per call by the entry point:
  * tvae_conv1_fwd / tvae_conv1_wgrad / tvae_linear_* compute exact fp32 products (v_mfma_f32_32x32x2_f32); the *_x6 and
  * *_dft entry points compute in the "x6" arithmetic (every fp32 operand split EXACTLY into three bf16 numbers, six
- * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results).  tvae_abi_version() == 3. */
+ * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results) when called with parts = 3, in the
+ * "h3" arithmetic (two fp16 parts under a power-of-two tensor scale, three v_mfma_f32_32x32x16_f16 products: fp32-equivalent
+ * results with half the matrix instructions; tvae_dense_split2h below) with parts = 2, and with operands rounded to one
+ * bf16 number (throughput mode, NOT fp32-equivalent) with parts = 1.  tvae_abi_version() == 4 (ABI 4: parts = 2,
+ * tvae_dense_split2h; the buffers sized by tvae_conv1_dft_at_floats and tvae_linear_wgrad_x6_ws_floats carry a few extra
+ * words -- the operand maxima of the h3 arithmetic -- behind their data). */
 
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
