@@ -442,16 +442,17 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     float va_x0 = 0.f, va_x1 = 0.f;
     if (XV == 2) {                                       // tables (w0, w1, bc, lb) of the recomputed activation, K <= 512
         const int img_ = n0 / va.Np;
-        if (tid < K) {
-            vwo_[tid] = va.wc[2 * tid];
-            vwo_[512 + tid] = va.wc[2 * tid + 1];
-            vwo_[1024 + tid] = va.bc[tid];
-            vwo_[1536 + tid] = va.lb ? va.lb[(long)img_ * K + tid] : 0.f;
-        }
+        // (rows k >= K of the table are zero: their values meet all-zero weight cells and only have to be finite, so the
+        // loop below needs no k < K test)
+        vwo_[tid] = tid < K ? va.wc[2 * tid] : 0.f;
+        vwo_[512 + tid] = tid < K ? va.wc[2 * tid + 1] : 0.f;
+        vwo_[1024 + tid] = tid < K ? va.bc[tid] : 0.f;
+        vwo_[1536 + tid] = (va.lb && tid < K) ? va.lb[(long)img_ * K + tid] : 0.f;
         va_x0 = va.xr[2 * (long)(n0 + nb)];
         va_x1 = va.xr[2 * (long)(n0 + nb) + 1];
     }
     const bool vwo_lds = K <= 512;
+    const bool va_lrelu = XV == 2 && va.act == ACT_LRELU;
     auto load_x = [&](int t, float (&x)[4]) {
         if (XV == 2) {
 #pragma unroll
@@ -474,11 +475,23 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             }
         }
         if (XV == 2) {
+            // LeakyReLU (every reference configuration) straight-line: the generic form put an exec-mask branch, a scalar
+            // switch on the activation and tanhf's own branches around EACH of the four values of a step -- inside the
+            // k-loop, between the MFMAs (found in the ISA, round 3)
+            if (va_lrelu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = (16 * t + 4 * kq + j) & 511;
-                const float pre = dec_l0_pre(vwo_[k], vwo_[512 + k], vwo_[1024 + k], vwo_[1536 + k], va_x0, va_x1);
-                x[j] = (16 * t + 4 * kq + j < K) ? act_apply(pre, va.act, va.slope) : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int k = (16 * t + 4 * kq + j) & 511;
+                    const float pre = dec_l0_pre(vwo_[k], vwo_[512 + k], vwo_[1024 + k], vwo_[1536 + k], va_x0, va_x1);
+                    x[j] = pre > 0.f ? pre : pre * va.slope;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = (16 * t + 4 * kq + j) & 511;
+                    const float pre = dec_l0_pre(vwo_[k], vwo_[512 + k], vwo_[1024 + k], vwo_[1536 + k], va_x0, va_x1);
+                    x[j] = act_apply(pre, va.act, va.slope);
+                }
             }
         }
     };
@@ -977,12 +990,19 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             gq[1] = *reinterpret_cast<const float4*>(sl + 4096 + 1024 + 32 * khalf + 16);
         }
     };
+    const bool xva_lrelu = XVA && va.act == ACT_LRELU;
     auto read_x = [&](int slot) -> float4 {
         const unsigned char* sl = ring + slot * WG_SLOT_BYTES + 4096;
         if (XVA) {
             const float4 c0 = *reinterpret_cast<const float4*>(sl + 32 * q4);
             const float4 c1 = *reinterpret_cast<const float4*>(sl + 32 * q4 + 16);
             const float lbv = *reinterpret_cast<const float*>(sl + 256 + 4 * lane) * lb_on;
+            if (xva_lrelu) {                             // straight-line LeakyReLU (see dense_x6_kernel: no per-value branches in the loop)
+                const float p0 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), p1 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w);
+                const float p2 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), p3 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.z, c1.w);
+                return make_float4(p0 > 0.f ? p0 : p0 * va.slope, p1 > 0.f ? p1 : p1 * va.slope, p2 > 0.f ? p2 : p2 * va.slope,
+                                   p3 > 0.f ? p3 : p3 * va.slope);
+            }
             return make_float4(act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), va.act, va.slope),
                                act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w), va.act, va.slope),
                                act_apply(dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), va.act, va.slope),
