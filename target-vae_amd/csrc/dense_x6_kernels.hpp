@@ -329,7 +329,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         sw[j] = (unsigned)(lane < 32 ? bl : bl >> 32);
                     }
                     if (m < M) {
-                        if (crow) crow[j * 32] = v;
+                        if (crow) __builtin_nontemporal_store(v, crow + j * 32);     // written once, read by a later launch: no reuse in L2
                         if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
                         if (it.xr) {                             // fused first-layer backward (see InTail)
                             rs[0] += v;
