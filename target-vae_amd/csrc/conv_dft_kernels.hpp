@@ -602,7 +602,7 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
             const int e = min(i * 64 + lane, cnt - 1);
             int o = e + (e >= thr ? jump : 0);
             if (HO < 32) o += e >= thr + P ? jump : 0;   // narrow outputs: 32 rows can span three images
-            obase[(unsigned)o] = stg[e];
+            __builtin_nontemporal_store(stg[e], obase + (unsigned)o);      // written once, read by later launches
         }
         __builtin_amdgcn_wave_barrier();
         slot = slot == 2 ? 0 : slot + 1;
@@ -735,14 +735,14 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
             for (int r = 0; r < 16; ++r) {
                 const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);             // kh = 0; kh = 1 adds 4
                 const unsigned o = ((kk0 & 1) ? lim : lre) + (unsigned)((kk0 >> 1) * 128);
-                if (kk0 + 4 < LH2) sb[o] = acc[rt][r];
-                else if (kk0 < LH2) { if (kh == 0) sb[o] = acc[rt][r]; }
+                if (kk0 + 4 < LH2) __builtin_nontemporal_store(acc[rt][r], sb + o);
+                else if (kk0 < LH2) { if (kh == 0) __builtin_nontemporal_store(acc[rt][r], sb + o); }
                 if (kk0 < LH2) mx = fmaxf(mx, fabsf(acc[rt][r]));      // (a few values beyond LH2 in the kh = 1 half: zero table rows)
             }
         if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
             const float tot = racc + __shfl_xor(racc, 32, 64);
             const unsigned o = (kh ? lim : lre) - (unsigned)(2 * kh * 128) + (unsigned)((LH2 / 2 - 1) * 128);
-            sb[o] = kh ? 0.f : tot;
+            __builtin_nontemporal_store(kh ? 0.f : tot, sb + o);
             mx = fmaxf(mx, fabsf(tot));
         }
     }

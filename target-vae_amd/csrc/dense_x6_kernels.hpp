@@ -463,7 +463,8 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             // result, makes the compiler wait for it on the spot -- these loads are issued two steps ahead on purpose
             const int kb = 16 * t + 4 * kq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = x_col[(long)min(kb + j, K - 1) * ldx];
+            for (int j = 0; j < 4; ++j)               // the saved activation of the two-valued forms is read exactly once
+                x[j] = MASKB ? __builtin_nontemporal_load(x_col + (long)min(kb + j, K - 1) * ldx) : x_col[(long)min(kb + j, K - 1) * ldx];
         }
     };
     auto virt_x = [&](int t, float (&x)[4]) {

@@ -122,7 +122,7 @@ __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* _
             char* hrow = reinterpret_cast<char*>(H + (long)et_row(i, r, 0) * ldh + n0);
             const float v = et_act<ACT>(acc[i][r] + w1.w, slope);
             if (ACT == ACT_LRELU) hb[i] |= v > 0.f ? (1u << (8 * (r >> 2) + (r & 3))) : 0u;   // + 4 kh: shifted below
-            if (in0) *reinterpret_cast<float*>(hrow + loff) = v;
+            if (in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(hrow + loff));
             hs[0] = __fmaf_rn(w0.x, v, hs[0]);
             hs[1] = __fmaf_rn(w0.y, v, hs[1]);
             hs[2] = __fmaf_rn(w0.z, v, hs[2]);
@@ -343,7 +343,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
             for (int r = 0; r < 16; ++r) {
                 char* drow = reinterpret_cast<char*>(dA1 + (long)et_row(i, r, 0) * lda + n0);
                 const float v = acc[i][r] * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
-                if (in0) *reinterpret_cast<float*>(drow + loff) = v;
+                if (in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(drow + loff));
             }
     }
 }

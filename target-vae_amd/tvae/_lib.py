@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libtvae_hip.so')
+# TVAE_LIB: another build of the library (same-box A/B of two builds: profiles/tools/ab_kernels.sh TVAE_LIB "a.so b.so")
+LIB_PATH = os.environ.get('TVAE_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libtvae_hip.so')
 
 # signature codes: p = device pointer (tensor or None), i = int, l = long, f = float; the trailing
 # stream argument is appended automatically (torch.cuda.current_stream()).
