@@ -458,8 +458,10 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // ==========================================================================================
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane BYTE offset (global "saddr" addressing): the
 // per-lane offsets are loop invariants kept in registers, so issuing a piece costs no vector-ALU work at all.
+// (nt on the 16-byte form: T is read exactly once, by dft_out_ring_kernel -- 884 -> 860 us; the dword form reads dY, which the
+// launch before it has just written: nontemporal loads and stores both measured slower there)
 #define TVAE_DFT_DMA_X4(dst, off, base) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(off), "s"(base) : "memory")
 #define TVAE_DFT_DMA_X1(dst, off, base) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory")
 #define TVAE_DFT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -735,14 +737,14 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
             for (int r = 0; r < 16; ++r) {
                 const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);             // kh = 0; kh = 1 adds 4
                 const unsigned o = ((kk0 & 1) ? lim : lre) + (unsigned)((kk0 >> 1) * 128);
-                if (kk0 + 4 < LH2) __builtin_nontemporal_store(acc[rt][r], sb + o);
-                else if (kk0 < LH2) { if (kh == 0) __builtin_nontemporal_store(acc[rt][r], sb + o); }
+                if (kk0 + 4 < LH2) sb[o] = acc[rt][r];
+                else if (kk0 < LH2) { if (kh == 0) sb[o] = acc[rt][r]; }
                 if (kk0 < LH2) mx = fmaxf(mx, fabsf(acc[rt][r]));      // (a few values beyond LH2 in the kh = 1 half: zero table rows)
             }
         if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
             const float tot = racc + __shfl_xor(racc, 32, 64);
             const unsigned o = (kh ? lim : lre) - (unsigned)(2 * kh * 128) + (unsigned)((LH2 / 2 - 1) * 128);
-            __builtin_nontemporal_store(kh ? 0.f : tot, sb + o);
+            sb[o] = kh ? 0.f : tot;
             mx = fmaxf(mx, fabsf(tot));
         }
     }
