@@ -67,10 +67,6 @@ long tvae_dense_x6_bytes(int rows, int K) { return dense_x6_bytes(rows, K); }
 // h3 cells (parts == 2) occupy two of the three part arrays the buffer is sized for; the first four floats of the third
 // hold the operand's maximum ([0], read again by the GEMM for its epilogue) and, for launches whose streamed operand is
 // recomputed, the three maxima of dec_l0_bound_kernel ([1..3], written by the GEMM entry point).
-static float* h3_trailer(const void* a3, int rows, int K) {
-    const long total = (long)dense_k8pad(K) * x6_round_up(rows, DX6_ROWS);
-    return reinterpret_cast<float*>(const_cast<void*>(a3)) + 2 * total * 4;
-}
 static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                        const float* scale, float* rowsum, int parts, tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;

@@ -59,23 +59,31 @@ int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads
                            tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3p) || !aligned16(wh3) || !aligned16(bits_h) || !aligned16(bits_a) ||
-        (parts != 1 && parts != 3) || !dheads || !bits_h || !bits_a || !dA1 || !et_ld_ok(N, ldd, lda, 0))
+        (parts != 1 && parts != 2 && parts != 3) || !dheads || !bits_h || !bits_a || !dA1 || !et_ld_ok(N, ldd, lda, 0))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
-    const size_t lds = (size_t)parts * 18 * ET_C * 16;
+    // parts == 2 (h3): w3p = tvae_dense_split2h cells (two fp16 parts), wh3 = tvae_dense_split3 cells (the skinny GEMM stays exact)
+    const size_t lds = ((size_t)parts * 16 + (parts == 2 ? 3 : parts) * 2) * ET_C * 16;
+    const float* amax_a = parts == 2 ? h3_trailer(w3p, ET_C, ET_C) : nullptr;
     hipError_t e;
     if (parts == 3) {
         e = allow_big_lds(enc_tail_dgrad_x6_kernel<3>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_dgrad_x6_kernel<3>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream),
                            (const uint4*)w3p, Rpad, (const uint4*)wh3, Rpad, dheads, ldd, nh, (const uint4*)bits_h,
-                           (const uint4*)bits_a, dA1, lda, N, slope);
+                           (const uint4*)bits_a, dA1, lda, N, slope, amax_a);
+    } else if (parts == 2) {
+        e = allow_big_lds(enc_tail_dgrad_x6_kernel<2>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_dgrad_x6_kernel<2>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream),
+                           (const uint4*)w3p, Rpad, (const uint4*)wh3, Rpad, dheads, ldd, nh, (const uint4*)bits_h,
+                           (const uint4*)bits_a, dA1, lda, N, slope, amax_a);
     } else {
         e = allow_big_lds(enc_tail_dgrad_x6_kernel<1>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_dgrad_x6_kernel<1>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream),
                            (const uint4*)w3p, Rpad, (const uint4*)wh3, Rpad, dheads, ldd, nh, (const uint4*)bits_h,
-                           (const uint4*)bits_a, dA1, lda, N, slope);
+                           (const uint4*)bits_a, dA1, lda, N, slope, amax_a);
     }
     TVAE_CHECK_LAUNCH();
     return 0;

@@ -46,6 +46,11 @@ __device__ __forceinline__ float et_act(float v, float slope) {
 __device__ __forceinline__ int et_row(int i, int r, int kh) { return 32 * i + 8 * (r >> 2) + (r & 3) + 4 * kh; }
 
 // split of the 8 k-values a lane holds for its column into the B-fragment cells of one 16-k step
+// (h3: the values scaled by the power of two s, two fp16 parts)
+__device__ __forceinline__ void et_split2h(const float (&x)[8], float s, Cell16 (&bf)[3]) {
+    const float y[8] = {x[0] * s, x[1] * s, x[2] * s, x[3] * s, x[4] * s, x[5] * s, x[6] * s, x[7] * s};
+    split2hx8(y, bf[0], bf[1]);
+}
 template <int NP>
 __device__ __forceinline__ void et_split(const float (&x)[8], Cell16 (&bf)[3]) {
     if (NP == 3) {
@@ -253,19 +258,26 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float et_mask(unsigned w, int bit, float slope) { return (w >> bit) & 1u ? 1.f : slope; }
 
+// NP == 2 (h3): the skinny first GEMM (one 16-k step) stays in the exact three-part split (Wh3: tvae_dense_split3); the
+// 128 x 128 second one runs on two fp16 parts (W3p: tvae_dense_split2h, its maximum at amax_a).  Its streamed operand G is
+// complete in this wave's registers before the first product, so its scale is EXACT and local: the power of two that brings
+// max |G| of the wave's 128 x 32 chunk below 2^15, undone on that chunk's accumulators -- no tensor-wide maximum needed.
 template <int NP>
 static __global__ __launch_bounds__(ET_THREADS, ET_WAVES / 4)
 void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uint4* __restrict__ Wh3, int Rpadh,
                               const float* __restrict__ dheads, long ldd, int nh, const uint4* __restrict__ bitsH,
-                              const uint4* __restrict__ bitsA, float* __restrict__ dA1, long lda, long N, float slope) {
-    extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128] W2^T (permuted k), then [NP][2][128] Wh^T
+                              const uint4* __restrict__ bitsA, float* __restrict__ dA1, long lda, long N, float slope,
+                              const float* __restrict__ amax_a) {
+    constexpr int NP1 = NP == 2 ? 3 : NP;                // parts of the first (head-row) GEMM
+    extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128] W2^T (permuted k), then [NP1][2][128] Wh^T
     uint4* Whs = Ws + NP * 16 * ET_C;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, kh = lane >> 5;
     for (int i = tid; i < NP * 16 * ET_C; i += ET_THREADS) Ws[i] = W3p[(long)(i >> 7) * Rpad + (i & (ET_C - 1))];
-    for (int i = tid; i < NP * 2 * ET_C; i += ET_THREADS) Whs[i] = Wh3[(long)(i >> 7) * Rpadh + (i & (ET_C - 1))];
+    for (int i = tid; i < NP1 * 2 * ET_C; i += ET_THREADS) Whs[i] = Wh3[(long)(i >> 7) * Rpadh + (i & (ET_C - 1))];
     __syncthreads();
+    const float inv_a = NP == 2 ? h3_inv(h3_scale(*amax_a)) : 1.f;
 
     const long nchunks = (N + ET_CHUNK - 1) / ET_CHUNK;
     const long gw = (long)blockIdx.x * (ET_THREADS / 64) + wave, gstride = (long)gridDim.x * (ET_THREADS / 64);
@@ -286,24 +298,33 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
     Cell16 dcell[3];
     unsigned wHs[4], wAs[4], wAsn[4];
     auto consume = [&]() {                               // everything loaded is read here (before the next stores)
-        et_split<NP>(dh, dcell);
+        et_split<NP1>(dh, dcell);
         if (kh) {                                        // k slots 8 .. 15 of the head-row reduction do not exist
 #pragma unroll
-            for (int p = 0; p < NP; ++p) dcell[p].u = make_uint4(0u, 0u, 0u, 0u);
+            for (int p = 0; p < NP1; ++p) dcell[p].u = make_uint4(0u, 0u, 0u, 0u);
         }
         wHs[0] = wHn.x >> (4 * kh); wHs[1] = wHn.y >> (4 * kh); wHs[2] = wHn.z >> (4 * kh); wHs[3] = wHn.w >> (4 * kh);
         wAsn[0] = wAn.x >> (4 * kh); wAsn[1] = wAn.y >> (4 * kh); wAsn[2] = wAn.z >> (4 * kh); wAsn[3] = wAn.w >> (4 * kh);
     };
     f32x16 acc[4], G[4];
+    float gs = 1.f;                                      // h3: scale of the chunk whose G is in registers
     auto g_phase = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             Cell16 wc[3];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wc[p].u = Whs[(p * 2 + kh) * ET_C + 32 * i + nl];
+            for (int p = 0; p < NP1; ++p) wc[p].u = Whs[(p * 2 + kh) * ET_C + 32 * i + nl];
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[i][r] = 0.f;
-            mfma_np<NP>(G[i], wc, dcell);
+            mfma_np<NP1>(G[i], wc, dcell);
+        }
+        if (NP == 2) {
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(G[i][r]));
+            gs = h3_scale(h3_wave_max(mx));
         }
     };
     load_in(0);
@@ -320,6 +341,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
+        const float gs_c = gs, inv_c = NP == 2 ? h3_inv(gs) * inv_a : 1.f;   // (both factors far inside the fp32 range here)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float xv[8];
@@ -329,7 +351,8 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
                 xv[j] = G[u >> 1][r] * et_mask(wHs[u >> 1], 8 * (r >> 2) + (r & 3), slope);
             }
             Cell16 bf[3];
-            et_split<NP>(xv, bf);
+            if (NP == 2) et_split2h(xv, gs_c, bf);
+            else et_split<NP>(xv, bf);
             et_step_mfma<NP>(acc, Ws, u, kh, nl, a0, a1, bf);
         }
         consume();
@@ -342,7 +365,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 char* drow = reinterpret_cast<char*>(dA1 + (long)et_row(i, r, 0) * lda + n0);
-                const float v = acc[i][r] * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
+                const float v = (NP == 2 ? acc[i][r] * inv_c : acc[i][r]) * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
                 if (in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(drow + loff));
             }
     }

@@ -443,14 +443,15 @@ class EncoderFn(torch.autograd.Function):
         dA1 = None
         if ctx.bits is not None:
             # dA1 straight from the head gradients and the sign words (dH is formed in registers, never stored)
-            w3p = _split_weight(W2.t()[:, _enc_tail_perm(y.device)], C, C2, False, 'enc_w2p')
+            p_e = 2 if parts() == 2 else _p3()      # h3 instance: 128 x 128 GEMM on two fp16 parts, scale per 32-column chunk
+            w3p = _split_weight(W2.t()[:, _enc_tail_perm(y.device)], C, C2, False, 'enc_w2p', nparts=p_e)
             wh3 = _scratch(y.device, 'enc_wh3', query('tvae_dense_x6_bytes', C2, nh) // 4)
             call('tvae_dense_split3', Wh.contiguous(), C2, wh3, wh3.numel() * 4, C2, nh, 1, None, None)
             dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
             _note('enc.tail_dgrad_x6')
             with _timed('tvae_enc_tail_dgrad_x6'):
                 call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, ctx.bits[0], ctx.bits[1], dA1, N, C, N,
-                     LRELU_SLOPE, _p3())
+                     LRELU_SLOPE, p_e)
         # conv2's weight gradient in one pass from A1, the head gradients and the sign words of H (dH is formed inside the
         # GEMM's operand build and never written); dWh / db2 from a sums-only pass over H
         fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0

@@ -667,6 +667,16 @@ def test_enc_tail_x6(N, nh, act, parts):
     dH = (Wh.double().t() @ dheads.double()) * dact_ref(Hs, 1)
     ref = (W2.double().t() @ dH) * dact_ref(A1.double(), 1)
     assert rel_err(dA1, ref) < tol
+    if parts == 3:
+        # the same launch in the h3 arithmetic (parts = 2: the 128 x 128 GEMM on two fp16 parts with the exact scale of each
+        # 32-column chunk; the skinny head-row GEMM stays in the three-part split), also for gradients of size 1e-7
+        w3p2 = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev())
+        call('tvae_dense_split2h', W2.t()[:, _enc_tail_perm().cpu()].contiguous().to(dev()), C, w3p2, w3p2.numel() * 4, C, C, 0,
+             None, None)
+        for sc in (1.0, 1e-7):
+            dA2 = torch.full((C, N), float('nan'), device=dev())
+            call('tvae_enc_tail_dgrad_x6', w3p2, wh3, (dheads * sc).to(dev()), N, nh, bits_h, bits_a, dA2, N, C, N, SLOPE, 2)
+            assert rel_err(dA2, ref * sc) < TOL, sc
     # conv2's weight gradient in one pass (dH formed from the head gradients and the sign words, never stored), and the
     # sums-only form of tvae_heads_bwd (dX = NULL) that supplies dWh / db2 beside it
     if N % 32 == 0:
