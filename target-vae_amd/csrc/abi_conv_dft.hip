@@ -123,7 +123,8 @@ extern "C" {
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
 }
-// A^T is followed by four words: the maxima of the h3 arithmetic ([0] max |A^T|, [1] max |W|, [2] max |S'|), written by
+// A^T is followed by four words: the maxima of the h3 arithmetic ([0] max |A^T|, [1] max |W|, [2] max |S'|, [3] max |out| of
+// the ring transform -- the streamed operand of the encoder tail that follows), written by
 // the kernels that produce those operands and read by the GEMMs that split them
 constexpr int DFT_AT_TRAILER = 4;
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
@@ -217,12 +218,12 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, true>, lds_r);                                    \
             if (e != hipSuccess) return (int)e;                                                                     \
             hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, true>), dim3(grid), dim3(256), lds_r, st,       \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);          \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, amax + 3);          \
         } else {                                                                                                    \
             e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, false>, lds_r);                                   \
             if (e != hipSuccess) return (int)e;                                                                     \
             hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, false>), dim3(grid), dim3(256), lds_r, st,      \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope);          \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, amax + 3);          \
         }                                                                                                           \
     } while (0)
             if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);

@@ -30,25 +30,32 @@ extern "C" {
 
 int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
                          int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
-                         int act, float slope, int parts, tvae_stream_t stream) {
+                         int act, float slope, int parts, const float* amax_a1, tvae_stream_t stream) {
     if (N <= 0) return 0;
-    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 3) || !A1 || !H || !heads || !Wh ||
+    if (parts == 2 && !amax_a1) return (int)hipErrorInvalidValue;        // h3 needs max |A1| from A1's producer
+    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3) || !A1 || !H || !heads || !Wh ||
         !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))) ||
         !et_ld_ok(N, lda, ldh, ldo))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
     const size_t lds = (size_t)parts * 16 * ET_C * 16;
+    const H3Scale hs = parts == 2 ? H3Scale{h3_trailer(w3, ET_C, ET_C), amax_a1} : H3_NONE;
     hipError_t e;
     if (parts == 3) {
         e = allow_big_lds(enc_tail_fwd_x6_kernel<3>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<3>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
-                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a);
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a, hs);
+    } else if (parts == 2) {
+        e = allow_big_lds(enc_tail_fwd_x6_kernel<2>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<2>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a, hs);
     } else {
         e = allow_big_lds(enc_tail_fwd_x6_kernel<1>, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_fwd_x6_kernel<1>), dim3(et_grid(N)), dim3(ET_THREADS), lds, S(stream), (const uint4*)w3,
-                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a);
+                           Rpad, A1, lda, b2, Wh, bh, nh, H, ldh, heads, ldo, N, act, slope, (uint4*)bits_h, (uint4*)bits_a, hs);
     }
     TVAE_CHECK_LAUNCH();
     return 0;
@@ -89,33 +96,46 @@ int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads
     return 0;
 }
 
-long tvae_enc_tail_wgrad_x6_ws_floats(long N) {
+static long ew_slab_floats(long N) {
     const long nchunks = N / EW_NC;
     const long g = nchunks < cu_count() ? nchunks : cu_count();
     return (g < 1 ? 1 : g) * (long)ET_C * ET_C;
 }
+long tvae_enc_tail_wgrad_x6_ws_floats(long N) { return ew_slab_floats(N) + 8; }     // + the operand maxima of the h3 arithmetic
 
 int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long ldd, int nh, const void* bits_h,
                            const float* Wh, float* dW2, float* ws, long ws_floats, int C, long N, float slope, int parts,
-                           tvae_stream_t stream) {
+                           const float* amax_a1, tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (C != ET_C || nh < 1 || nh > ET_MAXH || N % EW_NC != 0 || !aligned16(A1) || !aligned16(dheads) || !aligned16(bits_h) ||
-        lda % 4 != 0 || ldd % 4 != 0 || (parts != 1 && parts != 3) || !A1 || !dheads || !bits_h || !Wh || !dW2 || !ws ||
-        ws_floats < tvae_enc_tail_wgrad_x6_ws_floats(N))
+        lda % 4 != 0 || ldd % 4 != 0 || (parts != 1 && parts != 2 && parts != 3) || !A1 || !dheads || !bits_h || !Wh || !dW2 ||
+        !ws || ws_floats < tvae_enc_tail_wgrad_x6_ws_floats(N) || (parts == 2 && !amax_a1))
         return (int)hipErrorInvalidValue;
     const long nchunks = N / EW_NC;
     const int grid = (int)(nchunks < cu_count() ? nchunks : cu_count());
+    float* slots = ws + ew_slab_floats(N);
     hipError_t e;
     if (parts == 3) {
         e = allow_big_lds(enc_tail_wgrad_x6_kernel<3>, EW_LDS);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_wgrad_x6_kernel<3>), dim3(grid), dim3(ET_THREADS), EW_LDS, S(stream), A1, lda, dheads, ldd,
-                           nh, (const uint4*)bits_h, Wh, ws, N, slope);
+                           nh, (const uint4*)bits_h, Wh, ws, N, slope, amax_a1, (const float*)slots);
+    } else if (parts == 2) {
+        // max |dheads|: one pass over nh x N floats (62 MB at the bench shape)
+        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), slots, 1);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(h3_absmax_rows_kernel, dim3(grid1d(N / 4 + 1, 256, 512), nh), dim3(256), 0, S(stream), dheads, ldd, N,
+                           slots);
+        TVAE_CHECK_LAUNCH();
+        e = allow_big_lds(enc_tail_wgrad_x6_kernel<2>, EW_LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((enc_tail_wgrad_x6_kernel<2>), dim3(grid), dim3(ET_THREADS), EW_LDS, S(stream), A1, lda, dheads, ldd,
+                           nh, (const uint4*)bits_h, Wh, ws, N, slope, amax_a1, (const float*)slots);
     } else {
         e = allow_big_lds(enc_tail_wgrad_x6_kernel<1>, EW_LDS);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((enc_tail_wgrad_x6_kernel<1>), dim3(grid), dim3(ET_THREADS), EW_LDS, S(stream), A1, lda, dheads, ldd,
-                           nh, (const uint4*)bits_h, Wh, ws, N, slope);
+                           nh, (const uint4*)bits_h, Wh, ws, N, slope, amax_a1, (const float*)slots);
     }
     TVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(enc_tail_wgrad_total_kernel, dim3(ET_C * ET_C / 64), dim3(256), 0, S(stream), (const float*)ws, grid, dW2);

@@ -477,8 +477,10 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 template <int LHP, int NT, bool REM1, int HO, bool TANH>
 static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                                     int M, int R, int B, int Lh, int act, float slope) {
+                                                                     int M, int R, int B, int Lh, int act, float slope,
+                                                                     float* __restrict__ amax) {
     constexpr int NTT = NT + (REM1 ? 1 : 0), ND = (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
+    float amx = 0.f;                                     // max |out| of this wave (h3 arithmetic of the launches that read out)
     constexpr int SN = (32 * HO + 63) / 64, P = HO * HO;
     static_assert((HO & 1) == 1, "odd output width: the [column][HO] patch is conflict free and linear in memory order");
     static_assert(32 * HO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
@@ -604,12 +606,18 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
             const int e = min(i * 64 + lane, cnt - 1);
             int o = e + (e >= thr ? jump : 0);
             if (HO < 32) o += e >= thr + P ? jump : 0;   // narrow outputs: 32 rows can span three images
-            __builtin_nontemporal_store(stg[e], obase + (unsigned)o);      // written once, read by later launches
+            const float sv = stg[e];
+            amx = fmaxf(amx, fabsf(sv));
+            __builtin_nontemporal_store(sv, obase + (unsigned)o);          // written once, read by later launches
         }
         __builtin_amdgcn_wave_barrier();
         slot = slot == 2 ? 0 : slot + 1;
     }
     TVAE_DFT_VMCNT(0);                                   // the clamped tail DMAs still target this wave's ring
+    if (amax) {
+        amx = h3_wave_max(amx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
+    }
 }
 
 // number of store instructions dft_dy_ring_kernel issues per tile (rows 32 rt + (r & 3) + 8 (r >> 2) [+ 4] below LH2)

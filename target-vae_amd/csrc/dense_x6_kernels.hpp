@@ -64,6 +64,20 @@ static __global__ void dense_absmax_kernel(const float* __restrict__ W, long ldw
     }
     h3_block_amax(mx, amax);
 }
+// max |x| over `rows` (grid.y) rows of n floats with row stride ld (16-byte aligned rows): float4 loads
+static __global__ void h3_absmax_rows_kernel(const float* __restrict__ x, long ld, long n, float* __restrict__ amax) {
+    const float4* r4 = reinterpret_cast<const float4*>(x + (long)blockIdx.y * ld);
+    const long n4 = n / 4;
+    float mx = 0.f;
+#pragma unroll 4
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = r4[i];
+        mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        mx = fmaxf(mx, fabsf(x[(long)blockIdx.y * ld + i]));
+    h3_block_amax(mx, amax);
+}
 static __global__ void h3_zero_slots_kernel(float* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }

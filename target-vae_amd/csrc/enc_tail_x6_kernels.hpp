@@ -167,7 +167,9 @@ static __global__ __launch_bounds__(ET_THREADS, ET_WAVES / 4)
 void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float* __restrict__ X, long ldx,
                             const float* __restrict__ b2, const float* __restrict__ Wh, const float* __restrict__ bh, int nh,
                             float* __restrict__ H, long ldh, float* __restrict__ heads, long ldo, long N, int act,
-                            float slope, uint4* __restrict__ bitsH, uint4* __restrict__ bitsA) {
+                            float slope, uint4* __restrict__ bitsH, uint4* __restrict__ bitsA, H3Scale hs) {
+    // NP == 2 (h3): W3 = tvae_dense_split2h cells; the streamed operand arrives over eight k-steps into the SAME accumulators,
+    // so its scale is the tensor's: max |X| from the kernel that produced X (hs.amax_x; dft_out_ring_kernel's epilogue)
     extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128]
     __shared__ __attribute__((aligned(16))) float whs[ET_C * 8];          // row m: Wh[0..6][m], b2[m]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -205,6 +207,8 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
     for (int t = 0; t < ET_D; ++t) load_x(0, t, x[t]);
     Cell16 a0[3], a1[3];
     et_load_a<NP>(Ws, 0, 0, kh, nl, a0);
+    const float sx = NP == 2 ? h3_scale(hs.amax_x[0]) : 1.f;
+    const float inv = NP == 2 ? h3_inv(h3_scale(hs.amax_a[0])) * h3_inv(sx) : 1.f;    // (weights and activations: far inside the fp32 range)
     for (long ci = 0; ci < my; ++ci) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -218,9 +222,16 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ab[t >> 1] |= x[t % ET_D][j] > 0.f ? (1u << (16 * (t & 1) + j)) : 0u;
             }
-            et_split<NP>(x[t % ET_D], bf);
+            if (NP == 2) et_split2h(x[t % ET_D], sx, bf);
+            else et_split<NP>(x[t % ET_D], bf);
             load_x(ci + (t + ET_D) / 8, (t + ET_D) % 8, x[t % ET_D]);
             et_step_mfma<NP>(acc, Ws, t, kh, nl, a0, a1, bf);
+        }
+        if (NP == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= inv;
         }
         const long n0 = (gw + ci * gstride) * ET_CHUNK;
         if (bitsA) {
@@ -407,8 +418,13 @@ constexpr int EW_LDS = 2 * EW_STAGE + 4 * EW_CELLS;    // two stages, two sets o
 template <int NP>
 static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel(
     const float* __restrict__ A1, long lda, const float* __restrict__ dheads, long ldd, int nh,
-    const uint4* __restrict__ bitsH, const float* __restrict__ Wh, float* __restrict__ slabs, long N, float slope) {
+    const uint4* __restrict__ bitsH, const float* __restrict__ Wh, float* __restrict__ slabs, long N, float slope,
+    const float* __restrict__ amax_a1, const float* __restrict__ amax_dh) {
+    // NP == 2 (h3): both operands are split in here and accumulate over ALL chunks, so their scales are the tensors':
+    // max |A1| from A1's producer, and for dH = act'(H) . Wh^T dheads the bound max |dheads| * max_row sum_h |Wh[h][row]|
+    // (the second factor formed below from the Wh column every thread already holds)
     extern __shared__ __attribute__((aligned(16))) unsigned char ew_sm[];
+    __shared__ float red_[ET_WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ew_sm;
@@ -424,6 +440,20 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
     float wh[ET_MAXH];
 #pragma unroll
     for (int h = 0; h < ET_MAXH; ++h) wh[h] = h < nh ? Wh[(long)h * ET_C + row] : 0.f;
+    float sA = 1.f, sD = 1.f;
+    if (NP == 2) {
+        float rs = 0.f;
+#pragma unroll
+        for (int h = 0; h < ET_MAXH; ++h) rs += fabsf(wh[h]);
+        rs = h3_wave_max(rs);
+        if (lane == 0) red_[wave] = rs;
+        __syncthreads();
+        float whs_ = red_[0];
+#pragma unroll
+        for (int w = 1; w < ET_WAVES; ++w) whs_ = fmaxf(whs_, red_[w]);
+        sA = h3_scale(amax_a1[0]);
+        sD = h3_scale(amax_dh[0] * whs_);
+    }
     // DMA role (per wave and chunk: two pieces of A1 + one auxiliary piece = 3 instructions, uniform for the counting):
     //   A1 piece g = 2 wave + q: rows 8 g .. 8 g + 7, lane -> (row 8 g + (lane >> 3), 16-byte piece (lane & 7) of the stage row)
     //   aux: wave 1: the sign words (16 bytes) of column (lane & 31); every other wave: head-gradient row (lane >> 3) < nh
@@ -472,7 +502,8 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
             const float4 v0 = rp[(2 * oct) ^ sw], v1 = rp[(2 * oct + 1) ^ sw];
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             Cell16 c3[3];
-            et_split<NP>(x, c3);
+            if (NP == 2) et_split2h(x, sA, c3);
+            else et_split<NP>(x, c3);
 #pragma unroll
             for (int p = 0; p < NP; ++p) cA[(p * 4 + oct) * ET_C + row] = c3[p].u;
         }
@@ -495,7 +526,8 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
                 g[j] *= ((w >> (row & 31)) & 1u) ? 1.f : slope;
             }
             Cell16 c3[3];
-            et_split<NP>(g, c3);
+            if (NP == 2) et_split2h(g, sD, c3);
+            else et_split<NP>(g, c3);
 #pragma unroll
             for (int p = 0; p < NP; ++p) cD[(p * 4 + oct) * ET_C + row] = c3[p].u;
         }
@@ -537,7 +569,8 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] = acc[j][r];
+        for (int r = 0; r < 16; ++r)
+            slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] = NP == 2 ? (acc[j][r] * h3_inv(sD)) * h3_inv(sA) : acc[j][r];
 }
 
 // dW2[e] = sum over workgroups of slabs[g][e], in workgroup order

@@ -48,9 +48,9 @@ SIGNATURES = {
     'tvae_attn_head_fwd': 'plpppppppiiiiffppppppppl',
     'tvae_attn_head_bwd': 'plppppppppiiiiffpppppppppl',
     'tvae_get_latent': 'plpppiiiifppp',
-    'tvae_enc_tail_fwd_x6': 'pplpppiplplppilifi',
+    'tvae_enc_tail_fwd_x6': 'pplpppiplplppilifip',
     'tvae_enc_tail_dgrad_x6': 'ppplippplilfi',
-    'tvae_enc_tail_wgrad_x6': 'plplipppplilfi',
+    'tvae_enc_tail_wgrad_x6': 'plplipppplilfip',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',
@@ -204,6 +204,8 @@ def call(name, *args):
     """Invoke a C-ABI entry point on the current torch stream."""
     L = lib()
     sig = SIGNATURES[name]
+    if len(args) < len(sig) and set(sig[len(args):]) == {'p'}:
+        args = args + (None,) * (len(sig) - len(args))      # optional trailing pointer arguments (added by later ABI versions)
     if len(args) != len(sig):
         raise TvaeHipError(f'{name}: expected {len(sig)} arguments, got {len(args)}')
     conv = []

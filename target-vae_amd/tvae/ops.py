@@ -277,6 +277,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
                  LRELU_SLOPE, parts())
         if keep is not None:
             keep['at'] = at
+            keep['ring'] = (n + 2 * pad, n + 2 * pad - k + 1) in DFT_RING_FRAMES     # then at[-1] = max |out| (h3 scale of the tail)
         return out
     if _use_x6(Cin, n, k, pad):
         a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
@@ -410,14 +411,18 @@ class EncoderFn(torch.autograd.Function):
         bits = None
         if _enc_tail_fused(C, C2, nh, N):
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
-            w3 = _split_weight(W2, C2, C, False, 'enc_w2')
+            # h3 instance: needs max |A1| from A1's producer -- the ring transform of the frequency-domain convolution leaves it
+            # in the last word behind A^T (keep['at'])
+            a1max = keep['at'][-1:] if (parts() == 2 and keep.get('ring') and 'at' in keep) else None
+            p_f = 2 if a1max is not None else _p3()
+            w3 = _split_weight(W2, C2, C, False, 'enc_w2', nparts=p_f)
             _note('enc.tail_fwd_x6')
             if act == ACT_LRELU:                         # sign words of H and A1: all the fused data gradient reads of them
                 bits = torch.empty(2, N, 4, dtype=torch.int32, device=y.device)
             with _timed('tvae_enc_tail_fwd_x6'):
                 call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N,
                      bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act,
-                     LRELU_SLOPE, _p3())
+                     LRELU_SLOPE, p_f, a1max)
         else:
             call('tvae_linear_fwd', W2.contiguous(), A1, b2, None, 1, None, H, C2, N, C, N, N, act, LRELU_SLOPE)
             if nh <= SKINNY_MAX:
@@ -427,6 +432,7 @@ class EncoderFn(torch.autograd.Function):
                      LRELU_SLOPE)
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.bits = bits
+        ctx.a1max = a1max if _enc_tail_fused(C, C2, nh, N) else None      # (a view of keep['at']: max |A1| for the h3 weight gradient)
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
@@ -472,9 +478,10 @@ class EncoderFn(torch.autograd.Function):
             _note('enc.tail_wgrad_x6')
             dW2 = torch.empty(C2, C, dtype=torch.float32, device=y.device)
             wsw = _scratch(y.device, 'enc_wgrad_slabs', query('tvae_enc_tail_wgrad_x6_ws_floats', N))
+            p_w = 2 if (parts() == 2 and ctx.a1max is not None) else _p3()
             with _timed('tvae_enc_tail_wgrad_x6'):
                 call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, ctx.bits[0], Wh.contiguous(), dW2, wsw, wsw.numel(), C,
-                     N, LRELU_SLOPE, _p3())
+                     N, LRELU_SLOPE, p_w, ctx.a1max if p_w == 2 else None)
         else:
             dW2 = _wgrad(dH, A1, C2, N, C)
         if dA1 is None:

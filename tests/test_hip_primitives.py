@@ -642,6 +642,23 @@ def test_enc_tail_x6(N, nh, act, parts):
     tol = TOL if parts == 3 else 2e-2
     assert rel_err(H, Hr) < tol
     assert rel_err(heads, hr) < tol
+    if parts == 3:
+        # the same launch in the h3 arithmetic: two fp16 parts under the scale of max |A1| (a device word from A1's producer),
+        # for activations of size 1, 1e-5 and 1e3 (a bound 64 x too large must not matter either)
+        w32 = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev())
+        call('tvae_dense_split2h', W2.to(dev()), C, w32, w32.numel() * 4, C, C, 0, None, None)
+        # (tanh at 1e3 saturates: every arithmetic then differs where a pre-activation of size 1 is a difference of terms of size 1e3)
+        for sc, slack in ((1.0, 1.0), (1e-5, 1.0)) + (((1e3, 64.0),) if act != 2 else ()):
+            A1s = (A1 * sc).to(dev())
+            amax = (A1s.abs().max() * slack).reshape(1)
+            H2, h2 = torch.full((C, N), float('nan'), device=dev()), torch.full((nh, N), float('nan'), device=dev())
+            call('tvae_enc_tail_fwd_x6', w32, A1s, N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H2, N, h2, N, None, None, C, N,
+                 act, SLOPE, 2, amax)
+            Hr2 = act_ref(W2.double() @ (A1.double() * sc) + b2.double()[:, None], act)
+            assert rel_err(H2, Hr2) < TOL and rel_err(h2, Wh.double() @ Hr2 + bh.double()[:, None]) < TOL, sc
+        with pytest.raises(Exception):                   # h3 without the operand maximum
+            call('tvae_enc_tail_fwd_x6', w32, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, None,
+                 None, C, N, act, SLOPE, 2, None)
     with pytest.raises(Exception):                       # only the 128-channel layer is built
         call('tvae_enc_tail_fwd_x6', w3, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, None,
              None, 64, N, act, SLOPE, parts)
@@ -685,6 +702,12 @@ def test_enc_tail_x6(N, nh, act, parts):
         call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, dheads.to(dev()), N, nh, bits_h, Wh.to(dev()), dW2, wsl, wsl.numel(), C, N,
              SLOPE, parts)
         assert rel_err(dW2, dH @ A1.double().t()) < tol
+        if parts == 3:                       # the same in the h3 arithmetic, also for head gradients of size 1e-7
+            for sc in (1.0, 1e-7):
+                dW2h = torch.full((C, C), float('nan'), device=dev())
+                call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, (dheads * sc).to(dev()), N, nh, bits_h, Wh.to(dev()), dW2h, wsl,
+                     wsl.numel(), C, N, SLOPE, 2, A1.abs().max().reshape(1).to(dev()))
+                assert rel_err(dW2h, (dH @ A1.double().t()) * sc) < TOL, sc
         npan = (N + 511) // 512
         part = torch.empty(npan * C * (nh + 1), device=dev())
         tot = torch.empty(nh + 1, C, device=dev())
