@@ -150,7 +150,8 @@ MODE_INFO = {
                dtype='f32 (matrix products: operands as TWO fp16 parts under a power-of-two tensor scale, 3 fp16 MFMAs per '
                      'product -- 2 where one operand is the exact 0 / 1 matrix -- fp32 accumulate: at least as accurate '
                      'against fp64 as the fp32 matrix pipe (profiles/experiments/f16_split_probe.hip), same parity '
-                     'tolerances; launches without an h3 instance (encoder 1x1x1 layers) run the exact 3 x bf16 split)'),
+                     'tolerances; launches without an h3 instance (operands streamed from memory without a producer-side maximum) run the '
+                     'exact 3 x bf16 split)'),
     # opt-in throughput mode (TVAE_GEMM=bf16; BASELINE.json configs 2 / 5): NOT the headline, not fp32-equivalent
     'bf16': dict(peak=PEAK_BF16_MFMA_TFLOPS, insn='1 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                  kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
@@ -511,7 +512,7 @@ def main():
                          'algorithmic_bytes_per_launch': float(tail_bytes[k_]),
                          'achieved_GBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 1e9,
                          'frac_of_8TBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 8.0e12,
-                         'executed_bf16_pflops': (1 if mode == 'bf16' else 6) * entries[k_][0] / (kev[k_]['mean_ms'] * 1e-3) / 1e15}
+                         'executed_bf16_pflops': {'bf16': 1, 'h3': 3}.get(mode, 6) * entries[k_][0] / (kev[k_]['mean_ms'] * 1e-3) / 1e15}
                     for k_ in tail_bytes if k_ in kev}
         # the roofline object describes the dominant KERNEL FAMILY of the step, the split-pipe dense GEMM (decoder layers
         # and the spectral contraction of the convolution), on its LARGEST decoder launch (not its best one), with the
