@@ -109,7 +109,10 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.lds_sp = dft_lds_spectra(S, q.L, q.FXB);
     q.FXBd = q.Lh;
     auto lds_db = [&](int f) { return (size_t)q.L * f * 8 + (size_t)ksz * f * 8 + (size_t)q.L * 8 + (size_t)ksz * ksz * 4; };
-    for (int nb = 1; nb < 16 && lds_db(q.FXBd) > DFT_LDS_TARGET; ++nb) q.FXBd = (q.Lh + nb) / (nb + 1);
+    // the inverse transform runs one workgroup per (filter, channel): 1 024 of them at the bench shape = FOUR per CU, so its
+    // LDS is sized for four residents (<= 39 KB) -- with three, a quarter of the workgroups ran in a second, mostly empty round
+    constexpr size_t DFT_LDS_DBANK = 39 * 1024;
+    for (int nb = 1; nb < 16 && lds_db(q.FXBd) > DFT_LDS_DBANK; ++nb) q.FXBd = (q.Lh + nb) / (nb + 1);
     q.lds_db = lds_db(q.FXBd);
     q.ok = Cin >= 1 && q.Ho >= 1 && q.NT <= 5 && q.lds_sp <= 152 * 1024 && q.lds_db <= 152 * 1024 &&
            (long)q.Lh * q.Mb < 2000000000L && (size_t)4 * 32 * ((2 * q.NS) | 1) * 4 <= 150 * 1024 &&
