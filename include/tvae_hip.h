@@ -160,9 +160,9 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
  * tvae_linear_dgrad_x6 can also consume its result for the backward of SpatialGenerator's first layer (no Fourier
  * features, src/models.py:107-118): with in_xr [N][2], in_wc [K][2] it writes the coordinate gradient in_gxr [N][2] and
  * per-128-column panel row sums in_part [N/128][K][3] (K <= 512, panels must not straddle images); dX may then be NULL
- * (never materialised).  tvae_dec_in_total turns the panels into Simg [B][F], dbc [F], dWc [F][2] (cpi panels per image). */
-int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
-                      tvae_stream_t stream);
+ * (never materialised).  tvae_dec_in_total turns the panels into Simg [B][F], dbc [F], dWc [F][2] (cpi panels per image);
+ * it CONSUMES part (ABI 4: the first panel of every image is overwritten with the image's sums). */
+int tvae_dec_in_total(float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc, tvae_stream_t stream);
 /* tvae_linear_wgrad_x6: as tvae_linear_wgrad (both operands are split on the fly); needs N % 16 == 0, 16-byte aligned
  * rows and a workspace of tvae_linear_wgrad_x6_ws_floats(M, N, K) floats (hipErrorInvalidValue otherwise: use the fp32
  * entry).  The number of reduction slices -- i.e. the summation order -- depends on the shape only. */

@@ -128,10 +128,7 @@ int tvae_dec_in_bwd(const float* d, long ldd, const float* xr, const float* Wc, 
     hipLaunchKernelGGL(dec_in_bwd_kernel, dim3(B * cpi), dim3(256), 0, S(stream), d, ldd, xr, Wc, F, Np, cpi, gxr, part,
                        vec);
     TVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_in_total_kernel, dim3(F), dim3(256), 0, S(stream), (const float*)part, B, cpi, F, Simg, dbc,
-                       dWc);
-    TVAE_CHECK_LAUNCH();
-    return 0;
+    return tvae_dec_in_total(part, B, cpi, F, Simg, dbc, dWc, stream);
 }
 
 int tvae_heads_fwd(const float* W, const float* X, long ldx, const float* bias, float* Y, long ldy, int nh, int C,
@@ -390,11 +387,14 @@ int tvae_adam_flat(float* p, const float* g, float* m, float* v, long n, float l
     TVAE_CHECK_LAUNCH();
     return 0;
 }
-int tvae_dec_in_total(const float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc,
-                      tvae_stream_t stream) {
-    // second stage of the fused first-layer backward: part[B*cpi panels][F][3] -> per-image sums, bias and weight grads
-    if (B <= 0 || F <= 0) return 0;
-    hipLaunchKernelGGL(dec_in_total_kernel, dim3(F), dim3(256), 0, S(stream), part, B, cpi, F, Simg, dbc, dWc);
+int tvae_dec_in_total(float* part, int B, int cpi, int F, float* Simg, float* dbc, float* dWc, tvae_stream_t stream) {
+    // second stage of the fused first-layer backward: part[B*cpi panels][F][3] -> per-image sums, bias and weight grads.
+    // part is CONSUMED: the first panel of every image is overwritten with the image's sums.
+    if (B <= 0 || F <= 0 || cpi <= 0) return 0;
+    hipLaunchKernelGGL(dec_in_total_img_kernel, dim3(B), dim3(256), 0, S(stream), part, cpi, F, Simg);
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dec_in_total_sum_kernel, dim3((3 * F + 63) / 64), dim3(256), 0, S(stream), (const float*)part, B, cpi, F,
+                       dbc, dWc);
     TVAE_CHECK_LAUNCH();
     return 0;
 }
