@@ -69,8 +69,18 @@ static __global__ void h3_absmax_rows_kernel(const float* __restrict__ x, long l
     const float4* r4 = reinterpret_cast<const float4*>(x + (long)blockIdx.y * ld);
     const long n4 = n / 4;
     float mx = 0.f;
-#pragma unroll 4
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long gsz = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * gsz < n4; i += 4 * gsz) {             // four independent 16-byte loads in flight per thread
+        const float4 v0 = r4[i], v1 = r4[i + gsz];
+        const float4 v2 = r4[i + 2 * gsz], v3 = r4[i + 3 * gsz];
+        const float a0 = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+        const float a1 = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+        const float a2 = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w)));
+        const float a3 = fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)));
+        mx = fmaxf(mx, fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    }
+    for (; i < n4; i += gsz) {
         const float4 v = r4[i];
         mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
