@@ -156,9 +156,9 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         hipError_t e = dft_zero(at, q.at_floats, st);
         if (e != hipSuccess) return (int)e;
     }
-    // h3 arithmetic (two fp16 parts, three products): the 4-wave spectral GEMM has the instance; other shapes stay exact x6
-    const bool h3 = parts == 2 && q.K2 <= 256;
-    if (parts == 2 && !h3) parts = 3;
+    // h3 arithmetic (two fp16 parts, three products): both forms of the spectral GEMM (four-wave tile for reductions <= 256,
+    // eight-wave tile beyond: several channels, wide frames) take the operand maxima dft_spectra leaves behind A^T
+    const bool h3 = parts == 2;
     // the maxima are produced in every arithmetic (a 64-thread launch and a few atomics): the weight gradient may run in
     // h3 after a forward that did not
     float* amax = at + ((q.at_floats + 3) & ~3L);
@@ -200,7 +200,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
         rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st,
                                                 H3Scale{amax + 1, amax})
-                            : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st);
+                            : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st,
+                                               H3Scale{amax + 1, amax});
         if (rc) return rc;
     }
     {
@@ -281,7 +282,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         return (int)hipErrorInvalidValue;
     hipStream_t st = S(stream);
     // h3 arithmetic: max |A^T| was left behind A^T by the forward, max |S'| comes from the ring transform below
-    const bool h3 = parts == 2 && q.ring && q.K2 <= 256;
+    const bool h3 = parts == 2 && q.ring;
     if (parts == 2 && !h3) parts = 3;
     float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
     if (h3) {

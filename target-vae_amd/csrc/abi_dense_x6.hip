@@ -7,15 +7,16 @@ using namespace tvae;
 
 namespace tvae {
 int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
-                     int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st) {
+                     int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs) {
     const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);
     if (N % 128 != 0 || !aligned16(w3)) return (int)hipErrorInvalidValue;
-    if (parts != 1 && parts != 3) return (int)hipErrorInvalidValue;
+    if (parts != 1 && parts != 2 && parts != 3) return (int)hipErrorInvalidValue;
+    if (parts == 2 && (!hs.amax_a || !hs.amax_x)) return (int)hipErrorInvalidValue;
     return TVAE_DX6_DISPATCH(0, parts, (const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
                              ColDot{nullptr, nullptr, nullptr},
                              InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
                              VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st,
-                             H3_NONE);
+                             hs);
 }
 int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
                       int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs) {

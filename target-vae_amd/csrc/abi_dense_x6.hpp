@@ -85,7 +85,7 @@ TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, co
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
-                                   hipStream_t st);
+                                   hipStream_t st, H3Scale hs = H3_NONE);
 // batched weight-gradient GEMM into split-K slabs (abi_dense_wgrad_x6.hip)
 TVAE_INTERNAL int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M,
                                          int Kf, int N, int nchunk, const TileMap& tm, const DenseBatch& bt,
