@@ -136,8 +136,7 @@ int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int row
  * block instead of six; every operand tensor scaled by a power of two into fp16's range, undone in the epilogue; accuracy
  * against fp64 at least that of the fp32 matrix pipe, profiles/experiments/f16_split_probe.hip).  Same buffer size; the
  * operand's maximum is kept behind the two part arrays, and the GEMM entry points use the following 12 bytes as scratch.
- * Entry points / operand forms with an h3 instance: tvae_conv1_fwd_dft (every geometry) / tvae_conv1_wgrad_dft (the frames of the
- * ring transforms, whose epilogue measures S'),
+ * Entry points / operand forms with an h3 instance: tvae_conv1_fwd_dft / tvae_conv1_wgrad_dft (every geometry),
  * tvae_linear_fwd_x6 with the recomputed first-layer operand (va_xr), tvae_linear_dgrad_x6 in its two-valued form (vg_csum),
  * tvae_linear_wgrad_x6 from sign bits with the recomputed operand.  Elsewhere parts = 2 is rejected (hipErrorInvalidValue)
  * or, inside the *_dft entry points, runs the exact three-part split. */

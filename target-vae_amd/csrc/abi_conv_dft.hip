@@ -281,8 +281,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
     hipStream_t st = S(stream);
-    // h3 arithmetic: max |A^T| was left behind A^T by the forward, max |S'| comes from the ring transform below
-    const bool h3 = parts == 2 && q.ring;
+    // h3 arithmetic: max |A^T| was left behind A^T by the forward, max |S'| comes from the transform along w below
+    const bool h3 = parts == 2;                      // every transform along w measures max |S'| in its epilogue
     if (parts == 2 && !h3) parts = 3;
     float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
     if (h3) {
@@ -322,7 +322,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
             if (eg != hipSuccess) return (int)eg;
             const int gridg = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
             hipLaunchKernelGGL(dft_dy_gen_kernel, dim3(gridg), dim3(256), lds_g, st, dpre, (const float*)ED, Sp, q.M, R, B,
-                               q.Ho, q.Lh, q.NBpad, q.NS, q.NRT);
+                               q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, h3 ? amax + 2 : (float*)nullptr);
             TVAE_CHECK_LAUNCH();
         } else {
         const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
@@ -334,7 +334,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         e0 = allow_big_lds(dft_dy_mf_kernel<S_, T_, L2_, A_>, lds_d);                                               \
         if (e0 != hipSuccess) return (int)e0;                                                                       \
         hipLaunchKernelGGL((dft_dy_mf_kernel<S_, T_, L2_, A_>), dim3(grid), dim3(256), lds_d, st, dpre,             \
-                           (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, iters);                            \
+                           (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, iters,                             \
+                           h3 ? amax + 2 : (float*)nullptr);                                                        \
     } while (0)
         if (q.NS == 9) { if (q.Lh == 23) TVAE_DY_MF(9, 2, 46, true); else TVAE_DY_MF(9, 2, 0, true); }
         else if (q.NS == 17) { if (q.Lh == 49) TVAE_DY_MF(17, 4, 98, true); else TVAE_DY_MF(17, 4, 0, true); }

@@ -345,7 +345,8 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
 template <int NS, int NRT, int LH2, bool AREG>
 static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                            float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
-                                                           long NBpad, int iters) {
+                                                           long NBpad, int iters, float* __restrict__ amax) {
+    float amx = 0.f;                                             // max |S'| (h3 scale of the GEMM that reads S'; optional)
     constexpr int NL = NS;                                       // 64-element slices of the 32 x Ho tile: ceil(32*Ho/64) <= NS
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     float* ed = sm_w;                                            // [NS][NRT][64] (used when !AREG)
@@ -430,6 +431,7 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
                     const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);                 // kh = 0; kh = 1 adds 4
                     float* p = (kk0 & 1) ? p1 : p0;
                     const int fx0 = kk0 >> 1;
+                    amx = fmaxf(amx, fabsf(acc[rt][r]));          // (rows beyond Lh come from zero table rows: 0)
                     if (LH2 > 0) {
                         if (kk0 + 4 < LH2) p[fx0 * 128] = acc[rt][r];
                         else if (kk0 < LH2) { if (kh == 0) p[fx0 * 128] = acc[rt][r]; }
@@ -438,6 +440,10 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
                     }
                 }
         }
+    }
+    if (amax) {
+        amx = h3_wave_max(amx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 
@@ -842,8 +848,9 @@ static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __
 // wave's LDS patch ([32 columns][2*NS | 1]) into the B-operand layout; one 32-row tile of (fx, ri) at a time.
 static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                                 float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
-                                                                long NBpad, int NS, int NRT) {
+                                                                long NBpad, int NS, int NRT, float* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    float amx = 0.f;
     const int SWD = (2 * NS) | 1;
     float* stg = sm_w + (threadIdx.x >> 6) * (32 * SWD);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
@@ -880,9 +887,14 @@ static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __r
                 const int kk = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int fx = kk >> 1;
                 if (fx < Lh) ((kk & 1) ? p1 : p0)[(long)fx * 128] = acc[r];
+                amx = fmaxf(amx, fabsf(acc[r]));
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (amax) {
+        amx = h3_wave_max(amx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 
