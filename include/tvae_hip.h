@@ -271,8 +271,7 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
                          int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
                          int act, float slope, int parts, const float* amax_a1, tvae_stream_t stream);
 /* parts = 2 (h3; ABI 4): w3 = tvae_dense_split2h cells and amax_a1 = a device word holding max |A1| (or an upper bound) --
- * tvae_conv1_fwd_dft leaves it in the LAST word of the buffer sized by tvae_conv1_dft_at_floats when its ring transform
- * produced A1 (frames 44 / 66 / 96).  tvae_enc_tail_dgrad_x6 with parts = 2: w3p = tvae_dense_split2h cells, wh3 stays
+* tvae_conv1_fwd_dft leaves it in the LAST word of the buffer sized by tvae_conv1_dft_at_floats.  tvae_enc_tail_dgrad_x6 with parts = 2: w3p = tvae_dense_split2h cells, wh3 stays
  * tvae_dense_split3 (the skinny GEMM runs the exact split); its streamed operand is scaled per 32-column chunk inside the
  * kernel, no maximum is passed. */
 int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads, long ldd, int nh, const void* bits_h,

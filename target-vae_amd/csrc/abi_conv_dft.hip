@@ -127,7 +127,7 @@ int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int
     return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
 }
 // A^T is followed by four words: the maxima of the h3 arithmetic ([0] max |A^T|, [1] max |W|, [2] max |S'|, [3] max |out| of
-// the ring transform -- the streamed operand of the encoder tail that follows), written by
+// the output transform -- the streamed operand of the encoder tail that follows), written by
 // the kernels that produce those operands and read by the GEMMs that split them
 constexpr int DFT_AT_TRAILER = 4;
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
@@ -241,7 +241,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             const int grid = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
 #define TVAE_OUT_GEN(N_)                                                                                            \
     hipLaunchKernelGGL(dft_out_gen_kernel<N_>, dim3(grid), dim3(256), 0, st, (const float*)T, (const float*)EO, bias, out, \
-                       q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope)
+                       q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, amax + 3)
             switch (q.NT) {
                 case 1: TVAE_OUT_GEN(1); break;
                 case 2: TVAE_OUT_GEN(2); break;
@@ -261,7 +261,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         e = allow_big_lds(dft_out_mf_kernel<L_, N_, R_>, lds_o);                                                    \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((dft_out_mf_kernel<L_, N_, R_>), dim3(grid), dim3(256), lds_o, st, (const float*)T,      \
-                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters);        \
+                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters, amax + 3); \
     } while (0)
 #define TVAE_OUT_MF_L(L_)                                                                                           \
     do {                                                                                                            \

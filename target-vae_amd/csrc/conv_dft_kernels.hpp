@@ -247,7 +247,8 @@ template <int LHP, int NT, bool REM1>
 static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int M, int R, int B, int Ho, int Lh, long NBpad, int act,
-                                                            float slope, int iters) {
+                                                            float slope, int iters, float* __restrict__ amax) {
+    float amx = 0.f;                                             // max |out| (h3 scale of the encoder tail; optional)
     constexpr int NTT = NT + (REM1 ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     float* eo = sm_w;                                            // [LHP][NTT][64]
@@ -316,7 +317,9 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
         for (int e = lane; e < cnt; e += 64) {
             const int t = (int)(((float)e + 0.5f) * inv_ho), w = e - t * Ho;
             const int k = (int)(((float)(h0 + t) + 0.5f) * inv_ho);
-            obase[e + k * jump] = stg[t * SWO + w];
+            const float sv = stg[t * SWO + w];
+            amx = fmaxf(amx, fabsf(sv));
+            obase[e + k * jump] = sv;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -334,6 +337,10 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
         load_tile(tile_ptr(tile + 2 * stride, ma, na), va);
         compute(tile + stride, mb, nb, vb);
         tile += 2 * stride;
+    }
+    if (amax) {
+        amx = h3_wave_max(amx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 
@@ -781,7 +788,8 @@ template <int NT>
 static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int M, int R, int B, int Ho, int Lh, long NBpad, int act,
-                                                                 float slope) {
+                                                                 float slope, float* __restrict__ amax) {
+    float amx = 0.f;
     __shared__ float stg_all[4 * 32 * 33];
     float* stg = stg_all + (threadIdx.x >> 6) * 32 * 33;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, ri = lane >> 5;
@@ -836,11 +844,17 @@ static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __
                 if (w < wn) {
                     const long nn = n0 + col;
                     const int b = (int)(nn / Ho), h = (int)(nn - (long)b * Ho);
-                    out[(((long)c * B + b) * R + r_) * P + (long)h * Ho + 32 * t + w] = stg[col * 33 + w];
+                    const float sv = stg[col * 33 + w];
+                    amx = fmaxf(amx, fabsf(sv));
+                    out[(((long)c * B + b) * R + r_) * P + (long)h * Ho + 32 * t + w] = sv;
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    if (amax) {
+        amx = h3_wave_max(amx);
+        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 
