@@ -277,7 +277,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
                  LRELU_SLOPE, parts())
         if keep is not None:
             keep['at'] = at
-            keep['ring'] = True      # at[-1] = max |out|, left by the output transform (h3 scale of the encoder tail)
+            keep['out_max'] = at[-1:]      # max |out|, left by the output transform (h3 scale of the encoder tail)
         return out
     if _use_x6(Cin, n, k, pad):
         a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
@@ -413,7 +413,7 @@ class EncoderFn(torch.autograd.Function):
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
             # h3 instance: needs max |A1| from A1's producer -- the output transform of the frequency-domain convolution leaves
             # it in the last word behind A^T (keep['at'])
-            a1max = keep['at'][-1:] if (parts() == 2 and keep.get('ring') and 'at' in keep) else None
+            a1max = keep.get('out_max') if parts() == 2 else None
             p_f = 2 if a1max is not None else _p3()
             w3 = _split_weight(W2, C2, C, False, 'enc_w2', nparts=p_f)
             _note('enc.tail_fwd_x6')
