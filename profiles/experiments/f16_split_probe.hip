@@ -11,7 +11,7 @@
 // instruction -- with bf16 parts the products have 16 bits and 8 spare bits in the fp32 accumulator, with fp16 parts only 2.
 // This probe measures it: C = A B for several operand distributions and reduction lengths, against fp64, for
 //   f32   v_mfma_f32_32x32x2_f32 (the "fp32-MFMA kernel's own" error the verdict's gate refers to)
-//   x6    3 x bf16 parts, 6 products (shipped)
+//   x6    3 x bf16 parts (round-to-nearest residuals, as shipped), 6 products
 //   h3    2 x fp16 parts, 3 products, power-of-two tensor scales
 //   h4    2 x fp16 parts, 4 products (adds h2 k2)
 //   h3u   h3 without scaling (what the exponent range costs)
@@ -43,6 +43,9 @@ __device__ inline __bf16 bf16_trunc(float x) {
     return (__bf16)t;        // exact: low 16 bits are zero
 }
 
+#ifndef TRUNC
+#define TRUNC 0
+#endif
 // MODE 0: f32, 1: x6, 2: h3, 3: h4, 4: h3 unscaled
 template <int MODE>
 __global__ __launch_bounds__(64) void gemm_probe(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
@@ -63,10 +66,11 @@ __global__ __launch_bounds__(64) void gemm_probe(const float* __restrict__ A, co
             for (int e = 0; e < 8; ++e) {
                 float x = A[(long)(m0 + j) * K + k + 8 * kh + e];
                 float y = B[(long)(k + 8 * kh + e) * N + n0 + j];
-                __bf16 x1 = bf16_trunc(x); float rx = x - (float)x1;
-                __bf16 x2 = bf16_trunc(rx); float rx2 = rx - (float)x2;
-                __bf16 y1 = bf16_trunc(y); float ry = y - (float)y1;
-                __bf16 y2 = bf16_trunc(ry); float ry2 = ry - (float)y2;
+                // round-to-nearest residual split, as csrc/conv_x6_kernels.hpp:split3 does it (TRUNC = 1: truncated parts)
+                __bf16 x1 = TRUNC ? bf16_trunc(x) : (__bf16)x; float rx = x - (float)x1;
+                __bf16 x2 = TRUNC ? bf16_trunc(rx) : (__bf16)rx; float rx2 = rx - (float)x2;
+                __bf16 y1 = TRUNC ? bf16_trunc(y) : (__bf16)y; float ry = y - (float)y1;
+                __bf16 y2 = TRUNC ? bf16_trunc(ry) : (__bf16)ry; float ry2 = ry - (float)y2;
                 a[0][e] = x1; a[1][e] = x2; a[2][e] = (__bf16)rx2;
                 b[0][e] = y1; b[1][e] = y2; b[2][e] = (__bf16)ry2;
             }
