@@ -147,11 +147,13 @@ MODE_INFO = {
                      'gradient of the 128-wide encoder 1x1x1 layers likewise, their weight gradient on the fp32 MFMA)'),
     'h3': dict(peak=PEAK_BF16_MFMA_TFLOPS / 3.0, insn='3 x v_mfma_f32_32x32x16_f16 per product block', suffix='_x6',
                kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
-               dtype='f32 (matrix products: operands as TWO fp16 parts under a power-of-two tensor scale, 3 fp16 MFMAs per '
-                     'product -- 2 where one operand is the exact 0 / 1 matrix -- fp32 accumulate: at least as accurate '
-                     'against fp64 as the fp32 matrix pipe (profiles/experiments/f16_split_probe.hip), same parity '
-                     'tolerances; launches without an h3 instance (operands streamed from memory without a producer-side maximum) run the '
-                     'exact 3 x bf16 split)'),
+               dtype='f32 (matrix products: operands as TWO fp16 parts under one power-of-two scale PER ROW of the operand '
+                     '(row / column of the product), 3 fp16 MFMAs per product block -- 2 where one operand is the exact 0 / 1 '
+                     'matrix -- fp32 accumulate: at least as accurate against fp64 as the fp32 matrix pipe '
+                     '(profiles/experiments/f16_split_probe.hip), rows 2^-32 below their tensor to 1e-5 of themselves '
+                     '(tests/test_hip_primitives.py::test_h3_row_dynamic_range_*), same parity tolerances; launches without '
+                     'an h3 instance run the exact 3 x bf16 split and are priced as such: roofline.dense_launches.'
+                     'mfma_per_block_as_launched)'),
     # opt-in throughput mode (TVAE_GEMM=bf16; BASELINE.json configs 2 / 5): NOT the headline, not fp32-equivalent
     'bf16': dict(peak=PEAK_BF16_MFMA_TFLOPS, insn='1 x v_mfma_f32_32x32x16_bf16 per product block', suffix='_x6',
                  kernels={'tvae_conv1_fwd': 'conv1_fwd_x6_kernel', 'tvae_conv1_wgrad': 'conv1_wgrad_x6_kernel'},
@@ -512,7 +514,9 @@ def main():
                          'algorithmic_bytes_per_launch': float(tail_bytes[k_]),
                          'achieved_GBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 1e9,
                          'frac_of_8TBps': tail_bytes[k_] / (kev[k_]['mean_ms'] * 1e-3) / 8.0e12,
-                         'executed_bf16_pflops': {'bf16': 1, 'h3': 3}.get(mode, 6) * entries[k_][0] / (kev[k_]['mean_ms'] * 1e-3) / 1e15}
+                         'mfma_per_block_as_launched': kev[k_].get('mfma_per_block_seen'),
+                         'executed_bf16_pflops': (kev[k_].get('mfma_per_block') or {'bf16': 1, 'h3': 3}.get(mode, 6)) *
+                         entries[k_][0] / (kev[k_]['mean_ms'] * 1e-3) / 1e15}
                     for k_ in tail_bytes if k_ in kev}
         # the roofline object describes the dominant KERNEL FAMILY of the step, the split-pipe dense GEMM (decoder layers
         # and the spectral contraction of the convolution), on its LARGEST decoder launch (not its best one), with the
@@ -528,6 +532,11 @@ def main():
                         'tvae_linear_wgrad_x6': 2 if two_val else 6}
         if mode == 'bf16':
             products = {k_: 1 for k_ in products}
+        # ... as the MODE suggests; what counts is what was LAUNCHED: tvae.ops records the `parts` it passed to every entry
+        # point and the matrix instructions per product block that follow from them (ops._timed / mfma_per_block); a launch
+        # that fell back to the three-part split is then priced as six products, not three
+        products_by_mode = dict(products)
+        products = {k_: (kev.get(k_, {}).get('mfma_per_block') or products[k_]) for k_ in products}
         dense = [k_ for k_ in products if k_ in timed]
         if mode in ('x6', 'h3', 'bf16') and dense:
             dom = max(dense, key=lambda k_: kev[k_]['total_ms'])
@@ -572,6 +581,8 @@ def main():
                          'dense_launches': {k_: {'ms_per_step': round(kev[k_]['total_ms'] / args.steps, 3),
                                                  'launches_per_step': kev[k_]['launches'] / args.steps,
                                                  'bf16_mfma_per_product_block': products[k_],
+                                                 'mfma_per_block_as_launched': kev[k_].get('mfma_per_block_seen'),
+                                                 'mfma_per_block_expected_for_mode': products_by_mode[k_],
                                                  'algorithmic_tflops': dense_flops * kev[k_]['launches'] /
                                                  (kev[k_]['total_ms'] * 1e-3) / 1e12,
                                                  'executed_bf16_pflops': products[k_] * dense_flops * kev[k_]['launches'] /

@@ -24,11 +24,16 @@ int tvae_abi_version(void);
  * tvae_conv1_fwd / tvae_conv1_wgrad / tvae_linear_* compute exact fp32 products (v_mfma_f32_32x32x2_f32); the *_x6 and
  * *_dft entry points compute in the "x6" arithmetic (every fp32 operand split EXACTLY into three bf16 numbers, six
  * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results) when called with parts = 3, in the
- * "h3" arithmetic (two fp16 parts under a power-of-two tensor scale, three v_mfma_f32_32x32x16_f16 products: fp32-equivalent
+ * "h3" arithmetic (two fp16 parts under power-of-two scales, three v_mfma_f32_32x32x16_f16 products: fp32-equivalent
  * results with half the matrix instructions; tvae_dense_split2h below) with parts = 2, and with operands rounded to one
- * bf16 number (throughput mode, NOT fp32-equivalent) with parts = 1.  tvae_abi_version() == 4 (ABI 4: parts = 2,
- * tvae_dense_split2h; the buffers sized by tvae_conv1_dft_at_floats and tvae_linear_wgrad_x6_ws_floats carry a few extra
- * words -- the operand maxima of the h3 arithmetic -- behind their data). */
+ * bf16 number (throughput mode, NOT fp32-equivalent) with parts = 1.  tvae_abi_version() == 5.  ABI 4: parts = 2,
+ * tvae_dense_split2h; the buffers sized by tvae_conv1_dft_at_floats and tvae_linear_wgrad_x6_ws_floats carry extra words
+ * -- the operand maxima of the h3 arithmetic -- behind their data.  ABI 5: the h3 scale is ONE POWER OF TWO PER ROW of an
+ * operand in the sense of the product (a row / column of the output), not one per tensor: tvae_dense_split2h keeps one
+ * maximum per row; tvae_conv1_fwd_dft leaves per-(frequency, image), per-(frequency, filter row), per-filter-row and
+ * per-channel maxima behind A^T (the LAST C floats = max |out| per channel) and `amax_a1` of the encoder-tail entry points
+ * points to C words.  An output row whose operand row lies 2^-32 below the rest of its tensor is as accurate, relative to
+ * itself, as any other (tests/test_hip_primitives.py::test_h3_row_dynamic_range: 1e-5 per row against fp64). */
 
 /* ---- rotated filter bank: GroupConv.trans_filter, src/models.py:174-197 (F.affine_grid + F.grid_sample x R) ----
  * weight [C][Cin][k*k] -> bank [(c*R + r)][ci*k*k + d].  tap_idx/tap_w [R][k*k][4]: bilinear taps of the fixed
@@ -133,9 +138,10 @@ long tvae_dense_x6_bytes(int rows, int K);
 int tvae_dense_split3(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                       const float* scale, float* rowsum, tvae_stream_t stream);
 /* The same cells in the h3 arithmetic (parts = 2 of the entry points below: TWO fp16 parts per operand, THREE products per
- * block instead of six; every operand tensor scaled by a power of two into fp16's range, undone in the epilogue; accuracy
- * against fp64 at least that of the fp32 matrix pipe, profiles/experiments/f16_split_probe.hip).  Same buffer size; the
- * operand's maximum is kept behind the two part arrays, and the GEMM entry points use the following 12 bytes as scratch.
+ * block instead of six; every ROW of the operand scaled by its own power of two into fp16's range, undone per output row
+ * in the epilogue; accuracy against fp64 at least that of the fp32 matrix pipe, profiles/experiments/f16_split_probe.hip).
+ * Same buffer size; one maximum per padded row is kept behind the two part arrays, and the GEMM entry points use the words
+ * behind them as scratch (the bound words of a recomputed operand: 4 + K).
  * Entry points / operand forms with an h3 instance: tvae_conv1_fwd_dft / tvae_conv1_wgrad_dft (every geometry),
  * tvae_linear_fwd_x6 with the recomputed first-layer operand (va_xr), tvae_linear_dgrad_x6 in its two-valued form (vg_csum),
  * tvae_linear_wgrad_x6 from sign bits with the recomputed operand.  Elsewhere parts = 2 is rejected (hipErrorInvalidValue)
@@ -270,8 +276,10 @@ int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* 
 int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float* b2, const float* Wh, const float* bh,
                          int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
                          int act, float slope, int parts, const float* amax_a1, tvae_stream_t stream);
-/* parts = 2 (h3; ABI 4): w3 = tvae_dense_split2h cells and amax_a1 = a device word holding max |A1| (or an upper bound) --
-* tvae_conv1_fwd_dft leaves it in the LAST word of the buffer sized by tvae_conv1_dft_at_floats.  tvae_enc_tail_dgrad_x6 with parts = 2: w3p = tvae_dense_split2h cells, wh3 stays
+/* parts = 2 (h3): w3 = tvae_dense_split2h cells and amax_a1 = C device words holding max |A1[c][:]| per channel (or upper
+ * bounds; ABI 5) -- tvae_conv1_fwd_dft leaves them in the LAST C words of the buffer sized by tvae_conv1_dft_at_floats.  The
+ * forward scales A1 by the largest of them (the channels are its reduction index), tvae_enc_tail_wgrad_x6 every channel by
+ * its own (a channel is a column of dW2).  tvae_enc_tail_dgrad_x6 with parts = 2: w3p = tvae_dense_split2h cells, wh3 stays
  * tvae_dense_split3 (the skinny GEMM runs the exact split); its streamed operand is scaled per 32-column chunk inside the
  * kernel, no maximum is passed. */
 int tvae_enc_tail_dgrad_x6(const void* w3p, const void* wh3, const float* dheads, long ldd, int nh, const void* bits_h,

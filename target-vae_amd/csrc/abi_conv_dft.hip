@@ -52,6 +52,11 @@ struct DftPlan {
     long eo_floats, ed_floats, tab_floats;
     long g_floats;             // one split-K slab of G [Lh][2M][K2]
     size_t lds_sp, lds_db;
+    // operand maxima of the h3 arithmetic, behind A^T (offsets in floats from the 16-byte aligned end of A^T):
+    //   cmax [Lh][B]  per (frequency, image) bound of A^T's columns     fmax [Lh]  per frequency bound of A^T
+    //   wmax [Lh][Mb] per stacked row of the spectral weight            smax [M]   per filter row of S'
+    //   a1max [C]     per channel max |out| (LAST C words of the buffer: tvae_enc_tail_*_x6 take a pointer to them)
+    long o_cmax, o_fmax, o_wmax, o_smax, o_a1max, trailer_floats;
     bool ok;
 };
 static size_t dft_lds_spectra(int S, int L, int FXB) {
@@ -114,7 +119,13 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     constexpr size_t DFT_LDS_DBANK = 39 * 1024;
     for (int nb = 1; nb < 16 && lds_db(q.FXBd) > DFT_LDS_DBANK; ++nb) q.FXBd = (q.Lh + nb) / (nb + 1);
     q.lds_db = lds_db(q.FXBd);
-    q.ok = Cin >= 1 && q.Ho >= 1 && q.NT <= 5 && q.lds_sp <= 152 * 1024 && q.lds_db <= 152 * 1024 &&
+    q.o_cmax = 0;
+    q.o_fmax = q.o_cmax + (long)q.Lh * B;
+    q.o_wmax = q.o_fmax + q.Lh;
+    q.o_smax = q.o_wmax + (long)q.Lh * q.Mb;
+    q.o_a1max = (q.o_smax + q.M + 3) & ~3L;
+    q.trailer_floats = q.o_a1max + C;
+    q.ok = Cin >= 1 && q.Ho >= 1 && q.NT <= 5 && q.FXB <= 256 && q.lds_sp <= 152 * 1024 && q.lds_db <= 152 * 1024 &&
            (long)q.Lh * q.Mb < 2000000000L && (size_t)4 * 32 * ((2 * q.NS) | 1) * 4 <= 150 * 1024 &&
            (long)B * Cin * q.nblk + (long)q.M * Cin * q.nblk < 2000000000L && (long)q.M * (q.NBpad / 32) < 2000000000L;
     return q;
@@ -126,12 +137,12 @@ extern "C" {
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     return dft_plan(B, Cin, n, ksz, pad, C, R).ok ? 1 : 0;
 }
-// A^T is followed by four words: the maxima of the h3 arithmetic ([0] max |A^T|, [1] max |W|, [2] max |S'|, [3] max |out| of
-// the output transform -- the streamed operand of the encoder tail that follows), written by
-// the kernels that produce those operands and read by the GEMMs that split them
-constexpr int DFT_AT_TRAILER = 4;
+// A^T is followed by the operand maxima of the h3 arithmetic (DftPlan: cmax, fmax, wmax, smax, a1max), written by the kernels
+// that produce those operands and read by the GEMMs that split them; the LAST C floats of the buffer are the per-channel
+// maxima of the convolution's output (the streamed operand of the encoder tail that follows)
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
-    return ((dft_plan(B, Cin, n, ksz, pad, C, R).at_floats + 3) & ~3L) + DFT_AT_TRAILER;
+    const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
+    return ((q.at_floats + 3) & ~3L) + q.trailer_floats;
 }
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
@@ -159,11 +170,15 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     // h3 arithmetic (two fp16 parts, three products): both forms of the spectral GEMM (four-wave tile for reductions <= 256,
     // eight-wave tile beyond: several channels, wide frames) take the operand maxima dft_spectra leaves behind A^T
     const bool h3 = parts == 2;
-    // the maxima are produced in every arithmetic (a 64-thread launch and a few atomics): the weight gradient may run in
+    // the maxima are produced in every arithmetic (one small fill and a few atomics): the weight gradient may run in
     // h3 after a forward that did not
     float* amax = at + ((q.at_floats + 3) & ~3L);
-    hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, amax, DFT_AT_TRAILER);
-    TVAE_CHECK_LAUNCH();
+    {
+        hipError_t ez = dft_zero(amax, q.trailer_floats, st);
+        if (ez != hipSuccess) return (int)ez;
+    }
+    const DftMax mxp{amax + q.o_cmax, amax + q.o_fmax, amax + q.o_wmax};
+    float* a1max = amax + q.o_a1max;
     float* EO = tab;
     float* ED = EO + ((q.eo_floats + 3) & ~3L);
     hipError_t e = allow_big_lds(dft_spectra_kernel, q.lds_sp);
@@ -173,7 +188,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
-                       n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, amax);
+                       n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);
     TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
@@ -181,7 +196,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     if (h3) {
         const int Rp = x6_round_up(rows, DX6_ROWS), K8p = dense_k8pad(q.K2);
         hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d((long)K8p * Rp, 256)), dim3(256), 0, st, (const float*)W,
-                           (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, 0, (const float*)nullptr, (const float*)(amax + 1));
+                           (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, 0, (const float*)nullptr, (const float*)mxp.wmax);
         TVAE_CHECK_LAUNCH();
     } else {
         rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, nullptr, nullptr, stream);
@@ -198,10 +213,10 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         tm.bt = q.Mb / TR;                             // group = (fx, quarter of the column tiles): 4*Lh groups over 8 XCDs
         tm.nch = 4;
         const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
-        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st,
-                                                H3Scale{amax + 1, amax})
-                            : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st,
-                                               H3Scale{amax + 1, amax});
+        // h3: one scale per stacked row (fx, m') of the spectral weight, one per (fx, image) of A^T's columns
+        const H3Scale hs{mxp.wmax, mxp.cmax, 1, 0, 0, q.Ho, B};
+        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs)
+                            : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs);
         if (rc) return rc;
     }
     {
@@ -222,12 +237,12 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, true>, lds_r);                                    \
             if (e != hipSuccess) return (int)e;                                                                     \
             hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, true>), dim3(grid), dim3(256), lds_r, st,       \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, amax + 3);          \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, a1max);          \
         } else {                                                                                                    \
             e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, false>, lds_r);                                   \
             if (e != hipSuccess) return (int)e;                                                                     \
             hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, false>), dim3(grid), dim3(256), lds_r, st,      \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, amax + 3);          \
+                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, a1max);          \
         }                                                                                                           \
     } while (0)
             if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);
@@ -241,7 +256,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             const int grid = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
 #define TVAE_OUT_GEN(N_)                                                                                            \
     hipLaunchKernelGGL(dft_out_gen_kernel<N_>, dim3(grid), dim3(256), 0, st, (const float*)T, (const float*)EO, bias, out, \
-                       q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, amax + 3)
+                       q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, a1max)
             switch (q.NT) {
                 case 1: TVAE_OUT_GEN(1); break;
                 case 2: TVAE_OUT_GEN(2); break;
@@ -261,7 +276,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         e = allow_big_lds(dft_out_mf_kernel<L_, N_, R_>, lds_o);                                                    \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((dft_out_mf_kernel<L_, N_, R_>), dim3(grid), dim3(256), lds_o, st, (const float*)T,      \
-                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters, amax + 3); \
+                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, iters, a1max); \
     } while (0)
 #define TVAE_OUT_MF_L(L_)                                                                                           \
     do {                                                                                                            \
@@ -281,14 +296,12 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     if (!q.ok || ws_floats < tvae_conv1_dft_ws_floats(B, Cin, n, ksz, pad, C, R) || !aligned16(ws) || !aligned16(at))
         return (int)hipErrorInvalidValue;
     hipStream_t st = S(stream);
-    // h3 arithmetic: max |A^T| was left behind A^T by the forward, max |S'| comes from the transform along w below
-    const bool h3 = parts == 2;                      // every transform along w measures max |S'| in its epilogue
-    if (parts == 2 && !h3) parts = 3;
+    // h3 arithmetic: the bounds of A^T were left behind it by the forward; the per-row maxima of S' come from the transform
+    // along w below (every instance measures them, in every arithmetic: the ring kernels count the atomic in their waits)
     float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
-    if (h3) {
-        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, amax + 2, 1);
-        TVAE_CHECK_LAUNCH();
-    }
+    float* smax = amax + q.o_smax;
+    hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, st, smax, q.M);
+    TVAE_CHECK_LAUNCH();
     float* Sp = ws;
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
     float* tab = slabs + (((long)q.splits * q.g_floats + 3) & ~3L);
@@ -309,7 +322,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         er = allow_big_lds(dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>, lds_r);                                         \
         if (er != hipSuccess) return (int)er;                                                                       \
         hipLaunchKernelGGL((dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>), dim3(grid), dim3(256), lds_r, st, dpre,       \
-                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad, h3 ? amax + 2 : (float*)nullptr);         \
+                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad, smax);         \
     } while (0)
             if (q.ring == 1) TVAE_DY_RING(9, 2, 46, 17, false);
             else if (q.ring == 2) TVAE_DY_RING(17, 3, 98, 33, true);
@@ -322,7 +335,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
             if (eg != hipSuccess) return (int)eg;
             const int gridg = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
             hipLaunchKernelGGL(dft_dy_gen_kernel, dim3(gridg), dim3(256), lds_g, st, dpre, (const float*)ED, Sp, q.M, R, B,
-                               q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, h3 ? amax + 2 : (float*)nullptr);
+                               q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, smax);
             TVAE_CHECK_LAUNCH();
         } else {
         const size_t lds_d = ((size_t)q.NS * q.NRT * 64 + (size_t)4 * (32 * ((2 * q.NS) | 1) + 64)) * 4;
@@ -335,7 +348,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         if (e0 != hipSuccess) return (int)e0;                                                                       \
         hipLaunchKernelGGL((dft_dy_mf_kernel<S_, T_, L2_, A_>), dim3(grid), dim3(256), lds_d, st, dpre,             \
                            (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, iters,                             \
-                           h3 ? amax + 2 : (float*)nullptr);                                                        \
+                           smax);                                                        \
     } while (0)
         if (q.NS == 9) { if (q.Lh == 23) TVAE_DY_MF(9, 2, 46, true); else TVAE_DY_MF(9, 2, 0, true); }
         else if (q.NS == 17) { if (q.Lh == 49) TVAE_DY_MF(17, 4, 98, true); else TVAE_DY_MF(17, 4, 0, true); }
@@ -361,7 +374,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
                                         128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st,
-                                        H3Scale{amax + 2, amax});
+                                        // h3: one scale per filter row of S' (rows m and M + m), one per frequency of A^T
+                                        H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1});
         if (rc) return rc;
     }
     hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);

@@ -33,10 +33,10 @@ static int wgrad_x6_splits(int M, int N, int K) {
     const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
     return cdiv(N, nchunk);
 }
-constexpr int WG_H3_SLOTS = 8;         // behind the slabs: the operand maxima of the h3 arithmetic
+constexpr int WG_H3_SLOTS = 8;         // behind the slabs: the operand bounds of the h3 arithmetic (4 words + one per X row)
 long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K) {
     if (M <= 0 || K <= 0 || N < 32) return 0;
-    return (long)wgrad_x6_splits(M, N, K) * M * K + WG_H3_SLOTS;
+    return (long)wgrad_x6_splits(M, N, K) * M * K + WG_H3_SLOTS + K;
 }
 
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
@@ -70,7 +70,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     int rc;
     if (parts == 2) {
         float* slots = ws + (long)splits * per;
-        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), slots, 4);
+        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, S(stream), slots, 4 + K);
         TVAE_CHECK_LAUNCH();
         const long nlb = va_lb ? (long)(N / vas.Np) * K : 0;
         hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 128)), dim3(256), 0, S(stream), va_xr, 2L * N, va_wc,
@@ -80,7 +80,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                            0, (const float*)nullptr, slots + 3);
         TVAE_CHECK_LAUNCH();
         rc = dense_wgrad_x6_launch_p2(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas,
-                                      ATILE_PLAIN, S(stream), H3Scale{nullptr, slots});
+                                      ATILE_PLAIN, S(stream), H3Scale{nullptr, slots, 0, 0, 0, 0, 0});
     } else {
         rc = parts == 1
             ? dense_wgrad_x6_launch_p1(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas, ATILE_PLAIN, S(stream), H3_NONE)

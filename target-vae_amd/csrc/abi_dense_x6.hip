@@ -65,9 +65,9 @@ extern "C" {
 
 // ---- dense layers on the bf16 matrix pipe with exactly split operands (dense_x6_kernels.hpp) ---------------------
 long tvae_dense_x6_bytes(int rows, int K) { return dense_x6_bytes(rows, K); }
-// h3 cells (parts == 2) occupy two of the three part arrays the buffer is sized for; the first four floats of the third
-// hold the operand's maximum ([0], read again by the GEMM for its epilogue) and, for launches whose streamed operand is
-// recomputed, the three maxima of dec_l0_bound_kernel ([1..3], written by the GEMM entry point).
+// h3 cells (parts == 2) occupy two of the three part arrays the buffer is sized for; the third starts with one maximum per
+// padded row ([Rpad], read again by the GEMM for its scales) and, for launches whose streamed operand is recomputed, the
+// 4 + K bound words of dec_l0_bound_kernel behind them (written by the GEMM entry point).
 static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int rows, int K, int transpose,
                        const float* scale, float* rowsum, int parts, tvae_stream_t stream) {
     if (rows <= 0 || K <= 0) return 0;
@@ -75,11 +75,9 @@ static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int ro
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
     const long total = (long)K8pad * Rpad;
     if (parts == 2) {
-        float* tr = h3_trailer(a3, rows, K);
-        hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), tr, 4);
-        TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)rows * K, 256 * 8, 128)), dim3(256), 0, S(stream), W, ldw, rows, K,
-                           transpose, scale, tr);
+        float* tr = h3_trailer(a3, rows, K);             // [Rpad] row maxima, then the scratch words of the GEMM entry points
+        hipLaunchKernelGGL(dense_rowmax_kernel, dim3(Rpad / 64), dim3(1024), 0, S(stream), W, ldw, rows, Rpad, K, transpose, scale,
+                           tr);
         TVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
                            Rpad, K, K8pad, transpose, scale, (const float*)tr);
@@ -117,16 +115,18 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     if (parts == 2) {
         // h3 instances: the recomputed first-layer activation (its bound is formed here) and the exact 0 / 1 operand of the
         // two-valued gradient; an operand streamed from memory would need its maximum from its producer (not wired: x6)
-        float* tr = h3_trailer(a3, rows, K);
+        float* tr = h3_trailer(a3, rows, K);             // one maximum per row (tvae_dense_split2h)
         hs.amax_a = tr;
+        hs.a_rows = 1;
         if (va.xr) {
-            hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, st, tr + 1, 3);
+            float* bw = tr + Rpad;                       // bound words of the recomputed operand: [4 + K]
+            hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, st, bw, 4 + K);
             TVAE_CHECK_LAUNCH();
             const long nlb = va.lb ? (long)(N / va.Np) * K : 0;
             hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 128)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
-                               va.bc, va.lb, nlb, K, tr + 1);
+                               va.bc, va.lb, nlb, K, bw);
             TVAE_CHECK_LAUNCH();
-            hs.amax_x = tr + 1;
+            hs.amax_x = bw;
         } else if (!vg.csum) {
             return (int)hipErrorInvalidValue;
         }

@@ -13,7 +13,8 @@ static inline long dense_x6_bytes(int rows, int K) {
     return 3 * K8pad * Rpad * 16;
 }
 
-// h3 cells (tvae_dense_split2h): the operand's maximum (and scratch words of the GEMM entry points) behind the two part arrays
+// h3 cells (tvae_dense_split2h): one maximum per padded row (and, behind them, scratch words of the GEMM entry points) behind
+// the two part arrays
 static inline float* h3_trailer(const void* a3, int rows, int K) {
     const long total = (long)dense_k8pad(K) * x6_round_up(rows, DX6_ROWS);
     return reinterpret_cast<float*>(const_cast<void*>(a3)) + 2 * total * 4;

@@ -32,14 +32,14 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
                          int nh, float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N,
                          int act, float slope, int parts, const float* amax_a1, tvae_stream_t stream) {
     if (N <= 0) return 0;
-    if (parts == 2 && !amax_a1) return (int)hipErrorInvalidValue;        // h3 needs max |A1| from A1's producer
+    if (parts == 2 && !amax_a1) return (int)hipErrorInvalidValue;        // h3 needs the per-channel maxima of A1 (C words) from A1's producer
     if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3) || !A1 || !H || !heads || !Wh ||
         !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))) ||
         !et_ld_ok(N, lda, ldh, ldo))
         return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(ET_C, DX6_ROWS);
     const size_t lds = (size_t)parts * 16 * ET_C * 16;
-    const H3Scale hs = parts == 2 ? H3Scale{h3_trailer(w3, ET_C, ET_C), amax_a1} : H3_NONE;
+    const H3Scale hs = parts == 2 ? H3Scale{h3_trailer(w3, ET_C, ET_C), amax_a1, 1, 0, 0, 0, 0} : H3_NONE;
     hipError_t e;
     if (parts == 3) {
         e = allow_big_lds(enc_tail_fwd_x6_kernel<3>, lds);

@@ -147,10 +147,25 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
     __syncthreads();
 }
 
+// h3 arithmetic of the spectral GEMMs (round 4: one power-of-two scale per row / column group instead of one per tensor):
+// the workgroup that owns a plane and a block of frequencies also leaves, per frequency fx of its block,
+//   images : cmax[fx * B + b]   >= max over (ci, fy, h) |A^T[fx][(ci, ri, fy)][(b, h)]|  (the modulus |Yh| bounds both parts of
+//            Yh e^{i..}): the scale of image b's columns in problem fx of the forward GEMM;  fmax[fx] = max over b: the scale
+//            of the rows of A^T in problem fx of the weight-gradient GEMM;
+//   filters: wmax[fx * Mb + m] = wmax[fx * Mb + M + m] = max over (ci, fy) of |Kr|, |Ki|: the scale of the two stacked rows.
+// (atomic maxima on the bit patterns: Cin planes meet in a slot; the slots are zeroed by the entry point.)  An image
+// 2^-24 as bright as its neighbours, a filter that has not started to train, the DC plane of un-normalised data: each gets
+// the full two-part precision relative to ITSELF.
+struct DftMax {
+    float* cmax;    // [Lh][B]
+    float* fmax;    // [Lh]
+    float* wmax;    // [Lh][Mb]
+};
 static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
                                           int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
-                                          int M, int Mb, int L, int Lh, int FXB, int nblk, float* __restrict__ amax) {
+                                          int M, int Mb, int L, int Lh, int FXB, int nblk, DftMax mxp) {
     extern __shared__ float sm_dft[];
+    __shared__ unsigned fmx_[256];                       // per frequency of the block (host: FXB <= 256)
     const int nimg = B * Cin * nblk;
     int id = blockIdx.x;
     const bool is_img = id < nimg;
@@ -160,7 +175,7 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
     const int outer = id / (nblk * Cin);                 // image b or filter m
     const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
     float2 *Yh, *tw;
-    float mx = 0.f;                    // h3 arithmetic: largest magnitude this workgroup writes (amax[0]: A^T, amax[1]: W)
+    if (threadIdx.x < 256) fmx_[threadIdx.x] = 0u;       // (made visible by the barriers inside dft_plane_spectrum)
     if (is_img) {
         dft_plane_spectrum(sm_dft, y + ((long)outer * Cin + ci) * n * n, n, pad, L, fx0, nfx, FXB, Yh, tw);
         const int total = nfx * L * Ho;
@@ -172,7 +187,18 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             float* dst = AT + ((long)(fx0 + f) * 2 * L * Cin + (long)(2 * ci) * L + fy) * NBpad + (long)outer * Ho + h;
             dst[0] = v.x;
             dst[(long)L * NBpad] = v.y;
-            mx = fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
+            const int fy = i / nfx, f = i - fy * nfx;
+            const float2 k = Yh[fy * FXB + f];
+            // the modulus, rounded up a little: an upper bound of |Re|, |Im| of Yh e^{i phi} for every phi
+            atomicMax(&fmx_[f], __float_as_uint(sqrtf(__fmaf_rn(k.x, k.x, k.y * k.y)) * 1.000001f));
+        }
+        __syncthreads();
+        for (int f = threadIdx.x; f < nfx; f += blockDim.x) {
+            const float v = __uint_as_float(fmx_[f]);
+            h3_atomic_amax(mxp.cmax + (long)(fx0 + f) * B + outer, v);
+            h3_atomic_amax(mxp.fmax + fx0 + f, v);
         }
     } else {
         const int m = outer;
@@ -187,10 +213,19 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             r0[L + fy] = k.y;
             r1[fy] = -k.y;
             r1[L + fy] = k.x;
-            mx = fmaxf(mx, fmaxf(fabsf(k.x), fabsf(k.y)));
+        }
+        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
+            const int fy = i / nfx, f = i - fy * nfx;
+            const float2 k = Yh[fy * FXB + f];
+            atomicMax(&fmx_[f], __float_as_uint(fmaxf(fabsf(k.x), fabsf(k.y))));
+        }
+        __syncthreads();
+        for (int f = threadIdx.x; f < nfx; f += blockDim.x) {
+            const float v = __uint_as_float(fmx_[f]);
+            h3_atomic_amax(mxp.wmax + (long)(fx0 + f) * Mb + m, v);
+            h3_atomic_amax(mxp.wmax + (long)(fx0 + f) * Mb + M + m, v);
         }
     }
-    if (amax) h3_block_amax(mx, amax + (is_img ? 0 : 1));            // (uniform: every thread of the workgroup arrives)
 }
 
 // ==========================================================================================
@@ -248,7 +283,7 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int M, int R, int B, int Ho, int Lh, long NBpad, int act,
                                                             float slope, int iters, float* __restrict__ amax) {
-    float amx = 0.f;                                             // max |out| (h3 scale of the encoder tail; optional)
+    float amx = 0.f;                                             // max |out| per channel -> amax[C] (h3 scales of the encoder tail)
     constexpr int NTT = NT + (REM1 ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     float* eo = sm_w;                                            // [LHP][NTT][64]
@@ -321,6 +356,7 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
             amx = fmaxf(amx, fabsf(sv));
             obase[e + k * jump] = sv;
         }
+        h3_tile_flush(amx, amax + c, lane);              // max |out| of channel c (h3 scales of the encoder tail)
         __builtin_amdgcn_wave_barrier();
     };
     // two register buffers, the loop walks two tiles per trip: the loads of one buffer are in flight while the other
@@ -338,10 +374,6 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
         compute(tile + stride, mb, nb, vb);
         tile += 2 * stride;
     }
-    if (amax) {
-        amx = h3_wave_max(amx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
-    }
 }
 
 // S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]; dY is [c][b][r][h][w].  Same tile walk as above.  The 32 x Ho
@@ -353,7 +385,7 @@ template <int NS, int NRT, int LH2, bool AREG>
 static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                            float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
                                                            long NBpad, int iters, float* __restrict__ amax) {
-    float amx = 0.f;                                             // max |S'| (h3 scale of the GEMM that reads S'; optional)
+    float amx = 0.f;                                             // max |S'| per filter row -> amax[M] (h3 scales of the GEMM that reads S')
     constexpr int NL = NS;                                       // 64-element slices of the 32 x Ho tile: ceil(32*Ho/64) <= NS
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     float* ed = sm_w;                                            // [NS][NRT][64] (used when !AREG)
@@ -446,11 +478,8 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
                         if (fx0 + 2 * kh < Lh) p[fx0 * 128] = acc[rt][r];
                     }
                 }
+            h3_tile_flush(amx, amax + m, lane);          // max |S'| of filter row m (rows m and M + m of the GEMM operand)
         }
-    }
-    if (amax) {
-        amx = h3_wave_max(amx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 
@@ -493,11 +522,11 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
                                                                      int M, int R, int B, int Lh, int act, float slope,
                                                                      float* __restrict__ amax) {
     constexpr int NTT = NT + (REM1 ? 1 : 0), ND = (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
-    float amx = 0.f;                                     // max |out| of this wave (h3 arithmetic of the launches that read out)
+    float amx = 0.f;                                     // max |out| of the current tile -> amax[channel] (h3 scales of the launches that read out)
     constexpr int SN = (32 * HO + 63) / 64, P = HO * HO;
     static_assert((HO & 1) == 1, "odd output width: the [column][HO] patch is conflict free and linear in memory order");
     static_assert(32 * HO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
-    static_assert(ND + 2 * SN <= 63, "vmcnt is a 6-bit counter");
+    static_assert(ND + 2 * (SN + 1) <= 63, "vmcnt is a 6-bit counter");      // (+ 1: the per-tile atomic of h3_tile_flush)
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -550,8 +579,8 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     int slot = 0;
     for (int it = 0; it < my; ++it) {
         if (it == 0) TVAE_DFT_VMCNT(ND);
-        else if (it == 1) TVAE_DFT_VMCNT(ND + SN);
-        else TVAE_DFT_VMCNT(ND + 2 * SN);
+        else if (it == 1) TVAE_DFT_VMCNT(ND + SN + 1);
+        else TVAE_DFT_VMCNT(ND + 2 * (SN + 1));
         const float* tbn = dma_base(it + 2);
         const int slot2 = slot == 0 ? 2 : slot - 1;      // (it + 2) % 3: the slot tile it-1 has left
         const float* vs = ring + slot * SLOTF + lane;
@@ -623,14 +652,11 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
             amx = fmaxf(amx, fabsf(sv));
             __builtin_nontemporal_store(sv, obase + (unsigned)o);          // written once, read by later launches
         }
+        h3_tile_flush(amx, amax + c, lane);              // the (SN + 1)-th entry of this tile's store group
         __builtin_amdgcn_wave_barrier();
         slot = slot == 2 ? 0 : slot + 1;
     }
     TVAE_DFT_VMCNT(0);                                   // the clamped tail DMAs still target this wave's ring
-    if (amax) {
-        amx = h3_wave_max(amx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
-    }
 }
 
 // number of store instructions dft_dy_ring_kernel issues per tile (rows 32 rt + (r & 3) + 8 (r >> 2) [+ 4] below LH2)
@@ -656,7 +682,7 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     constexpr int NL = (32 * HO + 63) / 64, SLOTB = NL * 256, SLOTF = NL * 64, P = HO * HO;
     constexpr int ST = dft_dy_ring_stores(NRT, LH2, NYQ);
     static_assert((HO & 1) == 1 && 2 * NS <= HO + 1 && 2 * NS >= HO, "odd output width, NS = ceil(HO / 2)");
-    static_assert(ST <= 63, "vmcnt is a 6-bit counter");
+    static_assert(ST + 1 <= 63, "vmcnt is a 6-bit counter");                  // (+ 1: the per-tile atomic of h3_tile_flush)
     static_assert(!NYQ || LH2 == 32 * NRT + 2, "Nyquist rows on the vector ALU");
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, kh = lane >> 5;
@@ -722,11 +748,11 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     // store offsets (floats from Sp + dft_t_off(n0, m, 2M, Lh), wave uniform): real rows at j + 2 kh 128, imaginary rows
     // M * Lh * 128 further on
     const unsigned lre = (unsigned)(j + 2 * kh * 128), lim = lre + (unsigned)((long)M * Lh * 128);
-    float mx = 0.f;                                      // h3 arithmetic of the GEMM that follows: max |S'| (amax, optional)
+    float mx = 0.f;                                      // h3 arithmetic of the GEMM that follows: max |S'| of the tile's filter row -> amax[M]
     for (int it = 0; it < my; ++it) {
         const int slot = it & 1;
         if (it == 0) TVAE_DFT_VMCNT(0);
-        else TVAE_DFT_VMCNT(ST);
+        else TVAE_DFT_VMCNT(ST + 1);
         const Src qn = dma_src(it + 1);
         const float* bs = ring + slot * SLOTF + j * HO + kh;
         f32x16 acc[NRT];
@@ -768,12 +794,9 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
             sb[o] = kh ? 0.f : tot;
             mx = fmaxf(mx, fabsf(tot));
         }
+        h3_tile_flush(mx, amax + m, lane);               // the (ST + 1)-th entry of this tile's store group
     }
     TVAE_DFT_VMCNT(0);
-    if (amax) {
-        mx = h3_wave_max(mx);
-        if (lane == 0) h3_atomic_amax(amax, mx);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -851,10 +874,7 @@ static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __
             }
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    if (amax) {
-        amx = h3_wave_max(amx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
+        h3_tile_flush(amx, amax + c, lane);              // max |out| of channel c
     }
 }
 
@@ -904,11 +924,8 @@ static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __r
                 amx = fmaxf(amx, fabsf(acc[r]));
             }
         }
+        h3_tile_flush(amx, amax + m, lane);              // max |S'| of filter row m
         __builtin_amdgcn_wave_barrier();
-    }
-    if (amax) {
-        amx = h3_wave_max(amx);
-        if ((threadIdx.x & 63) == 0) h3_atomic_amax(amax, amx);
     }
 }
 

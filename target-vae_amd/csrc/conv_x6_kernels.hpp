@@ -78,16 +78,28 @@ __device__ __forceinline__ void split3x8(const float (&r)[8], Cell16& h, Cell16&
 
 // ------------------------------------------------------------------------------------------
 // "h3" arithmetic (round 3): TWO fp16 parts per operand, THREE partial products.
-// fp16 carries 11 significant bits, so with round-to-nearest parts  h = fp16(x), l = fp16(x - h)
-//   |x - h| <= 2^-12 |x|,   |x - h - l| <= 2^-24 |x|   (as long as l is a normal fp16 number),
-// i.e. two parts represent an fp32 value to half an ulp, and  h k + h k' + l k  leaves out only  l k' <= 2^-24 |x y|.
-// Products of fp16 numbers are exact in the fp32 accumulator (22 bits).  Against fp64 the result is at least as
-// accurate as the fp32 matrix pipe and as the six-product bf16 split for every distribution and reduction length
-// probed (profiles/experiments/f16_split_probe.hip: 2.6e-7 vs 4.1e-7 (fp32 MFMA) vs 3.5e-7 (x6) at K = 512), with
-// HALF the matrix instructions of x6.  The price is fp16's 5-bit exponent: every operand tensor is multiplied by a
-// power of two (exact) that brings its largest magnitude -- or an upper bound of it -- just below 2^15, and the
-// accumulators by the inverse powers in the epilogue.  Elements more than 2^16 below the tensor's maximum lose low
-// part bits to the subnormal range: their absolute error is <= 2^-40 of the maximum, which a sum does not see.
+// fp16 carries 11 significant bits (unit roundoff 2^-11), so with round-to-nearest parts  h = fp16(x), l = fp16(x - h)
+//   |x - h| <= 2^-11 |x|,   |x - h - l| <= 2^-23 |x|   (as long as l is a normal fp16 number):
+// x - h is an fp32 number of at most 13 significant bits, of which l keeps 11 -- two parts represent an fp32 value to ONE
+// ulp (exactly, whenever x - h fits 11 bits, which is the common case).  h k + h k' + l k  leaves out  l l' <= 2^-22 |x y|.
+// Worst case per product: 2^-23 + 2^-23 + 2^-22 = 2^-21 |x y| -- 8x the rounding of one fp32 FMA, but unbiased and not
+// accumulating through the sum the way an FMA chain's own roundings do: products of fp16 numbers are exact in the fp32
+// accumulator (22 bits).  What carries the accuracy claim is therefore the MEASUREMENT, not this bound: against fp64 the
+// result is at least as accurate as the fp32 matrix pipe and as the six-product bf16 split for every distribution and
+// reduction length probed (profiles/experiments/f16_split_probe.hip: 2.6e-7 vs 4.1e-7 (fp32 MFMA) vs 3.5e-7 (x6) at
+// K = 512), with HALF the matrix instructions of x6.
+// The price is fp16's 5-bit exponent: an operand is multiplied by a power of two (exact) that brings the largest
+// magnitude of its scale group -- or an upper bound of it -- into [2^14, 2^15), and the accumulators by the inverse powers
+// in the epilogue.  An element 2^j below the maximum of its group keeps min(23, 39 - j) significant bits (beyond j = 16
+// the low part enters fp16's subnormal range, absolute error 2^-25 of the scaled value): 2^-16 -> exact, 2^-24 -> 3e-5,
+// 2^-28 -> 5e-4 relative to ITSELF.  Round 3 used ONE group per operand tensor, which is fine normwise but lets a whole
+// row of small values (a dead unit, a dim image) come out with few correct bits.  Round 4: the scale group is a ROW of the
+// operand in the sense of the product (H3Scale, dense_x6_kernels.hpp) wherever its producer can supply row maxima -- a
+// row / column of the OUTPUT then has the full two-part precision relative to its own magnitude, and what remains under
+// one scale is the reduction index, where an element far below its row's maximum is negligible in the sum it enters
+// (error <= 2^-39 of max_row |a| max_col |b| per term).  The remaining per-tensor scales and why they are safe are listed
+// in DESIGN.md section 4 ("validity domain of h3"); tests/test_hip_primitives.py::test_h3_row_dynamic_range holds rows
+// scaled by 2^-16 .. 2^-32 to 1e-5 per row against fp64.
 // ------------------------------------------------------------------------------------------
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 // the power of two s with 2^14 <= s * amax < 2^15 (amax = 0, or absurdly small / large: clamped, s stays a normal number
@@ -132,6 +144,15 @@ __device__ __forceinline__ float h3_wave_max(float v) {          // in every lan
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Round 4 (h3 scales per row): a wave's tiles belong to different filter rows, so its running maximum is flushed once per
+// tile into the slot of that tile's row -- wave reduction, then ONE atomic without return from lane 0.  In the ring kernels
+// the atomic is issued unconditionally (it is one more entry of the tile's hand-counted store group: vmcnt counts it).
+__device__ __forceinline__ void h3_tile_flush(float& mx, float* slot, int lane) {
+    const float m = h3_wave_max(mx);
+    if (lane == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(slot), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mx = 0.f;
 }
 
 // block-wide maximum, then ONE atomic per workgroup (per-wave atomics on a single word serialise at the L2: 12 000 of

@@ -47,9 +47,36 @@ static __global__ void dense_split3_kernel(const float* __restrict__ W, long ldw
     }
 }
 
-// The same pre-pass in the h3 arithmetic: cells [part < 2][octet][row] of fp16 parts of A(row, k) * s, s = h3_scale(*amax);
-// *amax = max |A(row, k)| over the operand (dense_absmax_kernel), kept in the first word behind the two parts
-// (A3[2 * total]: the buffer is sized for three parts) where the GEMM finds it again for its epilogue.
+// The same pre-pass in the h3 arithmetic: cells [part < 2][octet][row] of fp16 parts of A(row, k) * s[row],
+// s[row] = h3_scale(rowmax[row]), rowmax[row] = max_k |A(row, k)| (dense_rowmax_kernel): ONE POWER OF TWO PER ROW (round 4).
+// A row of the operand is a row of the product, so the scale is undone per accumulator row in the GEMM's epilogue and a
+// row that lies 2^20 below the rest of the matrix (a dead unit, a filter that has not started to train) is computed with
+// the same relative accuracy as any other.  The row maxima live in the first Rpad words behind the two parts
+// (A3[2 * total]: the buffer is sized for three parts), where the GEMM finds them again.
+// Block = 64 rows x 16 k-slices, like dense_rowsum_kernel; rows >= Rrows (padding) get 0.
+static __global__ __launch_bounds__(1024) void dense_rowmax_kernel(const float* __restrict__ W, long ldw, int Rrows, int Rpad,
+                                                                   int K, int transpose, const float* __restrict__ scale,
+                                                                   float* __restrict__ rowmax) {
+    __shared__ float part[16][64];
+    const int r = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + r;
+    float mx = 0.f;
+    if (row < Rrows)
+        for (int k = sl; k < K; k += 16) {
+            float v = transpose ? W[(long)k * ldw + row] : W[(long)row * ldw + k];
+            if (scale) v *= scale[k];
+            mx = fmaxf(mx, fabsf(v));
+        }
+    part[sl][r] = mx;
+    __syncthreads();
+    if (sl == 0 && row < Rpad) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = fmaxf(t, part[q][r]);
+        rowmax[row] = t;
+    }
+}
+// max |x| of a vector into ONE word (the gy operand of the two-valued weight gradient)
 static __global__ void dense_absmax_kernel(const float* __restrict__ W, long ldw, int Rrows, int K, int transpose,
                                            const float* __restrict__ scale, float* __restrict__ amax) {
     const long total = (long)Rrows * K;
@@ -89,16 +116,17 @@ static __global__ void h3_absmax_rows_kernel(const float* __restrict__ x, long l
     h3_block_amax(mx, amax);
 }
 static __global__ void h3_zero_slots_kernel(float* p, int n) {
-    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
 }
+// rowmax: one maximum per row of the operand (row = i % Rpad, the stacked row index of batched operands)
 static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3, int Rrows, int Rpad,
                                             int K, int K8pad, int transpose, const float* __restrict__ scale,
-                                            const float* __restrict__ amax) {
+                                            const float* __restrict__ rowmax) {
     const long total = (long)K8pad * Rpad;
-    const float s = h3_scale(*amax);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = (int)(i % Rpad);
         const int o = (int)(i / Rpad);
+        const float s = h3_scale(rowmax[row]);
         float r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -116,7 +144,9 @@ static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ld
 
 // h3 scale of the recomputed first-layer activation (VirtAct): slots[0] = max |xr|, slots[1] = max_k (|wc[k][0]| + |wc[k][1]|),
 // slots[2] = max_{b,k} |bc[k] + lb[b][k]| (atomic maxima into zeroed slots); |act(pre)| <= |pre| <= slots[1] slots[0] + slots[2]
-// for LeakyReLU (slope <= 1), tanh and the identity.
+// for LeakyReLU (slope <= 1), tanh and the identity.  slots[3] is the caller's (max |gy| of the weight gradient) and
+// slots[4 + k] = max_b |bc[k] + lb[b][k]|: with it a consumer whose operand ROW is feature k (the weight gradient) bounds that
+// row alone, (|wc[k][0]| + |wc[k][1]|) slots[0] + slots[4 + k].
 static __global__ void dec_l0_bound_kernel(const float* __restrict__ xr, long nxr, const float* __restrict__ wc,
                                            const float* __restrict__ bc, const float* __restrict__ lb, long nlb, int K,
                                            float* __restrict__ slots) {
@@ -132,9 +162,16 @@ static __global__ void dec_l0_bound_kernel(const float* __restrict__ xr, long nx
     for (long i = 4 * n4 + gid; i < nxr; i += gsz) m0 = fmaxf(m0, fabsf(xr[i]));
     for (long i = gid; i < K; i += gsz) m1 = fmaxf(m1, fabsf(wc[2 * i]) + fabsf(wc[2 * i + 1]));
     if (lb) {
-        for (long i = gid; i < nlb; i += gsz) m2 = fmaxf(m2, fabsf(bc[i % K] + lb[i]));
+        for (long i = gid; i < nlb; i += gsz) {
+            const float v = fabsf(bc[i % K] + lb[i]);
+            m2 = fmaxf(m2, v);
+            h3_atomic_amax(slots + 4 + (i % K), v);
+        }
     } else {
-        for (long i = gid; i < K; i += gsz) m2 = fmaxf(m2, fabsf(bc[i]));
+        for (long i = gid; i < K; i += gsz) {
+            m2 = fmaxf(m2, fabsf(bc[i]));
+            slots[4 + i] = fabsf(bc[i]);
+        }
     }
     h3_block_amax(m0, slots);
     h3_block_amax(m1, slots + 1);
@@ -182,15 +219,22 @@ __device__ __forceinline__ void mfma_part(f32x16& acc, const Cell16& a, const Ce
     else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
 }
 template <int NP> struct OneBits { static constexpr unsigned lo = NP == 2 ? 0x3c00u : 0x3f80u, hi = lo << 16; };
-// h3 epilogue: the two inverse powers of two, one after the other (their product may leave the fp32 range, each
-// intermediate result does not unless the true value does)
-__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[2][4], float ia, float ix) {
+// h3 epilogue: the inverse powers of two of the accumulator's ROW (operand A, one scale per row: ia[row of the tile]) and
+// COLUMN (operand X: ix[column of the tile]; XS = false: the exact 0 / 1 operand has none), one after the other (their product
+// may leave the fp32 range, each intermediate result does not unless the true value does).  ia / ix are LDS tables.
+template <bool XS>
+__device__ __forceinline__ void h3_unscale_rc(f32x16 (&acc)[2][4], const float* ia, const float* ix, int wave, int lane) {
+    float ixv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ixv[j] = XS ? ix[j * 32 + (lane & 31)] : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const float a = ia[wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * ia) * ix;
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = XS ? (acc[i][j][r] * a) * ixv[j] : acc[i][j][r] * a;
+        }
 }
 // rounds two values to bf16 (RNE), packed (x0 in the low half): the whole "split" of the one-part mode
 __device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
@@ -198,11 +242,21 @@ __device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
 }
 
-struct H3Scale {           // h3 arithmetic (NP == 2) only: device words holding max |.| (or an upper bound) of the two
-    const float* amax_a;   // operands -- the pre-split cells were built with h3_scale(*amax_a), the streamed operand is
-    const float* amax_x;   // multiplied by h3_scale(*amax_x) when it is split; the epilogue undoes both (powers of two)
+// h3 arithmetic (NP == 2) only: device words holding max |.| (or an upper bound) of the operands.  Round 4: the scale is a
+// power of two PER ROW of each operand in the sense of the product -- per output row for A, per output column (forward form)
+// or per output column = row of X (weight-gradient form) for X -- wherever the producer of the operand can say what the
+// maximum of that row is; the epilogue undoes row and column factors separately.  What is left to one scale is the
+// reduction index, where an element far below its row's maximum is also negligible in the sum.
+struct H3Scale {
+    const float* amax_a;   // a_rows == 0: one word (max |A|).  a_rows != 0: one word per row -- forward form: indexed like the
+                           // stacked rows of A3 (row tile offset + row); weight-gradient form: [batch * a_bstride + (row % a_mod)]
+    const float* amax_x;   // x_group == 0: one word (or the bound words of a recomputed operand, dec_l0_bound_kernel).
+                           // x_group > 0, forward form: word [batch * x_bstride + min(column / x_group, x_bstride - 1)] (one per
+                           // image of x_group columns); weight-gradient form: word [batch * x_bstride + row / x_group]
+    int a_rows, a_bstride, a_mod;
+    int x_group, x_bstride;
 };
-constexpr H3Scale H3_NONE = {nullptr, nullptr};
+constexpr H3Scale H3_NONE = {nullptr, nullptr, 0, 0, 0, 0, 0};
 
 constexpr int DX6_THREADS = 512;                   // 8 waves: two per SIMD
 constexpr int DX6_ROWS = 512;                      // tile rows (8 waves x 64)
@@ -427,8 +481,20 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // h3 arithmetic: scale of the streamed operand.  The recomputed first-layer activation (XV == 2) has no producer that
     // could have measured it: hs.amax_x then holds three maxima {max |x'|, max_k (|wc[k][0]| + |wc[k][1]|), max |bc + lb|}
     // (dec_l0_bound_kernel) whose combination bounds every |act(pre)| <= |pre|.  The 0 / 1 operand needs none.
+    // Round 4: one scale per ROW of A (h3a_: their inverses for the epilogue) and, where the operand's producer measured it,
+    // one per column group of X (an image; h3x_: the inverse of every column of this tile).
+    __shared__ float h3a_[NP == 2 ? DX6_ROWS : 1];
+    __shared__ float h3x_[NP == 2 ? 128 : 1];
     float sx = 1.f;
-    if (NP == 2 && !MASKB) sx = h3_scale(XV == 2 ? __fmaf_rn(hs.amax_x[1], hs.amax_x[0], hs.amax_x[2]) : hs.amax_x[0]);
+    if (NP == 2) {
+        h3a_[tid] = h3_inv(h3_scale(hs.amax_a[hs.a_rows ? m0g + tid : 0]));
+        if (!MASKB) {
+            if (XV == 2) sx = h3_scale(__fmaf_rn(hs.amax_x[1], hs.amax_x[0], hs.amax_x[2]));
+            else if (hs.x_group > 0) sx = h3_scale(hs.amax_x[(long)batch * hs.x_bstride + min((n0 + (tid & 127)) / hs.x_group, hs.x_bstride - 1)]);
+            else sx = h3_scale(hs.amax_x[0]);
+            if (tid < 128) h3x_[tid] = h3_inv(sx);
+        }
+    }
     if (MASKB) bsm[tid] = (m0 + tid) < M ? vg.slope * vg.csum[m0 + tid] : 0.f;
     else bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
     if (it.xr) {
@@ -629,7 +695,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
-    if (NP == 2) h3_unscale(acc, h3_inv(h3_scale(hs.amax_a[0])), h3_inv(sx));
+    if (NP == 2) h3_unscale_rc<!MASKB>(acc, h3a_, h3x_, wave, lane);       // (tables written before the k-loop's barriers)
     if (RSUM) {                                          // (the loop's last barrier made every slot visible)
         if (tid < K) {
             float* rp = vg.rpart + ((long)tid * (N >> 7) + tile_n) * 2;   // [row][tile][2]: a row's partials are contiguous
@@ -729,7 +795,16 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
     const int khalf = lane >> 5;
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
-    const float sx = NP == 2 ? h3_scale(*hs.amax_x) : 1.f;             // h3: power-of-two scale of the streamed operand
+    // h3: power-of-two scales -- per row of A, per column group (image) of the streamed operand (see H3Scale)
+    __shared__ float h3a_[NP == 2 ? DX4_ROWS : 1];
+    __shared__ float h3x_[NP == 2 ? 128 : 1];
+    float sx = 1.f;
+    if (NP == 2) {
+        h3a_[tid] = h3_inv(h3_scale(hs.amax_a[hs.a_rows ? m0g + tid : 0]));
+        if (hs.x_group > 0) sx = h3_scale(hs.amax_x[(long)batch * hs.x_bstride + min((n0 + (tid & 127)) / hs.x_group, hs.x_bstride - 1)]);
+        else sx = h3_scale(hs.amax_x[0]);
+        if (tid < 128) h3x_[tid] = h3_inv(sx);
+    }
 
     const long part_cells = (long)K8pad * Mpad;
     const uint4* a_ptr = A3 + (long)khalf * Mpad + m0g + 64 * wave + (lane & 31);
@@ -818,7 +893,7 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
-    if (NP == 2) h3_unscale(acc, h3_inv(h3_scale(*hs.amax_a)), h3_inv(sx));
+    if (NP == 2) h3_unscale_rc<true>(acc, h3a_, h3x_, wave, lane);
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float gyv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -927,9 +1002,17 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     // h3 arithmetic: power-of-two scales of the two streamed operands (the 0 / 1 operand of the two-valued form has none)
     // The X operand of the two-valued decoder form is gy[n] * (recomputed first-layer activation): hs.amax_x then holds the
     // three maxima of dec_l0_bound_kernel and max |gy| ({max |x'|, max (|w0| + |w1|), max |bc + lb|, max |gy|}).
-    const float sa = (NP == 2 && !LRF) ? h3_scale(*hs.amax_a) : 1.f;
-    float sx = 1.f;
-    if (NP == 2) sx = h3_scale((XVA && LRF) ? __fmaf_rn(hs.amax_x[1], hs.amax_x[0], hs.amax_x[2]) * hs.amax_x[3] : hs.amax_x[0]);
+    // Round 4: one scale per ROW of either operand (a row of dY is a row of dW, a row of X a column of dW; see H3Scale); the
+    // recomputed operand of the two-valued decoder form bounds its own row k: ((|wc[k][0]| + |wc[k][1]|) max |x'| +
+    // max_b |bc[k] + lb[b][k]|) max |gy|  (hs.amax_x[4 + k]: dec_l0_bound_kernel).
+    auto a_scale_of = [&](int m) -> float {             // m: row of the problem, clamped by the caller
+        return h3_scale(hs.amax_a[hs.a_rows ? (long)batch * hs.a_bstride + (hs.a_mod > 0 ? m % hs.a_mod : m) : 0]);
+    };
+    float sa[2] = {1.f, 1.f};
+    if (NP == 2 && !LRF) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sa[i] = a_scale_of(min(m0 + 64 * wave + 32 * i + (lane & 31), M - 1));
+    }
     // ---- DMA sources
     const float* d_ptr[4];                               // A: instruction g, row 16g + lane/4 of this wave, swizzled piece
 #pragma unroll
@@ -952,6 +1035,12 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     const float lb_on = (XVA && va.lb) ? 1.f : 0.f;
     const float* g_src = VIRT ? vg.gy + nbeg + (lane & 15) : nullptr;
     const float va_w0 = XVA ? va.wc[2 * kx] : 0.f, va_w1 = XVA ? va.wc[2 * kx + 1] : 0.f, va_bc = XVA ? va.bc[kx] : 0.f;
+    float sx = 1.f;
+    if (NP == 2) {
+        if (XVA && LRF) sx = h3_scale(__fmaf_rn(fabsf(va_w0) + fabsf(va_w1), hs.amax_x[0], hs.amax_x[4 + kx]) * hs.amax_x[3]);
+        else if (hs.x_group > 0) sx = h3_scale(hs.amax_x[(long)batch * hs.x_bstride + kx / hs.x_group]);
+        else sx = h3_scale(hs.amax_x[0]);
+    }
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)wg_ring +
                               (unsigned)(wave * 3 * WG_SLOT_BYTES);
     const unsigned char* ring = wg_ring + wave * 3 * WG_SLOT_BYTES;
@@ -1075,7 +1164,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float f = NP == 2 ? a_ok[i] * sa : a_ok[i];
+            const float f = NP == 2 ? a_ok[i] * sa[i] : a_ok[i];
             const float v[8] = {r[i][0].x * f, r[i][0].y * f, r[i][0].z * f, r[i][0].w * f,
                                 r[i][1].x * f, r[i][1].y * f, r[i][1].z * f, r[i][1].w * f};
             if (NP == 1) {
@@ -1179,30 +1268,44 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's ring
-    if (NP == 2) h3_unscale(acc, h3_inv(sa), h3_inv(sx));
     float sk[4] = {0.f, 0.f, 0.f, 0.f};                  // slope * s[k] of this lane's four columns
+    float ixv[4] = {1.f, 1.f, 1.f, 1.f};                 // h3: inverse scale of the X row behind each of them
+    float* ssm = reinterpret_cast<float*>(Bs);           // the B stages are free after the loop's last barrier
     if (LRF) {
-        float* ssm = reinterpret_cast<float*>(Bs);       // the B stages are free after the loop's last barrier
         ssum += __shfl_xor(ssum, 1, 64);                 // the four n-quads (tid & 3) of feature row kr
         ssum += __shfl_xor(ssum, 2, 64);
         if (q4 == 0) ssm[kr] = ssum;
-        __syncthreads();
+    }
+    if (NP == 2) {                                       // [128 ..): per tile column (= X row), [256 ..): per tile row of dY
+        if (q4 == 0) ssm[128 + kr] = h3_inv(sx);
+        if (!LRF) ssm[256 + tid] = h3_inv(a_scale_of(min(m0 + tid, M - 1)));
+    }
+    if (LRF || NP == 2) __syncthreads();
+    if (LRF) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) sk[j] = vg.slope * ssm[j * 32 + (lane & 31)];
+    }
+    if (NP == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ixv[j] = ssm[128 + j * 32 + (lane & 31)];
     }
     const float oms = 1.f - vg.slope;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int rl = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + rl;
             if (m >= M) continue;
             const float wm = LRF ? vg.wo[m] : 1.f;       // the row factor of the factored implicit gradient
+            const float ia = (NP == 2 && !LRF) ? ssm[256 + rl] : 1.f;
             float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (k0 + j * 32 + (lane & 31) < Kf)
-                    wrow[j * 32] = LRF ? wm * __fmaf_rn(oms, acc[i][j][r], sk[j]) : acc[i][j][r];
+                if (k0 + j * 32 + (lane & 31) < Kf) {
+                    const float a = NP == 2 ? (acc[i][j][r] * ia) * ixv[j] : acc[i][j][r];     // one factor after the other
+                    wrow[j * 32] = LRF ? wm * __fmaf_rn(oms, a, sk[j]) : a;
+                }
         }
 }
 

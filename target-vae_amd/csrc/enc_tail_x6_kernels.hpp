@@ -172,6 +172,7 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
     // so its scale is the tensor's: max |X| from the kernel that produced X (hs.amax_x; dft_out_ring_kernel's epilogue)
     extern __shared__ __attribute__((aligned(16))) uint4 Ws[];            // [NP][16][128]
     __shared__ __attribute__((aligned(16))) float whs[ET_C * 8];          // row m: Wh[0..6][m], b2[m]
+    __shared__ float ia_sm[NP == 2 ? ET_C : 1];                           // h3: inverse scale of row m of W2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, kh = lane >> 5;
@@ -179,6 +180,7 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
         const int row = i & (ET_C - 1), po = i >> 7;                      // po = part * 16 + octet
         Ws[i] = W3[(long)po * Rpad + row];
     }
+    if (NP == 2 && tid < ET_C) ia_sm[tid] = h3_inv(h3_scale(hs.amax_a[tid]));
     for (int i = tid; i < ET_C * 8; i += ET_THREADS) {
         const int row = i >> 3, o = i & 7;
         whs[i] = o == 7 ? (b2 ? b2[row] : 0.f) : (o < nh ? Wh[o * ET_C + row] : 0.f);
@@ -207,8 +209,12 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
     for (int t = 0; t < ET_D; ++t) load_x(0, t, x[t]);
     Cell16 a0[3], a1[3];
     et_load_a<NP>(Ws, 0, 0, kh, nl, a0);
-    const float sx = NP == 2 ? h3_scale(hs.amax_x[0]) : 1.f;
-    const float inv = NP == 2 ? h3_inv(h3_scale(hs.amax_a[0])) * h3_inv(sx) : 1.f;    // (weights and activations: far inside the fp32 range)
+    // Round 4: hs.amax_a = one maximum per row of W2 (tvae_dense_split2h), hs.amax_x = one per CHANNEL of the streamed operand
+    // (its producer's epilogue).  The channels are this GEMM's reduction index, so the operand takes the largest of them;
+    // the rows of W2 are rows of the product: each accumulator row gets its own inverse (ia_sm).
+    float sx = 1.f;
+    if (NP == 2) sx = h3_scale(h3_wave_max(fmaxf(hs.amax_x[lane], hs.amax_x[64 + lane])));
+    const float ix = h3_inv(sx);
     for (long ci = 0; ci < my; ++ci) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -231,7 +237,7 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] *= inv;
+                for (int r = 0; r < 16; ++r) acc[i][r] = (acc[i][r] * ia_sm[et_row(i, r, kh)]) * ix;
         }
         const long n0 = (gw + ci * gstride) * ET_CHUNK;
         if (bitsA) {
@@ -287,8 +293,9 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
     const int nl = lane & 31, kh = lane >> 5;
     for (int i = tid; i < NP * 16 * ET_C; i += ET_THREADS) Ws[i] = W3p[(long)(i >> 7) * Rpad + (i & (ET_C - 1))];
     for (int i = tid; i < NP1 * 2 * ET_C; i += ET_THREADS) Whs[i] = Wh3[(long)(i >> 7) * Rpadh + (i & (ET_C - 1))];
+    __shared__ float ia_sm[NP == 2 ? ET_C : 1];          // h3: inverse scale of row c of W2^T (one maximum per row: tvae_dense_split2h)
+    if (NP == 2 && tid < ET_C) ia_sm[tid] = h3_inv(h3_scale(amax_a[tid]));
     __syncthreads();
-    const float inv_a = NP == 2 ? h3_inv(h3_scale(*amax_a)) : 1.f;
 
     const long nchunks = (N + ET_CHUNK - 1) / ET_CHUNK;
     const long gw = (long)blockIdx.x * (ET_THREADS / 64) + wave, gstride = (long)gridDim.x * (ET_THREADS / 64);
@@ -352,7 +359,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
-        const float gs_c = gs, inv_c = NP == 2 ? h3_inv(gs) * inv_a : 1.f;   // (both factors far inside the fp32 range here)
+        const float gs_c = gs, inv_c = NP == 2 ? h3_inv(gs) : 1.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float xv[8];
@@ -376,7 +383,7 @@ void enc_tail_dgrad_x6_kernel(const uint4* __restrict__ W3p, int Rpad, const uin
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 char* drow = reinterpret_cast<char*>(dA1 + (long)et_row(i, r, 0) * lda + n0);
-                const float v = (NP == 2 ? acc[i][r] * inv_c : acc[i][r]) * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
+                const float v = (NP == 2 ? (acc[i][r] * ia_sm[et_row(i, r, kh)]) * inv_c : acc[i][r]) * et_mask(wAs[i], 8 * (r >> 2) + (r & 3), slope);
                 if (in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(drow + loff));
             }
     }
@@ -424,7 +431,7 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
     // max |A1| from A1's producer, and for dH = act'(H) . Wh^T dheads the bound max |dheads| * max_row sum_h |Wh[h][row]|
     // (the second factor formed below from the Wh column every thread already holds)
     extern __shared__ __attribute__((aligned(16))) unsigned char ew_sm[];
-    __shared__ float red_[ET_WAVES];
+    __shared__ float red_[NP == 2 ? 2 * ET_C : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ew_sm;
@@ -440,19 +447,21 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
     float wh[ET_MAXH];
 #pragma unroll
     for (int h = 0; h < ET_MAXH; ++h) wh[h] = h < nh ? Wh[(long)h * ET_C + row] : 0.f;
+    // Round 4: the rows of both operands are rows / columns of dW2, so each gets its own power of two: channel `row` of A1 from
+    // its producer's per-channel maximum, row `row` of dH from the bound max |dheads| * sum_h |Wh[h][row]| of that row alone.
     float sA = 1.f, sD = 1.f;
+    float* is_sm = reinterpret_cast<float*>(red_);       // [0 .. 128): 1 / sD[row], [128 .. 256): 1 / sA[row]
     if (NP == 2) {
         float rs = 0.f;
 #pragma unroll
         for (int h = 0; h < ET_MAXH; ++h) rs += fabsf(wh[h]);
-        rs = h3_wave_max(rs);
-        if (lane == 0) red_[wave] = rs;
-        __syncthreads();
-        float whs_ = red_[0];
-#pragma unroll
-        for (int w = 1; w < ET_WAVES; ++w) whs_ = fmaxf(whs_, red_[w]);
-        sA = h3_scale(amax_a1[0]);
-        sD = h3_scale(amax_dh[0] * whs_);
+        sA = h3_scale(amax_a1[row]);
+        sD = h3_scale(amax_dh[0] * rs);
+        if (oct == 0) {
+            is_sm[row] = h3_inv(sD);
+            is_sm[ET_C + row] = h3_inv(sA);
+        }
+        __syncthreads();                                 // (a workgroup without chunks reaches the epilogue without another barrier)
     }
     // DMA role (per wave and chunk: two pieces of A1 + one auxiliary piece = 3 instructions, uniform for the counting):
     //   A1 piece g = 2 wave + q: rows 8 g .. 8 g + 7, lane -> (row 8 g + (lane >> 3), 16-byte piece (lane & 7) of the stage row)
@@ -570,7 +579,8 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] = NP == 2 ? (acc[j][r] * h3_inv(sD)) * h3_inv(sA) : acc[j][r];
+            slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] =
+                NP == 2 ? (acc[j][r] * is_sm[et_row(ti, r, kh)]) * is_sm[ET_C + 32 * (tj + j) + li] : acc[j][r];
 }
 
 // dW2[e] = sum over workgroups of slabs[g][e], in workgroup order

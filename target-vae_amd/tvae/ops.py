@@ -44,13 +44,26 @@ def act_code(activation) -> int:
 # optional in-run kernel timing (bench.py): events are recorded on the stream the kernels are launched on
 # ---------------------------------------------------------------------------------------------
 KERNEL_EVENTS = None     # set to {} to record (start, end) torch.cuda.Event pairs per entry point
+# set to {} to record, per split-pipe entry point, (parts, MFMAs per product block) of EVERY launch as it was actually
+# issued (not as the mode would suggest): bench.py derives its executed-FLOP figures from it, the tests assert on it
+PARTS_LOG = None
+
+
+def mfma_per_block(nparts: int, two_valued: bool = False) -> int:
+    """Matrix instructions per 32x32x16 product block of a split-pipe launch: 6 (three bf16 parts), 3 (two fp16 parts, h3),
+    1 (bf16); against the exact 0 / 1 operand of the two-valued gradient only the other operand's parts count (3 / 2 / 1)."""
+    return {3: 3 if two_valued else 6, 2: 2 if two_valued else 3, 1: 1}[nparts]
 
 
 class _timed:
-    def __init__(self, name):
+    def __init__(self, name, nparts=None, two_valued=False):
         self.name = name
+        self.nparts = nparts
+        self.products = mfma_per_block(nparts, two_valued) if nparts is not None else None
 
     def __enter__(self):
+        if PARTS_LOG is not None and self.nparts is not None:
+            PARTS_LOG.setdefault(self.name, []).append((self.nparts, self.products))
         if KERNEL_EVENTS is not None:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
@@ -60,7 +73,7 @@ class _timed:
     def __exit__(self, *exc):
         if KERNEL_EVENTS is not None:
             self.e.record()
-            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e, self.products))
         return False
 
 
@@ -87,8 +100,14 @@ def kernel_event_ms():
     """Mean milliseconds per launch for every recorded entry point (call after torch.cuda.synchronize())."""
     out = {}
     for k, v in (KERNEL_EVENTS or {}).items():
-        ts = [s.elapsed_time(e) for s, e in v]
-        out[k] = dict(launches=len(ts), mean_ms=sum(ts) / max(len(ts), 1), total_ms=sum(ts))
+        ts = [s.elapsed_time(e) for s, e, _ in v]
+        pr = [p_ for _, _, p_ in v if p_ is not None]
+        out[k] = dict(launches=len(ts), mean_ms=sum(ts) / max(len(ts), 1), total_ms=sum(ts),
+                      # MFMAs per product block as launched: time-weighted mean (all launches of an entry do the same
+                      # algorithmic work in the bench) and the distinct values seen
+                      mfma_per_block=(sum(p_ * t for (_, _, p_), t in zip(v, ts) if p_ is not None) /
+                                      max(sum(t for (_, _, p_), t in zip(v, ts) if p_ is not None), 1e-30)) if pr else None,
+                      mfma_per_block_seen=sorted(set(pr)))
     return out
 
 
@@ -189,7 +208,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None) -> torch.Tens
         ws = workspace(dpre.device, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
         # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
         p = 2 if (parts() == 2 and bits is not None and va and virt and virt[2] == ACT_LRELU) else _p3()
-        with _timed('tvae_linear_wgrad_x6'):
+        with _timed('tvae_linear_wgrad_x6', p, bool(virt) and virt[2] == ACT_LRELU):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
                  *(va if va else (None, None, None, None, 0)), bits, p)
@@ -272,18 +291,18 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
         _note('conv1.dft')
         if (n + 2 * pad, n + 2 * pad - k + 1) in DFT_RING_FRAMES:
             _note('conv1.dft_ring')      # ring (LDS-DMA) transforms along w: abi_conv_dft.hip dft_plan
-        with _timed('tvae_conv1_fwd'):
+        with _timed('tvae_conv1_fwd', parts()):
             call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,
                  LRELU_SLOPE, parts())
         if keep is not None:
             keep['at'] = at
-            keep['out_max'] = at[-1:]      # max |out|, left by the output transform (h3 scale of the encoder tail)
+            keep['out_max'] = at[-C:]      # max |out| per channel, left by the output transform (h3 scales of the encoder tail)
         return out
     if _use_x6(Cin, n, k, pad):
         a3 = _scratch(y.device, 'x6_bank', query('tvae_conv1_x6_bank_bytes', C, R, Cin, k) // 4)
         call('tvae_bank_split3', bank, a3, a3.numel() * 4, C, R, Cin, k)
         _note('conv1.x6')
-        with _timed('tvae_conv1_fwd'):
+        with _timed('tvae_conv1_fwd', 3):
             call('tvae_conv1_fwd_x6', y, a3, bias, out, B, Cin, n, k, pad, C, R, act, LRELU_SLOPE)
         return out
     _note('conv1.f32')
@@ -299,14 +318,14 @@ def conv1_wgrad(y, dpre, C, R, k, pad, at=None, dbias=None):
     dbank = torch.empty(C * R, Cin * k * k, dtype=torch.float32, device=y.device)
     if at is not None:
         wsd = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
-        with _timed('tvae_conv1_wgrad'):
+        with _timed('tvae_conv1_wgrad', parts()):
             call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, wsd, wsd.numel(), B, Cin, n, k, pad, C, R, parts())
         return dbank
     ws = workspace(y.device, max(1 << 24, 16 * dbank.numel()))
     if _use_x6(Cin, n, k, pad):
         d3 = _scratch(y.device, 'x6_dy', query('tvae_conv1_x6_dy_bytes', B, C, R, n, k, pad) // 4)
         call('tvae_dy_split3', dpre, d3, d3.numel() * 4, B, Cin, n, k, pad, C, R)
-        with _timed('tvae_conv1_wgrad'):
+        with _timed('tvae_conv1_wgrad', 3):
             call('tvae_conv1_wgrad_x6', y, d3, dbank, ws, ws.numel(), B, Cin, n, k, pad, C, R)
         return dbank
     with _timed('tvae_conv1_wgrad'):
@@ -419,7 +438,7 @@ class EncoderFn(torch.autograd.Function):
             _note('enc.tail_fwd_x6')
             if act == ACT_LRELU:                         # sign words of H and A1: all the fused data gradient reads of them
                 bits = torch.empty(2, N, 4, dtype=torch.int32, device=y.device)
-            with _timed('tvae_enc_tail_fwd_x6'):
+            with _timed('tvae_enc_tail_fwd_x6', p_f):
                 call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N,
                      bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act,
                      LRELU_SLOPE, p_f, a1max)
@@ -455,7 +474,7 @@ class EncoderFn(torch.autograd.Function):
             call('tvae_dense_split3', Wh.contiguous(), C2, wh3, wh3.numel() * 4, C2, nh, 1, None, None)
             dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
             _note('enc.tail_dgrad_x6')
-            with _timed('tvae_enc_tail_dgrad_x6'):
+            with _timed('tvae_enc_tail_dgrad_x6', p_e):
                 call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads, N, nh, ctx.bits[0], ctx.bits[1], dA1, N, C, N,
                      LRELU_SLOPE, p_e)
         # conv2's weight gradient in one pass from A1, the head gradients and the sign words of H (dH is formed inside the
@@ -479,7 +498,7 @@ class EncoderFn(torch.autograd.Function):
             dW2 = torch.empty(C2, C, dtype=torch.float32, device=y.device)
             wsw = _scratch(y.device, 'enc_wgrad_slabs', query('tvae_enc_tail_wgrad_x6_ws_floats', N))
             p_w = 2 if (parts() == 2 and ctx.a1max is not None) else _p3()
-            with _timed('tvae_enc_tail_wgrad_x6'):
+            with _timed('tvae_enc_tail_wgrad_x6', p_w):
                 call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, ctx.bits[0], Wh.contiguous(), dW2, wsw, wsw.numel(), C,
                      N, LRELU_SLOPE, p_w, ctx.a1max if p_w == 2 else None)
         else:
@@ -771,7 +790,7 @@ class DecoderFn(torch.autograd.Function):
                 if zx:
                     feat_all[Ff:].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
                 w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
-                with _timed('tvae_linear_fwd_x6'):
+                with _timed('tvae_linear_fwd_x6', _p3()):
                     call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
                          None, None, None, None, None, None, None, 0, None, _p3())
             else:
@@ -796,7 +815,7 @@ class DecoderFn(torch.autograd.Function):
                         and F_ >= 256 and Nt % 32 == 0):
                     sbits = torch.empty(F_, Nt // 32, dtype=torch.int32, device=dev)
                     _note('dec.sign_bits')
-                with _timed('tvae_linear_fwd_x6'):
+                with _timed('tvae_linear_fwd_x6', p_l):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
@@ -887,7 +906,7 @@ class DecoderFn(torch.autograd.Function):
                     part_f = workspace(dev, (Nt // 128) * F_ * 3)
                 rs = two_val and fuse_rs
                 rs_part = _scratch(dev, 'dec_rs_part', (Nt // 128) * F_ * 2) if rs else None
-                with _timed('tvae_linear_dgrad_x6'):
+                with _timed('tvae_linear_dgrad_x6', p_d, two_val):
                     call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
@@ -932,7 +951,7 @@ class DecoderFn(torch.autograd.Function):
             dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(Ff, Nt):
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
-                with _timed('tvae_linear_dgrad_x6'):
+                with _timed('tvae_linear_dgrad_x6', _p3()):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
                          None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, _p3())
             else:

@@ -129,16 +129,20 @@ def test_encoder_kink_free_probe_at_bench_size(B):
     g_o = {k_: v.grad for k_, v in encp.items()}
 
     enc = enc.to(dev())
-    ops.PATH_LOG = set()
+    ops.PATH_LOG, ops.PARTS_LOG = set(), {}
     try:
         heads = enc.encode_heads(y.to(dev()))                                  # [7][B*R*Ho*Ho] feature-major
         Wd = W.permute(1, 0, 2, 3, 4).reshape(heads.shape[0], -1).contiguous().to(dev())
         (heads * Wd).sum().backward()
         torch.cuda.synchronize()
-        took = set(ops.PATH_LOG)
+        took, parts_log = set(ops.PATH_LOG), dict(ops.PARTS_LOG)
     finally:
-        ops.PATH_LOG = None
-    assert {'conv1.dft', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'} <= took, took      # the timed branches ran
+        ops.PATH_LOG, ops.PARTS_LOG = None, None
+    assert {'conv1.dft', 'conv1.dft_ring', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6', 'enc.tail_wgrad_x6'} <= took, took   # the timed branches ran
+    from tvae import _lib
+    if _lib.get_gemm_mode() == 'h3':                     # ... in their two-part instances (parts as passed to the C ABI)
+        for k_ in ('tvae_conv1_fwd', 'tvae_conv1_wgrad', 'tvae_enc_tail_fwd_x6', 'tvae_enc_tail_dgrad_x6', 'tvae_enc_tail_wgrad_x6'):
+            assert parts_log.get(k_) == [(2, 3)], (k_, parts_log.get(k_))
     ho = heads_o.shape[-1]
     want_h = heads_o.detach().permute(1, 0, 2, 3, 4).reshape(heads.shape[0], -1)
     assert rel_err(heads.detach(), want_h) < 1e-4

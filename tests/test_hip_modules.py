@@ -205,8 +205,9 @@ def test_step_golden(name):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
 
 
-HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
-                                'dec.sign_bits', 'dec.fuse_in', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
+HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'conv1.dft_ring', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
+                                'dec.sign_bits', 'dec.fuse_in', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6',
+                                'enc.tail_wgrad_x6'}),
        'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
                                'dec.sign_bits', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
        # the reference's real MNIST-U / MNIST-N geometry (50x50, k = 28, p = 8: train_mnist.py:413-417): the 66-wide frame
@@ -229,19 +230,29 @@ def test_step_hot_widths_golden(name, gemm_mode):
     enc, gen = enc.to(dev()), gen.to(dev())
     x = O.image_coords(n).to(dev())
     noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
-    ops.PATH_LOG, ops.KERNEL_EVENTS = set(), {}
+    ops.PATH_LOG, ops.KERNEL_EVENTS, ops.PARTS_LOG = set(), {}, {}
     try:
         elbo, logp, kl = step.elbo_terms(x, torch.from_numpy(fx['y']).to(dev()), gen, enc, lik, noise)
         (-elbo).backward()
         torch.cuda.synchronize()
-        took, events = set(ops.PATH_LOG), set(ops.KERNEL_EVENTS)
+        took, events, parts_log = set(ops.PATH_LOG), set(ops.KERNEL_EVENTS), dict(ops.PARTS_LOG)
     finally:
-        ops.PATH_LOG, ops.KERNEL_EVENTS = None, None
+        ops.PATH_LOG, ops.KERNEL_EVENTS, ops.PARTS_LOG = None, None, None
     if gemm_mode in ('x6', 'h3'):
         assert want <= took, (want - took, took)
         assert ({'tvae_conv1_fwd', 'tvae_conv1_wgrad'} if name == 'hot_M50_B2' else
                 {'tvae_linear_fwd_x6', 'tvae_linear_dgrad_x6', 'tvae_linear_wgrad_x6', 'tvae_conv1_fwd',
                  'tvae_conv1_wgrad'}) <= events, events
+    if name == 'hot_S64_B2' and gemm_mode in ('x6', 'h3'):
+        # the arithmetic that REACHED the entry points: in h3 every big launch of the timed step runs
+        # its two-part instance (parts == 2; 3 / 2 matrix instructions per product block), in x6 the three-part one
+        p = 2 if gemm_mode == 'h3' else 3
+        blocks = {'tvae_conv1_fwd': ops.mfma_per_block(p), 'tvae_conv1_wgrad': ops.mfma_per_block(p),
+                  'tvae_linear_fwd_x6': ops.mfma_per_block(p), 'tvae_linear_dgrad_x6': ops.mfma_per_block(p, True),
+                  'tvae_linear_wgrad_x6': ops.mfma_per_block(p, True), 'tvae_enc_tail_fwd_x6': ops.mfma_per_block(p),
+                  'tvae_enc_tail_dgrad_x6': ops.mfma_per_block(p), 'tvae_enc_tail_wgrad_x6': ops.mfma_per_block(p)}
+        for k_, b_ in blocks.items():
+            assert parts_log.get(k_) == [(p, b_)], (k_, parts_log.get(k_))
     assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
     assert abs(float(logp) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
     assert abs(float(kl) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL

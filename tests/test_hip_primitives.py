@@ -473,6 +473,156 @@ def test_h3_decoder_entry_points(sw, sg, sx):
     assert rel_err(Yt, act_ref(W.double() @ h0t.double().cpu() + b.double()[:, None], 2)) < GEMM_TOL['f32']
 
 
+def row_rel_err(got, ref, dim=0):
+    """Largest PER-ROW relative error: max over the slices along `dim` of |got - ref|_2 / |ref|_2 (slices that are
+    exactly zero in the reference must be exactly zero)."""
+    g = got.detach().double().cpu().movedim(dim, 0).reshape(got.shape[dim], -1)
+    r = ref.detach().double().cpu().movedim(dim, 0).reshape(ref.shape[dim], -1)
+    num, den = (g - r).norm(dim=1), r.norm(dim=1)
+    assert bool((num[den == 0] == 0).all())
+    return float((num[den > 0] / den[den > 0]).max())
+
+
+ROW_TOL = 1e-5          # VERDICT r03 item 2b: per-ROW relative error against fp64, rows scaled by 2^-16 .. 2^-32 inside a tensor
+
+
+@pytest.mark.parametrize('e', [16, 24, 32])
+def test_h3_row_dynamic_range_decoder(e):
+    """h3 (parts = 2) with ONE ROW of an operand 2^-e below the rest of its tensor: the output row / column that row feeds
+    must be as accurate RELATIVE TO ITSELF as every other one (round 3 scaled per tensor: 4.8e-5 at e = 24, 1.3e-2 at e = 32).
+    Decoder launches: forward (a row of W), two-valued data gradient (a column of W = a row of W^T), weight gradient from sign
+    bits against the recomputed operand (a hidden unit of the coordinate layer = a row of the X operand)."""
+    from tvae._lib import query
+    s = 2.0 ** -e
+    F_, B, Np, M, act = 512, 2, 256, 512, 1
+    Nt = B * Np
+    r0, k0, u0 = 37, 301, 100
+    xr = rnd(Nt, 2, seed=1).to(dev())
+    Wc, bc, LB = rnd(F_, 2, seed=2), rnd(F_, seed=3), rnd(B, F_, seed=4)
+    Wc[u0] *= s; bc[u0] *= s; LB[:, u0] *= s             # hidden unit u0 of the coordinate layer: h0[u0][:] is 2^-e small
+    Wc, bc, LB = Wc.to(dev()), bc.to(dev()), LB.to(dev())
+    h0 = torch.empty(F_, Nt, device=dev())
+    call('tvae_dec_l0_fwd', xr, Wc, bc, LB, h0, Nt, F_, Nt, Np, act, SLOPE)
+    H0 = h0.double().cpu()
+    W, b = rnd(M, F_, seed=5, scale=F_ ** -0.5), rnd(M, seed=6)
+    W[r0] *= s; b[r0] *= s                                # output row r0 of the layer
+    W[:, k0] *= s                                         # input feature k0: row k0 of W^T (the data gradient's operand)
+    wo, gy = rnd(M, seed=8), rnd(Nt, seed=9)
+    va = (xr, Wc, bc, LB, Np)
+    w3 = torch.empty(query('tvae_dense_x6_bytes', M, F_) // 4, device=dev())
+    call('tvae_dense_split2h', W.to(dev()), F_, w3, w3.numel() * 4, M, F_, 0, None, None)
+    Y = torch.empty(M, Nt, device=dev())
+    bits = torch.empty(M, Nt // 32, dtype=torch.int32, device=dev())
+    call('tvae_linear_fwd_x6', w3, None, b.to(dev()), None, Y, M, Nt, F_, Nt, Nt, act, SLOPE, None, None, None, *va, bits, 2)
+    ref_Y = act_ref(W.double() @ H0 + b.double()[:, None], act)
+    assert row_rel_err(Y, ref_Y) < ROW_TOL
+    assert float(ref_Y[r0].abs().max()) < 64 * s          # (the scaled row really is that small)
+    Yd = Y.double().cpu()
+    w3t = torch.empty(query('tvae_dense_x6_bytes', F_, M) // 4, device=dev())
+    csum = torch.empty(F_, device=dev())
+    call('tvae_dense_split2h', W.to(dev()), F_, w3t, w3t.numel() * 4, F_, M, 1, wo.to(dev()), csum)
+    dX = torch.empty(F_, Nt, device=dev())
+    rs_part = torch.empty((Nt // 128) * M * 2, device=dev())
+    gys = gy.sum().reshape(1).to(dev())
+    rs_db, rs_dwo = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, Y, None, h0, dX, M, Nt, F_, Nt, Nt, 1, SLOPE, None, None, None, None, 0, None,
+         gy.to(dev()), csum, None, None, 0, rs_part, rs_part.numel(), wo.to(dev()), gys, rs_db, rs_dwo, 2)
+    d = wo.double()[:, None] * gy.double()[None, :] * dact_ref(Yd, 1)
+    ref_dX = (W.double().t() @ d) * dact_ref(H0, 1)
+    assert row_rel_err(dX, ref_dX) < ROW_TOL
+    ws = torch.empty(query('tvae_linear_wgrad_x6_ws_floats', M, Nt, F_), device=dev())
+    dW = torch.empty(M, F_, device=dev())
+    call('tvae_linear_wgrad_x6', None, None, dW, ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, wo.to(dev()), gy.to(dev()), 1, SLOPE,
+         *va, bits, 2)
+    ref_dW = d @ H0.t()
+    assert row_rel_err(dW, ref_dW, dim=1) < ROW_TOL      # per COLUMN of dW = per row of the X operand
+    assert float(ref_dW[:, u0].abs().max()) < 1e4 * s
+
+
+@pytest.mark.parametrize('e', [16, 24, 32])
+@pytest.mark.parametrize('B,n,k,pad,C,R', [(24, 64, 64, 16, 16, 8), (6, 28, 28, 8, 16, 8), (2, 96, 32, 16, 4, 4)])
+def test_h3_row_dynamic_range_conv1(B, n, k, pad, C, R, e):
+    """The frequency-domain lifting convolution in h3 with one FILTER (all its spectrum rows) and one IMAGE 2^-e below the
+    rest: the outputs of that filter / that image, and that filter's weight gradient, to 1e-5 relative to themselves (ring,
+    register-staged and generic transforms along w)."""
+    from tvae._lib import query
+    s = 2.0 ** -e
+    Cin = 1
+    c0, b0 = 3, 1
+    y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
+    y[b0] *= s
+    bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bank.view(C, R, -1)[c0] *= s
+    Ho = n + 2 * pad - k + 1
+    ref = F.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho)
+    at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev())
+    ws = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
+    out = torch.empty(C, B * R * Ho * Ho, device=dev())
+    call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), None, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, 0, SLOPE, 2)
+    got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+    # per (image, filter) block: the dim image under the dim filter is 2^-2e below the rest
+    g2 = got.reshape(B * C, -1)
+    r2 = ref.reshape(B * C, -1)
+    assert row_rel_err(g2, r2) < ROW_TOL
+    # the per-channel maxima the output transform leaves for the encoder tail (last C floats behind A^T)
+    assert torch.allclose(at[-C:].cpu(), got.abs().amax(dim=(0, 2, 3, 4)).cpu(), rtol=0, atol=0)
+    g = rnd(B, C, R, Ho, Ho, seed=4)
+    g[:, c0] *= s                                         # the gradient that reaches a dead filter
+    ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
+    dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
+    dbank = torch.empty(C * R, Cin * k * k, device=dev())
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, None, ws, ws.numel(), B, Cin, n, k, pad, C, R, 2)
+    assert row_rel_err(dbank.view(C * R, -1), ref_g.reshape(C * R, -1)) < ROW_TOL
+
+
+@pytest.mark.parametrize('e', [16, 24, 32])
+def test_h3_row_dynamic_range_enc_tail(e):
+    """The fused encoder tail in h3 with rows of its operands 2^-e below the rest: a row of W2 (forward), a column of W2
+    (data gradient), a channel of A1 and a column of Wh (= a row of dH) in the weight gradient."""
+    from tvae._lib import query
+    from tvae.ops import _enc_tail_perm
+    s = 2.0 ** -e
+    C, nh, N = 128, 7, 4096
+    r0, k0, a0, h0_ = 5, 77, 40, 19
+    W2, b2 = rnd(C, C, seed=1, scale=C ** -0.5), rnd(C, seed=2)
+    Wh, bh = rnd(nh, C, seed=3, scale=C ** -0.5), rnd(nh, seed=4)
+    A1 = rnd(C, N, seed=5)
+    W2[r0] *= s; b2[r0] *= s
+    W2[:, k0] *= s
+    A1[a0] *= s
+    Wh[:, h0_] *= s
+    a1max = A1.abs().amax(dim=1).contiguous().to(dev())
+    w32 = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev())
+    call('tvae_dense_split2h', W2.to(dev()), C, w32, w32.numel() * 4, C, C, 0, None, None)
+    H = torch.empty(C, N, device=dev())
+    heads = torch.empty(nh, N, device=dev())
+    bits_h = torch.zeros(N, 4, dtype=torch.int32, device=dev())
+    bits_a = torch.zeros(N, 4, dtype=torch.int32, device=dev())
+    call('tvae_enc_tail_fwd_x6', w32, A1.to(dev()), N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H, N, heads, N, bits_h, bits_a,
+         C, N, 1, SLOPE, 2, a1max)
+    Hr = act_ref(W2.double() @ A1.double() + b2.double()[:, None], 1)
+    assert row_rel_err(H, Hr) < ROW_TOL
+    Hs = H.double().cpu()
+    dheads = rnd(nh, N, seed=6)
+    w3p = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev())
+    call('tvae_dense_split2h', W2.t()[:, _enc_tail_perm(dev()).cpu()].contiguous().to(dev()), C, w3p, w3p.numel() * 4, C, C, 0,
+         None, None)
+    wh3 = torch.empty(query('tvae_dense_x6_bytes', C, nh) // 4, device=dev())
+    call('tvae_dense_split3', Wh.to(dev()), C, wh3, wh3.numel() * 4, C, nh, 1, None, None)
+    dA1 = torch.empty(C, N, device=dev())
+    call('tvae_enc_tail_dgrad_x6', w3p, wh3, dheads.to(dev()), N, nh, bits_h, bits_a, dA1, N, C, N, SLOPE, 2)
+    dH = (Wh.double().t() @ dheads.double()) * dact_ref(Hs, 1)
+    ref = (W2.double().t() @ dH) * dact_ref(A1.double(), 1)
+    assert row_rel_err(dA1, ref) < ROW_TOL
+    wsl = torch.empty(query('tvae_enc_tail_wgrad_x6_ws_floats', N), device=dev())
+    dW2 = torch.empty(C, C, device=dev())
+    call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, dheads.to(dev()), N, nh, bits_h, Wh.to(dev()), dW2, wsl, wsl.numel(), C, N,
+         SLOPE, 2, a1max)
+    ref_w = dH @ A1.double().t()
+    assert row_rel_err(dW2, ref_w, dim=0) < ROW_TOL      # rows = rows of dH (column h0_ of Wh)
+    assert row_rel_err(dW2, ref_w, dim=1) < ROW_TOL      # columns = channels of A1
+
+
 @pytest.mark.parametrize('F_,B,Np,act,has_lb', [(512, 3, 256, 1, True), (300, 2, 384, 2, True), (256, 2, 128, 1, False)])
 def test_linear_x6_recomputed_first_layer_operand(F_, B, Np, act, has_lb):
     """The output of the coordinate layer formed inside its three consumers (forward X, data-gradient mask, weight-gradient
@@ -655,14 +805,14 @@ def test_enc_tail_x6(N, nh, act, parts):
     assert rel_err(H, Hr) < tol
     assert rel_err(heads, hr) < tol
     if parts == 3:
-        # the same launch in the h3 arithmetic: two fp16 parts under the scale of max |A1| (a device word from A1's producer),
+        # the same launch in the h3 arithmetic: two fp16 parts under the scale of max |A1| (per-channel device words from A1's producer),
         # for activations of size 1, 1e-5 and 1e3 (a bound 64 x too large must not matter either)
         w32 = torch.empty(query('tvae_dense_x6_bytes', C, C) // 4, device=dev())
         call('tvae_dense_split2h', W2.to(dev()), C, w32, w32.numel() * 4, C, C, 0, None, None)
         # (tanh at 1e3 saturates: every arithmetic then differs where a pre-activation of size 1 is a difference of terms of size 1e3)
         for sc, slack in ((1.0, 1.0), (1e-5, 1.0)) + (((1e3, 64.0),) if act != 2 else ()):
             A1s = (A1 * sc).to(dev())
-            amax = (A1s.abs().max() * slack).reshape(1)
+            amax = (A1s.abs().amax(dim=1) * slack).contiguous()      # one maximum per channel (ABI 5), from A1's producer
             H2, h2 = torch.full((C, N), float('nan'), device=dev()), torch.full((nh, N), float('nan'), device=dev())
             call('tvae_enc_tail_fwd_x6', w32, A1s, N, b2.to(dev()), Wh.to(dev()), bh.to(dev()), nh, H2, N, h2, N, None, None, C, N,
                  act, SLOPE, 2, amax)
@@ -718,7 +868,7 @@ def test_enc_tail_x6(N, nh, act, parts):
             for sc in (1.0, 1e-7):
                 dW2h = torch.full((C, C), float('nan'), device=dev())
                 call('tvae_enc_tail_wgrad_x6', A1.to(dev()), N, (dheads * sc).to(dev()), N, nh, bits_h, Wh.to(dev()), dW2h, wsl,
-                     wsl.numel(), C, N, SLOPE, 2, A1.abs().max().reshape(1).to(dev()))
+                     wsl.numel(), C, N, SLOPE, 2, A1.abs().amax(dim=1).contiguous().to(dev()))
                 assert rel_err(dW2h, (dH @ A1.double().t()) * sc) < TOL, sc
         npan = (N + 511) // 512
         part = torch.empty(npan * C * (nh + 1), device=dev())
