@@ -111,6 +111,8 @@ def parse_args():
     ap.add_argument('--no-f32-companion', action='store_true',
                     help="skip the extra measurements of the same steps in the all-fp32-MFMA mode (TVAE_GEMM=f32) and in "
                          "the opt-in bf16 throughput mode")
+    ap.add_argument('--no-small-batch', action='store_true',
+                    help='skip the 32 / 64 / 128 images-per-step points and the one-rank all-reduce timing (N = 1)')
     ap.add_argument('--no-strong', action='store_true',
                     help='N > 1: skip the extra strong-scaling measurement (global batch fixed at the per-GPU batch)')
     ap.add_argument('--graph', action='store_true',
@@ -352,6 +354,57 @@ def main():
         strong = {'scaling': 'strong', 'global_batch': bs * world, 'per_gpu_batch': bs,
                   'value': world * bs * args.steps / dts, 'unit': 'images/sec', 'ms_per_step': 1e3 * dts / args.steps,
                   'steps': args.steps, 'warmup': 2}
+    # single-GPU proxy for the strong-scaling question: what does a step cost when the SAME global batch of
+    # 256 is divided over 8 / 4 / 2 GPUs, i.e. 32 / 64 / 128 images per step on one GPU -- ms per step, images/s and the ratio
+    # of the per-image rate to the B = 256 rate (1.0 = every grid still fills the chip).  Plus the measured duration of the
+    # gradient all-reduce's one-rank RCCL call on the real 3.2 MB flat buffer (launch + kernel; the multi-rank ring time is the
+    # driver's to measure).  If 32 images per GPU run well under 75 % of the B = 256 rate, 6x at 8 GPUs is out of reach for
+    # the strong-scaling line whatever the collective costs.
+    small_batch = None
+    if world == 1 and args.workload == 'S64' and not (args.no_small_batch or args.no_f32_companion) and gs_box[0] is None:
+        small_batch = {'per_image_rate_at_full_batch': B * args.steps / dt, 'full_batch': B, 'points': []}
+        for bs in (32, 64, 128):
+            if bs >= B:
+                continue
+            for i in range(2):
+                one_step(i, bs)
+            barrier()
+            tsb = time.perf_counter()
+            for i in range(args.steps):
+                one_step(args.warmup + i, bs)
+            barrier()
+            dsb = time.perf_counter() - tsb
+            small_batch['points'].append({'images_per_step': bs, 'ms_per_step': 1e3 * dsb / args.steps,
+                                          'value': bs * args.steps / dsb, 'unit': 'images/sec',
+                                          'ratio_to_full_batch_rate': (bs * args.steps / dsb) / (B * args.steps / dt),
+                                          'implied_speedup_at_%d_gpus' % (B // bs): (B // bs) * (bs * args.steps / dsb) /
+                                          (B * args.steps / dt)})
+        try:
+            if not dist.is_initialized():
+                import tempfile
+                store = tempfile.NamedTemporaryFile(prefix='tvae_bench_pg_', delete=True)
+                dist.init_process_group('nccl', init_method='file://' + store.name + '.store', rank=0, world_size=1)
+                made_pg = True
+            else:
+                made_pg = False
+            buf = torch.zeros_like(opt.flat_g)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(20):
+                dist.all_reduce(buf)
+            eb.record()
+            torch.cuda.synchronize()
+            small_batch['allreduce_one_rank'] = {'backend': dist.get_backend() + ' (RCCL)', 'payload_bytes': int(buf.numel()) * 4,
+                                                 'ms_per_call': ea.elapsed_time(eb) / 20,
+                                                 'note': 'world_size 1: launch + the collective kernel on the real gradient '
+                                                         'buffer; not a ring time'}
+            if made_pg:
+                dist.destroy_process_group()
+        except Exception as ex:       # the collective is a side measurement: never let it take the bench line down
+            small_batch['allreduce_one_rank'] = {'error': repr(ex)[:200]}
     # companion measurement: the same number of steps with every matrix product on the exact fp32 MFMA
     companion = None
     if world == 1 and mode in ('x6', 'h3') and not args.no_f32_companion:
@@ -605,6 +658,8 @@ def main():
         }
         if strong is not None:
             out['strong_scaling'] = strong
+        if small_batch is not None:
+            out['small_batch'] = small_batch
         if enc_fwd is not None:
             out['encoder_forward'] = enc_fwd
         if enc_tail:

@@ -157,7 +157,15 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
-                         float* rs_dwo, int parts, tvae_stream_t stream);
+                         float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
+                         tvae_stream_t stream);
+/* ABI 5, the two-valued form WITHOUT the saved activation (vg_bits != NULL; dpre may then be NULL): the 0 / 1 operand
+ * [H > 0] and the row sums sum_n gy[n] [H[m][n] > 0] come from the sign bits the forward launch stored (tvae_linear_fwd_x6
+ * sign_bits; that launch may then be given Y = NULL and never writes H), and the weight gradient of the single-output
+ * Linear behind the layer, dWo[m] = sum_n gy[n] H[m][n], from the identity act(p) = act'(p) p of LeakyReLU:
+ *     rs_dwo[m] = rs_rowdot[m] + rs_bias[m] * sum_n gy[n] act'(H[m][n]),   rs_rowdot[m] = sum_k W[m][k] G[m][k]
+ * (G = this layer's weight gradient before its row factor wo[m]: tvae_linear_wgrad_x6 rd_rowdot, which must run first;
+ * rs_bias = the layer's bias or NULL).  Requires vg_csum, rs_part .. rs_dwo, N % 32 == 0. */
 /* Row sums of the streamed activation (ABI 3; two-valued form only, i.e. vg_csum given; M <= 512): with rs_part
  * [M][N/128][2] (workspace), rs_wo [M] (the single-output Linear's weight, src/models.py:121-123), rs_gysum [1] = sum_n
  * vg_gy[n], the launch also returns rs_db [M] = wo[m] sum_n gy[n] act'(H[m][n]) (bias gradient of the layer that produced
@@ -176,7 +184,11 @@ long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K);
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, const void* vg_bits, int parts, tvae_stream_t stream);
+                         int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
+                         tvae_stream_t stream);
+/* rd_rowdot (optional, ABI 5; two-valued LeakyReLU form, accumulate = 0): also returns rd_rowdot[m] = sum_k rd_w[m][k] G[m][k]
+ * with G[m][k] = dW[m][k] / wo[m] taken BEFORE the multiplication (exact for wo[m] = 0); rd_w = the layer's weight, [M][K]
+ * with row stride rd_ldw. */
 /* `parts` (every *_x6 / *_dft compute entry): 3 = the exact three-part bf16 split (six products per block, fp32-equivalent
  * results: the default of the Python layer); 1 = operands rounded to ONE bf16 number (a single product per block, fp32
  * accumulate): the bf16 throughput mode BASELINE.json names for configs 2 and 5 -- about 3 significant digits per

@@ -190,6 +190,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
                        n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);
     TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dft_fmax_kernel, dim3(q.Lh), dim3(256), 0, st, (const float*)mxp.cmax, mxp.fmax, B);
+    TVAE_CHECK_LAUNCH();
     // split the stacked spectral weights [Lh*2M rows][2L] into cells, then ONE batched launch of the split dense GEMM
     const int rows = q.Lh * q.Mb;
     int rc = 0;

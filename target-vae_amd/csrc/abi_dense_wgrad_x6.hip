@@ -10,7 +10,7 @@ namespace tvae {
 int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M, int Kf, int N,
                            int nchunk, const TileMap& tm, const DenseBatch& bt, long dy_stride, const ATile& atile,
                            int parts, hipStream_t st, H3Scale hs) {
-    const VirtGrad vg{nullptr, nullptr, 0, 0.f};
+    const VirtGrad vg{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0};
     const VirtAct va{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f};
     if (parts == 1) return dense_wgrad_x6_launch_p1(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
     if (parts == 2 && hs.amax_a && hs.amax_x)
@@ -19,6 +19,27 @@ int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, 
     return (int)hipErrorInvalidValue;
 }
 }  // namespace tvae
+
+namespace {
+// Second half of the finalize of the two-valued weight gradient with RAW slabs (VirtGrad.raw: the row factor wo[m] left off;
+// the generic split-K finalize has just left G = sum of the slices in dW): one workgroup per row m writes
+// dW[m][k] = wo[m] G[m][k] in place and the row's dot product with the layer's own weight, rowdot[m] = sum_k W[m][k] G[m][k]
+// -- from which the weight gradient of the single-output Linear BEHIND this layer follows without the layer's activation
+// ever having been stored (VirtGrad, dense_x6_kernels.hpp).
+__global__ void wgrad_lrf_rowdot_kernel(int K, const float* __restrict__ wo, const float* __restrict__ W, long ldw,
+                                        float* __restrict__ dW, float* __restrict__ rowdot) {
+    __shared__ float sm[16];
+    const int m = blockIdx.x;
+    float acc[1] = {0.f};
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float g = dW[(long)m * K + k];
+        dW[(long)m * K + k] = wo[m] * g;
+        acc[0] = __fmaf_rn(W[(long)m * ldw + k], g, acc[0]);
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) rowdot[m] = acc[0];
+}
+}  // namespace
 
 extern "C" {
 
@@ -42,7 +63,8 @@ long tvae_linear_wgrad_x6_ws_floats(int M, int N, int K) {
 int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws, long ws_floats, int M, int N, int K,
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                         int va_np, const void* vg_bits, int parts, tvae_stream_t stream) {
+                         int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
+                         tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
     if (parts != 1 && parts != 2 && parts != 3) return (int)hipErrorInvalidValue;
@@ -55,7 +77,9 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     if (va_xr ? (va_np % 16 != 0 || !aligned16(va_xr))      // the DMA ring moves 16 columns of one image per step
             : (ldx % 4 != 0 || !X || !aligned16(X)))
         return (int)hipErrorInvalidValue;
-    const VirtGrad vgs{vg_wo, vg_gy, vg_act, vg_slope, nullptr, (const unsigned*)vg_bits};
+    // rowdot (optional; two-valued form only, no accumulation): rd_rowdot[m] = sum_k rd_w[m][k] G[m][k], G = dW before wo[m]
+    if (rd_rowdot && (!rd_w || !(vg_wo && vg_act == ACT_LRELU) || accumulate)) return (int)hipErrorInvalidValue;
+    const VirtGrad vgs{vg_wo, vg_gy, vg_act, vg_slope, nullptr, (const unsigned*)vg_bits, nullptr, rd_rowdot ? 1 : 0};
     const VirtAct vas{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, vg_act, vg_slope};
     const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
     const long per = (long)M * K;
@@ -95,6 +119,10 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, S(stream), (const float*)ws, splits, M, K, ep);
     TVAE_CHECK_LAUNCH();
+    if (rd_rowdot) {                                    // raw slabs: dW holds G; scale the rows by wo, take the row dot products
+        hipLaunchKernelGGL(wgrad_lrf_rowdot_kernel, dim3(M), dim3(128), 0, S(stream), K, vg_wo, rd_w, rd_ldw, dW, rd_rowdot);
+        TVAE_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -15,7 +15,7 @@ int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& e
     return TVAE_DX6_DISPATCH(0, parts, (const uint4*)w3, X, ldx, ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt,
                              ColDot{nullptr, nullptr, nullptr},
                              InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
-                             VirtGrad{nullptr, nullptr, 0, 0.f}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st,
+                             VirtGrad{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0}, VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, st,
                              hs);
 }
 int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
@@ -44,19 +44,23 @@ namespace {
 // One workgroup per row m.
 __global__ void dgrad_rowsum_total_kernel(const float* __restrict__ part, int ntiles, int K, const float* __restrict__ wo,
                                           const float* __restrict__ gysum, float slope, float* __restrict__ db,
-                                          float* __restrict__ dwo) {
+                                          float* __restrict__ dwo, const float* __restrict__ rowdot,
+                                          const float* __restrict__ bias) {
     __shared__ float sm[2 * 16];
     const int m = blockIdx.x;
     float s[2] = {0.f, 0.f};
     for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
         const float2 v = *reinterpret_cast<const float2*>(part + ((long)m * ntiles + t) * 2);
         s[0] += v.x;
-        s[1] += v.y;
+        if (!rowdot) s[1] += v.y;                        // (the bits form writes only the first word)
     }
     block_sum<2>(s, sm);
     if (threadIdx.x == 0) {
-        db[m] = wo[m] * __fmaf_rn(1.f - slope, s[0], slope * gysum[0]);
-        dwo[m] = s[1];
+        const float g0 = __fmaf_rn(1.f - slope, s[0], slope * gysum[0]);      // sum_n gy[n] act'(H[m][n])
+        db[m] = wo[m] * g0;
+        // dWo[m] = sum_n gy[n] H[m][n]: summed directly (s[1]), or -- H never stored -- from the layer's own weight gradient:
+        // sum_k W[m][k] G[m][k] + b[m] g0[m]  (VirtGrad, dense_x6_kernels.hpp; rowdot from wgrad_lrf_finalize_kernel)
+        dwo[m] = rowdot ? __fmaf_rn(bias ? bias[m] : 0.f, g0, rowdot[m]) : s[1];
     }
 }
 }  // namespace
@@ -104,7 +108,7 @@ int tvae_dense_split2h(const float* W, long ldw, void* a3, long a3_bytes, int ro
 static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilogue& ep, int rows, int N, int K, int parts,
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
                            InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
-                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f},
+                           VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0},
                            VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
@@ -132,14 +136,26 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
         }
     }
     // the recomputed operands need tiles inside one image and tables of <= 512 entries
-    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) || (!va.xr && !X))
+    if ((va.xr && (K > 512 || va.Np % 128 != 0 || vg.wo || vg.csum)) || (vg.csum && (!vg.gy || vg.act != ACT_LRELU)) || (it.bc && it.Np % 128 != 0) ||
+        (!va.xr && !X && !(vg.bits && vg.csum && vg.rpart)))
         return (int)hipErrorInvalidValue;
     const DenseBatch nb{0, 0, 0};
+    if (vg.csum && vg.rpart && vg.bits) {                                // operand and row sums from the stored sign bits
+        if (K > DX6_ROWS || N % 32 != 0) return (int)hipErrorInvalidValue;
+        // the hot shape has its own lean instance: ONE full row tile, result not stored, fused first-layer backward with the
+        // recomputed LeakyReLU mask, nothing else switched on
+        if (rows == DX6_ROWS && !ep.C && it.xr && it.bc && !ep.res && ep.mask == ACT_LRELU && !cd.w && !cd.bits)
+            return TVAE_DX6_DISPATCH_E(5, 2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+        return TVAE_DX6_DISPATCH(5, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    }
     if (vg.csum && vg.rpart) {
         if (K > DX6_ROWS) return (int)hipErrorInvalidValue;              // the row sums live in one 512-row LDS table
         return TVAE_DX6_DISPATCH(4, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     }
     if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    // forward of the decoder's last hidden layer with its activation not stored: lean instance (one full row tile)
+    if (va.xr && rows == DX6_ROWS && !ep.C && cd.w && cd.bits && !it.xr && !ep.res && ep.mask == ACT_NONE && ep.act == ACT_LRELU)
+        return TVAE_DX6_DISPATCH_E(2, 1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     return TVAE_DX6_DISPATCH(0, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
@@ -155,7 +171,7 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
     ep.res = res; ep.ldres = ldy;
     ep.act = act; ep.slope = slope;
     return launch_dense_x6(w3, X, ldx, ep, M, N, K, parts, S(stream), ColDot{col_w, col_b, col_y, (unsigned*)sign_bits},
-                           InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f},
+                           InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0},
                            VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
@@ -163,7 +179,8 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
-                         float* rs_dwo, int parts, tvae_stream_t stream) {
+                         float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
+                         tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -176,6 +193,9 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     } else if (!dX) {
         return (int)hipErrorInvalidValue;
     }
+    if (vg_bits && !(vg_csum && rs_part && rs_rowdot && N % 32 == 0))     // the bits form: two-valued, with its row sums and
+        return (int)hipErrorInvalidValue;                                // dWo from the weight-gradient identity
+    if (rs_rowdot && !vg_bits) return (int)hipErrorInvalidValue;
     if (rs_part) {       // row sums of the streamed activation (two-valued form only; M = rows of H <= 512)
         if (!vg_csum || !vg_gy || !rs_wo || !rs_gysum || !rs_db || !rs_dwo || M > DX6_ROWS || N % 128 != 0 ||
             rs_part_floats < (long)(N / 128) * M * 2 || (reinterpret_cast<size_t>(rs_part) & 7))
@@ -183,10 +203,10 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     }
     int rc = launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
                              InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
-                             VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, nullptr, rs_part});
+                             VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, (const unsigned*)vg_bits, rs_part, 0});
     if (rc || !rs_part || N <= 0 || K <= 0) return rc;
     hipLaunchKernelGGL(dgrad_rowsum_total_kernel, dim3(M), dim3(256), 0, S(stream), (const float*)rs_part, N / 128, M, rs_wo,
-                       rs_gysum, slope, rs_db, rs_dwo);
+                       rs_gysum, slope, rs_db, rs_dwo, rs_rowdot, rs_bias);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -31,7 +31,7 @@ static inline float* h3_trailer(const void* a3, int rows, int K) {
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p3(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p2(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##_p1(TVAE_DX6_LAUNCH_ARGS);
-TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DECL(4)
+TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DECL(4) TVAE_DX6_DECL(5)
 #define TVAE_DX6_LAUNCH_DEF(XV_, NP_)                                                                                 \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                       \
@@ -40,6 +40,24 @@ TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DEC
         return (int)hipGetLastError();                                                                                \
     }                                                                                                                 \
     }
+// lean-epilogue instances (dense_x6_kernel<XV, NP, EPI>): abi_dense_x6_v2e1{,b,h}.hip (forward without the stored
+// activation) and abi_dense_x6_v5e2{,b,h}.hip (two-valued data gradient from bits with the fused first-layer backward)
+#define TVAE_DX6_DECL_E(XV_, E_)                                              \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p3(TVAE_DX6_LAUNCH_ARGS); \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p2(TVAE_DX6_LAUNCH_ARGS); \
+    TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p1(TVAE_DX6_LAUNCH_ARGS);
+TVAE_DX6_DECL_E(2, 1) TVAE_DX6_DECL_E(5, 2)
+#define TVAE_DX6_LAUNCH_DEF_E(XV_, NP_, E_)                                                                           \
+    namespace tvae {                                                                                                  \
+    int dense_x6_launch_v##XV_##e##E_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                \
+        hipLaunchKernelGGL((dense_x6_kernel<XV_, NP_, E_>), dim3(tm.grid()), dim3(DX6_THREADS), 0, st, a3, X, ldx, ep, M, \
+                           Mpad, N, K, K8pad, tm, bt, cd, it, vg, va, hs);                                            \
+        return (int)hipGetLastError();                                                                                \
+    }                                                                                                                 \
+    }
+#define TVAE_DX6_DISPATCH_E(XV_, E_, parts_, ...)                            \
+    ((parts_) == 1 ? dense_x6_launch_v##XV_##e##E_##_p1(__VA_ARGS__)           \
+                   : ((parts_) == 2 ? dense_x6_launch_v##XV_##e##E_##_p2(__VA_ARGS__) : dense_x6_launch_v##XV_##e##E_##_p3(__VA_ARGS__)))
 // parts = 3 (exact split), 2 (h3: two fp16 parts) or 1 (bf16 throughput mode); anything else is rejected by the entry points
 #define TVAE_DX6_DISPATCH(XV_, parts_, ...)                            \
     ((parts_) == 1 ? dense_x6_launch_v##XV_##_p1(__VA_ARGS__)           \

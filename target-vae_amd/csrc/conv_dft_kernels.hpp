@@ -150,22 +150,34 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
 // h3 arithmetic of the spectral GEMMs (round 4: one power-of-two scale per row / column group instead of one per tensor):
 // the workgroup that owns a plane and a block of frequencies also leaves, per frequency fx of its block,
 //   images : cmax[fx * B + b]   >= max over (ci, fy, h) |A^T[fx][(ci, ri, fy)][(b, h)]|  (the modulus |Yh| bounds both parts of
-//            Yh e^{i..}): the scale of image b's columns in problem fx of the forward GEMM;  fmax[fx] = max over b: the scale
-//            of the rows of A^T in problem fx of the weight-gradient GEMM;
+//            Yh e^{i..}): the scale of image b's columns in problem fx of the forward GEMM;  fmax[fx] = max over b
+//            (dft_fmax_kernel): the scale of the rows of A^T in problem fx of the weight-gradient GEMM;
 //   filters: wmax[fx * Mb + m] = wmax[fx * Mb + M + m] = max over (ci, fy) of |Kr|, |Ki|: the scale of the two stacked rows.
 // (atomic maxima on the bit patterns: Cin planes meet in a slot; the slots are zeroed by the entry point.)  An image
 // 2^-24 as bright as its neighbours, a filter that has not started to train, the DC plane of un-normalised data: each gets
 // the full two-part precision relative to ITSELF.
 struct DftMax {
     float* cmax;    // [Lh][B]
-    float* fmax;    // [Lh]
+    float* fmax;    // [Lh]   (dft_fmax_kernel: max over the images of cmax)
     float* wmax;    // [Lh][Mb]
 };
+// a slot has one writer per input channel: a plain store with one channel, else a fire-and-forget atomic maximum (no read
+// first: a dependent load per frequency in lane 0 cost the spectra kernel 0.17 ms)
+__device__ __forceinline__ void dft_max_slot(float* slot, float v, bool single) {
+    if (single) *slot = v;
+    else __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(slot), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// fmax[fx] = max_b cmax[fx][b]: one workgroup per frequency (256 atomics from as many workgroups on two cache lines would
+// serialise in the memory system)
+static __global__ void dft_fmax_kernel(const float* __restrict__ cmax, float* __restrict__ fmax, int B) {
+    float m = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) m = fmaxf(m, cmax[(long)blockIdx.x * B + b]);
+    h3_block_amax(m, fmax + blockIdx.x);
+}
 static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
                                           int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
                                           int M, int Mb, int L, int Lh, int FXB, int nblk, DftMax mxp) {
     extern __shared__ float sm_dft[];
-    __shared__ unsigned fmx_[256];                       // per frequency of the block (host: FXB <= 256)
     const int nimg = B * Cin * nblk;
     int id = blockIdx.x;
     const bool is_img = id < nimg;
@@ -175,7 +187,6 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
     const int outer = id / (nblk * Cin);                 // image b or filter m
     const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
     float2 *Yh, *tw;
-    if (threadIdx.x < 256) fmx_[threadIdx.x] = 0u;       // (made visible by the barriers inside dft_plane_spectrum)
     if (is_img) {
         dft_plane_spectrum(sm_dft, y + ((long)outer * Cin + ci) * n * n, n, pad, L, fx0, nfx, FXB, Yh, tw);
         const int total = nfx * L * Ho;
@@ -188,17 +199,16 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             dst[0] = v.x;
             dst[(long)L * NBpad] = v.y;
         }
-        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
-            const int fy = i / nfx, f = i - fy * nfx;
-            const float2 k = Yh[fy * FXB + f];
-            // the modulus, rounded up a little: an upper bound of |Re|, |Im| of Yh e^{i phi} for every phi
-            atomicMax(&fmx_[f], __float_as_uint(sqrtf(__fmaf_rn(k.x, k.x, k.y * k.y)) * 1.000001f));
-        }
-        __syncthreads();
-        for (int f = threadIdx.x; f < nfx; f += blockDim.x) {
-            const float v = __uint_as_float(fmx_[f]);
-            h3_atomic_amax(mxp.cmax + (long)(fx0 + f) * B + outer, v);
-            h3_atomic_amax(mxp.fmax + fx0 + f, v);
+        // one frequency per wave and turn: lanes over fy, wave maximum of the SQUARED modulus (it bounds |Re|, |Im| of
+        // Yh e^{i phi} for every phi), rounded up a little after the root
+        for (int f = threadIdx.x >> 6; f < nfx; f += blockDim.x >> 6) {
+            float q = 0.f;
+            for (int fy = threadIdx.x & 63; fy < L; fy += 64) {
+                const float2 k = Yh[fy * FXB + f];
+                q = fmaxf(q, __fmaf_rn(k.x, k.x, k.y * k.y));
+            }
+            q = h3_wave_max(q);
+            if ((threadIdx.x & 63) == 0) dft_max_slot(mxp.cmax + (long)(fx0 + f) * B + outer, sqrtf(q) * 1.000001f, Cin == 1);
         }
     } else {
         const int m = outer;
@@ -214,16 +224,17 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
             r1[fy] = -k.y;
             r1[L + fy] = k.x;
         }
-        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
-            const int fy = i / nfx, f = i - fy * nfx;
-            const float2 k = Yh[fy * FXB + f];
-            atomicMax(&fmx_[f], __float_as_uint(fmaxf(fabsf(k.x), fabsf(k.y))));
-        }
-        __syncthreads();
-        for (int f = threadIdx.x; f < nfx; f += blockDim.x) {
-            const float v = __uint_as_float(fmx_[f]);
-            h3_atomic_amax(mxp.wmax + (long)(fx0 + f) * Mb + m, v);
-            h3_atomic_amax(mxp.wmax + (long)(fx0 + f) * Mb + M + m, v);
+        for (int f = threadIdx.x >> 6; f < nfx; f += blockDim.x >> 6) {
+            float q = 0.f;
+            for (int fy = threadIdx.x & 63; fy < L; fy += 64) {
+                const float2 k = Yh[fy * FXB + f];
+                q = fmaxf(q, fmaxf(fabsf(k.x), fabsf(k.y)));
+            }
+            q = h3_wave_max(q);
+            if ((threadIdx.x & 63) == 0) {
+                dft_max_slot(mxp.wmax + (long)(fx0 + f) * Mb + m, q, Cin == 1);
+                dft_max_slot(mxp.wmax + (long)(fx0 + f) * Mb + M + m, q, Cin == 1);
+            }
         }
     }
 }
@@ -356,7 +367,7 @@ static __global__ __launch_bounds__(256, 2) void dft_out_mf_kernel(const float* 
             amx = fmaxf(amx, fabsf(sv));
             obase[e + k * jump] = sv;
         }
-        h3_tile_flush(amx, amax + c, lane);              // max |out| of channel c (h3 scales of the encoder tail)
+        h3_tile_flush_rd(amx, amax + c, lane);              // max |out| of channel c (h3 scales of the encoder tail)
         __builtin_amdgcn_wave_barrier();
     };
     // two register buffers, the loop walks two tiles per trip: the loads of one buffer are in flight while the other
@@ -478,7 +489,7 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
                         if (fx0 + 2 * kh < Lh) p[fx0 * 128] = acc[rt][r];
                     }
                 }
-            h3_tile_flush(amx, amax + m, lane);          // max |S'| of filter row m (rows m and M + m of the GEMM operand)
+            h3_tile_flush_rd(amx, amax + m, lane);          // max |S'| of filter row m (rows m and M + m of the GEMM operand)
         }
     }
 }
@@ -503,9 +514,9 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // (nt on the 16-byte form: T is read exactly once, by dft_out_ring_kernel -- 884 -> 860 us; the dword form reads dY, which the
 // launch before it has just written: nontemporal loads and stores both measured slower there)
 #define TVAE_DFT_DMA_X4(dst, off, base) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(off), "s"(base) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(off), "s"(base) : "memory", "m0")
 #define TVAE_DFT_DMA_X1(dst, off, base) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory", "m0")
 #define TVAE_DFT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]) -- the contraction over fx.  One wave owns a tile
@@ -526,7 +537,7 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     constexpr int SN = (32 * HO + 63) / 64, P = HO * HO;
     static_assert((HO & 1) == 1, "odd output width: the [column][HO] patch is conflict free and linear in memory order");
     static_assert(32 * HO * 4 <= SLOTB, "the consumed slot must hold the transposition patch");
-    static_assert(ND + 2 * (SN + 1) <= 63, "vmcnt is a 6-bit counter");      // (+ 1: the per-tile atomic of h3_tile_flush)
+    static_assert(ND + 2 * SN <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -539,10 +550,14 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
         for (int t = 0; t < NTT; ++t) eo[fx][t] = EO[(fx * NTT + t) * 64 + lane];
     const long NB = (long)B * HO;
     const int tiles_n = (int)((NB + 31) / 32);           // n-tiles with at least one real column
-    const long ntiles = (long)M * tiles_n, stride = (long)gridDim.x * 4;
-    const long first = (long)blockIdx.x * 4 + wave;
-    if (first >= ntiles) return;                         // (no workgroup barrier anywhere in this kernel)
-    const int my = (int)((ntiles - first + stride - 1) / stride);
+    // A workgroup walks a CONTIGUOUS range of groups of four consecutive tiles (its four waves: the four 32-column tiles of one
+    // 128-column block, whose 512-byte rows of T they read together), so a wave stays on one filter row for many tiles.
+    const long ntiles = (long)M * tiles_n, stride = 4;
+    const long per = ((ntiles + 3) / 4 + gridDim.x - 1) / gridDim.x;                   // groups per workgroup
+    const long first = (long)blockIdx.x * per * 4 + wave;
+    const long tend = min(ntiles, ((long)blockIdx.x + 1) * per * 4);
+    if (first >= tend) return;                           // (no workgroup barrier anywhere in this kernel)
+    const int my = (int)((tend - first + stride - 1) / stride);
     // DMA piece g, lane -> (fx = 4 g + (lane >> 4), re | im = (lane >> 3) & 1, columns 4 (lane & 7) ..): byte offset of the
     // lane's 16 bytes from the tile's (wave-uniform) base; rows beyond Lh (last piece) re-read the last row, never used
     unsigned doff[ND];
@@ -577,10 +592,11 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     const float sl = act == ACT_LRELU ? slope : 1.f;     // ACT_NONE: slope 1
     const int jump = (R - 1) * P;
     int slot = 0;
+    int c_prev = -1;                                     // channel whose maximum `amx` is collecting
     for (int it = 0; it < my; ++it) {
         if (it == 0) TVAE_DFT_VMCNT(ND);
-        else if (it == 1) TVAE_DFT_VMCNT(ND + SN + 1);
-        else TVAE_DFT_VMCNT(ND + 2 * (SN + 1));
+        else if (it == 1) TVAE_DFT_VMCNT(ND + SN);
+        else TVAE_DFT_VMCNT(ND + 2 * SN);
         const float* tbn = dma_base(it + 2);
         const int slot2 = slot == 0 ? 2 : slot - 1;      // (it + 2) % 3: the slot tile it-1 has left
         const float* vs = ring + slot * SLOTF + lane;
@@ -605,6 +621,8 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
         int m, n0;
         tile_mn(it, m, n0);
         const int c = m / R, r_ = m - c * R;
+        if (c != c_prev && c_prev >= 0) h3_tile_flush(amx, amax + c_prev, lane);      // (wave uniform; a few times per wave)
+        c_prev = c;
         const float bv = bias ? bias[c] : 0.f;
         float* stg = ring + slot * SLOTF;                // the slot just consumed: [32 columns][HO]
         float rtot = 0.f;
@@ -652,10 +670,10 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
             amx = fmaxf(amx, fabsf(sv));
             __builtin_nontemporal_store(sv, obase + (unsigned)o);          // written once, read by later launches
         }
-        h3_tile_flush(amx, amax + c, lane);              // the (SN + 1)-th entry of this tile's store group
         __builtin_amdgcn_wave_barrier();
         slot = slot == 2 ? 0 : slot + 1;
     }
+    if (c_prev >= 0) h3_tile_flush(amx, amax + c_prev, lane);
     TVAE_DFT_VMCNT(0);                                   // the clamped tail DMAs still target this wave's ring
 }
 
@@ -682,7 +700,7 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     constexpr int NL = (32 * HO + 63) / 64, SLOTB = NL * 256, SLOTF = NL * 64, P = HO * HO;
     constexpr int ST = dft_dy_ring_stores(NRT, LH2, NYQ);
     static_assert((HO & 1) == 1 && 2 * NS <= HO + 1 && 2 * NS >= HO, "odd output width, NS = ceil(HO / 2)");
-    static_assert(ST + 1 <= 63, "vmcnt is a 6-bit counter");                  // (+ 1: the per-tile atomic of h3_tile_flush)
+    static_assert(ST <= 63, "vmcnt is a 6-bit counter");
     static_assert(!NYQ || LH2 == 32 * NRT + 2, "Nyquist rows on the vector ALU");
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, kh = lane >> 5;
@@ -696,10 +714,13 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
         for (int rt = 0; rt < NRT; ++rt) areg[s_][rt] = ED[(s_ * NRT + rt) * 64 + lane];
     const int tiles_n = (int)(NBpad / 32);
     const long ntiles = (long)M * tiles_n, NB = (long)B * HO;
-    const long stride = (long)gridDim.x * 4;
-    const long first = (long)blockIdx.x * 4 + wave;
-    if (first >= ntiles) return;
-    const int my = (int)((ntiles - first + stride - 1) / stride);
+    // contiguous ranges of groups of four consecutive tiles per workgroup (see dft_out_ring_kernel)
+    const long stride = 4;
+    const long per = ((ntiles + 3) / 4 + gridDim.x - 1) / gridDim.x;
+    const long first = (long)blockIdx.x * per * 4 + wave;
+    const long tend = min(ntiles, ((long)blockIdx.x + 1) * per * 4);
+    if (first >= tend) return;
+    const int my = (int)((tend - first + stride - 1) / stride);
     const int jump = (R - 1) * P;
     auto tile_mn = [&](int it, int& m, int& n0) {
         const int tl = (int)(first + (long)(it < my ? it : my - 1) * stride);
@@ -749,10 +770,11 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
     // M * Lh * 128 further on
     const unsigned lre = (unsigned)(j + 2 * kh * 128), lim = lre + (unsigned)((long)M * Lh * 128);
     float mx = 0.f;                                      // h3 arithmetic of the GEMM that follows: max |S'| of the tile's filter row -> amax[M]
+    int m_prev = -1;                                     // filter row whose maximum `mx` is collecting
     for (int it = 0; it < my; ++it) {
         const int slot = it & 1;
         if (it == 0) TVAE_DFT_VMCNT(0);
-        else TVAE_DFT_VMCNT(ST + 1);
+        else TVAE_DFT_VMCNT(ST);
         const Src qn = dma_src(it + 1);
         const float* bs = ring + slot * SLOTF + j * HO + kh;
         f32x16 acc[NRT];
@@ -776,6 +798,8 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
         for (int i = NS; i < NL; ++i) dma_piece(qn, slot ^ 1, i);
         int m, n0;
         tile_mn(it, m, n0);
+        if (m != m_prev && m_prev >= 0) h3_tile_flush(mx, amax + m_prev, lane);       // (wave uniform; a few times per wave)
+        m_prev = m;
         float* sb = Sp + ((((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127));   // wave uniform
         // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh: ri is a compile-time property of (rt, r)
 #pragma unroll
@@ -794,8 +818,8 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
             sb[o] = kh ? 0.f : tot;
             mx = fmaxf(mx, fabsf(tot));
         }
-        h3_tile_flush(mx, amax + m, lane);               // the (ST + 1)-th entry of this tile's store group
     }
+    if (m_prev >= 0) h3_tile_flush(mx, amax + m_prev, lane);
     TVAE_DFT_VMCNT(0);
 }
 
@@ -874,7 +898,7 @@ static __global__ __launch_bounds__(256) void dft_out_gen_kernel(const float* __
             }
             __builtin_amdgcn_wave_barrier();
         }
-        h3_tile_flush(amx, amax + c, lane);              // max |out| of channel c
+        h3_tile_flush_rd(amx, amax + c, lane);              // max |out| of channel c
     }
 }
 
@@ -924,7 +948,7 @@ static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __r
                 amx = fmaxf(amx, fabsf(acc[r]));
             }
         }
-        h3_tile_flush(amx, amax + m, lane);              // max |S'| of filter row m
+        h3_tile_flush_rd(amx, amax + m, lane);              // max |S'| of filter row m
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -146,12 +146,22 @@ __device__ __forceinline__ float h3_wave_max(float v) {          // in every lan
     return v;
 }
 
-// Round 4 (h3 scales per row): a wave's tiles belong to different filter rows, so its running maximum is flushed once per
-// tile into the slot of that tile's row -- wave reduction, then ONE atomic without return from lane 0.  In the ring kernels
-// the atomic is issued unconditionally (it is one more entry of the tile's hand-counted store group: vmcnt counts it).
+// Round 4 (h3 scales per row): the transforms along w leave one maximum per filter row / channel.  A wave's running
+// maximum is flushed into the slot of a row when the wave moves on to another row (and at its end): wave reduction, then ONE
+// atomic without return from lane 0.  (A first version flushed after every tile: 270 000 atomics on the 128 words = four
+// cache lines of the channel maxima serialised in the memory system and DOUBLED the output transform, 0.83 -> 1.51 ms; the
+// ring kernels now walk contiguous tile ranges, so a wave sees at most a handful of rows.)  In the ring kernels the atomic
+// is NOT part of the hand-counted waits: a wait that does not know about it merely asks for one more of the oldest stores.
 __device__ __forceinline__ void h3_tile_flush(float& mx, float* slot, int lane) {
     const float m = h3_wave_max(mx);
     if (lane == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(slot), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mx = 0.f;
+}
+// the same where the kernel's loads are the compiler's to count (generic / register-staged transforms, whose tiles go round
+// robin): read first, most tiles bring nothing new
+__device__ __forceinline__ void h3_tile_flush_rd(float& mx, float* slot, int lane) {
+    const float m = h3_wave_max(mx);
+    if (lane == 0) h3_atomic_amax(slot, m);
     mx = 0.f;
 }
 
@@ -440,7 +450,7 @@ void conv1_fwd_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__
                 const uint4* src = a_src + p * part_cells + (long)(o + oh) * Mpad;
                 const unsigned dst = ring_lds + (unsigned)((slot * 6 + p * 2 + oh) * 64 * 16);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(dst), "v"(src) : "memory");
+                             :: "s"(dst), "v"(src) : "memory", "m0");
             }
     };
     auto read_a = [&](int slot, Cell16 (&a)[2][3]) {

@@ -276,11 +276,22 @@ struct VirtGrad {          // the streamed gradient operand given implicitly (ba
     // bits[m * (N/32) + n/32]; the saved activation itself is then not read.  (The data gradient keeps reading H: its
     // operand loads are one instruction per k-row either way, and the bit form measured 0.2 ms slower.)
     const unsigned* bits;
+    // data gradient, dense_x6_kernel<5> (round 4): the 0 / 1 operand comes from these bits as well and H is not an argument at
+    // all -- the forward launch then need not store it.  Of the two row sums of <4> only the first is formed (from bits and
+    // gy); the second, dWo[m] = sum_n gy[n] H[m][n], follows from quantities the backward computes anyway:
+    //   H = act(pre), act(p) = act'(p) p for LeakyReLU, pre[m][n] = sum_k W[m][k] X[k][n] + b[m]
+    //   => dWo[m] = sum_n g'[m][n] pre[m][n] = sum_k W[m][k] G[m][k] + b[m] g0[m],   g'[m][n] = gy[n] act'(H[m][n]),
+    // with G[m][k] = sum_n g'[m][n] X[k][n] (the layer's weight gradient before its row factor wo[m]: `raw` below) and
+    // g0[m] = sum_n g'[m][n] (its bias gradient before wo[m]).  A 512 x 512 dot product per row instead of a 2.1 GB tensor
+    // written by the forward and read back by the backward.
     // data gradient only (dense_x6_kernel<4>): the launch that streams H for the two-valued operand also produces, per
     // 128-column tile, the two row sums the backward of the single-output Linear needs of H (tvae_dec_out_bwd's whole job):
     //   rpart[(m * (N/128) + tile_n) * 2 + 0] = sum_{n in tile} gy[n] [H[m][n] > 0]   -> bias gradient of the layer producing H
     //   rpart[(m * (N/128) + tile_n) * 2 + 1] = sum_{n in tile} gy[n] H[m][n]         -> dWo[m]
     float* rpart;
+    // weight gradient only (LRF): 1 = leave the row factor wo[m] off the slabs (the finalize applies it and forms
+    // sum_k W[m][k] G[m][k] from the raw sums: wgrad_lrf_finalize_kernel)
+    int raw;
 };
 __device__ __forceinline__ float virt_value(const VirtGrad& vg, float h, float wo, float g) {
     const float dv = vg.act == ACT_LRELU ? (h > 0.f ? 1.f : vg.slope) : (vg.act == ACT_TANH ? 1.f - h * h : 1.f);
@@ -402,13 +413,16 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         if (MASK == ACT_LRELU) v *= a > 0.f ? 1.f : ep.slope;
                         else v *= 1.f - a * a;
                     }
-                    if (sbits) {                                 // sign bits (ColDot.bits): lanes 0-31 hold one row, 32-63 the row + 4
+#ifndef TVAE_ABL
+#define TVAE_ABL 0
+#endif
+                    if (sbits && !(TVAE_ABL & 1)) {                                 // sign bits (ColDot.bits): lanes 0-31 hold one row, 32-63 the row + 4
                         const unsigned long long bl = __ballot(v > 0.f);
                         sw[j] = (unsigned)(lane < 32 ? bl : bl >> 32);
                     }
                     if (m < M) {
-                        if (crow) __builtin_nontemporal_store(v, crow + j * 32);     // written once, read by a later launch: no reuse in L2
-                        if (wsm) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
+                        if (crow && !(TVAE_ABL & 4)) __builtin_nontemporal_store(v, crow + j * 32);     // written once, read by a later launch: no reuse in L2
+                        if (wsm && !(TVAE_ABL & 2)) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
                         if (it.xr) {                             // fused first-layer backward (see InTail)
                             rs[0] += v;
                             rs[1] += v * x0[j];
@@ -418,7 +432,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         }
                     }
                 }
-                if (sbits && (lane & 31) == 0 && m < M)          // the tile's 128 columns of a row are ONE aligned 16-byte store
+                if (sbits && !(TVAE_ABL & 1) && (lane & 31) == 0 && m < M)          // the tile's 128 columns of a row are ONE aligned 16-byte store
                     *reinterpret_cast<uint4*>(sbits + (long)m * bitw + (n0 >> 5)) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
                 if (it.xr) {
                     // row sums over this panel's 128 columns: the 32 lanes of a half wave hold the same row
@@ -435,6 +449,131 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
         }
 }
 
+// Lean epilogue of the decoder's LAST hidden layer when its activation is not stored (round 4: VirtGrad / dec.no_h): bias +
+// LeakyReLU, the sign bits and the fused column dot of a full 512-row tile -- nothing else, no per-element uniform branches,
+// no addresses of an output that is not written.  The generic epilogue spent 0.62 ms of the 2.0 ms launch here with one
+// workgroup per CU and the matrix pipe idle (ablations, profiles/README.md round 4: sign bits 0.16, column dot 0.16, the
+// rest 0.30); this one reads its per-row constants four rows at a time (rows 8 q + 4 half + p, p < 4, are consecutive:
+// one ds_read_b128 per table) and folds the h3 row factor into the bias FMA (products with powers of two are exact, so
+// the result is bitwise that of unscale-then-add).  max(v, slope v) IS LeakyReLU for 0 < slope < 1, signed zeros and NaN
+// included.  bsm / wsm / h3a: 16-byte aligned LDS tables indexed by the row of the tile.
+template <int NP>
+__device__ __forceinline__ void dense_x6_epilogue_lean(f32x16 (&acc)[2][4], const float* bsm, const float* wsm, const float* h3a,
+                                                       const float* h3x, float slope, int wave, int lane, int m0, int n0,
+                                                       float (&ysum)[4], unsigned* sbits, long bitw) {
+    float ixv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ixv[j] = NP == 2 ? h3x[j * 32 + (lane & 31)] : 1.f;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rb = wave * 64 + i * 32 + 8 * q + 4 * half;        // rows rb .. rb + 3 <-> registers r = 4 q + p
+            const float4 b4 = *reinterpret_cast<const float4*>(bsm + rb);
+            const float4 w4 = *reinterpret_cast<const float4*>(wsm + rb);
+            float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (NP == 2) a4 = *reinterpret_cast<const float4*>(h3a + rb);
+            const float bq[4] = {b4.x, b4.y, b4.z, b4.w}, wq[4] = {w4.x, w4.y, w4.z, w4.w}, aq[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = 4 * q + p;
+                unsigned sw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = NP == 2 ? __fmaf_rn(acc[i][j][r] * ixv[j], aq[p], bq[p]) : acc[i][j][r] + bq[p];
+                    v = fmaxf(v, v * slope);
+                    ysum[j] = __fmaf_rn(wq[p], v, ysum[j]);
+                    const unsigned long long bl = __ballot(v > 0.f);     // lanes 0-31 hold one row, 32-63 the row + 4
+                    sw[j] = (unsigned)(half ? bl >> 32 : bl);
+                }
+                if ((lane & 31) == 0)
+                    *reinterpret_cast<uint4*>(sbits + (long)(m0 + rb + p) * bitw + (n0 >> 5)) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // one row group at a time: no hoisting of later groups' reads over this one
+        }
+}
+
+// Sum over the 32 lanes of each half wave WITHOUT the LDS crossbar: four DPP adds inside the 16-lane rows, then row_bcast15
+// (lane 15 of rows 0 / 2 into rows 1 / 3).  The total is valid in lanes 16-31 (first half) and 48-63 (second half) only.
+__device__ __forceinline__ float half_wave_sum_hi(float x) {
+    x = dpp_add<0xB1>(x);
+    x = dpp_add<0x4E>(x);
+    x = dpp_add<0x141>(x);
+    x = dpp_add<0x140>(x);
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xA, 0xF, false));
+}
+
+// Lean epilogue of the two-valued data gradient of the decoder's FIRST hidden layer with the coordinate layer's backward fused
+// into it (InTail with the recomputed mask operand; nothing is stored but the per-panel row sums and the coordinate
+// gradient): the hot shape of every reference decoder without Fourier features.  The generic epilogue took 0.83 ms of this
+// 1.79 ms launch (ablation, profiles/README.md round 4) -- per-element uniform branches on options that are off, 64-bit
+// addresses of an output that does not exist, one LDS read per row and table, five dependent crossbar permutes per row sum.
+// Here: per-row constants four rows at a time (ds_read_b128), u = act'(h0) (oms acc + slope csum) without the column
+// factor gy[n], which moves into the three column vectors (gy, gy x0, gy x1) of the row sums and onto the finished
+// coordinate sums; row sums reduced by DPP only.  13 vector instructions per element instead of ~40.
+//   part[(tile_n M + f) 3 + k] = sum_{n in panel} dX[f][n] (1, x'_0[n], x'_1[n]),   gsum[j][c] = sum_f wc[f][c] dX[f][n_j]
+template <int NP>
+__device__ __forceinline__ void dense_x6_epilogue_lean_in(f32x16 (&acc)[2][4], const float* bsm, const float* wc2,
+                                                          const float* cbm, const float* h3a, float slope, float oms, int wave,
+                                                          int lane, int m0, int M, int tile_n, const float (&gyv)[4],
+                                                          const float (&x0)[4], const float (&x1)[4], float* part,
+                                                          float (&gsum)[4][2]) {
+    float gx0[4], gx1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gx0[j] = gyv[j] * x0[j];
+        gx1[j] = gyv[j] * x1[j];
+    }
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rb = wave * 64 + i * 32 + 8 * q + 4 * half;        // rows rb .. rb + 3 <-> registers r = 4 q + p
+            const float4 b4 = *reinterpret_cast<const float4*>(bsm + rb);
+            const float4 c4 = *reinterpret_cast<const float4*>(cbm + rb);
+            const float4 l4 = *reinterpret_cast<const float4*>(cbm + DX6_ROWS + rb);
+            const float4 wA = *reinterpret_cast<const float4*>(wc2 + 2 * rb), wB = *reinterpret_cast<const float4*>(wc2 + 2 * rb + 4);
+            float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (NP == 2) a4 = *reinterpret_cast<const float4*>(h3a + rb);
+            const float bq[4] = {b4.x, b4.y, b4.z, b4.w}, cq[4] = {c4.x, c4.y, c4.z, c4.w}, lq[4] = {l4.x, l4.y, l4.z, l4.w};
+            const float aq[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float w0q[4] = {wA.x, wA.z, wB.x, wB.z}, w1q[4] = {wA.y, wA.w, wB.y, wB.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = 4 * q + p;
+                float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = __fmaf_rn(oms, NP == 2 ? acc[i][j][r] * aq[p] : acc[i][j][r], bq[p]);
+                    const float pre = dec_l0_pre(w0q[p], w1q[p], cq[p], lq[p], x0[j], x1[j]);
+                    const float u = pre > 0.f ? t : t * slope;
+                    rs0 = __fmaf_rn(u, gyv[j], rs0);
+                    rs1 = __fmaf_rn(u, gx0[j], rs1);
+                    rs2 = __fmaf_rn(u, gx1[j], rs2);
+                    gsum[j][0] = __fmaf_rn(w0q[p], u, gsum[j][0]);
+                    gsum[j][1] = __fmaf_rn(w1q[p], u, gsum[j][1]);
+                }
+                rs0 = half_wave_sum_hi(rs0);
+                rs1 = half_wave_sum_hi(rs1);
+                rs2 = half_wave_sum_hi(rs2);
+                if ((lane & 31) == 16) {
+                    float* pp = part + ((long)tile_n * M + m0 + rb + p) * 3;
+                    pp[0] = rs0;
+                    pp[1] = rs1;
+                    pp[2] = rs2;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gsum[j][0] *= gyv[j];
+        gsum[j][1] *= gyv[j];
+    }
+}
+
 // Tile 512 x 128: eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step), two per
 // SIMD, so one wave's split arithmetic, LDS traffic and load waits run under the other's MFMAs.  Every k-value of X is
 // split once per 512 output rows (4 per thread per step).
@@ -446,20 +585,28 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 
 // XV: 0 = X is read from memory, 1 = implicit gradient operand (VirtGrad), 2 = implicit first-layer activation (VirtAct),
 //     3 = two-valued implicit gradient (VirtGrad.csum: X is the saved activation H, the operand is [H > 0]),
+//     5 = 3 with the operand taken from the stored sign bits (VirtGrad.bits; X is not read) + the row sums
+//         sum_n gy[n] [H[m][n] > 0] per column tile (rpart[(m * (N/128) + tile) * 2], the second word is not written)
 //     4 = 3 + the row sums of H against gy per column tile (VirtGrad.rpart): the threads that load H for the operand
 //         also form gy[n] [H > 0] and gy[n] H, reduce them over their wave's 64 columns (wave_sum8: 8 values per step)
 //         and leave them in LDS; a 2.1 GB pass of its own over H (tvae_dec_out_bwd) is then not needed
-template <int XV, int NP>
+// EPI (compile time: the lean epilogues must not share a kernel with the generic one -- as run-time branches of ONE kernel
+// they made the register allocator spill 152 registers per lane around the k-loop and the launch 10 % slower):
+//   0 = generic epilogue (every option a uniform run-time branch)
+//   1 = dense_x6_epilogue_lean: output not stored, fused column dot + sign bits, LeakyReLU, ONE full 512-row tile (M == 512)
+//   2 = dense_x6_epilogue_lean_in: two-valued data gradient, fused first-layer backward with the recomputed mask, M == 512
+// The host picks the instance (abi_dense_x6.hip: launch_dense_x6) when the call has exactly that shape.
+template <int XV, int NP, int EPI = 0>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                      int N, int K, int K8pad, TileMap tm, DenseBatch bt, ColDot cd, InTail it, VirtGrad vg, VirtAct va,
                      H3Scale hs) {
-    constexpr bool VIRT = XV == 1, MASKB = XV == 3 || XV == 4, RSUM = XV == 4;
+    constexpr bool VIRT = XV == 1, MASKB = XV == 3 || XV == 4 || XV == 5, RSUM = XV == 4 || XV == 5, FROMBITS = XV == 5;
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][n]
-    __shared__ float bsm[DX6_ROWS];
-    __shared__ float wsm_[2 * DX6_ROWS];
+    __shared__ __attribute__((aligned(16))) float bsm[DX6_ROWS];
+    __shared__ __attribute__((aligned(16))) float wsm_[2 * DX6_ROWS];
     __shared__ float vwo_[XV == 1 ? 512 : (XV == 2 ? 2048 : 1)];   // tables of the implicit operand (K <= 512)
-    __shared__ float cbm_[2 * DX6_ROWS];                 // (bc, lb) rows of the recomputed mask operand (InTail.bc)
+    __shared__ __attribute__((aligned(16))) float cbm_[2 * DX6_ROWS];     // (bc, lb) rows of the recomputed mask operand (InTail.bc)
     __shared__ float rsm_[RSUM ? 2 * 2 * DX6_ROWS + 8 : 1];   // [column half of the tile][row of H][2]: row sums (VirtGrad.rpart) + a dump slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -483,7 +630,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // (dec_l0_bound_kernel) whose combination bounds every |act(pre)| <= |pre|.  The 0 / 1 operand needs none.
     // Round 4: one scale per ROW of A (h3a_: their inverses for the epilogue) and, where the operand's producer measured it,
     // one per column group of X (an image; h3x_: the inverse of every column of this tile).
-    __shared__ float h3a_[NP == 2 ? DX6_ROWS : 1];
+    __shared__ __attribute__((aligned(16))) float h3a_[NP == 2 ? DX6_ROWS : 4];
     __shared__ float h3x_[NP == 2 ? 128 : 1];
     float sx = 1.f;
     if (NP == 2) {
@@ -543,10 +690,18 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     }
     const bool vwo_lds = K <= 512;
     const bool va_lrelu = XV == 2 && va.act == ACT_LRELU;
+    const unsigned* bit_col = FROMBITS ? vg.bits + ((n0 + nb) >> 5) : nullptr;      // this thread's word of a row of bits
+    const long bitw_ = (long)(N >> 5);
     auto load_x = [&](int t, float (&x)[4]) {
         if (XV == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = 0.f;
+        } else if (FROMBITS) {
+            // the word that holds bit (row, column nb): 32 lanes share it (one 4-byte request per row and half wave); the
+            // value travels as the 0 / 1 it stands for (clamped rows meet all-zero weight cells)
+            const int kb = 16 * t + 4 * kq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = __uint_as_float(bit_col[(long)min(kb + j, K - 1) * bitw_]);
         } else {
             // unconditional loads from a CLAMPED row and no masking: rows k >= K meet all-zero weight cells, so any
             // finite value will do (the clamped row is real data).  A load under an exec-mask branch, or a select on its
@@ -589,8 +744,11 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     auto store_b = [&](int stage, const float (&x)[4]) {
         uint2* dst = reinterpret_cast<uint2*>(Bs + stage * 768 + (kq >> 1) * 128 + nb) + (kq & 1);
         if (MASKB) {                                     // [H > 0]: 1.0 = 0x3f80 (bf16) / 0x3c00 (fp16), one part (rows k >= K meet zero weights)
-            dst[0] = make_uint2((x[0] > 0.f ? OneBits<NP>::lo : 0u) | (x[1] > 0.f ? OneBits<NP>::hi : 0u),
-                                (x[2] > 0.f ? OneBits<NP>::lo : 0u) | (x[3] > 0.f ? OneBits<NP>::hi : 0u));
+            bool p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = FROMBITS ? ((__float_as_uint(x[j]) >> (nb & 31)) & 1u) != 0u : x[j] > 0.f;
+            dst[0] = make_uint2((p[0] ? OneBits<NP>::lo : 0u) | (p[1] ? OneBits<NP>::hi : 0u),
+                                (p[2] ? OneBits<NP>::lo : 0u) | (p[3] ? OneBits<NP>::hi : 0u));
             return;
         }
         if (NP == 1) {
@@ -618,6 +776,17 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     // every (t, kq, j) row is visited once, so the slots are plain stores (rows >= K are never read back).
     auto row_sums = [&](int t, bool real, const float (&x)[4]) {
         if (!RSUM) return;
+        // `real` = false: the register set holds a step that does not exist (the loop's clamped prefetch past the end
+        // re-reads an EARLIER step): its sums go to the dump slot -- branch free, like the rest of the operand path
+        const int slot = real ? ((wave & 1) * DX6_ROWS + ((16 * t + 4 * kq) & (DX6_ROWS - 1))) * 2 : 2 * 2 * DX6_ROWS;
+        if (FROMBITS) {                                  // one value per row: gy [bit]; lane v < 4 stores row j = v
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = ((__float_as_uint(x[j]) >> (nb & 31)) & 1u) ? vg_g : 0.f;
+            const float tot = wave_sum4(a, lane);
+            if (lane < 4) rsm_[slot + 2 * lane] = tot;
+            return;
+        }
         float a[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -625,9 +794,6 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
             a[2 * j + 1] = vg_g * x[j];
         }
         const float tot = wave_sum8(a, lane);
-        // `real` = false: the register set holds a step that does not exist (the loop's clamped prefetch past the end
-        // re-reads an EARLIER step): its sums go to the dump slot -- branch free, like the rest of the operand path
-        const int slot = real ? ((wave & 1) * DX6_ROWS + ((16 * t + 4 * kq) & (DX6_ROWS - 1))) * 2 : 2 * 2 * DX6_ROWS;
         if (lane < 8) rsm_[slot + lane] = tot;
     };
 
@@ -695,12 +861,12 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
-    if (NP == 2) h3_unscale_rc<!MASKB>(acc, h3a_, h3x_, wave, lane);       // (tables written before the k-loop's barriers)
+    if (NP == 2 && EPI == 0) h3_unscale_rc<!MASKB>(acc, h3a_, h3x_, wave, lane);       // (tables written before the k-loop's barriers)
     if (RSUM) {                                          // (the loop's last barrier made every slot visible)
         if (tid < K) {
             float* rp = vg.rpart + ((long)tid * (N >> 7) + tile_n) * 2;   // [row][tile][2]: a row's partials are contiguous
             rp[0] = rsm_[tid * 2] + rsm_[(DX6_ROWS + tid) * 2];
-            rp[1] = rsm_[tid * 2 + 1] + rsm_[(DX6_ROWS + tid) * 2 + 1];
+            if (!FROMBITS) rp[1] = rsm_[tid * 2 + 1] + rsm_[(DX6_ROWS + tid) * 2 + 1];
         }
     }
     // epilogue specialised on (activation, mask, residual): no per-element branches
@@ -718,6 +884,29 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
                                              gyv, oms, cd.bits, (long)(N >> 5))
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
+    if (EPI == 2) {
+        float x0_[4], x1_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long nn = n0 + j * 32 + (lane & 31);
+            x0_[j] = it.xr[2 * nn];
+            x1_[j] = it.xr[2 * nn + 1];
+        }
+        dense_x6_epilogue_lean_in<NP>(acc, bsm, wsm_, cbm_, h3a_, ep.slope, oms, wave, lane, m0, M, tile_n, gyv, x0_, x1_, it.part,
+                                      gsum);
+    } else if (EPI == 1) {
+        dense_x6_epilogue_lean<NP>(acc, bsm, wsm_, h3a_, h3x_, ep.slope, wave, lane, m0, n0, ysum, cd.bits, (long)(N >> 5));
+    } else
+    if (TVAE_ABL & 8) {                                  // ablation: no epilogue (keep the accumulators alive)
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
+        if (t_ == 123.456f && cd.y) cd.y[n0] = t_;
+    } else
     if (ep.mask == ACT_NONE) {
         if (ep.act == ACT_LRELU) TVAE_DX6_EPI_R(ACT_LRELU, ACT_NONE, false);
         else if (ep.act == ACT_TANH) TVAE_DX6_EPI_R(ACT_TANH, ACT_NONE, false);
@@ -1053,32 +1242,32 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             for (int i = 0; i < 2; ++i) {
                 const unsigned* src = b_ptr[i] + (na >> 5);
                 const unsigned dst = sl + (unsigned)(i * 256);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dst), "v"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
             }
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float* src = d_ptr[g] + off;
                 const unsigned dst = sl + (unsigned)(g * 1024);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
             }
         }
         if (XVA) {
             const float* sx = x_src + 32 * t;
             const unsigned dx = sl + 4096u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dx), "v"(sx) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dx), "v"(sx) : "memory", "m0");
             const float* slb = lb_src + (long)(lb_on != 0.f ? na / va.Np : 0) * Kf;
             const unsigned dl = sl + 4096u + 256u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dl), "v"(slb) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dl), "v"(slb) : "memory", "m0");
         } else {
             const float* sx = x_src + 16 * t;
             const unsigned dx = sl + 4096u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dx), "v"(sx) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dx), "v"(sx) : "memory", "m0");
         }
         if (VIRT) {
             const float* sg = g_src + 16 * t;
             const unsigned dg = sl + 4096u + 1024u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dg), "v"(sg) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(dg), "v"(sg) : "memory", "m0");
         }
     };
     // ---- reads from a landed slot
@@ -1297,7 +1486,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             const int rl = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int m = m0 + rl;
             if (m >= M) continue;
-            const float wm = LRF ? vg.wo[m] : 1.f;       // the row factor of the factored implicit gradient
+            const float wm = (LRF && !vg.raw) ? vg.wo[m] : 1.f;       // the row factor of the factored implicit gradient
             const float ia = (NP == 2 && !LRF) ? ssm[256 + rl] : 1.f;
             float* wrow = ws + (((long)split * nbatch + batch) * M + m) * Kf + k0 + (lane & 31);
 #pragma unroll

@@ -420,7 +420,7 @@ constexpr int EW_CELLS = 3 * 4 * ET_C * 16;            // one operand of one chu
 constexpr int EW_LDS = 2 * EW_STAGE + 4 * EW_CELLS;    // two stages, two sets of (dH cells, A1 cells)
 
 #define TVAE_EW_DMA_X4(dst, src) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0")
 
 template <int NP>
 static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel(

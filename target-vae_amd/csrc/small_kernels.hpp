@@ -47,6 +47,20 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane) {
     return d;
 }
 
+// the same for FOUR values (2 + 1 + 4 exchange steps): lane l returns the total of value (l & 3)
+__device__ __forceinline__ float wave_sum4(const float (&a)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (b0 ? a[2 * i + 1] : a[2 * i]) + dpp_get<0xB1>(b0 ? a[2 * i] : a[2 * i + 1]);
+    float d = (b1 ? b[1] : b[0]) + dpp_get<0x4E>(b1 ? b[0] : b[1]);          // original index 2 b1 + b0 = lane & 3
+    d += __shfl_xor(d, 4, 64);
+    d += __shfl_xor(d, 8, 64);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    return d;
+}
+
 // Sum NV values over the workgroup; every thread returns with the totals.  sm: >= NV*16 floats.
 template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* sm) {

@@ -30,9 +30,9 @@ SIGNATURES = {
     'tvae_dense_split3': 'plpliiipp',
     'tvae_dense_split2h': 'plpliiipp',
     'tvae_linear_fwd_x6': 'pppppiiillifpppppppipi',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppi',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppippp',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipi',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplp',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -80,6 +80,9 @@ QUERIES = {
     'tvae_enc_tail_wgrad_x6_ws_floats': ('l', 'l'),
     'tvae_linear_wgrad_x6_ws_floats': ('iii', 'l'),
 }
+
+# trailing arguments a caller may leave out (beyond all-pointer tails, which are always optional)
+OPTIONAL_TAIL = {'tvae_linear_wgrad_x6': 3}      # rd_w, rd_ldw, rd_rowdot (ABI 5)
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None
@@ -204,8 +207,9 @@ def call(name, *args):
     """Invoke a C-ABI entry point on the current torch stream."""
     L = lib()
     sig = SIGNATURES[name]
-    if len(args) < len(sig) and set(sig[len(args):]) == {'p'}:
-        args = args + (None,) * (len(sig) - len(args))      # optional trailing pointer arguments (added by later ABI versions)
+    if len(args) < len(sig) and (set(sig[len(args):]) == {'p'} or len(sig) - len(args) <= OPTIONAL_TAIL.get(name, 0)):
+        # optional trailing arguments (added by later ABI versions): NULL pointers / zero strides
+        args = args + tuple(None if c == 'p' else 0 for c in sig[len(args):])
     if len(args) != len(sig):
         raise TvaeHipError(f'{name}: expected {len(sig)} arguments, got {len(args)}')
     conv = []

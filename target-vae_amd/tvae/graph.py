@@ -41,6 +41,10 @@ class GraphedStep:
         with torch.cuda.graph(self.graph, stream=side):
             self.terms = self._fwd_bwd()
         torch.cuda.synchronize(dev)
+        # the graph now holds raw pointers into the scratch buffers of tvae.ops: from here on an outgrown buffer is kept
+        # alive instead of freed (a larger eager batch later must not hand the graph's blocks back to the allocator)
+        from . import ops as _ops
+        _ops.pin_scratch()
         optim.flat_g.zero_()
 
     def _fwd_bwd(self):

@@ -116,6 +116,25 @@ def kernel_event_ms():
 # ---------------------------------------------------------------------------------------------
 _WS = {}
 _TABLES = {}
+# Buffers a captured hipGraph holds raw pointers to (tvae/graph.py calls pin_scratch() after capture).  Growing a scratch
+# buffer REPLACES its tensor; without this list the old block would go back to the caching allocator while the graph still
+# writes into it on every replay (a later, larger eager batch -- an uneven shard, a test set larger than the captured
+# minibatch -- would trigger exactly that: ADVICE r03).  Once pinned, outgrown buffers are kept alive instead of freed: the
+# graph keeps its blocks, eager calls get the new, larger ones.
+_PINNED = None
+
+
+def pin_scratch() -> None:
+    global _PINNED
+    if _PINNED is None:
+        _PINNED = []
+
+
+def _replace_ws(key, new):
+    old = _WS.get(key)
+    if old is not None and _PINNED is not None:
+        _PINNED.append(old)
+    _WS[key] = new
 
 
 # debugging aid (TVAE_POISON_WS=1; off by default, costs a fill per call): every workspace view handed out, and every named
@@ -133,7 +152,7 @@ def workspace(device, floats: int) -> torch.Tensor:
     t = _WS.get(key)
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
-        _WS[key] = t
+        _replace_ws(key, t)
     if POISON_WS:
         t[:int(floats)].fill_(float('nan'))
     return t[:int(floats)]
@@ -199,22 +218,27 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None) -> torch.Tensor:
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None):
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
-    on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only)."""
-    dW = torch.empty(M, K, dtype=torch.float32, device=dpre.device)
+    on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only).
+    bits: [H > 0] as stored sign bits (dpre may then be None).  rowdot_w = the layer's own weight [M][K]: also returns
+    rowdot[m] = sum_k W[m][k] dW[m][k] / wo[m] (taken before the multiplication), as (dW, rowdot)."""
+    dev_ = (dpre if dpre is not None else (X if X is not None else virt[0])).device
+    dW = torch.empty(M, K, dtype=torch.float32, device=dev_)
     need = 64 * max(M, 128) * max(K, 128)
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
-        ws = workspace(dpre.device, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
+        ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
         # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
         p = 2 if (parts() == 2 and bits is not None and va and virt and virt[2] == ACT_LRELU) else _p3()
+        rowdot = torch.empty(M, dtype=torch.float32, device=dev_) if rowdot_w is not None else None
         with _timed('tvae_linear_wgrad_x6', p, bool(virt) and virt[2] == ACT_LRELU):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
-                 *(va if va else (None, None, None, None, 0)), bits, p)
-        return dW
-    _expect(virt is None and va is None, 'implicit operands need the split-pipe weight gradient')
-    ws = workspace(dpre.device, max(need, 1 << 24))
+                 *(va if va else (None, None, None, None, 0)), bits, p,
+                 rowdot_w.contiguous() if rowdot_w is not None else None, K, rowdot)
+        return dW if rowdot_w is None else (dW, rowdot)
+    _expect(virt is None and va is None and rowdot_w is None, 'implicit operands need the split-pipe weight gradient')
+    ws = workspace(dev_, max(need, 1 << 24))
     call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
     return dW
 
@@ -253,7 +277,7 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
         if POISON_WS:
             t.fill_(float('nan'))
-        _WS[k_] = t
+        _replace_ws(k_, t)
     return t
 
 
@@ -267,6 +291,7 @@ FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
 FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
 FUSE_ROW_SUMS = os.environ.get('TVAE_FUSE_ROW_SUMS', '1') != '0'
 FUSE_ENC_WGRAD = os.environ.get('TVAE_FUSE_ENC_WGRAD', '1') != '0'
+FUSE_NO_H = os.environ.get('TVAE_FUSE_NO_H', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -802,7 +827,7 @@ class DecoderFn(torch.autograd.Function):
         fused_out = False
         sbits = None
         for li, (W, b) in enumerate(hidden):
-            hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+            hn = None
             if _dense_x6_ok(F_, Nt):
                 # h3 instance: the layer whose streamed operand is the recomputed first-layer activation
                 p_l = 2 if (parts() == 2 and va and li == 0) else _p3()
@@ -815,6 +840,16 @@ class DecoderFn(torch.autograd.Function):
                         and F_ >= 256 and Nt % 32 == 0):
                     sbits = torch.empty(F_, Nt // 32, dtype=torch.int32, device=dev)
                     _note('dec.sign_bits')
+                # Round 4: with the fused output dot AND the sign bits, nothing downstream needs this layer's activation
+                # itself -- the backward takes [H > 0] from the bits and dWo from the identity sum_k W[m][k] G[m][k] +
+                # b[m] g0[m] (include/tvae_hip.h: tvae_linear_dgrad_x6 vg_bits) -- so the 2.1 GB tensor is neither written
+                # here nor read there.  Same conditions as the backward's row-sum fusion (it forms g0).
+                no_h = (FUSE_NO_H and fuse and sbits is not None and li == n_hidden - 1 and FUSE_ROW_SUMS and F_ <= 512
+                        and Nt % 128 == 0 and not resid)
+                if no_h:
+                    _note('dec.no_h')
+                else:
+                    hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
                 with _timed('tvae_linear_fwd_x6', p_l):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
@@ -823,6 +858,7 @@ class DecoderFn(torch.autograd.Function):
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
+                hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
                      Nt, Nt, act, LRELU_SLOPE)
             hs.append(hn)
@@ -865,6 +901,8 @@ class DecoderFn(torch.autograd.Function):
         # two-valued implicit gradient: the data-gradient launch of the last hidden layer streams H anyway and returns the
         # two row sums this layer's backward needs of it (tot[0] = bias gradient below, tot[1] = dWo): no pass of its own
         fuse_rs = (FUSE_ROW_SUMS and virt and act == ACT_LRELU and F_ <= 512 and Nt % 128 == 0)
+        no_h = hs[-1] is None                            # the forward did not store the last hidden activation (dec.no_h)
+        _expect(not no_h or (fuse_rs and ctx.sbits is not None), 'decoder backward without the saved activation needs the bits path')
         if not fuse_rs:
             part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
             call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
@@ -884,7 +922,11 @@ class DecoderFn(torch.autograd.Function):
             dsrc = hs[-1] if use_vg else d             # implicit operand: pass the saved activation instead
             va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if hprev is None else None   # recomputed first layer
             sbits = ctx.sbits if (use_vg and act == ACT_LRELU) else None      # [h > 0] as stored bits (two-valued form)
-            dW = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits)
+            from_bits = use_vg and no_h
+            if from_bits:                                # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
+                dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W)
+            else:
+                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits), None
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
@@ -913,7 +955,8 @@ class DecoderFn(torch.autograd.Function):
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
                          bc if va else None, LB if va else None, Np if va else 0,
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
-                         tot[0] if rs else None, tot[1] if rs else None, p_d)
+                         tot[0] if rs else None, tot[1] if rs else None, p_d,
+                         sbits if from_bits else None, rowdot, b if from_bits else None)
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')

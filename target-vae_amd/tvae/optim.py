@@ -65,8 +65,15 @@ class FlatAdam(torch.optim.Optimizer):
                 p.register_post_accumulate_grad_hook(self._early_hook)
 
     def _early_hook(self, _p):
+        # Contract: ONE backward per optimizer step.  Once the early segment has been posted, the collective is reading and
+        # writing flat_g[:early_end] on its own stream; a second backward before step() (gradient accumulation, a probe)
+        # would accumulate into it underneath the all-reduce and produce wrong gradients without an error.
+        if self._early_posted:
+            raise RuntimeError('FlatAdam: a second backward reached the early gradient bucket before step(); with the '
+                               'two-bucket all-reduce exactly one backward per step is supported (TVAE_DP_EARLY=0 '
+                               'restores the single collective at step())')
         self._early_seen += 1
-        if self._early_seen != self._early_n or self._early_posted:
+        if self._early_seen != self._early_n:
             return
         for p, gv in zip(self._ps[:self._early_n], self._gviews[:self._early_n]):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():

@@ -206,8 +206,7 @@ def test_step_golden(name):
 
 
 HOT = {'hot_S64_B2': ('gauss', {'conv1.dft', 'conv1.dft_ring', 'dec.virt_act', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
-                                'dec.sign_bits', 'dec.fuse_in', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6',
-                                'enc.tail_wgrad_x6'}),
+                                'dec.sign_bits', 'dec.fuse_in', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
        'hot_S28F_B8': ('bce', {'conv1.dft', 'dec.four_x6', 'dec.fused_out', 'dec.virt_grad', 'dec.virt_grad_2val',
                                'dec.sign_bits', 'dec.row_sums_in_dgrad', 'enc.tail_fwd_x6', 'enc.tail_dgrad_x6'}),
        # the reference's real MNIST-U / MNIST-N geometry (50x50, k = 28, p = 8: train_mnist.py:413-417): the 66-wide frame
@@ -250,7 +249,7 @@ def test_step_hot_widths_golden(name, gemm_mode):
         blocks = {'tvae_conv1_fwd': ops.mfma_per_block(p), 'tvae_conv1_wgrad': ops.mfma_per_block(p),
                   'tvae_linear_fwd_x6': ops.mfma_per_block(p), 'tvae_linear_dgrad_x6': ops.mfma_per_block(p, True),
                   'tvae_linear_wgrad_x6': ops.mfma_per_block(p, True), 'tvae_enc_tail_fwd_x6': ops.mfma_per_block(p),
-                  'tvae_enc_tail_dgrad_x6': ops.mfma_per_block(p), 'tvae_enc_tail_wgrad_x6': ops.mfma_per_block(p)}
+                  'tvae_enc_tail_dgrad_x6': ops.mfma_per_block(p)}     # (conv2's fused weight gradient needs N % 32 == 0: bench-size test)
         for k_, b_ in blocks.items():
             assert parts_log.get(k_) == [(p, b_)], (k_, parts_log.get(k_))
     assert abs(float(elbo) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
@@ -649,9 +648,12 @@ def test_full_size_properties():
             e_, _, _ = step.elbo_terms(x, yy, gen, enc, 'gauss', noise)
         (-e_).backward()
         return {nm: p.grad.clone() for nm, p in params}
-    g1, g2 = grads(y, 'x6'), grads(y, 'x6')
-    for nm, _ in params:
-        assert torch.equal(g1[nm], g2[nm]), nm
+    # bitwise-reproducible gradients in BOTH split-pipe arithmetics: the shipped default (h3: its operand maxima come from
+    # atomic maxima on bit patterns -- order independent -- and fire-and-forget slot updates) and the exact split
+    for mode_ in ('h3', 'x6'):
+        g1, g2 = grads(y, mode_), grads(y, mode_)
+        for nm, _ in params:
+            assert torch.equal(g1[nm], g2[nm]), (mode_, nm)
     gf = grads(y, 'f32')
     gp = grads(y * (1 + 1e-6 * torch.randn_like(y)), 'f32')
     for nm, _ in params:

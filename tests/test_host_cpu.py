@@ -325,3 +325,32 @@ def test_shape_validation_happens_before_any_launch():
     tb = type('T', (), dict(R=4, P=9))()
     with pytest.raises(ValueError):
         ops.HeadFn.apply(torch.zeros(7, 10), torch.zeros(2, 36), torch.zeros(2, 2), torch.zeros(2), tb, 2, 2)
+
+
+def test_scratch_buffers_outlive_a_captured_graph():
+    """once a hipGraph has been captured (tvae/graph.py -> ops.pin_scratch), growing a scratch buffer
+    or the shared workspace must not free the block the graph still points to."""
+    import torch
+    from tvae import ops
+    cpu = torch.device('cpu')
+    saved = dict(ops._WS), ops._PINNED
+    try:
+        ops._WS.clear()
+        ops._PINNED = None
+        a = ops._scratch(cpu, 'k', 16)
+        w = ops.workspace(cpu, 8)
+        ops._scratch(cpu, 'k', 32)                       # before pinning: plain replacement
+        assert ops._PINNED is None
+        b = ops._scratch(cpu, 'k', 32)
+        ops.pin_scratch()
+        c = ops._scratch(cpu, 'k', 64)
+        w2 = ops.workspace(cpu, 64)
+        assert c.numel() >= 64 and w2.numel() == 64
+        kept = {t.data_ptr() for t in ops._PINNED}
+        assert b.data_ptr() in kept and w.data_ptr() in kept and a.data_ptr() not in kept
+        assert ops._scratch(cpu, 'k', 8) is c            # no growth: same buffer, nothing new pinned
+        assert len(ops._PINNED) == 2
+    finally:
+        ops._WS.clear()
+        ops._WS.update(saved[0])
+        ops._PINNED = saved[1]
