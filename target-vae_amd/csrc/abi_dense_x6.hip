@@ -23,15 +23,16 @@ int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& 
     const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);     // the cells keep their 512-row padding
     if (N % 128 != 0 || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
     if (parts == 2 && (!hs.amax_a || !hs.amax_x)) return (int)hipErrorInvalidValue;
-    if (parts == 3)
-        hipLaunchKernelGGL((dense_x6_plain4_kernel<3>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
-                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
-    else if (parts == 2)
-        hipLaunchKernelGGL((dense_x6_plain4_kernel<2>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
-                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
-    else
-        hipLaunchKernelGGL((dense_x6_plain4_kernel<1>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, ep,
-                           rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs);
+    // the spectral contraction's own shape (plain column-tiled output, whole row tiles) has a lean store epilogue
+    const bool lean = !ep.bias && !ep.res && !ep.aux && ep.act == ACT_NONE && ep.mask == ACT_NONE && ep.ctile > 0 && ep.C &&
+                      !ep.accumulate && rows_per_problem % DX4_ROWS == 0 && ep.ldc * 8 * 4 < (1L << 31);
+#define TVAE_DX4_LAUNCH(NP_, E_)                                                                                       \
+    hipLaunchKernelGGL((dense_x6_plain4_kernel<NP_, E_>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, \
+                       ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs)
+    if (parts == 3) { if (lean) TVAE_DX4_LAUNCH(3, 1); else TVAE_DX4_LAUNCH(3, 0); }
+    else if (parts == 2) { if (lean) TVAE_DX4_LAUNCH(2, 1); else TVAE_DX4_LAUNCH(2, 0); }
+    else { if (lean) TVAE_DX4_LAUNCH(1, 1); else TVAE_DX4_LAUNCH(1, 0); }
+#undef TVAE_DX4_LAUNCH
     return (int)hipGetLastError();
 }
 }  // namespace tvae

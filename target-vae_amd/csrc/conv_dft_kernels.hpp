@@ -513,8 +513,13 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // per-lane offsets are loop invariants kept in registers, so issuing a piece costs no vector-ALU work at all.
 // (nt on the 16-byte form: T is read exactly once, by dft_out_ring_kernel -- 884 -> 860 us; the dword form reads dY, which the
 // launch before it has just written: nontemporal loads and stores both measured slower there)
+#ifdef TVAE_T_CACHED
+#define TVAE_DFT_DMA_X4(dst, off, base) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory", "m0")
+#else
 #define TVAE_DFT_DMA_X4(dst, off, base) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(off), "s"(base) : "memory", "m0")
+#endif
 #define TVAE_DFT_DMA_X1(dst, off, base) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(off), "s"(base) : "memory", "m0")
 #define TVAE_DFT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")

@@ -19,6 +19,12 @@
 #include "conv_x6_kernels.hpp"
 #include "small_kernels.hpp"
 
+// Timing ablations (-DTVAE_ABL=bits, never in the shipped build; results are then WRONG): 1 no sign bits, 2 no column dot,
+// 4 no output stores, 8 no epilogue at all (generic forward epilogue / plain4 / weight gradient).  profiles/README.md round 4.
+#ifndef TVAE_ABL
+#define TVAE_ABL 0
+#endif
+
 namespace tvae {
 
 // Pre-pass: W fp32 -> cells [part][octet][row < Rpad].
@@ -413,9 +419,6 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         if (MASK == ACT_LRELU) v *= a > 0.f ? 1.f : ep.slope;
                         else v *= 1.f - a * a;
                     }
-#ifndef TVAE_ABL
-#define TVAE_ABL 0
-#endif
                     if (sbits && !(TVAE_ABL & 1)) {                                 // sign bits (ColDot.bits): lanes 0-31 hold one row, 32-63 the row + 4
                         const unsigned long long bl = __ballot(v > 0.f);
                         sw[j] = (unsigned)(lane < 32 ? bl : bl >> 32);
@@ -963,7 +966,45 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
 constexpr int DX4_THREADS = 256;
 constexpr int DX4_ROWS = 256;
 
+// Lean epilogue of the spectral contraction (no bias, no activation, every row of the tile real): scale, store.  The generic
+// epilogue's per-row work -- options tested per element, a 64-bit address per row and column group -- cost 0.54 ms of the
+// 1.47 ms launch (ablation without any epilogue: 0.94 ms, profiles/README.md round 4).  Here a row's base address is wave
+// uniform (SGPRs), the lane's byte offset one register for the whole tile, and the h3 factors fold into one product per
+// element and column group ((acc ix) ia: exact powers of two).
 template <int NP>
+__device__ __forceinline__ void dense_x6_epilogue_store(f32x16 (&acc)[2][4], float* C, long ldc, long coff, const float* h3a,
+                                                        const float* h3x, int wave, int lane, int m0) {
+    float ixv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ixv[j] = NP == 2 ? h3x[j * 32 + (lane & 31)] : 1.f;
+    const int half = lane >> 5;
+    const unsigned loff = (unsigned)((4 * half * ldc + (lane & 31)) * 4);          // bytes (host: 8 ldc floats fit 2^31 bytes)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rb = wave * 64 + i * 32 + 8 * q;                   // rows rb + 4 half + p <-> registers r = 4 q + p
+            float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (NP == 2) a4 = *reinterpret_cast<const float4*>(h3a + rb + 4 * half);
+            const float aq[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                char* rowp = reinterpret_cast<char*>(C + (long)(m0 + rb + p) * ldc + coff);      // wave uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = NP == 2 ? (acc[i][j][4 * q + p] * ixv[j]) * aq[p] : acc[i][j][4 * q + p];
+#ifdef TVAE_T_CACHED      // experiment (profiles/tools/batch_sweep_dft.sh): default cache policy for T -- does the Infinity Cache keep it?
+                    reinterpret_cast<float*>(rowp + loff)[j * 32] = v;
+#else
+                    __builtin_nontemporal_store(v, reinterpret_cast<float*>(rowp + loff) + j * 32);
+#endif
+                }
+            }
+        }
+}
+
+// EPI = 1: dense_x6_epilogue_store (host: no bias / activation, column-tiled output, rows per problem a multiple of 256)
+template <int NP, int EPI = 0>
 static __global__ __launch_bounds__(DX4_THREADS, 2)
 void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
                             int N, int K, int K8pad, TileMap tm, DenseBatch bt, H3Scale hs) {
@@ -985,7 +1026,7 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
     const int nk = K8pad >> 1;
     bsm[tid] = (ep.bias && (m0 + tid) < M) ? ep.bias[(m0 + tid) >> ep.bias_shift] : 0.f;
     // h3: power-of-two scales -- per row of A, per column group (image) of the streamed operand (see H3Scale)
-    __shared__ float h3a_[NP == 2 ? DX4_ROWS : 1];
+    __shared__ __attribute__((aligned(16))) float h3a_[NP == 2 ? DX4_ROWS : 4];
     __shared__ float h3x_[NP == 2 ? 128 : 1];
     float sx = 1.f;
     if (NP == 2) {
@@ -1082,11 +1123,25 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
         step(tt + 1, afB, afA, xA);
     }
     if (nk & 1) step(nk - 1, afA, afB, xB);
+    if (EPI == 1) {      // (M is a multiple of the tile: a tile is all real rows, or all rows that pad the stacked problems to 512)
+        if (m0 < M) dense_x6_epilogue_store<NP>(acc, ep.C, ep.ldc, (long)tile_n * ep.ctile, h3a_, h3x_, wave, lane, m0);
+        return;
+    }
     if (NP == 2) h3_unscale_rc<true>(acc, h3a_, h3x_, wave, lane);
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float gyv[4] = {0.f, 0.f, 0.f, 0.f};
     const InTail it{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    if (TVAE_ABL & 8) {                                  // ablation: no epilogue (keep the accumulators alive)
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
+        if (t_ == 123.456f) ep.C[0] = t_;
+    } else
     if (ep.act == ACT_LRELU)
         dense_x6_epilogue<ACT_LRELU, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
                                                                      gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
@@ -1479,6 +1534,17 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         for (int j = 0; j < 4; ++j) ixv[j] = ssm[128 + j * 32 + (lane & 31)];
     }
     const float oms = 1.f - vg.slope;
+    if (TVAE_ABL & 8) {                                  // ablation: no epilogue (keep the accumulators alive)
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
+        if (t_ == 123.456f) ws[0] = t_;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
