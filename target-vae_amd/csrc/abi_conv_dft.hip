@@ -100,7 +100,11 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.ed_floats = (long)q.NS * q.NRT * 64;
     q.tab_floats = ((q.eo_floats + 3) & ~3L) + ((q.ed_floats + 3) & ~3L) + q.M;   // EO + ED + per-row bias-gradient sums
     q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
-    q.splits = (int)(q.NBpad / 1024);                          // 8 slices deal one to each XCD; short reductions take fewer
+    // 8 reduction slices deal one to each XCD (TileMap: a slice lives on ONE XCD).  Round 4: also for short reductions --
+    // with NBpad / 1024 slices a 32-image step (the per-GPU share of a 256-image global batch on 8 GPUs) ran its 392 tiles on
+    // ONE slice = one XCD = 32 of the 256 CUs: 0.81 ms for an eighth of the work the full batch does in 1.56 ms.  Now every
+    // slice of >= 2 k-steps gets its own XCD (0.81 -> 0.23 ms at B = 32; B = 256 unchanged: 8 slices either way).
+    q.splits = (int)(q.NBpad / 32);
     if (q.splits < 1) q.splits = 1;
     if (q.splits > 8) q.splits = 8;
     // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)

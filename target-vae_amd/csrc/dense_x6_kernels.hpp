@@ -1358,6 +1358,10 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             if (xva_lrelu) {                             // straight-line LeakyReLU (see dense_x6_kernel: no per-value branches in the loop)
                 const float p0 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.x, c0.y), p1 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c0.z, c0.w);
                 const float p2 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.x, c1.y), p3 = dec_l0_pre(va_w0, va_w1, va_bc, lbv, c1.z, c1.w);
+                // max(p, slope p) IS LeakyReLU for 0 < slope < 1 (signed zeros and NaN included): two instructions, not three
+                if (va.slope > 0.f && va.slope < 1.f)
+                    return make_float4(fmaxf(p0, p0 * va.slope), fmaxf(p1, p1 * va.slope), fmaxf(p2, p2 * va.slope),
+                                       fmaxf(p3, p3 * va.slope));
                 return make_float4(p0 > 0.f ? p0 : p0 * va.slope, p1 > 0.f ? p1 : p1 * va.slope, p2 > 0.f ? p2 : p2 * va.slope,
                                    p3 > 0.f ? p3 : p3 * va.slope);
             }
@@ -1386,13 +1390,15 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     };
     auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3], int t) {
         if (LRF == 2) {                                  // eight sign bits of the word -> one cell of 0 / 1.0
+            // y = b | b << 15 puts bit 2q at 2q and bit 2q + 1 at 16 + 2q: one mask and one 24-bit multiply per word (the
+            // multiplier (lo >> 2q) is exact for both encodings of 1.0: 0x3c00 = 0xf << 10, 0x3f80 = 0x7f << 7)
             const int sh = ((nbeg + 16 * t) & 31) + 8 * khalf;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const unsigned b = __float_as_uint(r[i][0].x) >> sh;
+                const unsigned b = (__float_as_uint(r[i][0].x) >> sh) & 0xffu;
+                const unsigned y = b | (b << 15);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    a[i][0].w[q] = ((b >> (2 * q)) & 1u) * OneBits<NP>::lo | ((b >> (2 * q + 1)) & 1u) * OneBits<NP>::hi;
+                for (int q = 0; q < 4; ++q) a[i][0].w[q] = (y & (0x00010001u << (2 * q))) * (OneBits<NP>::lo >> (2 * q));
             }
             return;
         }
@@ -1422,12 +1428,15 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
     };
     float ssum = 0.f;
+    // the row's validity and (h3) its power-of-two scale are ONE per-thread factor: the values are born scaled, s[k] is
+    // accumulated scaled and unscaled once at the end -- exact, bitwise what scaling at the split gave
+    const float bsx = NP == 2 ? b_ok * sx : b_ok;
     auto store_b = [&](int stage, const float4& x, int slot, bool real_step) {
         unsigned hw[2], mw[2], lw[2];
-        float4 gm = make_float4(b_ok, b_ok, b_ok, b_ok);
+        float4 gm = make_float4(bsx, bsx, bsx, bsx);
         if (LRF) {                                       // gy of this thread's four columns joins the X values
             const float4 g4 = *reinterpret_cast<const float4*>(ring + slot * WG_SLOT_BYTES + 4096 + 1024 + 16 * q4);
-            gm = make_float4(g4.x * b_ok, g4.y * b_ok, g4.z * b_ok, g4.w * b_ok);
+            gm = make_float4(g4.x * bsx, g4.y * bsx, g4.z * bsx, g4.w * bsx);
         }
         const float v[4] = {x.x * gm.x, x.y * gm.y, x.z * gm.z, x.w * gm.w};
         // s[k] of the two-valued form: this thread's share of row kr (the clamped step past the end must not count)
@@ -1439,7 +1448,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
         if (NP == 2) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) split2h_pair(v[2 * q] * sx, v[2 * q + 1] * sx, hw[q], lw[q]);
+            for (int q = 0; q < 2; ++q) split2h_pair(v[2 * q], v[2 * q + 1], hw[q], lw[q]);
             dst[0] = make_uint2(hw[0], hw[1]);
             dst[2 * 256] = make_uint2(lw[0], lw[1]);
             return;
@@ -1518,7 +1527,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     if (LRF) {
         ssum += __shfl_xor(ssum, 1, 64);                 // the four n-quads (tid & 3) of feature row kr
         ssum += __shfl_xor(ssum, 2, 64);
-        if (q4 == 0) ssm[kr] = ssum;
+        if (q4 == 0) ssm[kr] = NP == 2 ? ssum * h3_inv(sx) : ssum;
     }
     if (NP == 2) {                                       // [128 ..): per tile column (= X row), [256 ..): per tile row of dY
         if (q4 == 0) ssm[128 + kr] = h3_inv(sx);
