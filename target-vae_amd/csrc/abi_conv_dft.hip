@@ -104,7 +104,9 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     // with NBpad / 1024 slices a 32-image step (the per-GPU share of a 256-image global batch on 8 GPUs) ran its 392 tiles on
     // ONE slice = one XCD = 32 of the 256 CUs: 0.81 ms for an eighth of the work the full batch does in 1.56 ms.  Now every
     // slice of >= 2 k-steps gets its own XCD (0.81 -> 0.23 ms at B = 32; B = 256 unchanged: 8 slices either way).
-    q.splits = (int)(q.NBpad / 32);
+    // (Problems with >= 8 column tiles -- several input channels, wide frames: K2 = 1 152 at the galaxy shape -- already
+    // spread over the XCDs by their column tiles and keep few slices: a slab there is as large as S' itself.)
+    q.splits = (int)(cdiv(q.K2, 128) >= 8 ? q.NBpad / 1024 : q.NBpad / 32);
     if (q.splits < 1) q.splits = 1;
     if (q.splits > 8) q.splits = 8;
     // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)

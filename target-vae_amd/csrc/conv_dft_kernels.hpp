@@ -80,6 +80,10 @@ __device__ __forceinline__ void dft_plane_spectrum(float* sm_dft, const float* _
         Rw[yy * FXB + f] = make_float2(re, im);
     }
     __syncthreads();
+#ifdef TVAE_SPECTRA_EXTRA_SYNC
+    __builtin_amdgcn_s_waitcnt(0);                       // investigation build (profiles/README.md round 4): drain every counter,
+    __syncthreads();                                     // a second barrier after the row transform
+#endif
     // Yh[fy][f] = sum_y Rw[y][f] e^{-2 pi i fy (y+pad) / L}
     if ((L & 3) == 0) {
         // radix-4 step over the output index: the four outputs fy + q L/4 share their twiddles up to (-i)^(q (y+pad)), so
