@@ -386,10 +386,19 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
                                         H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1});
         if (rc) return rc;
     }
-    hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits, q.g_floats,
-                       dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
+    // both contractions on the fp32 matrix pipe where the tiles are not mostly padding (ksz <= 64, >= 17 frequencies per block)
+    static const bool dbank_mf = !(getenv("TVAE_DBANK_MF") && getenv("TVAE_DBANK_MF")[0] == '0');
+    if (dbank_mf && ksz <= 64 && q.FXBd >= 17 && q.FXBd <= 64) {
+        hipError_t e = allow_big_lds(dft_dbank_mf_kernel, q.lds_db);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(dft_dbank_mf_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits,
+                           q.g_floats, dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
+    } else {
+        hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits, q.g_floats,
+                           dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
+    }
     TVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -1052,4 +1052,109 @@ static __global__ void dft_dbank_kernel(const float* __restrict__ G, int nsl, lo
     for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) dbank[((long)m * Cin + ci) * ksz * ksz + i] = outp[i] * inv;
 }
 
+// ------------------------------------------------------------------------------------------
+// The same inverse transform with both contractions on the fp32 matrix pipe (round 4; ksz <= 64, >= 17 frequencies per
+// block).  The direct sums above spend ~18 000 vector instructions per thread on 1.6 M complex multiply-adds per filter;
+// as two small real GEMMs with twiddle operands they are 242 v_mfma_f32_32x32x2_f32 per wave:
+//   stage 1   [Zr; Zi][u][f] = sum_fy [c, -s; s, c](fy u) [Kr; Ki][fy][f]       rows u (32 per tile), columns f, k = fy pairs
+//   stage 2   out[u][v]     += sum_fx c_fx ( Zr[u][fx] cos(fx v) - Zi[u][fx] sin(fx v) )   rows u, columns v, k = fx pairs
+// Four waves, one 32 x 32 output tile each ((u tile, f tile) resp. (u tile, v tile)).  The twiddle operand of a lane is
+// tw[(fy u) mod L] with a running phase (u resp. v fixed per lane, +2u / +2v per k-step): one 8-byte LDS read per step and
+// operand, next to one of the data (Kh[fy][f] = (Kr, Ki), Z[u][fx] = (Zr, Zi)).  Indices past the ends are clamped and
+// meet a zero on the other side.  Same LDS footprint, slab summation and accumulation over frequency blocks as above.
+// ------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void dft_dbank_mf_kernel(const float* __restrict__ G, int nsl, long gs,
+                                                                  float* __restrict__ dbank, int ksz, int L, int Lh, int M,
+                                                                  int Cin, int FXB) {
+    extern __shared__ float sm_dft[];
+    float2* Kh = reinterpret_cast<float2*>(sm_dft);
+    float2* Z = Kh + L * FXB;
+    float2* tw = Z + ksz * FXB;
+    float* outp = reinterpret_cast<float*>(tw + L);
+    const int m = blockIdx.x / Cin, ci = blockIdx.x - m * Cin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
+    const int ut = wave & 1, xt = wave >> 1;              // this wave's tile: rows 32 ut .., columns 32 xt .. (f resp. v)
+    fill_twiddles(tw, L);
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) outp[i] = 0.f;
+    const long rowlen = 2L * L * Cin;
+    const int u = 32 * ut + li;                           // A row of stage 1 and 2 (twiddle resp. data row)
+    for (int fx0 = 0; fx0 < Lh; fx0 += FXB) {
+        const int nfx = min(FXB, Lh - fx0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nfx * L; i += blockDim.x) {
+            const int fy = i % L, f = i / L;
+            const float* r0 = G + ((long)(fx0 + f) * 2 * M + m) * rowlen + (long)(2 * ci) * L;
+            const float* r1 = G + ((long)(fx0 + f) * 2 * M + M + m) * rowlen + (long)(2 * ci) * L;
+            float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+            for (int sl = 0; sl < nsl; ++sl) {
+                a += r0[sl * gs + fy];
+                b += r1[sl * gs + L + fy];
+                c += r0[sl * gs + L + fy];
+                d += r1[sl * gs + fy];
+            }
+            Kh[fy * FXB + f] = make_float2(a + b, c - d);
+        }
+        __syncthreads();
+        if (32 * ut < ksz && 32 * xt < nfx) {             // ---- stage 1: Z[u][f], this wave's (u tile, f tile)
+            f32x16 zr, zi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[r] = zi[r] = 0.f;
+            const int f = min(32 * xt + li, nfx - 1);     // B column (clamped: columns >= nfx are not stored)
+            int ph = (kh * u) % L;                        // (fy u) mod L for fy = kh
+            const int dph = (2 * u) % L;
+            for (int t = 0; 2 * t < L; ++t) {
+                const int fy = 2 * t + kh;
+                const float2 w = tw[ph];
+                const float2 kv = Kh[min(fy, L - 1) * FXB + f];
+                const float ok = fy < L ? 1.f : 0.f;      // odd frames: the last pair's second row does not exist
+                const float c = w.x * ok, s_ = w.y * ok;
+                zr = __builtin_amdgcn_mfma_f32_32x32x2f32(c, kv.x, zr, 0, 0, 0);
+                zr = __builtin_amdgcn_mfma_f32_32x32x2f32(-s_, kv.y, zr, 0, 0, 0);
+                zi = __builtin_amdgcn_mfma_f32_32x32x2f32(s_, kv.x, zi, 0, 0, 0);
+                zi = __builtin_amdgcn_mfma_f32_32x32x2f32(c, kv.y, zi, 0, 0, 0);
+                ph += dph;
+                if (ph >= L) ph -= L;
+            }
+            const int fc = 32 * xt + li;                  // D layout: lane = column f, registers = rows u
+            if (fc < nfx) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ur = 32 * ut + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (ur < ksz) Z[ur * FXB + fc] = make_float2(zr[r], zi[r]);
+                }
+            }
+        }
+        __syncthreads();
+        if (32 * ut < ksz && 32 * xt < ksz) {             // ---- stage 2: out[u][v] += ..., this wave's (u tile, v tile)
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const int v = 32 * xt + li;                   // B column
+            const int ua = min(u, ksz - 1);               // A row (clamped: rows >= ksz are not stored)
+            int ph = (int)(((long)(fx0 + kh) * v) % L);   // (fx v) mod L for fx = fx0 + kh
+            const int dph = (2 * v) % L;
+            for (int t = 0; 2 * t < nfx; ++t) {
+                const int fl = 2 * t + kh, fx = fx0 + fl;
+                const float2 z = Z[ua * FXB + min(fl, nfx - 1)];
+                const float cf = fl < nfx ? (((fx == 0) || (2 * fx == L)) ? 1.f : 2.f) : 0.f;
+                const float2 w = tw[ph];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(z.x, cf * w.x, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(z.y, -cf * w.y, o, 0, 0, 0);
+                ph += dph;
+                if (ph >= L) ph -= L;
+            }
+            if (v < ksz) {                                // D layout: lane = column v, registers = rows u
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ur = 32 * ut + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (ur < ksz) outp[ur * ksz + v] += o[r];      // (one owner per element in every block: no race)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float inv = 1.f / ((float)L * (float)L);
+    for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) dbank[((long)m * Cin + ci) * ksz * ksz + i] = outp[i] * inv;
+}
+
 }  // namespace tvae

@@ -130,8 +130,13 @@ static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ld
                                             const float* __restrict__ rowmax) {
     const long total = (long)K8pad * Rpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(i % Rpad);
-        const int o = (int)(i / Rpad);
+        // row-major operands (forward form): consecutive threads take consecutive octets of a ROW, i.e. consecutive 32-byte
+        // pieces of memory -- with the row fastest every lane of a load touched its own 768-byte-strided line (the spectral
+        // weight's 77 MB: 100 -> 60 us); the 16-byte cell stores of eight neighbouring rows still complete one line.
+        // Transposed operands keep the row fastest (there it IS the contiguous index).
+        const int row = transpose ? (int)(i % Rpad) : (int)(i / K8pad);
+        const int o = transpose ? (int)(i / Rpad) : (int)(i % K8pad);
+        const long ci = (long)o * Rpad + row;            // cell index
         const float s = h3_scale(rowmax[row]);
         float r[8];
 #pragma unroll
@@ -143,8 +148,8 @@ static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ld
         }
         Cell16 h, l;
         split2hx8(r, h, l);
-        A3[i] = h.u;
-        A3[total + i] = l.u;
+        A3[ci] = h.u;
+        A3[total + ci] = l.u;
     }
 }
 
