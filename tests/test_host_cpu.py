@@ -354,3 +354,40 @@ def test_scratch_buffers_outlive_a_captured_graph():
         ops._WS.clear()
         ops._WS.update(saved[0])
         ops._PINNED = saved[1]
+
+
+def test_hand_counted_kernels_use_no_scratch_and_no_packed_fp32():
+    """the LDS-DMA ring kernels wait with hand-counted `s_waitcnt vmcnt(N)`; a compiler-emitted scratch spill (or
+    any other vector-memory instruction it adds) would inflate the count and let a wave read LDS before its DMA has landed.
+    Gate on the BUILT library: those kernels, and the lean epilogue instances whose point is a register budget, must have a
+    private segment of 0 bytes; and no code object may contain packed-fp32 vector instructions (csrc/Makefile NOPK:
+    profiles/README.md, rounds 3-4).  Reads the code objects embedded in libtvae_hip.so with llvm-readelf / llvm-objdump."""
+    import re
+    import subprocess
+    import tempfile
+    from tvae import _lib
+    readelf, objdump = '/opt/rocm/lib/llvm/bin/llvm-readelf', '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not (os.path.exists(readelf) and os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        import pytest
+        pytest.skip('needs the ROCm llvm tools and the built library')
+    data = open(_lib.LIB_PATH, 'rb').read()
+    offs = [m.start() for m in re.finditer(b'\x7fELF\x02\x01\x01\x40', data)]
+    assert len(offs) >= 20
+    must_be_zero = re.compile(r'dft_out_ring_kernel|dft_dy_ring_kernel|dense_wgrad_x6_dma_kernel|enc_tail_wgrad_x6_kernel|'
+                              r'dense_x6_kernelILi2ELi\dELi1E|dense_x6_kernelILi5ELi\dELi2E|dense_x6_plain4_kernelILi\dELi1E')
+    seen, npk = 0, 0
+    for o in offs:
+        with tempfile.NamedTemporaryFile(suffix='.co') as f:
+            f.write(data[o:])
+            f.flush()
+            notes = subprocess.run([readelf, '--notes', f.name], capture_output=True, text=True).stdout
+            dis = subprocess.run([objdump, '-d', f.name], capture_output=True, text=True).stdout
+        npk += len(re.findall(r'\bv_pk_(?:fma|mul|add)_f32\b', dis))
+        for blk in re.split(r'\n\s+- ', notes):
+            n = re.search(r'\.name:\s+(\S+)', blk)
+            p = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
+            if n and p and must_be_zero.search(n.group(1)):
+                seen += 1
+                assert int(p.group(1)) == 0, (n.group(1), int(p.group(1)))
+    assert seen >= 20, seen
+    assert npk == 0, npk
