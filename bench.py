@@ -471,8 +471,11 @@ def main():
         _lib.set_gemm_mode(mode)
         companion_bf16 = {'value': B * args.steps / dt2, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt2 / args.steps,
                           'arithmetic': 'TVAE_GEMM=bf16: operands of the convolution and decoder GEMMs rounded to one bf16 '
-                                        'number, fp32 accumulate (tolerance 2e-2 on the ELBO terms, tests/test_hip_modules.py'
-                                        '::test_bf16_throughput_mode); not fp32-equivalent, not the headline',
+                                        'number, fp32 accumulate; since round 4 the two large intermediates of the frequency-'
+                                        'domain convolution, T and S\', are also STORED as bf16 (TVAE_BF16_STORE=0: fp32 storage) '
+                                        '(tolerance 2e-2 on the ELBO terms, tests/test_hip_modules.py::test_bf16_throughput_mode; '
+                                        '1.5e-2 on the convolution, tests/test_hip_primitives.py::test_conv1_dft_bf16_mode); not '
+                                        'fp32-equivalent, not the headline',
                           'elbo': float(lastb),
                           'entry_points_ms': {k_: round(v['mean_ms'], 3) for k_, v in sorted(kev2.items())
                                               if k_.startswith('tvae_linear') or k_.startswith('tvae_conv1')}}

@@ -176,6 +176,10 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     // h3 arithmetic (two fp16 parts, three products): both forms of the spectral GEMM (four-wave tile for reductions <= 256,
     // eight-wave tile beyond: several channels, wide frames) take the operand maxima dft_spectra leaves behind A^T
     const bool h3 = parts == 2;
+    // bf16 STORAGE of T (round 4): the one-part throughput mode on a ring geometry with whole 256-row tiles writes and reads T
+    // as 2-byte elements (TVAE_BF16_STORE=0 keeps fp32 storage; the fp32-class arithmetics never take this path)
+    static const bool bf16_store = !(getenv("TVAE_BF16_STORE") && getenv("TVAE_BF16_STORE")[0] == '0');
+    const bool t16 = bf16_store && parts == 1 && q.ring && q.K2 <= 256 && (2 * q.M) % DX4_ROWS == 0;
     // the maxima are produced in every arithmetic (one small fill and a few atomics): the weight gradient may run in
     // h3 after a forward that did not
     float* amax = at + ((q.at_floats + 3) & ~3L);
@@ -223,7 +227,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
         // h3: one scale per stacked row (fx, m') of the spectral weight, one per (fx, image) of A^T's columns
         const H3Scale hs{mxp.wmax, mxp.cmax, 1, 0, 0, q.Ho, B};
-        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs)
+        rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs, t16)
                             : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs);
         if (rc) return rc;
     }
@@ -238,25 +242,24 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             const long vt = (long)q.M * ((q.NB + 31) / 32);           // tiles with at least one real column
             const int cus = dev_cu_count();
             const int grid = (int)((vt + 3) / 4 < cus ? (vt + 3) / 4 : cus);
+#define TVAE_OUT_RING_ONE(L_, N_, R_, H_, TH_, T16_)                                                                  \
+    do {                                                                                                            \
+        const size_t lds_r = (size_t)4 * 3 * ((T16_) ? (2 * L_ + 15) / 16 : (L_ + 3) / 4) * 1024;                   \
+        e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, TH_, T16_>, lds_r);                                   \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, TH_, T16_>), dim3(grid), dim3(256), lds_r, st,      \
+                           (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, a1max);       \
+    } while (0)
 #define TVAE_OUT_RING(L_, N_, R_, H_)                                                                               \
     do {                                                                                                            \
-        const size_t lds_r = (size_t)4 * 3 * ((L_ + 3) / 4) * 1024;                                                 \
-        if (act == ACT_TANH) {                                                                                      \
-            e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, true>, lds_r);                                    \
-            if (e != hipSuccess) return (int)e;                                                                     \
-            hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, true>), dim3(grid), dim3(256), lds_r, st,       \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, a1max);          \
-        } else {                                                                                                    \
-            e = allow_big_lds(dft_out_ring_kernel<L_, N_, R_, H_, false>, lds_r);                                   \
-            if (e != hipSuccess) return (int)e;                                                                     \
-            hipLaunchKernelGGL((dft_out_ring_kernel<L_, N_, R_, H_, false>), dim3(grid), dim3(256), lds_r, st,      \
-                               (const float*)T, (const float*)EO, bias, out, q.M, R, B, q.Lh, act, slope, a1max);          \
-        }                                                                                                           \
+        if (act == ACT_TANH) { if (t16) TVAE_OUT_RING_ONE(L_, N_, R_, H_, true, true); else TVAE_OUT_RING_ONE(L_, N_, R_, H_, true, false); } \
+        else { if (t16) TVAE_OUT_RING_ONE(L_, N_, R_, H_, false, true); else TVAE_OUT_RING_ONE(L_, N_, R_, H_, false, false); } \
     } while (0)
             if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);
             else if (q.ring == 2) TVAE_OUT_RING(49, 1, true, 33);
             else TVAE_OUT_RING(34, 2, false, 39);
 #undef TVAE_OUT_RING
+#undef TVAE_OUT_RING_ONE
             TVAE_CHECK_LAUNCH();
             return 0;
         }
@@ -308,6 +311,9 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     // along w below (every instance measures them, in every arithmetic: the ring kernels count the atomic in their waits)
     float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
     float* smax = amax + q.o_smax;
+    // bf16 STORAGE of S' (round 4): one-part mode on a ring geometry (see tvae_conv1_fwd_dft)
+    static const bool bf16_store = !(getenv("TVAE_BF16_STORE") && getenv("TVAE_BF16_STORE")[0] == '0');
+    const bool s16 = bf16_store && parts == 1 && q.ring;
     hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, st, smax, q.M);
     TVAE_CHECK_LAUNCH();
     float* Sp = ws;
@@ -324,18 +330,21 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
             const int cus = dev_cu_count();
             const int grid = (int)((ntiles + 3) / 4 < 2 * cus ? (ntiles + 3) / 4 : 2 * cus);
             hipError_t er = hipSuccess;
-#define TVAE_DY_RING(S_, T_, L2_, H_, Q_)                                                                           \
+#define TVAE_DY_RING_ONE(S_, T_, L2_, H_, Q_, S16_)                                                                  \
     do {                                                                                                            \
         const size_t lds_r = (size_t)4 * 2 * ((32 * H_ + 63) / 64) * 256;                                           \
-        er = allow_big_lds(dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>, lds_r);                                         \
+        er = allow_big_lds(dft_dy_ring_kernel<S_, T_, L2_, H_, Q_, S16_>, lds_r);                                   \
         if (er != hipSuccess) return (int)er;                                                                       \
-        hipLaunchKernelGGL((dft_dy_ring_kernel<S_, T_, L2_, H_, Q_>), dim3(grid), dim3(256), lds_r, st, dpre,       \
-                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad, smax);         \
+        hipLaunchKernelGGL((dft_dy_ring_kernel<S_, T_, L2_, H_, Q_, S16_>), dim3(grid), dim3(256), lds_r, st, dpre, \
+                           (const float*)ED, Sp, q.M, R, B, q.Lh, q.NBpad, smax);                                   \
     } while (0)
+#define TVAE_DY_RING(S_, T_, L2_, H_, Q_)                                                                           \
+    do { if (s16) TVAE_DY_RING_ONE(S_, T_, L2_, H_, Q_, true); else TVAE_DY_RING_ONE(S_, T_, L2_, H_, Q_, false); } while (0)
             if (q.ring == 1) TVAE_DY_RING(9, 2, 46, 17, false);
             else if (q.ring == 2) TVAE_DY_RING(17, 3, 98, 33, true);
             else TVAE_DY_RING(20, 3, 68, 39, false);
 #undef TVAE_DY_RING
+#undef TVAE_DY_RING_ONE
             TVAE_CHECK_LAUNCH();
         } else if (q.gen) {
             const size_t lds_g = (size_t)4 * 32 * ((2 * q.NS) | 1) * 4;
@@ -367,7 +376,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     }
     if (dbias) {
         float* dbpart = ED + ((q.ed_floats + 3) & ~3L);           // M floats behind the transform tables
-        hipLaunchKernelGGL(dft_dbias_rows_kernel, dim3(q.M), dim3(256), 0, st, (const float*)Sp, dbpart, q.Lh, q.NB, q.M);
+        hipLaunchKernelGGL(dft_dbias_rows_kernel, dim3(q.M), dim3(256), 0, st, (const float*)Sp, dbpart, q.Lh, q.NB, q.M,
+                           s16 ? 1 : 0);
         TVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(dft_dbias_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)dbpart, dbias, R, C);
         TVAE_CHECK_LAUNCH();
@@ -383,7 +393,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
                                         128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st,
                                         // h3: one scale per filter row of S' (rows m and M + m), one per frequency of A^T
-                                        H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1});
+                                        H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1}, s16);
         if (rc) return rc;
     }
     // both contractions on the fp32 matrix pipe where the tiles are not mostly padding (ksz <= 64, >= 17 frequencies per block)

@@ -19,7 +19,7 @@ int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& e
                              hs);
 }
 int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int rows_total,
-                      int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs) {
+                      int N, int K, const TileMap& tm, const DenseBatch& bt, int parts, hipStream_t st, H3Scale hs, bool out_bf16) {
     const int Rpad = x6_round_up(rows_total, DX6_ROWS), K8pad = dense_k8pad(K);     // the cells keep their 512-row padding
     if (N % 128 != 0 || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
     if (parts == 2 && (!hs.amax_a || !hs.amax_x)) return (int)hipErrorInvalidValue;
@@ -29,6 +29,11 @@ int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& 
 #define TVAE_DX4_LAUNCH(NP_, E_)                                                                                       \
     hipLaunchKernelGGL((dense_x6_plain4_kernel<NP_, E_>), dim3(tm.grid()), dim3(DX4_THREADS), 0, st, (const uint4*)w3, X, ldx, \
                        ep, rows_per_problem, Rpad, N, K, K8pad, tm, bt, hs)
+    if (out_bf16) {      // bf16 STORAGE of the output (one-part mode only; the caller reads 2-byte elements)
+        if (!lean || parts != 1) return (int)hipErrorInvalidValue;
+        TVAE_DX4_LAUNCH(1, 2);
+        return (int)hipGetLastError();
+    }
     if (parts == 3) { if (lean) TVAE_DX4_LAUNCH(3, 1); else TVAE_DX4_LAUNCH(3, 0); }
     else if (parts == 2) { if (lean) TVAE_DX4_LAUNCH(2, 1); else TVAE_DX4_LAUNCH(2, 0); }
     else { if (lean) TVAE_DX4_LAUNCH(1, 1); else TVAE_DX4_LAUNCH(1, 0); }

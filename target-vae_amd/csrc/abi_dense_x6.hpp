@@ -97,10 +97,24 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1(TVAE_WG_LAUNCH_ARGS);
     }                                                                                                                 \
     }
 
+// one-part mode with the A operand STORED as bf16 (dense_wgrad_x6_dma_kernel<.., ABF>; abi_dense_wgrad_x6_b.hip)
+TVAE_INTERNAL int dense_wgrad_x6_launch_p1_abf(TVAE_WG_LAUNCH_ARGS);
+#define TVAE_WG_LAUNCH_DEF_ABF                                                                                        \
+    namespace tvae {                                                                                                  \
+    int dense_wgrad_x6_launch_p1_abf(TVAE_WG_LAUNCH_ARGS) {                                                           \
+        if (variant != 0) return (int)hipErrorInvalidValue;                                                           \
+        hipError_t e_ = allow_big_lds(dense_wgrad_x6_dma_kernel<false, false, 0, 1, true>, WG_RING_BYTES);            \
+        if (e_ != hipSuccess) return (int)e_;                                                                         \
+        hipLaunchKernelGGL((dense_wgrad_x6_dma_kernel<false, false, 0, 1, true>), dim3(tm.grid()), dim3(DX6_THREADS),  \
+                           WG_RING_BYTES, st, dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, hs); \
+        return (int)hipGetLastError();                                                                                \
+    }                                                                                                                 \
+    }
+
 // the same with the 256-row / four-wave tile (dense_x6_plain4_kernel: short reductions); tm / bt count 256-row tiles
 TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                     int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
-                                    hipStream_t st, H3Scale hs = H3_NONE);
+                                    hipStream_t st, H3Scale hs = H3_NONE, bool out_bf16 = false);
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
@@ -109,6 +123,6 @@ TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, con
 TVAE_INTERNAL int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M,
                                          int Kf, int N, int nchunk, const TileMap& tm, const DenseBatch& bt,
                                          long dy_stride, const ATile& atile, int parts, hipStream_t st,
-                                         H3Scale hs = H3_NONE);
+                                         H3Scale hs = H3_NONE, bool a_bf16 = false);
 
 }  // namespace tvae

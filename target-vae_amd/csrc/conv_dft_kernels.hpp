@@ -536,12 +536,16 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_mf_kernel(const float* _
 // epilogue ([32 columns][HO], HO odd: its linear order IS the order of the tile's outputs in memory).  One 4-wave
 // workgroup per CU (3 x 13 KB per wave at the 96-wide frame).  Per tile: ND DMAs, then SN stores; at the top of
 // iteration it >= 2 the operations younger than tile it's DMAs are stores(it-2), DMAs(it+1), stores(it-1).
-template <int LHP, int NT, bool REM1, int HO, bool TANH>
+// T16 (round 4, one-part bf16 mode only): T holds 2-byte bf16 elements in the same element layout.  A DMA piece is then 16
+// rows x 32 columns (lane -> row 16 g + (lane >> 2) = 2 fx + (re | im), columns 8 (lane & 3) ..), the LDS image
+// [fx][re | im][32 columns] of bf16, and a lane widens its operand (one ds_read_u16 + shift) before the fp32 MFMA: half the
+// bytes to fetch, seven DMAs per tile instead of thirteen at the 96-wide frame.
+template <int LHP, int NT, bool REM1, int HO, bool TANH, bool T16 = false>
 static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float* __restrict__ T, const float* __restrict__ EO,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int M, int R, int B, int Lh, int act, float slope,
                                                                      float* __restrict__ amax) {
-    constexpr int NTT = NT + (REM1 ? 1 : 0), ND = (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
+    constexpr int NTT = NT + (REM1 ? 1 : 0), ND = T16 ? (2 * LHP + 15) / 16 : (LHP + 3) / 4, SLOTB = ND * 1024, SLOTF = SLOTB / 4;
     float amx = 0.f;                                     // max |out| of the current tile -> amax[channel] (h3 scales of the launches that read out)
     constexpr int SN = (32 * HO + 63) / 64, P = HO * HO;
     static_assert((HO & 1) == 1, "odd output width: the [column][HO] patch is conflict free and linear in memory order");
@@ -570,7 +574,14 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     // DMA piece g, lane -> (fx = 4 g + (lane >> 4), re | im = (lane >> 3) & 1, columns 4 (lane & 7) ..): byte offset of the
     // lane's 16 bytes from the tile's (wave-uniform) base; rows beyond Lh (last piece) re-read the last row, never used
     unsigned doff[ND];
-    {
+    if (T16) {
+        const int c8 = (lane & 3) * 8;
+#pragma unroll
+        for (int g = 0; g < ND; ++g) {
+            const int rr = 16 * g + (lane >> 2);         // row of the LDS image: 2 fx + (re | im)
+            doff[g] = (unsigned)(((long)(rr & 1) * M * Lh + min(rr >> 1, Lh - 1)) * 128 + c8) * 2u;
+        }
+    } else {
         const int fxl = lane >> 4, rid = (lane >> 3) & 1, c4 = (lane & 7) * 4;
 #pragma unroll
         for (int g = 0; g < ND; ++g)
@@ -584,7 +595,8 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
     auto dma_base = [&](int it) -> const float* {        // wave uniform: T + dft_t_off(n0, m, 2M, Lh)
         int m, n0;
         tile_mn(it, m, n0);
-        return T + ((((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127));
+        const long eo_ = (((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127);      // element offset
+        return T16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(T) + eo_) : T + eo_;
     };
     auto dma_piece = [&](const float* tb, int slot, int g) {
         const unsigned dst = ring_lds + (unsigned)(slot * SLOTB + g * 1024);
@@ -615,18 +627,23 @@ static __global__ __launch_bounds__(256, 1) void dft_out_ring_kernel(const float
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
         float racc = 0.f;
+        const unsigned short* vs16 = reinterpret_cast<const unsigned short*>(ring + slot * SLOTF) + ri * 32 + j;
 #pragma unroll
         for (int fx = 0; fx < LHP; ++fx) {
-            const float v = vs[fx * 64];
+            const float v = T16 ? __uint_as_float((unsigned)vs16[fx * 64] << 16) : vs[fx * 64];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t][fx & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx][t], v, acc[t][fx & 1], 0, 0, 0);
             if (REM1) racc = __fmaf_rn(eo[fx][NTT - 1], v, racc);
-            if ((fx & 3) == 1) dma_piece(tbn, slot2, fx >> 2);               // tile it+2, one piece per four MFMA steps
+            if (T16) {
+                if ((fx & 7) == 1) dma_piece(tbn, slot2, fx >> 3);           // tile it+2, one piece per eight MFMA steps
+            } else {
+                if ((fx & 3) == 1) dma_piece(tbn, slot2, fx >> 2);           // tile it+2, one piece per four MFMA steps
+            }
         }
 #pragma unroll
         for (int g = 0; g < ND; ++g)
-            if (4 * g + 1 >= LHP) dma_piece(tbn, slot2, g);                  // pieces the unrolled loop did not reach
+            if ((T16 ? 8 * g + 1 : 4 * g + 1) >= LHP) dma_piece(tbn, slot2, g);          // pieces the unrolled loop did not reach
         int m, n0;
         tile_mn(it, m, n0);
         const int c = m / R, r_ = m - c * R;
@@ -702,7 +719,9 @@ constexpr int dft_dy_ring_stores(int NRT, int LH2, bool NYQ) {
 // between the MFMAs of tile it, and the only operations younger than them at the next wait are this tile's ST stores.
 // NYQ (2 Lh = 32 NRT + 2, even frame): the Nyquist row is an alternating sum on the vector ALU (its sine row is zero),
 // one store for both; without it those two rows would cost a whole fourth tile of MFMAs (17 of 68 at the 96-wide frame).
-template <int NS, int NRT, int LH2, int HO, bool NYQ>
+// S16 (round 4, one-part bf16 mode only): S' is STORED as bf16 -- the same element layout, 2-byte elements, rounded (RNE) as
+// it leaves the accumulators; the weight-gradient GEMM then DMAs ready-made one-part cells (dense_wgrad_x6_dma_kernel<.., ABF>).
+template <int NS, int NRT, int LH2, int HO, bool NYQ, bool S16 = false>
 static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                                     float* __restrict__ Sp, int M, int R, int B, int Lh,
                                                                     long NBpad, float* __restrict__ amax) {
@@ -809,7 +828,13 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
         tile_mn(it, m, n0);
         if (m != m_prev && m_prev >= 0) h3_tile_flush(mx, amax + m_prev, lane);       // (wave uniform; a few times per wave)
         m_prev = m;
-        float* sb = Sp + ((((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127));   // wave uniform
+        const long sbo = (((long)(n0 >> 7) * (2 * M) + m) * Lh) * 128 + (n0 & 127);     // element offset (wave uniform)
+        float* sb = Sp + sbo;
+        unsigned short* sb16 = reinterpret_cast<unsigned short*>(Sp) + sbo;
+        auto put = [&](unsigned o, float v) {            // one store instruction either way (the waits count them)
+            if (S16) sb16[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            else sb[o] = v;
+        };
         // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh: ri is a compile-time property of (rt, r)
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
@@ -817,14 +842,14 @@ static __global__ __launch_bounds__(256, 2) void dft_dy_ring_kernel(const float*
             for (int r = 0; r < 16; ++r) {
                 const int kk0 = 32 * rt + (r & 3) + 8 * (r >> 2);             // kh = 0; kh = 1 adds 4
                 const unsigned o = ((kk0 & 1) ? lim : lre) + (unsigned)((kk0 >> 1) * 128);
-                if (kk0 + 4 < LH2) sb[o] = acc[rt][r];
-                else if (kk0 < LH2) { if (kh == 0) sb[o] = acc[rt][r]; }
+                if (kk0 + 4 < LH2) put(o, acc[rt][r]);
+                else if (kk0 < LH2) { if (kh == 0) put(o, acc[rt][r]); }
                 if (kk0 < LH2) mx = fmaxf(mx, fabsf(acc[rt][r]));      // (a few values beyond LH2 in the kh = 1 half: zero table rows)
             }
         if (NYQ) {                                       // fx = L/2: cosine row = the alternating sum, sine row = 0
             const float tot = racc + __shfl_xor(racc, 32, 64);
             const unsigned o = (kh ? lim : lre) - (unsigned)(2 * kh * 128) + (unsigned)((LH2 / 2 - 1) * 128);
-            sb[o] = kh ? 0.f : tot;
+            put(o, kh ? 0.f : tot);
             mx = fmaxf(mx, fabsf(tot));
         }
     }
@@ -965,10 +990,16 @@ static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __r
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
 // db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  Two stages: one workgroup per
 // filter row m (1 024 of them: the single-stage version had 128 workgroups walking 51 MB-strided runs), then R sums.
-static __global__ void dft_dbias_rows_kernel(const float* __restrict__ Sp, float* __restrict__ part, int Lh, long NB, int M) {
+static __global__ void dft_dbias_rows_kernel(const float* __restrict__ Sp, float* __restrict__ part, int Lh, long NB, int M,
+                                             int s16) {
     __shared__ float sm[16];
     const int m = blockIdx.x;
     float acc[1] = {0.f};
+    if (s16) {           // S' stored as bf16 (one-part mode)
+        const unsigned short* S16p = reinterpret_cast<const unsigned short*>(Sp);
+        for (long n = threadIdx.x; n < NB; n += blockDim.x)
+            acc[0] += __uint_as_float((unsigned)S16p[dft_t_off(n, m, 2 * M, Lh)] << 16);
+    } else
     for (long n = threadIdx.x; n < NB; n += blockDim.x) acc[0] += Sp[dft_t_off(n, m, 2 * M, Lh)];
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) part[m] = acc[0];

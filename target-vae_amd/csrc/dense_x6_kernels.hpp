@@ -1008,7 +1008,32 @@ __device__ __forceinline__ void dense_x6_epilogue_store(f32x16 (&acc)[2][4], flo
         }
 }
 
+// The same for the bf16 STORAGE of the one-part throughput mode (round 4; TVAE_GEMM=bf16 only, never the fp32-class
+// arithmetics): the accumulators are rounded to bf16 (RNE) and T is written as 2-byte elements in the same element layout,
+// half the bytes for the GEMM to write and for the contraction over fx (dft_out_ring_kernel<.., T16>) to read.
+__device__ __forceinline__ void dense_x6_epilogue_store_bf16(f32x16 (&acc)[2][4], unsigned short* C, long ldc, long coff,
+                                                             int wave, int lane, int m0) {
+    const int half = lane >> 5;
+    const unsigned loff = (unsigned)((4 * half * ldc + (lane & 31)) * 2);          // bytes
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rb = wave * 64 + i * 32 + 8 * q;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                char* rowp = reinterpret_cast<char*>(C + (long)(m0 + rb + p) * ldc + coff);      // wave uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)acc[i][j][4 * q + p]);
+                    __builtin_nontemporal_store(b, reinterpret_cast<unsigned short*>(rowp + loff) + j * 32);
+                }
+            }
+        }
+}
+
 // EPI = 1: dense_x6_epilogue_store (host: no bias / activation, column-tiled output, rows per problem a multiple of 256)
+// EPI = 2: dense_x6_epilogue_store_bf16 (the same shape, NP == 1, ep.C points to 2-byte elements)
 template <int NP, int EPI = 0>
 static __global__ __launch_bounds__(DX4_THREADS, 2)
 void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, Epilogue ep, int M, int Mpad,
@@ -1132,6 +1157,11 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
         if (m0 < M) dense_x6_epilogue_store<NP>(acc, ep.C, ep.ldc, (long)tile_n * ep.ctile, h3a_, h3x_, wave, lane, m0);
         return;
     }
+    if (EPI == 2) {      // (ep.C was advanced by the batch offset in 4-byte units above: undo half of it for 2-byte elements)
+        unsigned short* c16 = reinterpret_cast<unsigned short*>(ep.C - (long)batch * bt.c_stride) + (long)batch * bt.c_stride;
+        if (m0 < M) dense_x6_epilogue_store_bf16(acc, c16, ep.ldc, (long)tile_n * ep.ctile, wave, lane, m0);
+        return;
+    }
     if (NP == 2) h3_unscale_rc<true>(acc, h3a_, h3x_, wave, lane);
     float ysum[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1208,12 +1238,17 @@ constexpr int WG_RING_BYTES = 8 * 3 * WG_SLOT_BYTES;
 // that build the X cells (each owns one feature row k of the tile) and joins the partial slab in the epilogue.
 // LRF: 0 = off, 1 = two-valued form with [H > 0] taken from the saved activation (dY = H), 2 = from the sign bits a forward
 // launch stored (VirtGrad.bits: one word per row and 32 columns, two dword DMAs per wave and step instead of four 1 KB ones)
-template <bool VIRT, bool XVA, int LRF, int NP>
+// ABF (round 4; NP == 1, plain operands only): the A operand is STORED as bf16 (S' of the one-part mode, written by
+// dft_dy_ring_kernel<.., S16>): 8 consecutive n of a row ARE a one-part cell, so the two 1 KB DMAs of a step (instruction g:
+// rows 32 g .. 32 g + 31, lane -> (row lane & 31, 16-byte piece lane >> 5)) land lane-linear in exactly the order in which
+// the fragments read them back -- no split, no vector-ALU work at all on this operand, half the bytes.
+template <bool VIRT, bool XVA, int LRF, int NP, bool ABF = false>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
 void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws,
                                int M, int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, VirtGrad vg,
                                VirtAct va, ATile atile, H3Scale hs) {
-    constexpr int NDMA = (LRF == 2 ? 2 : 4) + (XVA ? 2 : 1) + (VIRT ? 1 : 0);   // DMA instructions per wave and step
+    static_assert(!ABF || (NP == 1 && !VIRT && !XVA && LRF == 0), "bf16-stored A: one-part mode, plain operands");
+    constexpr int NDMA = (ABF ? 2 : (LRF == 2 ? 2 : 4)) + (XVA ? 2 : 1) + (VIRT ? 1 : 0);   // DMA instructions per wave and step
     __shared__ __attribute__((aligned(16))) uint4 Bs[2 * 3 * 2 * 128];    // [stage][part][octet half][k row]
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_ring[];   // [wave][slot < 3][WG_SLOT_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1225,7 +1260,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         batch = tile_m / bt.tiles_per_batch;
         nbatch = tm.tilesM / bt.tiles_per_batch;
         tile_m -= batch * bt.tiles_per_batch;
-        dY += batch * dy_stride;
+        dY += (ABF ? batch * dy_stride / 2 : batch * dy_stride);        // (dy_stride counts elements: 2-byte ones with ABF; even)
         X += batch * bt.x_stride;
     }
     const int m0 = tile_m * DX6_ROWS, k0 = tile_k * 128;
@@ -1266,8 +1301,14 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
     const float* d_ptr[4];                               // A: instruction g, row 16g + lane/4 of this wave, swizzled piece
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int row = m0 + 64 * wave + 16 * g + (lane >> 2);
-        d_ptr[g] = dY + (long)min(row, M - 1) * ldd + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+        if (ABF) {                                       // bf16 rows: instruction g < 2, row 32 g + (lane & 31), piece lane >> 5
+            const int row = m0 + 64 * wave + 32 * (g & 1) + (lane & 31);
+            d_ptr[g] = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dY) +
+                                                      (long)min(row, M - 1) * ldd + 8 * (lane >> 5));
+        } else {
+            const int row = m0 + 64 * wave + 16 * g + (lane >> 2);
+            d_ptr[g] = dY + (long)min(row, M - 1) * ldd + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+        }
     }
     const unsigned* b_ptr[2] = {nullptr, nullptr};       // LRF == 2: the bit row of this lane's fragment row i
     if (LRF == 2) {
@@ -1297,7 +1338,14 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         const int na = nbeg + 16 * t;                    // wave-uniform; a 16-wide step never straddles a column tile
         const long off = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
         const unsigned sl = ring_lds + (unsigned)(slot * WG_SLOT_BYTES);
-        if (LRF == 2) {                                  // each lane fetches the word that holds its row's 16 columns
+        if (ABF) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned short* src = reinterpret_cast<const unsigned short*>(d_ptr[g]) + off;
+                const unsigned dst = sl + (unsigned)(g * 1024);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
+            }
+        } else if (LRF == 2) {                           // each lane fetches the word that holds its row's 16 columns
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned* src = b_ptr[i] + (na >> 5);
@@ -1339,6 +1387,11 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
             a_at[i][h] = (2 * i + ((lane >> 4) & 1)) * 1024 + (lane & 15) * 64 + (((2 * khalf + h) ^ ((lane >> 2) & 3)) * 16);
     auto read_a = [&](int slot, float4 (&r)[2][2], float4 (&gq)[2]) {
         const unsigned char* sl = ring + slot * WG_SLOT_BYTES;
+        if (ABF) {                                       // the cell of fragment i: lane-linear, as the DMA left it
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i][0] = *reinterpret_cast<const float4*>(sl + i * 1024 + 16 * lane);
+            return;
+        }
         if (LRF == 2) {                                  // the word this lane fetched for fragment i (bit-cast into r[i][0].x)
 #pragma unroll
             for (int i = 0; i < 2; ++i) r[i][0].x = *reinterpret_cast<const float*>(sl + i * 256 + 4 * lane);
@@ -1394,6 +1447,13 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
     };
     auto split_a = [&](const float4 (&r)[2][2], Cell16 (&a)[2][3], int t) {
+        if (ABF) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i][0].u = make_uint4(__float_as_uint(r[i][0].x), __float_as_uint(r[i][0].y), __float_as_uint(r[i][0].z),
+                                       __float_as_uint(r[i][0].w));
+            return;
+        }
         if (LRF == 2) {                                  // eight sign bits of the word -> one cell of 0 / 1.0
             // y = b | b << 15 puts bit 2q at 2q and bit 2q + 1 at 16 + 2q: one mask and one 24-bit multiply per word (the
             // multiplier (lo >> 2q) is exact for both encodings of 1.0: 0x3c00 = 0xf << 10, 0x3f80 = 0x7f << 7)

@@ -292,6 +292,40 @@ def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin, nparts):
     assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < GEMM_TOL['f32']
 
 
+@pytest.mark.parametrize('B,n,k,pad,C,R,act', [
+    (24, 64, 64, 16, 16, 8, 1), (40, 28, 28, 8, 32, 8, 1), (12, 50, 28, 8, 32, 8, 2),      # ring frames: bf16 STORAGE of T and S'
+    (5, 40, 32, 6, 64, 4, 0), (3, 28, 28, 8, 16, 8, 1)])                                  # register-staged frame; ragged ring batch
+def test_conv1_dft_bf16_mode(B, n, k, pad, C, R, act):
+    """The one-part bf16 throughput mode of the frequency-domain convolution (parts = 1; never fp32-equivalent): operands
+    rounded to bf16 and, on the ring frames, T and S' STORED as bf16 (round 4).  Own tolerance: 1.5e-2 relative Frobenius
+    against fp64 for the output and the weight gradient (the exact modes hold 2e-5 on the same geometries)."""
+    from tvae._lib import query
+    Cin = 1
+    y = torch.rand(B, Cin, n, n, generator=torch.Generator().manual_seed(1))
+    bank = rnd(C * R, Cin * k * k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(C, seed=3, scale=0.1)
+    Ho = n + 2 * pad - k + 1
+    ref = act_ref(F.conv2d(y.double(), bank.double().view(C * R, Cin, k, k), None, 1, pad).view(B, C, R, Ho, Ho)
+                  + bias.double().view(1, C, 1, 1, 1), act)
+    at = torch.zeros(query('tvae_conv1_dft_at_floats', B, Cin, n, k, pad, C, R), device=dev())
+    ws = torch.empty(query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R), device=dev())
+    out = torch.full((C, B * R * Ho * Ho), float('nan'), device=dev())
+    call('tvae_conv1_fwd_dft', y.to(dev()), bank.to(dev()), bias.to(dev()), out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,
+         SLOPE, 1)
+    got = out.view(C, B, R, Ho, Ho).permute(1, 0, 2, 3, 4)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < 1.5e-2
+    g = rnd(B, C, R, Ho, Ho, seed=4)
+    ref_g = torch.nn.grad.conv2d_weight(y.double(), (C * R, Cin, k, k), g.double().view(B, C * R, Ho, Ho), padding=pad)
+    dpre = g.permute(1, 0, 2, 3, 4).contiguous().view(C, -1).to(dev())
+    dbank = torch.full((C * R, Cin * k * k), float('nan'), device=dev())
+    dbias = torch.empty(C, device=dev())
+    call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, 1)
+    assert torch.isfinite(dbank).all()
+    assert rel_err(dbank.view(C * R, Cin, k, k), ref_g) < 1.5e-2
+    assert rel_err(dbias, g.double().sum(dim=(0, 2, 3, 4))) < 1.5e-2
+
+
 @pytest.mark.parametrize('F_,B,Np,M,act', [(512, 3, 256, 512, 1), (300, 2, 384, 512, 1), (64, 2, 128, 200, 2)])
 def test_linear_dgrad_x6_fused_first_layer(F_, B, Np, M, act):
     """Data gradient of the first hidden layer fused with the backward of the coordinate layer: dX is never stored."""
