@@ -151,14 +151,19 @@ int tvae_dense_split2h(const float* W, long ldw, void* a3, long a3_bytes, int ro
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, void* sign_bits, int parts, tvae_stream_t stream);
+                       int va_np, void* sign_bits, int parts, const float* x_amax, tvae_stream_t stream);
+/* x_amax (optional, ABI 5): with parts = 2 and X read from memory, ONE device word holding max |X| or an upper bound of it
+ * (the h3 scale of the streamed operand); the same argument of tvae_linear_dgrad_x6 (plain form: X = dpre) and a_amax /
+ * x_amax of tvae_linear_wgrad_x6 (plain form: max |dpre|, max |X|; two-valued form from sign bits against an operand from
+ * memory: x_amax >= max |gy[n] X[k][n]|).  A bound that is 2^j too large costs j of the 16 bits by which an element may lie
+ * below its group's maximum before its low part goes subnormal (csrc/conv_x6_kernels.hpp). */
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
                          float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
-                         tvae_stream_t stream);
+                         const float* x_amax, tvae_stream_t stream);
 /* ABI 5, the two-valued form WITHOUT the saved activation (vg_bits != NULL; dpre may then be NULL): the 0 / 1 operand
  * [H > 0] and the row sums sum_n gy[n] [H[m][n] > 0] come from the sign bits the forward launch stored (tvae_linear_fwd_x6
  * sign_bits; that launch may then be given Y = NULL and never writes H), and the weight gradient of the single-output
@@ -185,7 +190,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
                          int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
-                         tvae_stream_t stream);
+                         const float* a_amax, const float* x_amax, tvae_stream_t stream);
 /* rd_rowdot (optional, ABI 5; two-valued LeakyReLU form, accumulate = 0): also returns rd_rowdot[m] = sum_k rd_w[m][k] G[m][k]
  * with G[m][k] = dW[m][k] / wo[m] taken BEFORE the multiplication (exact for wo[m] = 0); rd_w = the layer's weight, [M][K]
  * with row stride rd_ldw. */

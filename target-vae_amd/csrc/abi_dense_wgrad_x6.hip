@@ -68,13 +68,18 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
                          int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
-                         tvae_stream_t stream) {
+                         const float* a_amax, const float* x_amax, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
     if (parts != 1 && parts != 2 && parts != 3) return (int)hipErrorInvalidValue;
     const bool from_bits = vg_bits && vg_wo && vg_act == ACT_LRELU;        // two-valued form from stored sign bits: dpre unused
-    // h3 instance: sign bits (exact 0 / 1 operand) against gy x the recomputed first-layer activation, whose bound is formed here
-    if (parts == 2 && !(from_bits && va_xr && vg_gy)) return (int)hipErrorInvalidValue;
+    // h3 instances: (a) sign bits (exact 0 / 1 operand) against gy x the recomputed first-layer activation, whose bound is formed
+    // here; (b) sign bits against gy x an operand from memory whose bound the caller supplies (x_amax: max |gy[n] X[k][n]| or
+    // more); (c) two plain operands from memory with both bounds supplied (a_amax, x_amax)
+    const bool h3_recomp = from_bits && va_xr && vg_gy;
+    const bool h3_bits_mem = from_bits && !va_xr && vg_gy && x_amax;
+    const bool h3_plain = !vg_wo && !va_xr && !vg_bits && a_amax && x_amax;
+    if (parts == 2 && !(h3_recomp || h3_bits_mem || h3_plain)) return (int)hipErrorInvalidValue;
     if (vg_bits && !from_bits) return (int)hipErrorInvalidValue;
     if (N <= 0 || N % 16 != 0 || !ws || (from_bits ? N % 32 != 0 : (ldd % 4 != 0 || !dpre || !aligned16(dpre))))
         return (int)hipErrorInvalidValue;
@@ -96,7 +101,10 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     const bool lrf = vg_wo && vg_act == ACT_LRELU;
     const int variant = (vg_wo ? 1 : 0) | (va_xr ? 2 : 0) | (lrf ? (from_bits ? 8 : 4) : 0);
     int rc;
-    if (parts == 2) {
+    if (parts == 2 && !h3_recomp) {
+        rc = dense_wgrad_x6_launch_p2(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas,
+                                      ATILE_PLAIN, S(stream), H3Scale{a_amax, x_amax, 0, 0, 0, 0, 0});
+    } else if (parts == 2) {
         float* slots = ws + (long)splits * per;
         hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, S(stream), slots, 4 + K);
         TVAE_CHECK_LAUNCH();

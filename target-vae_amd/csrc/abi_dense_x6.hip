@@ -115,7 +115,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
                            hipStream_t st, ColDot cd = ColDot{nullptr, nullptr, nullptr},
                            InTail it = InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
                            VirtGrad vg = VirtGrad{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0},
-                           VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}) {
+                           VirtAct va = VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, const float* x_amax = nullptr) {
     if ((cd.w || it.xr) && rows > DX6_ROWS) return (int)hipErrorInvalidValue;   // the fused tails need ONE row tile
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
@@ -137,6 +137,11 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
                                va.bc, va.lb, nlb, K, bw);
             TVAE_CHECK_LAUNCH();
             hs.amax_x = bw;
+        } else if (x_amax && !vg.wo && !vg.csum) {
+            // an operand streamed from memory: the caller supplies max |X| or an upper bound of it (one device word) -- e.g.
+            // |cos| <= 1 for Fourier features, the first-layer bound for a stored coordinate layer, a row-sum bound for the
+            // output of a layer (tvae/ops.py: _h3_bounds)
+            hs.amax_x = x_amax;
         } else if (!vg.csum) {
             return (int)hipErrorInvalidValue;
         }
@@ -169,7 +174,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, void* sign_bits, int parts, tvae_stream_t stream) {
+                       int va_np, void* sign_bits, int parts, const float* x_amax, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
     if (sign_bits && (act != ACT_LRELU || N % 32 != 0)) return (int)hipErrorInvalidValue;
@@ -178,7 +183,7 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
     ep.act = act; ep.slope = slope;
     return launch_dense_x6(w3, X, ldx, ep, M, N, K, parts, S(stream), ColDot{col_w, col_b, col_y, (unsigned*)sign_bits},
                            InTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1}, VirtGrad{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0},
-                           VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope});
+                           VirtAct{va_xr, va_wc, va_bc, va_lb, va_np > 0 ? va_np : 1, act, slope}, x_amax);
 }
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
@@ -186,7 +191,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
                          float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
-                         tvae_stream_t stream) {
+                         const float* x_amax, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
@@ -209,7 +214,8 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     }
     int rc = launch_dense_x6(w3t, dpre, ldd, ep, K, N, M, parts, S(stream), ColDot{nullptr, nullptr, nullptr},
                              InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
-                             VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, (const unsigned*)vg_bits, rs_part, 0});
+                             VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, (const unsigned*)vg_bits, rs_part, 0},
+                             VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, x_amax);
     if (rc || !rs_part || N <= 0 || K <= 0) return rc;
     hipLaunchKernelGGL(dgrad_rowsum_total_kernel, dim3(M), dim3(256), 0, S(stream), (const float*)rs_part, N / 128, M, rs_wo,
                        rs_gysum, slope, rs_db, rs_dwo, rs_rowdot, rs_bias);

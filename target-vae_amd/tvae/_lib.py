@@ -29,10 +29,10 @@ SIGNATURES = {
     'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
     'tvae_dense_split2h': 'plpliiipp',
-    'tvae_linear_fwd_x6': 'pppppiiillifpppppppipi',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppippp',
+    'tvae_linear_fwd_x6': 'pppppiiillifpppppppipip',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppipppp',
     'tvae_dec_in_total': 'piiippp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplp',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplppp',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -82,7 +82,7 @@ QUERIES = {
 }
 
 # trailing arguments a caller may leave out (beyond all-pointer tails, which are always optional)
-OPTIONAL_TAIL = {'tvae_linear_wgrad_x6': 3}      # rd_w, rd_ldw, rd_rowdot (ABI 5)
+OPTIONAL_TAIL = {'tvae_linear_wgrad_x6': 5}      # rd_w, rd_ldw, rd_rowdot, a_amax, x_amax (ABI 5)
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

@@ -205,6 +205,12 @@ def _p3() -> int:
     return 3 if p == 2 else p
 
 
+def _inf_norm(t: torch.Tensor) -> torch.Tensor:
+    """max |t| as a one-element device tensor (one reduction launch, no temporary, no host synchronisation): the h3 scale
+    word of an operand that is streamed from memory (include/tvae_hip.h: x_amax)."""
+    return torch.linalg.vector_norm(t.reshape(-1), float('inf')).reshape(1)
+
+
 def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str, scale=None, nparts: int = 3):
     """W (out, in) -> fragment-ready cells for A(row, k) = W[row][k] (forward) or W[k][row] (dgrad): 3 x bf16 parts, or
     (nparts = 2) the 2 x fp16 parts of the h3 arithmetic.
@@ -218,7 +224,7 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None):
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None):
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only).
     bits: [H > 0] as stored sign bits (dpre may then be None).  rowdot_w = the layer's own weight [M][K]: also returns
@@ -229,13 +235,18 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
         ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
         # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
-        p = 2 if (parts() == 2 and bits is not None and va and virt and virt[2] == ACT_LRELU) else _p3()
+        # ... or (round 4) against an operand from memory whose bound the caller supplies (x_amax), or two plain operands
+        # from memory with both bounds (a_amax, x_amax)
+        lrf_bits = bits is not None and virt and virt[2] == ACT_LRELU
+        p = 2 if (parts() == 2 and ((lrf_bits and (va or x_amax is not None)) or
+                                    (virt is None and va is None and a_amax is not None and x_amax is not None))) else _p3()
         rowdot = torch.empty(M, dtype=torch.float32, device=dev_) if rowdot_w is not None else None
         with _timed('tvae_linear_wgrad_x6', p, bool(virt) and virt[2] == ACT_LRELU):
             call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
                  *(va if va else (None, None, None, None, 0)), bits, p,
-                 rowdot_w.contiguous() if rowdot_w is not None else None, K, rowdot)
+                 rowdot_w.contiguous() if rowdot_w is not None else None, K, rowdot,
+                 a_amax if p == 2 else None, x_amax if p == 2 else None)
         return dW if rowdot_w is None else (dW, rowdot)
     _expect(virt is None and va is None and rowdot_w is None, 'implicit operands need the split-pipe weight gradient')
     ws = workspace(dev_, max(need, 1 << 24))
@@ -795,6 +806,7 @@ class DecoderFn(torch.autograd.Function):
             LB = torch.empty(B, F_, dtype=torch.float32, device=dev)
             call('tvae_latent_bias', Wl.contiguous(), z, LB, B, F_, zd)
         feat = None
+        feat_amax = h_bound = None       # h3 bounds of operands that are streamed from memory (include/tvae_hip.h: x_amax)
         # without Fourier features the coordinate layer's output is two FMAs and an activation per element: the layers
         # that consume it (first hidden layer: forward, mask of the data gradient, weight gradient) recompute it and the
         # [hid][B*n^2] tensor is never written or read
@@ -814,14 +826,25 @@ class DecoderFn(torch.autograd.Function):
                 _note('dec.four_x6')
                 if zx:
                     feat_all[Ff:].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
-                w3c = _split_weight(torch.cat([Wc, Wl], 1) if zx else Wc, F_, Ff + zx, False, 'x6_dense_wc')
-                with _timed('tvae_linear_fwd_x6', _p3()):
+                Wfull = torch.cat([Wc, Wl], 1) if zx else Wc
+                # h3 (round 4): the streamed operand is cos(.) <= 1 over the latent rows: its bound max(1, max |z|) is known
+                # without looking at it; the layer's OUTPUT is then bounded by the largest absolute row sum of the weights
+                p_c = parts() if parts() != 2 else 2
+                if p_c == 2:
+                    feat_amax = torch.clamp(_inf_norm(z), min=1.0) if zx else torch.ones(1, dtype=torch.float32, device=dev)
+                    h_bound = Wfull.detach().abs().sum(1).amax().reshape(1) * feat_amax + _inf_norm(bc)
+                    _note('dec.four_h3')
+                w3c = _split_weight(Wfull, F_, Ff + zx, False, 'x6_dense_wc', nparts=p_c)
+                with _timed('tvae_linear_fwd_x6', p_c):
                     call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
-                         None, None, None, None, None, None, None, 0, None, _p3())
+                         None, None, None, None, None, None, None, 0, None, p_c, feat_amax if p_c == 2 else None)
             else:
                 call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
         else:
             call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
+            if parts() == 2 and _dense_x6_ok(F_, Nt):      # the stored coordinate layer: |act(pre)| <= |pre| <= this bound
+                h_bound = _inf_norm(xr) * Wc.detach().abs().sum(1).amax().reshape(1) + \
+                    (_inf_norm(bc.detach()[None, :] + LB) if LB is not None else _inf_norm(bc))
         hs = [h]
         yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
         fused_out = False
@@ -829,8 +852,12 @@ class DecoderFn(torch.autograd.Function):
         for li, (W, b) in enumerate(hidden):
             hn = None
             if _dense_x6_ok(F_, Nt):
-                # h3 instance: the layer whose streamed operand is the recomputed first-layer activation
-                p_l = 2 if (parts() == 2 and va and li == 0) else _p3()
+                # h3 instances: the layer whose streamed operand is the recomputed first-layer activation, or (round 4) the
+                # stored output of the first layer under its bound (deeper layers have no bound worth the name: x6)
+                h3_mem = parts() == 2 and li == 0 and not va and h_bound is not None and not resid
+                p_l = 2 if (parts() == 2 and ((va and li == 0) or h3_mem)) else _p3()
+                if h3_mem:
+                    _note('dec.hidden_h3_mem')
                 w3 = _split_weight(W, F_, F_, False, 'x6_dense_w', nparts=p_l)
                 # the last hidden layer also applies the single-output Linear that follows it (one pass less over h)
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
@@ -854,7 +881,7 @@ class DecoderFn(torch.autograd.Function):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
-                         p_l)
+                         p_l, h_bound if h3_mem else None)
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
@@ -869,6 +896,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
         ctx.arith = get_gemm_mode()
         ctx.sbits = sbits
+        ctx.h_bound, ctx.feat_amax = h_bound, feat_amax
         return yh
 
     @staticmethod
@@ -923,10 +951,15 @@ class DecoderFn(torch.autograd.Function):
             va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if hprev is None else None   # recomputed first layer
             sbits = ctx.sbits if (use_vg and act == ACT_LRELU) else None      # [h > 0] as stored bits (two-valued form)
             from_bits = use_vg and no_h
+            # h3 with the layer's input read from memory (round 4): the stored first-layer output under its forward bound,
+            # times max |gy| (the operand of the two-valued form is gy[n] X[k][n])
+            xg_amax = None
+            if parts() == 2 and use_vg and sbits is not None and va is None and li == 0 and ctx.h_bound is not None:
+                xg_amax = ctx.h_bound * _inf_norm(vg[1])
             if from_bits:                                # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
-                dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W)
+                dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax)
             else:
-                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits), None
+                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits, x_amax=xg_amax), None
             db = drow if drow is not None else _rowsum(d, F_, Nt)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
@@ -957,6 +990,10 @@ class DecoderFn(torch.autograd.Function):
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
                          tot[0] if rs else None, tot[1] if rs else None, p_d,
                          sbits if from_bits else None, rowdot, b if from_bits else None)
+                if two_val and li == 0 and n_hidden == 1:
+                    # bound of the gradient this launch leaves in `dprev` (read again by the Fourier first layer's backward):
+                    # |dX[k][n]| <= max |gy| * sum_m |wo[m] W[m][k]|
+                    ctx.d_bound = _inf_norm(vg[1]) * (W.detach().abs() * vg[0].detach().abs()[:, None]).sum(0).amax().reshape(1)
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
@@ -990,13 +1027,19 @@ class DecoderFn(torch.autograd.Function):
             call('tvae_latent_bwd', Simg, Wl.contiguous(), z, dWl, dz, B, F_, zd)
         if has_f:
             Ff = Wf.shape[0]
-            dWc = _wgrad(d, feat, F_, Nt, Ff)
+            # h3 for the Fourier first layer's backward (round 4): both operands come from memory with known bounds -- the
+            # features are cosines (<= 1), d is bounded by the two-valued data gradient that produced it (ctx.d_bound)
+            d_bound = getattr(ctx, 'd_bound', None) if parts() == 2 else None
+            one = torch.ones(1, dtype=torch.float32, device=dev) if d_bound is not None else None
+            dWc = _wgrad(d, feat, F_, Nt, Ff, a_amax=d_bound, x_amax=one)
             dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
             if _dense_x6_ok(Ff, Nt):
-                w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct')
-                with _timed('tvae_linear_dgrad_x6', _p3()):
+                p_f = 2 if d_bound is not None else _p3()
+                w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct', nparts=p_f)
+                with _timed('tvae_linear_dgrad_x6', p_f):
                     call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
-                         None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, _p3())
+                         None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, p_f,
+                         None, None, None, d_bound)
             else:
                 call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
             call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
