@@ -507,6 +507,41 @@ def test_h3_decoder_entry_points(sw, sg, sx):
     assert rel_err(Yt, act_ref(W.double() @ h0t.double().cpu() + b.double()[:, None], 2)) < GEMM_TOL['f32']
 
 
+@pytest.mark.parametrize('slack', [1.0, 256.0])
+def test_linear_x6_h3_memory_operand_bounds(slack):
+    """h3 (parts = 2) with the streamed operand READ FROM MEMORY under a caller-supplied bound (ABI 5: x_amax / a_amax): forward,
+    plain data gradient and plain weight gradient against fp64 at the fp32 tolerance, with the exact maximum and with a bound
+    2^8 too large (a loose bound costs head room, not correctness: include/tvae_hip.h)."""
+    from tvae._lib import query
+    M, N, K = 512, 1024, 384
+    W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
+    w3 = torch.empty(query('tvae_dense_x6_bytes', M, K) // 4, device=dev())
+    call('tvae_dense_split2h', W.to(dev()), K, w3, w3.numel() * 4, M, K, 0, None, None)
+    xmax = (X.abs().max() * slack).reshape(1).to(dev())
+    Y = torch.full((M, N), float('nan'), device=dev())
+    call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N, K, N, N, 1, SLOPE, None, None, None, None, None, None,
+         None, 0, None, 2, xmax)
+    assert rel_err(Y, act_ref(W.double() @ X.double() + b.double()[:, None], 1)) < GEMM_TOL['f32']
+    with pytest.raises(Exception):                       # h3 with an operand from memory needs its bound
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N, K, N, N, 1, SLOPE, None, None, None, None, None,
+             None, None, 0, None, 2, None)
+    # plain data gradient dX = W^T d
+    d = rnd(M, N, seed=4)
+    w3t = torch.empty(query('tvae_dense_x6_bytes', K, M) // 4, device=dev())
+    call('tvae_dense_split2h', W.to(dev()), K, w3t, w3t.numel() * 4, K, M, 1, None, None)
+    dX = torch.full((K, N), float('nan'), device=dev())
+    dmax = (d.abs().max() * slack).reshape(1).to(dev())
+    call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, None, dX, M, N, K, N, N, 0, SLOPE, None, None, None, None, 0, None, None,
+         None, None, None, 0, None, 0, None, None, None, None, 2, None, None, None, dmax)
+    assert rel_err(dX, W.double().t() @ d.double()) < GEMM_TOL['f32']
+    # plain weight gradient dW = d X^T
+    ws = torch.empty(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), device=dev())
+    dW = torch.full((M, K), float('nan'), device=dev())
+    call('tvae_linear_wgrad_x6', d.to(dev()), X.to(dev()), dW, ws, ws.numel(), M, N, K, N, N, 0, None, None, 0, SLOPE, None, None,
+         None, None, 0, None, 2, None, 0, None, dmax, xmax)
+    assert rel_err(dW, d.double() @ X.double().t()) < GEMM_TOL['f32']
+
+
 def row_rel_err(got, ref, dim=0):
     """Largest PER-ROW relative error: max over the slices along `dim` of |got - ref|_2 / |ref|_2 (slices that are
     exactly zero in the reference must be exactly zero)."""
