@@ -546,9 +546,9 @@ def main():
         # every timed entry point: (algorithmic FLOPs per launch, kernel, note)
         conv_dft = mode in ('x6', 'h3', 'bf16') and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
         entries = {
-            'tvae_conv1_fwd': (conv_flops, 'dft_image + dft_bank + batched dense_x6_kernel + dft_out_mf_kernel'
+            'tvae_conv1_fwd': (conv_flops, 'dft_spectra_kernel + batched dense_x6_plain4_kernel + dft_out_ring_kernel'
                                if conv_dft else info['kernels']['tvae_conv1_fwd']),
-            'tvae_conv1_wgrad': (conv_flops, 'dft_dy_mf_kernel + batched dense_wgrad_x6_kernel + dft_dbank_kernel'
+            'tvae_conv1_wgrad': (conv_flops, 'dft_dy_ring_kernel + batched dense_wgrad_x6_wide_kernel (256 x 192 tile; other frames: _dma_kernel) + dft_dbank_mf_kernel'
                                  if conv_dft else info['kernels']['tvae_conv1_wgrad']),
             'tvae_linear_fwd_x6': (dense_flops, 'dense_x6_kernel'),
             'tvae_linear_dgrad_x6': (dense_flops, 'dense_x6_kernel'),

@@ -43,6 +43,7 @@ struct DftPlan {
     int FXB, nblk;             // spectra: frequencies per workgroup, blocks per plane
     int FXBd;                  // inverse transform of the weight gradient: frequencies per pass
     int splits;                // reduction slices of the weight-gradient GEMM
+    int wsplits;               // the same for its exact-fit tile (dense_wgrad_x6_wide_kernel), 0: geometry not eligible
     int Mb;                    // rows per fx in the stacked spectral weight (2M rounded up to the 512-row tile)
     long NB, NBpad;            // (image, output row) columns
     long at_floats;            // A^T [Lh][K2][NBpad]
@@ -109,6 +110,9 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.splits = (int)(cdiv(q.K2, 128) >= 8 ? q.NBpad / 1024 : q.NBpad / 32);
     if (q.splits < 1) q.splits = 1;
     if (q.splits > 8) q.splits = 8;
+    // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles.  (Its slices are not pinned to XCDs, so
+    // their number is free: 9 slices, whose groups fill 7 whole rounds of the 256 CUs where 8 run 6.125, measured the same.)
+    q.wsplits = ((2 * q.M) % WW_ROWS == 0 && q.K2 > 128 && q.K2 <= 192) ? q.splits : 0;
     // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)
     const int S = n > ksz ? n : ksz;
     q.nblk = 1;
@@ -154,7 +158,7 @@ long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, in
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     // forward: W + W3 + T + tables; backward: S' (= T) + split-K slabs of G + tables
     const long fwd = q.w_floats + q.w3_floats + q.t_floats + q.tab_floats + 64;
-    const long bwd = q.t_floats + q.splits * q.g_floats + q.tab_floats + 64;
+    const long bwd = q.t_floats + (q.splits > q.wsplits ? q.splits : q.wsplits) * q.g_floats + q.tab_floats + 64;
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -318,7 +322,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     TVAE_CHECK_LAUNCH();
     float* Sp = ws;
     float* slabs = Sp + ((q.t_floats + 3) & ~3L);
-    float* tab = slabs + (((long)q.splits * q.g_floats + 3) & ~3L);
+    float* tab = slabs + (((long)(q.splits > q.wsplits ? q.splits : q.wsplits) * q.g_floats + 3) & ~3L);
     float* EO = tab;
     float* ED = EO + ((q.eo_floats + 3) & ~3L);
     {
@@ -382,18 +386,23 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         hipLaunchKernelGGL(dft_dbias_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)dbpart, dbias, R, C);
         TVAE_CHECK_LAUNCH();
     }
-    // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM, two reduction slices
+    // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM into reduction-slice slabs
+    // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles (dense_wgrad_x6_wide_kernel)
+    static const bool wide_on = !(getenv("TVAE_WG_WIDE") && getenv("TVAE_WG_WIDE")[0] == '0');
+    const bool wide = wide_on && parts != 1 && q.wsplits > 0;       // (the one-part mode keeps its bf16-stored S' path)
+    const int nslabs = wide ? q.wsplits : q.splits;
     {
-        const int M2 = 2 * q.M, tiles_b = q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = cdiv(q.K2, 128);
+        const int M2 = 2 * q.M;
+        const int tiles_b = wide ? M2 / WW_ROWS : q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = wide ? 1 : cdiv(q.K2, 128);
         // 8 reduction slices at the 64x64 configuration: TileMap deals the slices round-robin to the 8 XCDs
-        const int splits = q.splits;
+        const int splits = nslabs;
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;
         const TileMap tmk{tilesM, tilesK, splits};
         const DenseBatch bt{tiles_b, (long)q.K2 * q.NBpad, 0};
         int rc = dense_wgrad_x6_batched(Sp, (long)q.Lh * 128, at, q.NBpad, slabs, M2, q.K2, (int)q.NBpad, nchunk, tmk, bt,
                                         128L, ATile{7, 127, (long)M2 * q.Lh * 128}, parts, st,
                                         // h3: one scale per filter row of S' (rows m and M + m), one per frequency of A^T
-                                        H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1}, s16);
+                                        H3Scale{smax, amax + q.o_fmax, 1, 0, q.M, 1 << 30, 1}, s16, wide);
         if (rc) return rc;
     }
     // both contractions on the fp32 matrix pipe where the tiles are not mostly padding (ksz <= 64, >= 17 frequencies per block)
@@ -401,12 +410,12 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     if (dbank_mf && ksz <= 64 && q.FXBd >= 17 && q.FXBd <= 64) {
         hipError_t e = allow_big_lds(dft_dbank_mf_kernel, q.lds_db);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(dft_dbank_mf_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits,
+        hipLaunchKernelGGL(dft_dbank_mf_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, nslabs,
                            q.g_floats, dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
     } else {
         hipError_t e = allow_big_lds(dft_dbank_kernel, q.lds_db);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, q.splits, q.g_floats,
+        hipLaunchKernelGGL(dft_dbank_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, nslabs, q.g_floats,
                            dbank, ksz, q.L, q.Lh, q.M, Cin, q.FXBd);
     }
     TVAE_CHECK_LAUNCH();

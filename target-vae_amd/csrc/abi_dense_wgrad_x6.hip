@@ -5,16 +5,23 @@
 using namespace tvae;
 
 TVAE_WG_LAUNCH_DEF(3)
+TVAE_WGW_LAUNCH_DEF(3)
 
 namespace tvae {
 int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M, int Kf, int N,
                            int nchunk, const TileMap& tm, const DenseBatch& bt, long dy_stride, const ATile& atile,
-                           int parts, hipStream_t st, H3Scale hs, bool a_bf16) {
+                           int parts, hipStream_t st, H3Scale hs, bool a_bf16, bool wide) {
     const VirtGrad vg{nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0};
     const VirtAct va{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f};
     if (a_bf16) {        // dY holds 2-byte bf16 elements (ldd, dy_stride, atile in elements): one-part mode only
         if (parts != 1 || dy_stride % 2 != 0) return (int)hipErrorInvalidValue;
         return dense_wgrad_x6_launch_p1_abf(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
+    }
+    if (wide) {          // exact-fit tile (tm / bt in 256-row tiles, one column tile); two- and three-part arithmetic
+        if (parts == 2 && hs.amax_a && hs.amax_x)
+            return dense_wgrad_x6_wide_p2(dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, atile, st, hs);
+        if (parts == 3) return dense_wgrad_x6_wide_p3(dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, atile, st, hs);
+        return (int)hipErrorInvalidValue;
     }
     if (parts == 1) return dense_wgrad_x6_launch_p1(0, dY, ldd, X, ldx, slabs, M, Kf, N, nchunk, tm, bt, dy_stride, vg, va, atile, st, hs);
     if (parts == 2 && hs.amax_a && hs.amax_x)

@@ -111,6 +111,26 @@ TVAE_INTERNAL int dense_wgrad_x6_launch_p1_abf(TVAE_WG_LAUNCH_ARGS);
     }                                                                                                                 \
     }
 
+// the exact-fit 256 x 192 tile of the spectral weight gradient (dense_wgrad_x6_wide_kernel; tm / bt count 256-row tiles)
+#define TVAE_WGW_LAUNCH_ARGS                                                                                          \
+    const float *dY, long ldd, const float *X, long ldx, float *ws, int M, int Kf, int N, int nchunk, const TileMap &tm, \
+        const DenseBatch &bt, long dy_stride, const ATile &atile, hipStream_t st, const H3Scale &hs
+TVAE_INTERNAL int dense_wgrad_x6_wide_p3(TVAE_WGW_LAUNCH_ARGS);
+TVAE_INTERNAL int dense_wgrad_x6_wide_p2(TVAE_WGW_LAUNCH_ARGS);
+#define TVAE_WGW_LAUNCH_DEF(NP_)                                                                                      \
+    namespace tvae {                                                                                                  \
+    int dense_wgrad_x6_wide_p##NP_(TVAE_WGW_LAUNCH_ARGS) {                                                            \
+        if (M % WW_ROWS != 0 || Kf <= 128 || Kf > 192 || tm.tilesN != 1 || bt.tiles_per_batch <= 0)                 \
+            return (int)hipErrorInvalidValue;                                                                         \
+        hipError_t e_ = allow_big_lds(dense_wgrad_x6_wide_kernel<NP_, 6>, WW_RING_BYTES);                             \
+        if (e_ != hipSuccess) return (int)e_;                                                                         \
+        const unsigned grid_ = 8u * cdiv(tm.splits * (tm.tilesM / bt.tiles_per_batch), 8) * bt.tiles_per_batch;       \
+        hipLaunchKernelGGL((dense_wgrad_x6_wide_kernel<NP_, 6>), dim3(grid_), dim3(DX6_THREADS), WW_RING_BYTES, st,   \
+                           dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, atile, hs);                      \
+        return (int)hipGetLastError();                                                                                \
+    }                                                                                                                 \
+    }
+
 // the same with the 256-row / four-wave tile (dense_x6_plain4_kernel: short reductions); tm / bt count 256-row tiles
 TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                     int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
@@ -123,6 +143,6 @@ TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, con
 TVAE_INTERNAL int dense_wgrad_x6_batched(const float* dY, long ldd, const float* X, long ldx, float* slabs, int M,
                                          int Kf, int N, int nchunk, const TileMap& tm, const DenseBatch& bt,
                                          long dy_stride, const ATile& atile, int parts, hipStream_t st,
-                                         H3Scale hs = H3_NONE, bool a_bf16 = false);
+                                         H3Scale hs = H3_NONE, bool a_bf16 = false, bool wide = false);
 
 }  // namespace tvae

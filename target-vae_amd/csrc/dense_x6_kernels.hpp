@@ -1638,4 +1638,246 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4: the spectral weight gradient on a tile that FITS it.  The frequency-domain convolution's weight gradient is a
+// batched GEMM with 2 L Cin columns -- 192 at the 96-wide frame of the 64 x 64 configuration -- so the 512 x 128 tile of
+// dense_wgrad_x6_dma_kernel spent a quarter of its matrix instructions on the zero half of a second column tile, split
+// every value of the large operand S' twice (once per column tile) and read it twice.  Here the tile is 256 rows x 32 NJ
+// columns (NJ = 6: all 192 columns at once): eight waves, each ONE 32-row fragment of dY against all column groups
+// (acc[NJ]: 96 registers), the same per-wave LDS-DMA ring with hand-counted waits (A: two 1 KB pieces per step, 16 rows x
+// one 64-byte line each, XOR swizzled; X: every lane its own 16 bytes of row tid / 4, waves 0-3 a second piece for the rows
+// beyond 128 -- waves 4-7 issue a clamped duplicate so that the count stays uniform), the same cooperative B stage
+// ([part][octet half][32 NJ rows] cells, two stages, one barrier per step).  Plain operands only (no implicit forms);
+// NP = 3 / 2 / 1 as everywhere.  Host: M % 256 == 0, 32 (NJ - 2) < Kf <= 32 NJ.
+// Measured (64 x 64 step, h3): 1.58 -> 1.28 ms.  Ablation builds (-DTVAE_WW_ABL=bits: 1 no matrix instructions, 2 no
+// B-fragment reads, 4 no A split, 8 no B build; profiles/tools/build_variant.sh): the bare ring + barriers stream the 4.3 GB
+// in 0.95 ms (4.5 TB/s); a ring of four slots, a contiguous S' layout, nine reduction slices (whole rounds of the 256 CUs)
+// and waiting for step t+1 after the first matrix instructions of step t all changed nothing (profiles/README.md, round 4).
+// ------------------------------------------------------------------------------------------
+constexpr int WW_SLOT_BYTES = 2048 + 2048;            // A (32 rows x 16 n) | X (two pieces)
+#ifndef TVAE_WW_SLOTS
+#define TVAE_WW_SLOTS 3
+#endif
+constexpr int WW_SLOTS = TVAE_WW_SLOTS;               // ring depth: steps in flight per wave
+constexpr int WW_RING_BYTES = 8 * WW_SLOTS * WW_SLOT_BYTES;
+constexpr int WW_ROWS = 256;
+
+template <int NP, int NJ>
+static __global__ __launch_bounds__(DX6_THREADS, 2)
+void dense_wgrad_x6_wide_kernel(const float* __restrict__ dY, long ldd, const float* __restrict__ X, long ldx, float* ws, int M,
+                                int Kf, int N, int nchunk, TileMap tm, DenseBatch bt, long dy_stride, ATile atile, H3Scale hs) {
+    constexpr int KR = 32 * NJ;                          // feature rows (= tile columns)
+    constexpr int STG = NP * 2 * KR;                     // cells per B stage
+    constexpr int NDMA = 2 + 2;                          // DMA instructions per wave and step (A x 2, X x 2)
+    static_assert(NJ >= 5 && NJ <= 8, "one full pass of the 512 build threads plus a partial second one");
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2 * STG];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_ring[];   // [wave][slot < WW_SLOTS][WW_SLOT_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroup -> (reduction slice, problem, row tile).  A group is the row tiles of one (slice, problem): they share the
+    // X panel, so they run back to back on ONE XCD; groups are dealt round-robin to the 8 XCDs.  Slices are therefore NOT
+    // pinned to XCDs as TileMap does it, and their number is free: the host picks it so that the groups fill whole rounds
+    // of the 256 CUs (9 slices of 49 problems x 4 tiles: 7 rounds at 98 %, where 8 slices ran 6.125 rounds in 7).
+    const int tiles_b = bt.tiles_per_batch, nbatch = tm.tilesM / tiles_b;
+    const int g = ((blockIdx.x >> 3) / tiles_b) * 8 + (blockIdx.x & 7);
+    if (g >= tm.splits * nbatch) return;
+    const int tile_m = (blockIdx.x >> 3) % tiles_b, split = g / nbatch, batch = g - split * nbatch;
+    dY += batch * dy_stride;
+    X += batch * bt.x_stride;
+    const int m0 = tile_m * WW_ROWS;
+    const int nbeg = split * nchunk;
+    const int nend = min(N, nbeg + nchunk);
+    const int nk = (nend - nbeg) >> 4;
+    const int khalf = lane >> 5;
+    float* slab = ws + (((long)split * nbatch + batch) * M) * Kf;
+    if (nk <= 0) {                                      // empty reduction slice: zero partial
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (j * 32 + (lane & 31) < Kf) slab[(long)m * Kf + j * 32 + (lane & 31)] = 0.f;
+        }
+        return;
+    }
+    // ---- h3 scales: one per row of either operand (H3Scale)
+    auto a_scale_of = [&](int m) -> float {
+        return h3_scale(hs.amax_a[hs.a_rows ? (long)batch * hs.a_bstride + (hs.a_mod > 0 ? m % hs.a_mod : m) : 0]);
+    };
+    const float sa = NP == 2 ? a_scale_of(min(m0 + 32 * wave + (lane & 31), M - 1)) : 1.f;
+    // B build roles: (row kr, n-quad q4) and, for the first 4 (KR - 128) threads, (row 128 + kr, q4)
+    const int kr = tid >> 2, q4 = tid & 3;
+    const bool two = tid < 4 * (KR - 128);               // wave uniform: KR - 128 is a multiple of 16 rows = one wave
+    const int kr2 = 128 + kr;
+    const int kx0 = min(kr, Kf - 1), kx1 = min(two ? kr2 : kr, Kf - 1);
+    auto x_scale_of = [&](int kx) -> float {
+        if (NP != 2) return 1.f;
+        return h3_scale(hs.x_group > 0 ? hs.amax_x[(long)batch * hs.x_bstride + kx / hs.x_group] : hs.amax_x[0]);
+    };
+    const float b0s = (kr < Kf ? 1.f : 0.f) * x_scale_of(kx0);
+    const float b1s = ((two && kr2 < Kf) ? 1.f : 0.f) * x_scale_of(kx1);
+    // ---- DMA sources
+    const float* d_ptr[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row = m0 + 32 * wave + 16 * g + (lane >> 2);
+        d_ptr[g] = dY + (long)min(row, M - 1) * ldd + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+    }
+    const float* x_src0 = X + (long)kx0 * ldx + nbeg + 4 * q4;
+    const float* x_src1 = X + (long)kx1 * ldx + nbeg + 4 * q4;      // (waves beyond the partial pass: a duplicate of piece 0)
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)wg_ring +
+                              (unsigned)(wave * WW_SLOTS * WW_SLOT_BYTES);
+    const unsigned char* ring = wg_ring + wave * WW_SLOTS * WW_SLOT_BYTES;
+    auto dma_step = [&](int slot, int t) {
+        const int na = nbeg + 16 * t;                    // wave-uniform; a 16-wide step never straddles a column tile
+        const long off = (long)(na >> atile.sh) * atile.ts + (na & atile.mask);
+        const unsigned sl = ring_lds + (unsigned)(slot * WW_SLOT_BYTES);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+                const float* src = d_ptr[g] + off;
+            const unsigned dst = sl + (unsigned)(g * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
+        }
+        {
+            const float* s0 = x_src0 + 16 * t;
+            const unsigned d0 = sl + 2048u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(d0), "v"(s0) : "memory", "m0");
+            const float* s1 = x_src1 + 16 * t;
+            const unsigned d1 = sl + 3072u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(d1), "v"(s1) : "memory", "m0");
+        }
+    };
+    // ---- reads from a landed slot: this lane's two 16-byte pieces of the A fragment (rows lane & 31, n-half khalf)
+    int a_at[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        a_at[h] = ((lane >> 4) & 1) * 1024 + (lane & 15) * 64 + (((2 * khalf + h) ^ ((lane >> 2) & 3)) * 16);
+    const float a_ok = (m0 + 32 * wave + (lane & 31)) < M ? 1.f : 0.f;
+    auto build_a = [&](int slot, Cell16 (&a)[3]) {
+        const unsigned char* sl = ring + slot * WW_SLOT_BYTES;
+        const float4 r0 = *reinterpret_cast<const float4*>(sl + a_at[0]);
+        const float4 r1 = *reinterpret_cast<const float4*>(sl + a_at[1]);
+        const float f = NP == 2 ? a_ok * sa : a_ok;
+        const float v[8] = {r0.x * f, r0.y * f, r0.z * f, r0.w * f, r1.x * f, r1.y * f, r1.z * f, r1.w * f};
+#if defined(TVAE_WW_ABL) && (TVAE_WW_ABL & 4)
+        a[0].u = make_uint4(__float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z), __float_as_uint(r0.w));
+        a[1].u = make_uint4(__float_as_uint(r1.x), __float_as_uint(r1.y), __float_as_uint(r1.z), __float_as_uint(r1.w));
+        a[2].u = a[0].u;
+        return;                                          // ablation: no split arithmetic of the A operand
+#endif
+        if (NP == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[0].w[q] = bf16_pair(v[2 * q], v[2 * q + 1]);
+        } else if (NP == 2) {
+            split2hx8(v, a[0], a[1]);
+        } else {
+            split3x8(v, a[0], a[1], a[2]);
+        }
+    };
+    auto store_b = [&](int stage, int slot, int which) {
+        const float4 x = *reinterpret_cast<const float4*>(ring + slot * WW_SLOT_BYTES + 2048 + 1024 * which + 16 * lane);
+        const float f = which ? b1s : b0s;
+        const float v[4] = {x.x * f, x.y * f, x.z * f, x.w * f};
+        const int row = which ? kr2 : kr;
+        uint2* dst = reinterpret_cast<uint2*>(Bs + stage * STG + (q4 >> 1) * KR + row) + (q4 & 1);
+#if defined(TVAE_WW_ABL) && (TVAE_WW_ABL & 8)
+        if (x.x == 1.2345f) dst[0] = make_uint2(0, 0);   // ablation: no B-stage build
+        return;
+#endif
+        unsigned hw[2], mw[2], lw[2];
+        if (NP == 1) {
+            dst[0] = make_uint2(bf16_pair(v[0], v[1]), bf16_pair(v[2], v[3]));
+            return;
+        }
+        if (NP == 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) split2h_pair(v[2 * q], v[2 * q + 1], hw[q], lw[q]);
+            dst[0] = make_uint2(hw[0], hw[1]);
+            dst[2 * 2 * KR] = make_uint2(lw[0], lw[1]);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) split3_pair(v[2 * q], v[2 * q + 1], hw[q], mw[q], lw[q]);
+        dst[0] = make_uint2(hw[0], hw[1]);
+        dst[2 * 2 * KR] = make_uint2(mw[0], mw[1]);
+        dst[2 * 4 * KR] = make_uint2(lw[0], lw[1]);
+    };
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    Cell16 af[3];
+    const int tl = nk - 1;
+    {   // prologue: WW_SLOTS steps in flight, step 0 split as soon as its slot has landed
+#pragma unroll
+        for (int i = 0; i < WW_SLOTS; ++i) dma_step(i, min(i, tl));
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WW_SLOTS - 1) * NDMA) : "memory");
+        build_a(0, af);
+        store_b(0, 0, 0);
+        if (two) store_b(0, 0, 1);
+    }
+    __syncthreads();
+    int s_next = 1, s_dma = 0;                           // slot of step t+1, slot the DMAs of step t+WW_SLOTS go to (= t % WW_SLOTS)
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WW_SLOTS - 2) * NDMA) : "memory");      // slot of step t+1 has landed
+        dma_step(s_dma, min(t + WW_SLOTS, tl));                 // unconditional (clamped): uniform vmcnt bookkeeping
+        Cell16 an[3];
+        const uint4* bs = Bs + cur * STG + khalf * KR + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            Cell16 bf[3];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 2 * KR + j * 32];
+#if defined(TVAE_WW_ABL) && (TVAE_WW_ABL & 2)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bf[p].u = af[p].u;        // ablation: no B-fragment LDS reads
+#endif
+#if !(defined(TVAE_WW_ABL) && (TVAE_WW_ABL & 1))
+            mfma_np<NP>(acc[j], af, bf);
+#else
+            acc[j][0] += __uint_as_float(bf[0].w[0] ^ af[0].w[1]);  // ablation: no matrix instructions
+#endif
+            if (j == 0) build_a(s_next, an);             // A cells of step t+1 from the ring
+            if (j == 1) store_b(cur ^ 1, s_next, 0);     // B cells of step t+1
+            if (j == 2 && two) store_b(cur ^ 1, s_next, 1);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = an[p];
+        s_next = s_next == WW_SLOTS - 1 ? 0 : s_next + 1;
+        s_dma = s_dma == WW_SLOTS - 1 ? 0 : s_dma + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this wave's ring
+    float* ssm = reinterpret_cast<float*>(Bs);           // the B stages are free after the loop's last barrier
+    float ixv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ixv[j] = 1.f;
+    if (NP == 2) {                                       // [0 .. KR): inverse scale per tile column (= X row), [KR ..): per tile row
+        if (q4 == 0) {
+            ssm[kr] = h3_inv(x_scale_of(kx0));
+            if (two) ssm[kr2] = h3_inv(x_scale_of(kx1));
+        }
+        if (tid < WW_ROWS) ssm[KR + tid] = h3_inv(a_scale_of(min(m0 + tid, M - 1)));
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ixv[j] = ssm[j * 32 + (lane & 31)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + rl;
+        if (m >= M) continue;
+        const float ia = NP == 2 ? ssm[KR + rl] : 1.f;
+        float* wrow = slab + (long)m * Kf + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j * 32 + (lane & 31) < Kf) wrow[j * 32] = NP == 2 ? (acc[j][r] * ia) * ixv[j] : acc[j][r];
+    }
+}
+
 }  // namespace tvae
