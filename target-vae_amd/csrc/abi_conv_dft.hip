@@ -231,6 +231,11 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         const DenseBatch bt{q.Mb / TR, (long)q.K2 * q.NBpad, 128};
         // h3: one scale per stacked row (fx, m') of the spectral weight, one per (fx, image) of A^T's columns
         const H3Scale hs{mxp.wmax, mxp.cmax, 1, 0, 0, q.Ho, B};
+        // the panel of A^T resident in LDS, weight cells streamed by free-running waves (dense_x6_xres_kernel)
+        if (TR == DX4_ROWS && !t16 &&
+            dense_x6_batched_xres(W3, at, q.NBpad, ep, 2 * q.M, q.Mb, q.Lh, (int)q.NBpad, q.K2, bt.x_stride, 128, parts, st, hs, &rc)) {
+            if (rc) return rc;
+        } else
         rc = TR == DX4_ROWS ? dense_x6_batched4(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs, t16)
                             : dense_x6_batched(W3, at, q.NBpad, ep, 2 * q.M, rows, (int)q.NBpad, q.K2, tm, bt, parts, st, hs);
         if (rc) return rc;

@@ -40,6 +40,36 @@ int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& 
 #undef TVAE_DX4_LAUNCH
     return (int)hipGetLastError();
 }
+// The same contraction with the streamed panel resident in LDS (dense_x6_xres_kernel): false when the shape is not its own
+// (the caller then takes dense_x6_batched4).  ep as for the lean store epilogue; Mb = rows per problem in the cell array.
+bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int Mb, int nprob,
+                           int N, int K, long x_stride, long c_stride, int parts, hipStream_t st, H3Scale hs, int* rc) {
+    static const bool on = !(getenv("TVAE_FWD_XRES") && getenv("TVAE_FWD_XRES")[0] == '0');
+    const int K8pad = dense_k8pad(K), nk = K8pad / 2;
+    const size_t lds = (size_t)nk * parts * 256 * 16 + (size_t)(Mb + 128) * 4;
+    const bool lean = !ep.bias && !ep.res && !ep.aux && ep.act == ACT_NONE && ep.mask == ACT_NONE && ep.ctile > 0 && ep.C &&
+                      !ep.accumulate && rows_per_problem % DX6_ROWS == 0 && ep.ldc * 8 * 4 < (1L << 31);
+    if (!on || !lean || parts != 2 || N % 128 != 0 || nk != 12 || Mb < rows_per_problem ||
+        lds > X6_LDS_MAX || !aligned16(w3) || !hs.amax_a || !hs.amax_x)
+        return false;
+    const int Rpad = x6_round_up(nprob * Mb, DX6_ROWS), tilesN = N / 128, nch = 4, cs = cdiv(tilesN, nch);
+    const unsigned grid = 8u * cdiv(nprob * nch, 8) * cs;
+#define TVAE_XRES_LAUNCH(NP_, NK_)                                                                                     \
+    do {                                                                                                               \
+        hipError_t e_ = allow_big_lds(dense_x6_xres_kernel<NP_, NK_>, lds);                                            \
+        if (e_ != hipSuccess) { *rc = (int)e_; return true; }                                                          \
+        hipLaunchKernelGGL((dense_x6_xres_kernel<NP_, NK_>), dim3(grid), dim3(DX6_THREADS), lds, st, (const uint4*)w3, X, ldx, \
+                           ep.C, ep.ldc, ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs); \
+    } while (0)
+    // twelve k-steps only (the 96-wide frame of the 64 x 64 configuration): at six steps (28 x 28: 44-wide frame) the stores
+    // per step double and the kernel measured 2 % behind dense_x6_plain4_kernel; nine steps (50 x 50) were not measured
+    // h3 only: with three parts (x6: six products per block, three operand registers sets) the kernel spills and measured
+    // 2.11 ms against plain4's 1.81
+    TVAE_XRES_LAUNCH(2, 12);
+#undef TVAE_XRES_LAUNCH
+    *rc = (int)hipGetLastError();
+    return true;
+}
 }  // namespace tvae
 
 namespace {

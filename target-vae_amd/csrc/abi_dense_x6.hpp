@@ -135,6 +135,10 @@ TVAE_INTERNAL int dense_wgrad_x6_wide_p2(TVAE_WGW_LAUNCH_ARGS);
 TVAE_INTERNAL int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                     int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
                                     hipStream_t st, H3Scale hs = H3_NONE, bool out_bf16 = false);
+// the spectral contraction with the streamed panel resident in LDS (dense_x6_xres_kernel); false: shape not handled, nothing launched
+TVAE_INTERNAL bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
+                                         int Mb, int nprob, int N, int K, long x_stride, long c_stride, int parts,
+                                         hipStream_t st, H3Scale hs, int* rc);
 // batched forward GEMM of the spectral contraction: rows of all problems stacked in w3 (abi_dense_x6.hip)
 TVAE_INTERNAL int dense_x6_batched(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem,
                                    int rows_total, int N, int K, const TileMap& tm, const DenseBatch& bt, int parts,
