@@ -31,7 +31,7 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          'dense_x6_kernel<5, 2>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<5, 3>': 'tvae_linear_dgrad_x6',
          'dense_x6_kernel<2, 2, 1>': 'tvae_linear_fwd_x6', 'dense_x6_kernel<2, 3, 1>': 'tvae_linear_fwd_x6',
          'dense_x6_kernel<5, 2, 2>': 'tvae_linear_dgrad_x6', 'dense_x6_kernel<5, 3, 2>': 'tvae_linear_dgrad_x6',
-         'dense_x6_plain4_kernel': 'tvae_spectral_fwd',
+         'dense_x6_plain4_kernel': 'tvae_spectral_fwd', 'dense_x6_xres_kernel': 'tvae_spectral_fwd',
          'dft_out_ring_kernel': 'tvae_dft_out', 'dft_dy_ring_kernel': 'tvae_dft_dy',
          'enc_tail_wgrad_x6_kernel': 'tvae_enc_tail_wgrad_x6', 'dft_dbank_kernel': 'tvae_dft_dbank',
          'dft_spectra_kernel': 'tvae_dft_spectra',
