@@ -1656,8 +1656,13 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 // loads): stores alone 0.61 ms (5.5 TB/s), products alone 0.95, products + stores WITHOUT the weight-cell loads 1.05 -- but 1.33
 // with them: loads and stores share the in-order vmcnt counter, so waiting for the cells of step t also waits for every older
 // store's acknowledgement from a saturated write path.  A fourth operand buffer (one more step of distance) gave 2 %, six spilled;
-// default-policy stores were slower (1.55).  What would decouple them -- the cells through LDS by a loader wave of their own --
-// was not built.
+// default-policy stores were slower (1.55).  Two forms that take the weight-cell loads out of the wave's way were built and
+// measured SLOWER, so the in-order counter is not the whole story: 64-column panels with four waves per SIMD (64 x 64 blocks,
+// stored after their k-loop: 1.44 ms against 1.27 on the same box -- twice the weight-cell traffic), and the weight cells of a
+// wave's 32 rows RESIDENT in 96 registers with the panels double-buffered in LDS (no load needed sooner than a panel later:
+// 1.46-1.50 against 1.30-1.38).  Common to all three: a 32-row wave block feeds every 1 KB B-fragment read from LDS into ONE
+// group of three MFMAs (dense_x6_plain4_kernel's 64-row wave tile into two) -- about two thirds of the LDS read rate of a CU
+// while the matrix pipe is busy -- and that is the price of a second accumulator set.
 // Host: lean epilogue shape of the spectral contraction (plain column-tiled fp32 output), N % 128 == 0, rows per problem a
 // multiple of 512 (M; Mb >= M is their stride in the cell array), NK = K8pad / 2 steps, NP = 3 or 2.  Grid: groups (problem,
 // quarter of the column tiles) dealt round-robin to the XCDs: a problem's weight cells (0.8 MB) stay in one L2.
