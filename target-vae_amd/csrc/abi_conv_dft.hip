@@ -112,7 +112,10 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     if (q.splits > 8) q.splits = 8;
     // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles.  (Its slices are not pinned to XCDs, so
     // their number is free: 9 slices, whose groups fill 7 whole rounds of the 256 CUs where 8 run 6.125, measured the same.)
-    q.wsplits = ((2 * q.M) % WW_ROWS == 0 && q.K2 > 128 && q.K2 <= 192) ? q.splits : 0;
+    // Wider problems take it in 192-column tiles when those pad no more than the 128-wide ones (1 152 columns at the galaxy
+    // shape: 6 tiles instead of 9, i.e. S' read and split 6 times instead of 9).
+    q.wsplits = ((2 * q.M) % WW_ROWS == 0 && q.K2 > 128 &&
+                 (q.K2 <= 192 || cdiv(q.K2, 192) * 192 <= cdiv(q.K2, 128) * 128)) ? q.splits : 0;
     // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)
     const int S = n > ksz ? n : ksz;
     q.nblk = 1;
@@ -398,7 +401,8 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     const int nslabs = wide ? q.wsplits : q.splits;
     {
         const int M2 = 2 * q.M;
-        const int tiles_b = wide ? M2 / WW_ROWS : q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b, tilesK = wide ? 1 : cdiv(q.K2, 128);
+        const int tiles_b = wide ? M2 / WW_ROWS : q.Mb / DX6_ROWS, tilesM = q.Lh * tiles_b;
+        const int tilesK = wide ? (q.K2 <= 160 ? 1 : cdiv(q.K2, 192)) : cdiv(q.K2, 128);
         // 8 reduction slices at the 64x64 configuration: TileMap deals the slices round-robin to the 8 XCDs
         const int splits = nslabs;
         const int nchunk = cdiv(cdiv((int)q.NBpad, splits), 16) * 16;

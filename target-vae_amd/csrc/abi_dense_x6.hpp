@@ -120,11 +120,20 @@ TVAE_INTERNAL int dense_wgrad_x6_wide_p2(TVAE_WGW_LAUNCH_ARGS);
 #define TVAE_WGW_LAUNCH_DEF(NP_)                                                                                      \
     namespace tvae {                                                                                                  \
     int dense_wgrad_x6_wide_p##NP_(TVAE_WGW_LAUNCH_ARGS) {                                                            \
-        if (M % WW_ROWS != 0 || Kf <= 128 || Kf > 192 || tm.tilesN != 1 || bt.tiles_per_batch <= 0)                 \
+        if (M % WW_ROWS != 0 || Kf <= 128 || bt.tiles_per_batch <= 0 ||                                             \
+            tm.tilesN != (Kf <= 160 ? 1 : cdiv(Kf, 192)))                                                             \
             return (int)hipErrorInvalidValue;                                                                         \
+        const unsigned grid_ =                                                                                        \
+            8u * cdiv(tm.splits * (tm.tilesM / bt.tiles_per_batch), 8) * bt.tiles_per_batch * tm.tilesN;              \
+        if (Kf <= 160) {             /* five column groups: the 66-wide frame of the 50 x 50 geometry (132 columns) */ \
+            hipError_t e_ = allow_big_lds(dense_wgrad_x6_wide_kernel<NP_, 5>, WW_RING_BYTES);                         \
+            if (e_ != hipSuccess) return (int)e_;                                                                     \
+            hipLaunchKernelGGL((dense_wgrad_x6_wide_kernel<NP_, 5>), dim3(grid_), dim3(DX6_THREADS), WW_RING_BYTES, st, \
+                               dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, atile, hs);                  \
+            return (int)hipGetLastError();                                                                            \
+        }                                                                                                             \
         hipError_t e_ = allow_big_lds(dense_wgrad_x6_wide_kernel<NP_, 6>, WW_RING_BYTES);                             \
         if (e_ != hipSuccess) return (int)e_;                                                                         \
-        const unsigned grid_ = 8u * cdiv(tm.splits * (tm.tilesM / bt.tiles_per_batch), 8) * bt.tiles_per_batch;       \
         hipLaunchKernelGGL((dense_wgrad_x6_wide_kernel<NP_, 6>), dim3(grid_), dim3(DX6_THREADS), WW_RING_BYTES, st,   \
                            dY, ldd, X, ldx, ws, M, Kf, N, nchunk, tm, bt, dy_stride, atile, hs);                      \
         return (int)hipGetLastError();                                                                                \

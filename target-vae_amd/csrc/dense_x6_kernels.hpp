@@ -1828,7 +1828,7 @@ void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict_
 // one 64-byte line each, XOR swizzled; X: every lane its own 16 bytes of row tid / 4, waves 0-3 a second piece for the rows
 // beyond 128 -- waves 4-7 issue a clamped duplicate so that the count stays uniform), the same cooperative B stage
 // ([part][octet half][32 NJ rows] cells, two stages, one barrier per step).  Plain operands only (no implicit forms);
-// NP = 3 / 2 / 1 as everywhere.  Host: M % 256 == 0, 32 (NJ - 2) < Kf <= 32 NJ.
+// NP = 3 / 2 / 1 as everywhere.  Host: M % 256 == 0; tm.tilesN column tiles of 32 NJ columns cover Kf.
 // Measured (64 x 64 step, h3): 1.58 -> 1.28 ms.  Ablation builds (-DTVAE_WW_ABL=bits: 1 no matrix instructions, 2 no
 // B-fragment reads, 4 no A split, 8 no B build; profiles/tools/build_variant.sh): the bare ring + barriers stream the 4.3 GB
 // in 0.95 ms (4.5 TB/s); a ring of four slots, a contiguous S' layout, nine reduction slices (whole rounds of the 256 CUs)
@@ -1856,12 +1856,14 @@ void dense_wgrad_x6_wide_kernel(const float* __restrict__ dY, long ldd, const fl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Workgroup -> (reduction slice, problem, row tile).  A group is the row tiles of one (slice, problem): they share the
     // X panel, so they run back to back on ONE XCD; groups are dealt round-robin to the 8 XCDs.  Slices are therefore NOT
-    // pinned to XCDs as TileMap does it, and their number is free: the host picks it so that the groups fill whole rounds
-    // of the 256 CUs (9 slices of 49 problems x 4 tiles: 7 rounds at 98 %, where 8 slices ran 6.125 rounds in 7).
-    const int tiles_b = bt.tiles_per_batch, nbatch = tm.tilesM / tiles_b;
-    const int g = ((blockIdx.x >> 3) / tiles_b) * 8 + (blockIdx.x & 7);
+    // pinned to XCDs as TileMap does it, and their number is free (9 slices of 49 problems x 4 tiles fill 7 whole rounds of
+    // the 256 CUs where 8 run 6.125: measured the same, the host keeps 8).
+    // (Wider problems -- 1 152 columns at the galaxy shape -- are several such column tiles; the tiles of a group are row
+    //  tile fastest, so the row tiles that share an X panel stay adjacent.)
+    const int tiles_b = bt.tiles_per_batch, nbatch = tm.tilesM / tiles_b, gsz = tiles_b * tm.tilesN;
+    const int g = ((blockIdx.x >> 3) / gsz) * 8 + (blockIdx.x & 7), rr = (blockIdx.x >> 3) % gsz;
     if (g >= tm.splits * nbatch) return;
-    const int tile_m = (blockIdx.x >> 3) % tiles_b, split = g / nbatch, batch = g - split * nbatch;
+    const int tile_m = rr % tiles_b, k0 = (rr / tiles_b) * (32 * NJ), split = g / nbatch, batch = g - split * nbatch;
     dY += batch * dy_stride;
     X += batch * bt.x_stride;
     const int m0 = tile_m * WW_ROWS;
@@ -1877,7 +1879,7 @@ void dense_wgrad_x6_wide_kernel(const float* __restrict__ dY, long ldd, const fl
             if (m >= M) continue;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                if (j * 32 + (lane & 31) < Kf) slab[(long)m * Kf + j * 32 + (lane & 31)] = 0.f;
+                if (k0 + j * 32 + (lane & 31) < Kf) slab[(long)m * Kf + k0 + j * 32 + (lane & 31)] = 0.f;
         }
         return;
     }
@@ -1890,13 +1892,13 @@ void dense_wgrad_x6_wide_kernel(const float* __restrict__ dY, long ldd, const fl
     const int kr = tid >> 2, q4 = tid & 3;
     const bool two = tid < 4 * (KR - 128);               // wave uniform: KR - 128 is a multiple of 16 rows = one wave
     const int kr2 = 128 + kr;
-    const int kx0 = min(kr, Kf - 1), kx1 = min(two ? kr2 : kr, Kf - 1);
+    const int kx0 = min(k0 + kr, Kf - 1), kx1 = min(k0 + (two ? kr2 : kr), Kf - 1);
     auto x_scale_of = [&](int kx) -> float {
         if (NP != 2) return 1.f;
         return h3_scale(hs.x_group > 0 ? hs.amax_x[(long)batch * hs.x_bstride + kx / hs.x_group] : hs.amax_x[0]);
     };
-    const float b0s = (kr < Kf ? 1.f : 0.f) * x_scale_of(kx0);
-    const float b1s = ((two && kr2 < Kf) ? 1.f : 0.f) * x_scale_of(kx1);
+    const float b0s = (k0 + kr < Kf ? 1.f : 0.f) * x_scale_of(kx0);
+    const float b1s = ((two && k0 + kr2 < Kf) ? 1.f : 0.f) * x_scale_of(kx1);
     // ---- DMA sources
     const float* d_ptr[2];
 #pragma unroll
@@ -2053,10 +2055,10 @@ void dense_wgrad_x6_wide_kernel(const float* __restrict__ dY, long ldd, const fl
         const int m = m0 + rl;
         if (m >= M) continue;
         const float ia = NP == 2 ? ssm[KR + rl] : 1.f;
-        float* wrow = slab + (long)m * Kf + (lane & 31);
+        float* wrow = slab + (long)m * Kf + k0 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (j * 32 + (lane & 31) < Kf) wrow[j * 32] = NP == 2 ? (acc[j][r] * ia) * ixv[j] : acc[j][r];
+            if (k0 + j * 32 + (lane & 31) < Kf) wrow[j * 32] = NP == 2 ? (acc[j][r] * ia) * ixv[j] : acc[j][r];
     }
 }
 
