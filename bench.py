@@ -314,7 +314,7 @@ def main():
         elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, c['lik'])
         (-elbo).backward()
         opt.step()
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)      # as the training loop (tvae/step.py): gradients gathered by one multi-tensor copy
         return elbo.detach()
 
     def barrier():

@@ -74,4 +74,6 @@ class GraphedStep:
             self.ez.copy_(noise[1].reshape(self.ez.shape))
             self.et.copy_(noise[2].reshape(self.et.shape))
         self.graph.replay()
+        for p, gv in zip(self.opt._ps, self.opt._gviews):      # the replay wrote the flat buffer: step() must not gather
+            p.grad = gv
         return self.terms

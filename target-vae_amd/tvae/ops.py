@@ -990,7 +990,7 @@ class DecoderFn(torch.autograd.Function):
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
                          tot[0] if rs else None, tot[1] if rs else None, p_d,
                          sbits if from_bits else None, rowdot, b if from_bits else None)
-                if two_val and li == 0 and n_hidden == 1:
+                if two_val and li == 0 and n_hidden == 1 and has_f and parts() == 2:
                     # bound of the gradient this launch leaves in `dprev` (read again by the Fourier first layer's backward):
                     # |dX[k][n]| <= max |gy| * sum_m |wo[m] W[m][k]|
                     ctx.d_bound = _inf_norm(vg[1]) * (W.detach().abs() * vg[0].detach().abs()[:, None]).sum(0).amax().reshape(1)

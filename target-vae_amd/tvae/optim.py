@@ -75,25 +75,45 @@ class FlatAdam(torch.optim.Optimizer):
         self._early_seen += 1
         if self._early_seen != self._early_n:
             return
-        for p, gv in zip(self._ps[:self._early_n], self._gviews[:self._early_n]):
-            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
-                return                      # a gradient was not accumulated in place: step() reduces everything
+        if any(p.grad is None for p in self._ps[:self._early_n]):
+            return                          # a parameter of the bucket got no gradient: step() reduces everything
+        self._gather(0, self._early_n)      # (gradients that were taken over instead of added in place: one multi-tensor copy)
         self._early_posted = True
         self.reducer.begin(self.flat_g[:self._early_end])
 
     def zero_grad(self, set_to_none: bool = False):
+        """set_to_none=False: the flat gradient buffer is zeroed and every `p.grad` is its view of it (the next backward ADDS
+        into the buffer: one elementwise launch per parameter).  set_to_none=True (the training loops): `p.grad = None`, so
+        the next backward's AccumulateGrad nodes keep the gradient tensors their producers return, and step() (or the early
+        bucket's hook) gathers them into the flat buffer with ONE multi-tensor copy -- 17 adds and the zero fill per step
+        become one or two launches (round 4: profiles/tools/step_timeline.sh).  The buffer's padding is never written."""
+        if set_to_none:
+            for p in self._ps:
+                p.grad = None
+            return
         self.flat_g.zero_()
         for p, gv in zip(self._ps, self._gviews):
             p.grad = gv
 
     @torch.no_grad()
-    def step(self, closure=None):
-        for p, gv in zip(self._ps, self._gviews):
+    def _gather(self, lo: int, hi: int) -> None:
+        """Gradients of parameters lo .. hi-1 into their slices of the flat buffer; `p.grad` becomes the view again."""
+        dst, src = [], []
+        for p, gv in zip(self._ps[lo:hi], self._gviews[lo:hi]):
             if p.grad is None:
                 gv.zero_()
             elif p.grad.data_ptr() != gv.data_ptr():
-                gv.copy_(p.grad)
+                dst.append(gv)
+                src.append(p.grad if p.grad.shape == gv.shape else p.grad.reshape(gv.shape))
             p.grad = gv
+        if len(dst) == 1:
+            dst[0].copy_(src[0])
+        elif dst:
+            torch._foreach_copy_(dst, src)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._gather(self._early_n if self._early_posted else 0, len(self._ps))
         scale = 1.0
         if self.reducer is not None:
             if self._early_n and not self._early_posted:

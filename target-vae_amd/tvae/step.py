@@ -166,7 +166,7 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
                                                  theta_prior, groupconv, image_dim, likelihood, noise)
             (-elbo).backward()
             optim.step()
-            optim.zero_grad()
+            optim.zero_grad(set_to_none=True)
             stats = torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()]).tolist()
         elbo_v, gen_loss, kl_loss = stats[0], -stats[1], stats[2]   # one sync instead of three .item()
         c += b

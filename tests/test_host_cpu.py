@@ -192,6 +192,59 @@ def test_flat_adam_views_and_update_cpu():
     assert opt.param_groups[0]['lr'] == pytest.approx(5e-3)
 
 
+def test_flat_adam_takes_gradients_over_when_grads_are_none():
+    """zero_grad(set_to_none=True), the training loops' form (round 4): the backward's AccumulateGrad nodes keep the gradient
+    tensors (no add into a zeroed buffer); step() -- or the early bucket's hook, before it posts its all-reduce -- gathers them
+    into the flat buffer.  Same trajectory as torch.optim.Adam; a parameter without a gradient gets a zero slice; the early
+    bucket is posted with the gathered values."""
+    from tvae import optim
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+
+    def upd(p, g, m, v, step, lr, b1, b2, eps, scale):
+        O.adam_update([p], [g * scale], [m], [v], step, lr, b1, b2, eps)
+
+    class Reducer:
+        active = True
+
+        def __init__(self):
+            self.begun = []
+
+        def begin(self, seg):
+            self.begun.append(seg.clone())
+
+        def __call__(self, flat_g, start=0):
+            return 1.0
+
+    red = Reducer()
+    opt = optim.FlatAdam(ps, lr=1e-2, update_fn=upd, reducer=red, early_params=2)
+    ropt = torch.optim.Adam(ref, lr=1e-2)
+    opt.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in ps)
+    for it in range(3):
+        use = ps if it != 1 else ps[:2]                  # step 1: the last parameter gets no gradient
+        ruse = ref if it != 1 else ref[:2]
+        sum(((p * (i + 1 + it)) ** 2).sum() for i, p in enumerate(use)).backward()
+        sum(((p * (i + 1 + it)) ** 2).sum() for i, p in enumerate(ruse)).backward()
+        assert len(red.begun) == it + 1                  # the early bucket (two parameters) was posted from inside the backward
+        assert torch.equal(red.begun[-1][:12], ref[0].grad.reshape(-1)) and torch.equal(red.begun[-1][64:69], ref[1].grad)
+        assert ps[0].grad.data_ptr() == opt.flat_g.data_ptr()
+        opt.step()
+        for p, r in zip(ps, ref):
+            if r.grad is None:
+                assert float(p.grad.abs().sum()) == 0.0
+                r.grad = torch.zeros_like(r)             # (FlatAdam steps every parameter, with a zero gradient if it got none)
+            else:
+                assert torch.equal(p.grad, r.grad) and p.grad.data_ptr() >= opt.flat_g.data_ptr()
+        assert float(opt.flat_g[12:64].abs().sum()) == 0.0           # padding never written
+        ropt.step()
+        opt.zero_grad(set_to_none=True)
+        ropt.zero_grad(set_to_none=True)
+    for p, r in zip(ps, ref):
+        assert rel_err(p.detach(), r.detach()) < 1e-6
+
+
 def test_resident_shard_plan_visits_every_image_once():
     """Shard-resident batches: every image exactly once per epoch, each rank only its own rows, global minibatch sizes
     known to every rank without communication."""
