@@ -214,8 +214,12 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     int rc = 0;
     if (h3) {
         const int Rp = x6_round_up(rows, DX6_ROWS), K8p = dense_k8pad(q.K2);
-        hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d((long)K8p * Rp, 256)), dim3(256), 0, st, (const float*)W,
-                           (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, 0, (const float*)nullptr, (const float*)mxp.wmax);
+        if (K8p <= 48)       // both sides coalesced through LDS (<= 48 KB)
+            hipLaunchKernelGGL(dense_split2h_rows_kernel, dim3(Rp / 32), dim3(256), (size_t)32 * K8p * 32, st, (const float*)W,
+                               (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, (const float*)nullptr, (const float*)mxp.wmax);
+        else
+            hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d((long)K8p * Rp, 256)), dim3(256), 0, st, (const float*)W,
+                               (long)q.K2, (uint4*)W3, rows, Rp, q.K2, K8p, 0, (const float*)nullptr, (const float*)mxp.wmax);
         TVAE_CHECK_LAUNCH();
     } else {
         rc = tvae_dense_split3(W, q.K2, W3, q.w3_floats * 4, rows, q.K2, 0, nullptr, nullptr, stream);

@@ -116,10 +116,10 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
         hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, S(stream), slots, 4 + K);
         TVAE_CHECK_LAUNCH();
         const long nlb = va_lb ? (long)(N / vas.Np) * K : 0;
-        hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 128)), dim3(256), 0, S(stream), va_xr, 2L * N, va_wc,
+        hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 512)), dim3(256), 0, S(stream), va_xr, 2L * N, va_wc,
                            va_bc, va_lb, nlb, K, slots);
         TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)N, 256 * 8, 128)), dim3(256), 0, S(stream), vg_gy, (long)N, 1, N,
+        hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid1d((long)N, 256 * 8, 512)), dim3(256), 0, S(stream), vg_gy, (long)N, 1, N,
                            0, (const float*)nullptr, slots + 3);
         TVAE_CHECK_LAUNCH();
         rc = dense_wgrad_x6_launch_p2(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas,

@@ -116,11 +116,18 @@ static int dense_split(const float* W, long ldw, void* a3, long a3_bytes, int ro
     const long total = (long)K8pad * Rpad;
     if (parts == 2) {
         float* tr = h3_trailer(a3, rows, K);             // [Rpad] row maxima, then the scratch words of the GEMM entry points
-        hipLaunchKernelGGL(dense_rowmax_kernel, dim3(Rpad / 64), dim3(1024), 0, S(stream), W, ldw, rows, Rpad, K, transpose, scale,
-                           tr);
+        if (transpose)
+            hipLaunchKernelGGL(dense_rowmax_kernel, dim3(Rpad / 64), dim3(1024), 0, S(stream), W, ldw, rows, Rpad, K, transpose,
+                               scale, tr);
+        else             // row-major operand: one wave per row, lanes along k
+            hipLaunchKernelGGL(dense_rowmax_rows_kernel, dim3(Rpad / 4), dim3(256), 0, S(stream), W, ldw, rows, Rpad, K, scale, tr);
         TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
-                           Rpad, K, K8pad, transpose, scale, (const float*)tr);
+        if (!transpose && K8pad <= 48)                   // both sides coalesced through LDS (32 rows per workgroup, <= 48 KB)
+            hipLaunchKernelGGL(dense_split2h_rows_kernel, dim3(Rpad / 32), dim3(256), (size_t)32 * K8pad * 32, S(stream), W, ldw,
+                               (uint4*)a3, rows, Rpad, K, K8pad, scale, (const float*)tr);
+        else
+            hipLaunchKernelGGL(dense_split2h_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
+                               Rpad, K, K8pad, transpose, scale, (const float*)tr);
     } else {
         hipLaunchKernelGGL(dense_split3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), W, ldw, (uint4*)a3, rows,
                            Rpad, K, K8pad, transpose, scale);
@@ -163,7 +170,7 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
             hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, st, bw, 4 + K);
             TVAE_CHECK_LAUNCH();
             const long nlb = va.lb ? (long)(N / va.Np) * K : 0;
-            hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 128)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
+            hipLaunchKernelGGL(dec_l0_bound_kernel, dim3(grid1d(N / 2, 256, 512)), dim3(256), 0, st, va.xr, 2L * N, va.wc,
                                va.bc, va.lb, nlb, K, bw);
             TVAE_CHECK_LAUNCH();
             hs.amax_x = bw;

@@ -124,7 +124,7 @@ int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long 
         // max |dheads|: one pass over nh x N floats (62 MB at the bench shape)
         hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(64), 0, S(stream), slots, 1);
         TVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(h3_absmax_rows_kernel, dim3(grid1d(N / 16 + 1, 256, 512), nh), dim3(256), 0, S(stream), dheads, ldd, N,
+        hipLaunchKernelGGL(h3_absmax_rows_kernel, dim3(grid1d(N / 16 + 1, 256, 96), nh), dim3(256), 0, S(stream), dheads, ldd, N,
                            slots);
         TVAE_CHECK_LAUNCH();
         e = allow_big_lds(enc_tail_wgrad_x6_kernel<2>, EW_LDS);

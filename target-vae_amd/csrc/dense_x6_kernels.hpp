@@ -82,11 +82,40 @@ static __global__ __launch_bounds__(1024) void dense_rowmax_kernel(const float* 
         rowmax[row] = t;
     }
 }
+// The same for a row-major operand (transpose == 0), where the kernel above has every lane on a row of its own (64 rows x 4 B
+// per load instruction): one WAVE per row, lanes along k (19 -> ~6 us for a 512 x 512 weight).  Block = 4 rows.
+static __global__ __launch_bounds__(256) void dense_rowmax_rows_kernel(const float* __restrict__ W, long ldw, int Rrows, int Rpad,
+                                                                      int K, const float* __restrict__ scale,
+                                                                      float* __restrict__ rowmax) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Rpad) return;
+    float mx = 0.f;
+    if (row < Rrows)
+        for (int k = lane; k < K; k += 64) {
+            float v = W[(long)row * ldw + k];
+            if (scale) v *= scale[k];
+            mx = fmaxf(mx, fabsf(v));
+        }
+    mx = h3_wave_max(mx);
+    if (lane == 0) rowmax[row] = mx;
+}
 // max |x| of a vector into ONE word (the gy operand of the two-valued weight gradient)
 static __global__ void dense_absmax_kernel(const float* __restrict__ W, long ldw, int Rrows, int K, int transpose,
                                            const float* __restrict__ scale, float* __restrict__ amax) {
     const long total = (long)Rrows * K;
     float mx = 0.f;
+    if (!scale && (transpose ? ldw == Rrows : ldw == K) && (reinterpret_cast<size_t>(W) & 15) == 0) {
+        // one contiguous vector: 16-byte loads (18 -> ~6 us for the 1 M values of gy)
+        const float4* w4 = reinterpret_cast<const float4*>(W);
+        const long n4 = total / 4, gsz = (long)gridDim.x * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gsz) {
+            const float4 v = w4[i];
+            mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gsz) mx = fmaxf(mx, fabsf(W[i]));
+        h3_block_amax(mx, amax);
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         // consecutive threads read consecutive addresses in either orientation
         const int k = transpose ? (int)(i / Rrows) : (int)(i % K);
@@ -153,6 +182,55 @@ static __global__ void dense_split2h_kernel(const float* __restrict__ W, long ld
     }
 }
 
+// The same split for row-major operands (transpose == 0) with BOTH sides coalesced: a workgroup takes 32 rows; its threads read
+// consecutive octets of a row (consecutive 32-byte pieces of memory), park the cells in LDS as [octet][row] and write each
+// octet's 32 cells as one 512-byte run (the kernel above stores 16-byte cells 16 Rpad bytes apart: 62 us for the 38 MB of the
+// spectral weight; this one ~25).  Dynamic LDS: 32 K8pad cells x 2 parts.
+static __global__ __launch_bounds__(256) void dense_split2h_rows_kernel(const float* __restrict__ W, long ldw, uint4* __restrict__ A3,
+                                                                        int Rrows, int Rpad, int K, int K8pad,
+                                                                        const float* __restrict__ scale,
+                                                                        const float* __restrict__ rowmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char split_lds[];
+    uint4* Hs = reinterpret_cast<uint4*>(split_lds);
+    uint4* Ls = Hs + 32 * K8pad;
+    const long total = (long)K8pad * Rpad;
+    const int r0 = blockIdx.x * 32, ncell = 32 * K8pad;
+    const bool vec = (ldw & 3) == 0 && (reinterpret_cast<size_t>(W) & 15) == 0;
+    for (int c = threadIdx.x; c < ncell; c += 256) {
+        const int rl = c / K8pad, o = c - rl * K8pad, row = r0 + rl;
+        const float s = h3_scale(rowmax[row]);
+        float r[8];
+        if (vec && row < Rrows && 8 * o + 8 <= K) {      // two 16-byte loads
+            const float4 a = *reinterpret_cast<const float4*>(W + (long)row * ldw + 8 * o);
+            const float4 b = *reinterpret_cast<const float4*>(W + (long)row * ldw + 8 * o + 4);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * o + j;
+                r[j] = (row < Rrows && k < K) ? W[(long)row * ldw + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * o + j;
+            if (scale && k < K) r[j] *= scale[k];
+            r[j] *= s;
+        }
+        Cell16 h, l;
+        split2hx8(r, h, l);
+        Hs[o * 32 + rl] = h.u;
+        Ls[o * 32 + rl] = l.u;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncell; c += 256) {
+        const int o = c >> 5, rl = c & 31;
+        const long ci = (long)o * Rpad + r0 + rl;
+        A3[ci] = Hs[c];
+        A3[total + ci] = Ls[c];
+    }
+}
+
 // h3 scale of the recomputed first-layer activation (VirtAct): slots[0] = max |xr|, slots[1] = max_k (|wc[k][0]| + |wc[k][1]|),
 // slots[2] = max_{b,k} |bc[k] + lb[b][k]| (atomic maxima into zeroed slots); |act(pre)| <= |pre| <= slots[1] slots[0] + slots[2]
 // for LeakyReLU (slope <= 1), tanh and the identity.  slots[3] is the caller's (max |gy| of the weight gradient) and
@@ -173,10 +251,18 @@ static __global__ void dec_l0_bound_kernel(const float* __restrict__ xr, long nx
     for (long i = 4 * n4 + gid; i < nxr; i += gsz) m0 = fmaxf(m0, fabsf(xr[i]));
     for (long i = gid; i < K; i += gsz) m1 = fmaxf(m1, fabsf(wc[2 * i]) + fabsf(wc[2 * i + 1]));
     if (lb) {
-        for (long i = gid; i < nlb; i += gsz) {
-            const float v = fabsf(bc[i % K] + lb[i]);
-            m2 = fmaxf(m2, v);
-            h3_atomic_amax(slots + 4 + (i % K), v);
+        // thread = (feature k, one of 16 image chunks): a local maximum over its images, then ONE atomic per thread (one atomic
+        // per (image, feature) pair -- 256 per word at the bench shape -- made this loop the kernel's cost)
+        const long nimg = nlb / K, per = (nimg + 15) / 16;
+        for (long t = gid; t < 16L * K; t += gsz) {
+            const int k = (int)(t % K);
+            const long b0 = (t / K) * per, b1 = b0 + per < nimg ? b0 + per : nimg;
+            float v = 0.f;
+            for (long b = b0; b < b1; ++b) v = fmaxf(v, fabsf(bc[k] + lb[b * K + k]));
+            if (b1 > b0) {
+                m2 = fmaxf(m2, v);
+                h3_atomic_amax(slots + 4 + k, v);
+            }
         }
     } else {
         for (long i = gid; i < K; i += gsz) {
