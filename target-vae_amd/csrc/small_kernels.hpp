@@ -353,31 +353,57 @@ static __global__ __launch_bounds__(1024) void latent_bwd_kernel(const float* __
 static __global__ void fourier_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
                                    const float* __restrict__ bf, float sigma, float* __restrict__ feat, long ld, int F,
                                    long Ntot) {
+    // (the workgroup's 16 features once into LDS: the two divisions per feature were done by every thread -- round 4)
+    __shared__ float wsm[16][3];
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int fbeg = blockIdx.y * 16, fend = min(F, fbeg + 16);
+    if ((int)threadIdx.x < fend - fbeg) {
+        const int f = fbeg + threadIdx.x;
+        wsm[threadIdx.x][0] = Wf[2 * f] / sigma;
+        wsm[threadIdx.x][1] = Wf[2 * f + 1] / sigma;
+        wsm[threadIdx.x][2] = bf[f];
+    }
+    __syncthreads();
     if (n >= Ntot) return;
     const float x0 = xr[2 * n], x1 = xr[2 * n + 1];
-    const int fbeg = blockIdx.y * 16, fend = min(F, fbeg + 16);
     for (int f = fbeg; f < fend; ++f) {
-        const float w0 = Wf[2 * f] / sigma, w1 = Wf[2 * f + 1] / sigma;
-        feat[(long)f * ld + n] = cosf(x0 * w0 + x1 * w1 + bf[f]);
+        const float w0 = wsm[f - fbeg][0], w1 = wsm[f - fbeg][1];
+        feat[(long)f * ld + n] = cosf(x0 * w0 + x1 * w1 + wsm[f - fbeg][2]);
     }
 }
 // gxr[pix][j] = sum_f -sin(arg_f) * (Wf[f][j]/sigma) * dfeat[f][pix]
 static __global__ void fourier_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ Wf,
                                    const float* __restrict__ bf, float sigma, const float* __restrict__ dfeat, long ld,
                                    int F, long Ntot, float* __restrict__ gxr) {
+    // (features in chunks of 256 through LDS: the divisions once per workgroup instead of once per thread and feature; the sum
+    //  over f keeps its order -- round 4)
+    __shared__ float wsm[256][3];
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Ntot) return;
-    const float x0 = xr[2 * n], x1 = xr[2 * n + 1];
+    const bool live = n < Ntot;
+    const float x0 = live ? xr[2 * n] : 0.f, x1 = live ? xr[2 * n + 1] : 0.f;
     float g0 = 0.f, g1 = 0.f;
-    for (int f = 0; f < F; ++f) {
-        const float w0 = Wf[2 * f] / sigma, w1 = Wf[2 * f + 1] / sigma;
-        const float t = -sinf(x0 * w0 + x1 * w1 + bf[f]) * dfeat[(long)f * ld + n];
-        g0 += t * w0;
-        g1 += t * w1;
+    for (int f0 = 0; f0 < F; f0 += 256) {
+        __syncthreads();
+        if (f0 + (int)threadIdx.x < F) {
+            const int f = f0 + threadIdx.x;
+            wsm[threadIdx.x][0] = Wf[2 * f] / sigma;
+            wsm[threadIdx.x][1] = Wf[2 * f + 1] / sigma;
+            wsm[threadIdx.x][2] = bf[f];
+        }
+        __syncthreads();
+        const int fe = min(256, F - f0);
+        if (live)
+            for (int q = 0; q < fe; ++q) {
+                const float w0 = wsm[q][0], w1 = wsm[q][1];
+                const float t = -sinf(x0 * w0 + x1 * w1 + wsm[q][2]) * dfeat[(long)(f0 + q) * ld + n];
+                g0 += t * w0;
+                g1 += t * w1;
+            }
     }
-    gxr[2 * n] = g0;
-    gxr[2 * n + 1] = g1;
+    if (live) {
+        gxr[2 * n] = g0;
+        gxr[2 * n + 1] = g1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
