@@ -67,7 +67,7 @@ def _train(rank, world, epochs=2):
                                      eps_theta=et[idx], **CFG)
             (-elbo).backward()
             opt.step()
-            opt.zero_grad()
+            opt.zero_grad(set_to_none=True)
             stats[0] += float(elbo) * (hi - lo)
             stats[1] += hi - lo
     if world > 1:           # two buckets: the decoder segment was posted from inside every backward (tvae/optim.py)

@@ -67,7 +67,7 @@ def _train(rank, world, dev_index=0, always=False, turns=False):
                 if turns:
                     dist.barrier()
             opt.step()
-            opt.zero_grad()
+            opt.zero_grad(set_to_none=True)      # the training loops' form: gradients gathered by step() / the early hook
             if turns:
                 torch.cuda.synchronize()
                 dist.barrier()
