@@ -260,7 +260,11 @@ def test_linear_wgrad_x6(M, N, K, acc):
     (3, 28, 28, 8, 16, 8, 1, 3), (2, 20, 9, 2, 5, 4, 0, 2),
     # frames beyond the specialised transforms along w (Lh > 64 or Ho > 64): spectra in frequency blocks, generic
     # transforms -- the galaxy configuration's shape class (192-wide frame, 3 channels) at a small size
-    (2, 96, 32, 16, 4, 4, 1, 2), (2, 128, 64, 32, 2, 16, 1, 3)])
+    (2, 96, 32, 16, 4, 4, 1, 2), (2, 128, 64, 32, 2, 16, 1, 3),
+    # round 4: the spectral GEMM kernels of their own shape at their edges -- one image (a single 128-column panel, two k-steps
+    # per reduction slice), 2 M = 512 / 1 024 rows; and the weight gradient's 192-column tiles on a 1 152-column problem
+    # (galaxy frame, three channels) with 2 M = 512 rows
+    (1, 64, 64, 16, 32, 8, 1, 1), (2, 64, 64, 16, 32, 16, 1, 1), (3, 128, 64, 32, 16, 16, 1, 3)])
 @pytest.mark.parametrize('nparts', [3, 2])
 def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin, nparts):
     """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64, in the exact
