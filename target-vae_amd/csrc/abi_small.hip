@@ -168,6 +168,18 @@ int tvae_heads_bwd(const float* W, const float* dY, long ldy, const float* X, lo
         default: launch_heads_bwd<8>(W, dY, ldy, X, ldx, dX, lddx, C, N, act, slope, part, vec, S(stream)); break;
     }
     TVAE_CHECK_LAUNCH();
+    // totals of the panels: two coalesced stages when the caller's workspace has room for the PT_GROUPS partials behind them
+    const long used = (long)np * C * (nh + 1), mv = (long)C * (nh + 1);
+    if (np >= 4 * PT_GROUPS && mv % 4 == 0 && part_floats >= ((used + 3) & ~3L) + PT_GROUPS * mv && aligned16(part)) {
+        float* partial = part + ((used + 3) & ~3L);
+        hipLaunchKernelGGL(part_total_s1_kernel, dim3(PT_GROUPS), dim3(256), 0, S(stream), (const float*)part, np, (int)(mv / 4),
+                           partial);
+        TVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(part_total_s2_kernel, dim3((unsigned)((mv + 255) / 256)), dim3(256), 0, S(stream),
+                           (const float*)partial, C, nh + 1, tot);
+        TVAE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(part_total_kernel, dim3(C), dim3(256), 0, S(stream), (const float*)part, np, C, nh + 1, tot);
     TVAE_CHECK_LAUNCH();
     return 0;

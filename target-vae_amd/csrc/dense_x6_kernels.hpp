@@ -1741,7 +1741,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 // Measured (same box): 1.46 -> 1.38 ms.  Ablation builds (-DTVAE_XRES_ABL=bits: 1 one k-step only, 2 no stores, 4 no weight-cell
 // loads): stores alone 0.61 ms (5.5 TB/s), products alone 0.95, products + stores WITHOUT the weight-cell loads 1.05 -- but 1.33
 // with them: loads and stores share the in-order vmcnt counter, so waiting for the cells of step t also waits for every older
-// store's acknowledgement from a saturated write path.  A fourth operand buffer (one more step of distance) gave 2 %, six spilled;
+// store's acknowledgement from a saturated write path.  A fourth operand buffer (one more step of distance: shipped) gave 2 %, six spilled;
 // default-policy stores were slower (1.55).  Two forms that take the weight-cell loads out of the wave's way were built and
 // measured SLOWER, so the in-order counter is not the whole story: 64-column panels with four waves per SIMD (64 x 64 blocks,
 // stored after their k-loop: 1.44 ms against 1.27 on the same box -- twice the weight-cell traffic), and the weight cells of a
@@ -1863,7 +1863,7 @@ void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict_
 #pragma unroll
             for (int r_ = 0; r_ < 16; ++r_) accC[j][r_] = 0.f;
 #ifndef TVAE_XRES_NB
-#define TVAE_XRES_NB 3
+#define TVAE_XRES_NB 4
 #endif
         constexpr int NB = NP == 3 ? 2 : TVAE_XRES_NB;   // operand buffers: the weight cells of steps t .. t + NB - 1
         Cell16 af[NB][3];

@@ -520,7 +520,7 @@ class EncoderFn(torch.autograd.Function):
         if nh <= SKINNY_MAX:
             # one pass over H: masked dgrad + dWh + the row sums of dH (= db2)
             npan = (N + 511) // 512
-            part = workspace(y.device, npan * C2 * (nh + 1))
+            part = workspace(y.device, npan * C2 * (nh + 1) + 4 + 64 * C2 * (nh + 1))      # + room for the two-stage total
             tot = torch.empty(nh + 1, C2, dtype=torch.float32, device=y.device)
             call('tvae_heads_bwd', Wh.contiguous(), dheads, N, H, N, dH, N, nh, C2, N, act, LRELU_SLOPE, part,
                  part.numel(), tot)
@@ -604,7 +604,7 @@ class TransAttnEncoderFn(torch.autograd.Function):
         dH = torch.empty(C2, N, dtype=torch.float32, device=dev)
         if nh <= SKINNY_MAX:
             npan = (N + 511) // 512
-            part = workspace(dev, npan * C2 * (nh + 1))
+            part = workspace(dev, npan * C2 * (nh + 1) + 4 + 64 * C2 * (nh + 1))      # + room for the two-stage total
             tot = torch.empty(nh + 1, C2, dtype=torch.float32, device=dev)
             call('tvae_heads_bwd', Wh.contiguous(), dheads, N, H, N, dH, N, nh, C2, N, act, LRELU_SLOPE, part,
                  part.numel(), tot)
