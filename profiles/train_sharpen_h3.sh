@@ -33,7 +33,5 @@ run() {
     --seed 0 --log-root ../gpurun_out/logs_sharp_$1 > ../gpurun_out/sharp_$1.log 2>&1
   echo "== $1"; grep -aoP "^\d+\t(train|test)\t\S+\t\S+\t\S+" ../gpurun_out/sharp_$1.log | awk 'NR==2 || NR==20 || NR==40' ; grep -aoP "^\d+\t(train|test)\t\S+\t\S+\t\S+" ../gpurun_out/sharp_$1.log | tail -3
 }
-run h3
-run x6
-run f32
+for m in ${MODES:-h3 x6 f32}; do run $m; done        # MODES=h3 bash profiles/train_sharpen_h3.sh: one arithmetic only
 rm -rf data/mnist_U
