@@ -54,19 +54,13 @@ bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilo
         return false;
     const int Rpad = x6_round_up(nprob * Mb, DX6_ROWS), tilesN = N / 128, nch = 4, cs = cdiv(tilesN, nch);
     const unsigned grid = 8u * cdiv(nprob * nch, 8) * cs;
-#define TVAE_XRES_LAUNCH(NP_, NK_)                                                                                     \
-    do {                                                                                                               \
-        hipError_t e_ = allow_big_lds(dense_x6_xres_kernel<NP_, NK_>, lds);                                            \
-        if (e_ != hipSuccess) { *rc = (int)e_; return true; }                                                          \
-        hipLaunchKernelGGL((dense_x6_xres_kernel<NP_, NK_>), dim3(grid), dim3(DX6_THREADS), lds, st, (const uint4*)w3, X, ldx, \
-                           ep.C, ep.ldc, ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs); \
-    } while (0)
     // twelve k-steps only (the 96-wide frame of the 64 x 64 configuration): at six steps (28 x 28: 44-wide frame) the stores
-    // per step double and the kernel measured 2 % behind dense_x6_plain4_kernel; nine steps (50 x 50) were not measured
-    // h3 only: with three parts (x6: six products per block, three operand registers sets) the kernel spills and measured
-    // 2.11 ms against plain4's 1.81
-    TVAE_XRES_LAUNCH(2, 12);
-#undef TVAE_XRES_LAUNCH
+    // per step double and the first form of this kernel measured 2 % behind dense_x6_plain4_kernel; nine steps (50 x 50) were not measured
+    // h3 only (with three parts the first form of this kernel spilled and measured 2.11 ms against plain4's 1.81)
+    hipError_t e_ = allow_big_lds(dense_x6_xres_kernel<2, 12>, lds);
+    if (e_ != hipSuccess) { *rc = (int)e_; return true; }
+    hipLaunchKernelGGL((dense_x6_xres_kernel<2, 12>), dim3(grid), dim3(256), lds, st, (const uint4*)w3, X, ldx, ep.C, ep.ldc,
+                       ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs);
     *rc = (int)hipGetLastError();
     return true;
 }

@@ -1727,37 +1727,32 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 // ------------------------------------------------------------------------------------------
 // Round 4: the spectral forward GEMM with the STREAMED operand resident and its stores inside the k-loop.
 // T[fx][m'][n] = sum_k W[fx][m'][k] A^T[fx][k][n] has a short reduction (k = 2 L Cin: 192 at the 64 x 64 frame, twelve 16-wide
-// steps) and a huge output (3.4 GB).  Ablations of this very kernel: its stores alone take 0.81 ms (4.2 TB/s), its matrix work
-// alone 0.93 ms -- and dense_x6_plain4_kernel, which computes a tile and THEN stores it, took 1.39: a wave cannot overlap its
-// own stores with its own products, and with one or two workgroups per CU nobody else does it either (first version of this
-// kernel, 64-row blocks stored after their k-loop: 1.50 ms).  So:
+// steps) and a huge output (3.4 GB).  dense_x6_plain4_kernel computes a tile and THEN stores it: a wave cannot overlap its own
+// stores with its own products, and with two workgroups per CU nobody else does it reliably either (1.39-1.46 ms; its stores
+// alone 0.6-0.8 ms, its matrix work alone 0.93).  Here:
 //   * a workgroup owns ONE panel (problem fx, 128 columns): phase 1 builds the B cells of all k-steps once into LDS (98 KB in
 //     the h3 arithmetic; plain4 rebuilt -- loaded, scaled, split -- the panel once per 256-row tile, with a barrier per step);
-//   * phase 2 has NO barrier: each of the eight waves walks its own 32-row blocks of the problem (rows 32 wave + 256 i),
-//     streaming the weight cells from L2 into double-buffered MFMA operands against the static cells;
-//   * two accumulator sets (2 x 64 registers): while block i + 1 is being multiplied, the 64 store instructions of block i are
-//     issued a few per k-step (the loop is unrolled over NK), so the write stream is continuous.  Only the last block of a
-//     wave stores alone.
-// Measured (same box): 1.46 -> 1.38 ms.  Ablation builds (-DTVAE_XRES_ABL=bits: 1 one k-step only, 2 no stores, 4 no weight-cell
-// loads): stores alone 0.61 ms (5.5 TB/s), products alone 0.95, products + stores WITHOUT the weight-cell loads 1.05 -- but 1.33
-// with them: loads and stores share the in-order vmcnt counter, so waiting for the cells of step t also waits for every older
-// store's acknowledgement from a saturated write path.  A fourth operand buffer (one more step of distance: shipped) gave 2 %, six spilled;
-// default-policy stores were slower (1.55).  Two forms that take the weight-cell loads out of the wave's way were built and
-// measured SLOWER, so the in-order counter is not the whole story: 64-column panels with four waves per SIMD (64 x 64 blocks,
-// stored after their k-loop: 1.44 ms against 1.27 on the same box -- twice the weight-cell traffic), and the weight cells of a
-// wave's 32 rows RESIDENT in 96 registers with the panels double-buffered in LDS (no load needed sooner than a panel later:
-// 1.46-1.50 against 1.30-1.38).  Common to all three: a 32-row wave block feeds every 1 KB B-fragment read from LDS into ONE
-// group of three MFMAs (dense_x6_plain4_kernel's 64-row wave tile into two) -- about two thirds of the LDS read rate of a CU
-// while the matrix pipe is busy -- and that is the price of a second accumulator set.
+//   * phase 2 has NO barrier: each wave walks its own 64-row blocks of the problem (rows 64 wave + 256 i), streaming the weight
+//     cells from L2 into EIGHT register buffers (seven k-steps of distance) against the static cells;
+//   * FOUR waves per workgroup, one per SIMD, so that a wave owns 512 registers: two accumulator sets of 128 (one lives in
+//     AGPRs) -- while block i + 1 is being multiplied, the 128 store instructions of block i are issued a few per k-step (the
+//     loop is unrolled over NK), so the write stream is continuous.  Only the last block of a wave stores alone.
+// History of the forms, each parity-green and measured (profiles/README.md, round 4): eight waves with 32-row blocks and
+// 64-register accumulator sets: 1.37 ms -- every 1 KB B-fragment read from LDS feeds ONE group of MFMAs there, two here, and the
+// weight-cell loads (three to four buffers were all the registers allowed) waited behind the wave's own stores on the one
+// in-order vmcnt counter (57 % of wave cycles parked; without those loads 1.05 ms); the same with the stores after the k-loop
+// 1.51; 64-column panels at four waves per SIMD 1.44; weight cells resident in registers with double-buffered panels 1.46-1.50.
+// This form: 1.24-1.30 ms; buffers 3 / 6 / 8: 1 437 / 1 272 / 1 235 us on one box; all twelve steps as one stream across the
+// blocks: no better.
 // Host: lean epilogue shape of the spectral contraction (plain column-tiled fp32 output), N % 128 == 0, rows per problem a
-// multiple of 512 (M; Mb >= M is their stride in the cell array), NK = K8pad / 2 steps, NP = 3 or 2.  Grid: groups (problem,
+// multiple of 512 (M; Mb >= M is their stride in the cell array), NK = K8pad / 2 steps, NP = 2.  Grid: groups (problem,
 // quarter of the column tiles) dealt round-robin to the XCDs: a problem's weight cells (0.8 MB) stay in one L2.
 // ------------------------------------------------------------------------------------------
 template <int NP, int NK>
-static __global__ __launch_bounds__(DX6_THREADS, 2)
+static __global__ __launch_bounds__(256, 1)
 void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, long ldx, float* __restrict__ C, long ldc,
-                          long ctile, int M, int Mb, int Mpad, int K, int nprob, int tilesN, int nch, long x_stride,
-                          long c_stride, H3Scale hs) {
+                           long ctile, int M, int Mb, int Mpad, int K, int nprob, int tilesN, int nch, long x_stride,
+                           long c_stride, H3Scale hs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xres_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1765,7 +1760,6 @@ void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict_
     uint4* Bs = reinterpret_cast<uint4*>(xres_lds);                        // [step][part][octet half][128 n]
     float* h3a_ = reinterpret_cast<float*>(xres_lds + (size_t)NK * NP * 256 * 16);     // [Mb] inverse row scales
     float* h3x_ = h3a_ + Mb;                                               // [128] inverse column scales
-    // workgroup -> (problem, column tile)
     const int cs = (tilesN + nch - 1) / nch;
     const int g = ((blockIdx.x >> 3) / cs) * 8 + (blockIdx.x & 7), r = (blockIdx.x >> 3) % cs;
     const int batch = g / nch, tile_n = (g - batch * nch) * cs + r;
@@ -1774,99 +1768,95 @@ void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict_
     C += batch * c_stride + (long)tile_n * ctile;
     const int n0 = tile_n * 128;
     const int khalf = lane >> 5;
-    // ---- phase 1: the panel's cells, once
-    {
+    {   // phase 1: the panel's cells, once (256 threads: k-quads kq and kq + 2 of a step)
         const int kq = tid >> 7, nb = tid & 127;
         float sx = 1.f;
         if (NP == 2) {
             sx = hs.x_group > 0 ? h3_scale(hs.amax_x[(long)batch * hs.x_bstride + min((n0 + nb) / hs.x_group, hs.x_bstride - 1)])
                                 : h3_scale(hs.amax_x[0]);
             if (tid < 128) h3x_[tid] = h3_inv(sx);
-            for (int m = tid; m < Mb; m += DX6_THREADS) h3a_[m] = h3_inv(h3_scale(hs.amax_a[hs.a_rows ? batch * Mb + m : 0]));
+            for (int m = tid; m < Mb; m += 256) h3a_[m] = h3_inv(h3_scale(hs.amax_a[hs.a_rows ? batch * Mb + m : 0]));
         }
         const float* x_col = X + n0 + nb;
 #pragma unroll
-        for (int t0 = 0; t0 < NK; t0 += 6) {              // six steps of loads in flight
-            float x[6][4];
+        for (int t0 = 0; t0 < NK; t0 += 3) {              // three steps (24 loads) in flight
+            float x[3][2][4];
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
+            for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 16 * (t0 + u < NK ? t0 + u : NK - 1) + 4 * kq + j;
-                    x[u][j] = x_col[(long)min(k, K - 1) * ldx];           // clamped rows meet zero weights
-                }
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 16 * (t0 + u < NK ? t0 + u : NK - 1) + 4 * (kq + 2 * h) + j;
+                        x[u][h][j] = x_col[(long)min(k, K - 1) * ldx];
+                    }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
                 if (t0 + u >= NK) break;
-                uint2* dst = reinterpret_cast<uint2*>(Bs + (size_t)(t0 + u) * NP * 256 + (kq >> 1) * 128 + nb) + (kq & 1);
-                if (NP == 2) {
-                    unsigned hw[2], lw[2];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) split2h_pair(x[u][2 * q] * sx, x[u][2 * q + 1] * sx, hw[q], lw[q]);
-                    dst[0] = make_uint2(hw[0], hw[1]);
-                    dst[2 * 256] = make_uint2(lw[0], lw[1]);
-                } else {
-                    unsigned hw[2], mw[2], lw[2];
+                for (int h = 0; h < 2; ++h) {
+                    uint2* dst = reinterpret_cast<uint2*>(Bs + (size_t)(t0 + u) * NP * 256 + h * 128 + nb) + kq;
+                    if (NP == 2) {
+                        unsigned hw[2], lw[2];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) split3_pair(x[u][2 * q], x[u][2 * q + 1], hw[q], mw[q], lw[q]);
-                    dst[0] = make_uint2(hw[0], hw[1]);
-                    dst[2 * 256] = make_uint2(mw[0], mw[1]);
-                    dst[2 * 512] = make_uint2(lw[0], lw[1]);
+                        for (int q = 0; q < 2; ++q) split2h_pair(x[u][h][2 * q] * sx, x[u][h][2 * q + 1] * sx, hw[q], lw[q]);
+                        dst[0] = make_uint2(hw[0], hw[1]);
+                        dst[2 * 256] = make_uint2(lw[0], lw[1]);
+                    } else {
+                        unsigned hw[2], mw[2], lw[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) split3_pair(x[u][h][2 * q], x[u][h][2 * q + 1], hw[q], mw[q], lw[q]);
+                        dst[0] = make_uint2(hw[0], hw[1]);
+                        dst[2 * 256] = make_uint2(mw[0], mw[1]);
+                        dst[2 * 512] = make_uint2(lw[0], lw[1]);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // ---- phase 2: every wave its own row blocks, no barrier
     const long part_cells = (long)K8pad * Mpad;
     const uint4* bs0 = Bs + khalf * 128 + (lane & 31);
     const uint4* a_base = A3 + (long)khalf * Mpad + (long)batch * Mb + (lane & 31);
     float ixv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) ixv[j] = NP == 2 ? h3x_[j * 32 + (lane & 31)] : 1.f;
-    const unsigned loff = (unsigned)((4 * khalf * ldc + (lane & 31)) * 4);      // bytes (host: 8 ldc floats fit 2^31 bytes)
-    // store row s (0 .. 15) of a finished block: row mp + 8 q + p (+ 4 for the upper half wave), its four column groups
-    auto store_row = [&](const f32x16 (&acc)[4], int mp, int s_) {
-        const int q = s_ >> 2, p = s_ & 3;
-        float* rowp = reinterpret_cast<float*>(reinterpret_cast<char*>(C + (long)(mp + 8 * q + p) * ldc) + loff);
-        const float ia = NP == 2 ? h3a_[mp + 8 * q + 4 * khalf + p] : 1.f;
+    const unsigned loff = (unsigned)((4 * khalf * ldc + (lane & 31)) * 4);
+    // store row s (0 .. 31) of a finished 64-row block: fragment i = s >> 4, row mp + 32 i + 8 q + p (+ 4 upper half wave)
+    auto store_row = [&](const f32x16 (&acc)[2][4], int mp, int s_) {
+        const int i = s_ >> 4, q = (s_ >> 2) & 3, p = s_ & 3;
+        const int row = mp + 32 * i + 8 * q + p;
+        float* rowp = reinterpret_cast<float*>(reinterpret_cast<char*>(C + (long)row * ldc) + loff);
+        const float ia = NP == 2 ? h3a_[row + 4 * khalf] : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = NP == 2 ? (acc[j][4 * q + p] * ixv[j]) * ia : acc[j][4 * q + p];
-#if defined(TVAE_XRES_PLAIN_STORE)
-            rowp[j * 32] = v;                            // experiment: default cache policy
-#elif !(defined(TVAE_XRES_ABL) && (TVAE_XRES_ABL & 2))
+            const float v = NP == 2 ? (acc[i][j][4 * q + p] * ixv[j]) * ia : acc[i][j][4 * q + p];
             __builtin_nontemporal_store(v, rowp + j * 32);
-#else
-            if (v == 123.456f) C[0] = v;                 // ablation: no stores
-#endif
         }
     };
-    // one block: products of rows mc into accC, the stores of the previous block (accP, rows mp) spread over the k-steps
-    auto block = [&](f32x16 (&accC)[4], int mc, const f32x16 (&accP)[4], int mp, bool have_prev) {
-        const uint4* a_run[NP];                          // running pointers (one per part): the next step's weight cells
+    auto block = [&](f32x16 (&accC)[2][4], int mc, const f32x16 (&accP)[2][4], int mp, bool have_prev) {
+        const uint4* a_run[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) a_run[p] = a_base + mc + p * part_cells;
-        auto load_next = [&](Cell16 (&a)[3]) {           // (past the last step: the padding rows behind the cells are never read:
-#pragma unroll                                          //  the caller stops advancing)
-            for (int p = 0; p < NP; ++p) {
-#if defined(TVAE_XRES_ABL) && (TVAE_XRES_ABL & 4)
-                a[p].u = make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);     // ablation: no weight-cell loads
-#else
-                a[p].u = *a_run[p];
+#ifndef TVAE_XRES2_NB
+#define TVAE_XRES2_NB 8
 #endif
+        constexpr int NB = TVAE_XRES2_NB;                // operand buffers: the weight cells of steps t .. t + NB - 1 (measured:
+        Cell16 af[NB][2][3];                             //  3: 1 437 us, 6: 1 272, 8: 1 235; all twelve as one stream across blocks: no better)
+        auto load_next = [&](Cell16 (&a)[2][3]) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                a[0][p].u = a_run[p][0];
+                a[1][p].u = a_run[p][32];
                 a_run[p] += 2 * (long)Mpad;
             }
         };
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) accC[j][r_] = 0.f;
-#ifndef TVAE_XRES_NB
-#define TVAE_XRES_NB 4
-#endif
-        constexpr int NB = NP == 3 ? 2 : TVAE_XRES_NB;   // operand buffers: the weight cells of steps t .. t + NB - 1
-        Cell16 af[NB][3];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) accC[i][j][r_] = 0.f;
 #pragma unroll
         for (int u = 0; u + 1 < NB; ++u)
             if (u < NK) load_next(af[u]);
@@ -1874,34 +1864,32 @@ void dense_x6_xres_kernel(const uint4* __restrict__ A3, const float* __restrict_
         for (int t = 0; t < NK; ++t) {
             if (t + NB - 1 < NK) load_next(af[(t + NB - 1) % NB]);
             const uint4* bs = bs0 + (size_t)t * NP * 256;
-#if defined(TVAE_XRES_ABL) && (TVAE_XRES_ABL & 1)
-            if (t == 0)                                  // ablation: one k-step only
-#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 Cell16 bf[3];
 #pragma unroll
                 for (int p = 0; p < NP; ++p) bf[p].u = bs[p * 256 + j * 32];
-                mfma_np<NP>(accC[j], af[t % NB], bf);
+                mfma_np<NP>(accC[0][j], af[t % NB][0], bf);
+                mfma_np<NP>(accC[1][j], af[t % NB][1], bf);
             }
             if (have_prev) {
 #pragma unroll
-                for (int s_ = (16 * t) / NK; s_ < (16 * (t + 1)) / NK; ++s_) store_row(accP, mp, s_);
+                for (int s_ = (32 * t) / NK; s_ < (32 * (t + 1)) / NK; ++s_) store_row(accP, mp, s_);
             }
-            __builtin_amdgcn_sched_barrier(0);           // keep the steps apart: no hoisting of later loads over earlier stores
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    f32x16 accA[4], accB[4];
+    f32x16 accA[2][4], accB[2][4];
     int mprev = 0;
     bool have = false;
-    for (int m0 = 32 * wave; m0 < M; m0 += 512) {        // two blocks per trip, so that the accumulator sets swap statically
+    for (int m0 = 64 * wave; m0 < M; m0 += 512) {        // two blocks per trip (rows m0 and m0 + 256): static accumulator sets
         block(accA, m0, accB, mprev, have);
         block(accB, m0 + 256, accA, m0, true);
         mprev = m0 + 256;
         have = true;
     }
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) store_row(accB, mprev, s_);
+    for (int s_ = 0; s_ < 32; ++s_) store_row(accB, mprev, s_);
 }
 
 // ------------------------------------------------------------------------------------------
