@@ -49,18 +49,24 @@ bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilo
     const size_t lds = (size_t)nk * parts * 256 * 16 + (size_t)(Mb + 128) * 4;
     const bool lean = !ep.bias && !ep.res && !ep.aux && ep.act == ACT_NONE && ep.mask == ACT_NONE && ep.ctile > 0 && ep.C &&
                       !ep.accumulate && rows_per_problem % DX6_ROWS == 0 && ep.ldc * 8 * 4 < (1L << 31);
-    if (!on || !lean || parts != 2 || N % 128 != 0 || nk != 12 || Mb < rows_per_problem ||
-        lds > X6_LDS_MAX || !aligned16(w3) || !hs.amax_a || !hs.amax_x)
+    // twelve k-steps only (the 96-wide frame of the 64 x 64 configuration): at six steps (28 x 28: 44-wide frame) the stores per
+    // step double and the kernel measured 213 us against dense_x6_plain4_kernel's 195; nine steps (50 x 50) were not measured.
+    // Two parts (h3): 1.21 against 1.38 ms; three (x6): 1.76 against 1.80.
+    const bool shape_ok = (parts == 2 || parts == 3) && nk == 12;
+    if (!on || !lean || !shape_ok || N % 128 != 0 || Mb < rows_per_problem ||
+        lds > X6_LDS_MAX || !aligned16(w3) || (parts == 2 && (!hs.amax_a || !hs.amax_x)))
         return false;
     const int Rpad = x6_round_up(nprob * Mb, DX6_ROWS), tilesN = N / 128, nch = 4, cs = cdiv(tilesN, nch);
     const unsigned grid = 8u * cdiv(nprob * nch, 8) * cs;
-    // twelve k-steps only (the 96-wide frame of the 64 x 64 configuration): at six steps (28 x 28: 44-wide frame) the stores
-    // per step double and the first form of this kernel measured 2 % behind dense_x6_plain4_kernel; nine steps (50 x 50) were not measured
-    // h3 only (with three parts the first form of this kernel spilled and measured 2.11 ms against plain4's 1.81)
-    hipError_t e_ = allow_big_lds(dense_x6_xres_kernel<2, 12>, lds);
-    if (e_ != hipSuccess) { *rc = (int)e_; return true; }
-    hipLaunchKernelGGL((dense_x6_xres_kernel<2, 12>), dim3(grid), dim3(256), lds, st, (const uint4*)w3, X, ldx, ep.C, ep.ldc,
-                       ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs);
+#define TVAE_XRES_LAUNCH(NP_, NK_)                                                                                     \
+    do {                                                                                                               \
+        hipError_t e_ = allow_big_lds(dense_x6_xres_kernel<NP_, NK_>, lds);                                            \
+        if (e_ != hipSuccess) { *rc = (int)e_; return true; }                                                          \
+        hipLaunchKernelGGL((dense_x6_xres_kernel<NP_, NK_>), dim3(grid), dim3(256), lds, st, (const uint4*)w3, X, ldx, ep.C,  \
+                           ep.ldc, ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs);  \
+    } while (0)
+    if (parts == 3) TVAE_XRES_LAUNCH(3, 12); else TVAE_XRES_LAUNCH(2, 12);
+#undef TVAE_XRES_LAUNCH
     *rc = (int)hipGetLastError();
     return true;
 }

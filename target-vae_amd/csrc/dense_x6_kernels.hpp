@@ -1745,7 +1745,7 @@ void dense_wgrad_x6_dma_kernel(const float* __restrict__ dY, long ldd, const flo
 // This form: 1.24-1.30 ms; buffers 3 / 6 / 8: 1 437 / 1 272 / 1 235 us on one box; all twelve steps as one stream across the
 // blocks: no better.
 // Host: lean epilogue shape of the spectral contraction (plain column-tiled fp32 output), N % 128 == 0, rows per problem a
-// multiple of 512 (M; Mb >= M is their stride in the cell array), NK = K8pad / 2 steps, NP = 2.  Grid: groups (problem,
+// multiple of 512 (M; Mb >= M is their stride in the cell array), NK = K8pad / 2 = 12 steps, NP = 2 or 3.  Grid: groups (problem,
 // quarter of the column tiles) dealt round-robin to the XCDs: a problem's weight cells (0.8 MB) stay in one L2.
 // ------------------------------------------------------------------------------------------
 template <int NP, int NK>
