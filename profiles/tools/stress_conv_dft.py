@@ -12,6 +12,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'target-vae_amd')]
 import torch
 import torch.multiprocessing as mp
 
+PARTS = int(os.environ.get('STRESS_PARTS', '3'))      # 3: exact bf16 split (x6), 2: h3
+
 
 def worker(rank, iters, geo, out):
     from tvae._lib import call, query
@@ -60,11 +62,11 @@ def worker(rank, iters, geo, out):
         th.start()
     ref, bad = None, {}
     for it in range(iters):
-        call('tvae_conv1_fwd_dft', y, bank, bias, outp, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, 1, 0.01, 3)
-        cur = dict(out=outp.clone(), at=at.clone(), W=ws[:w_fl].clone(), W3=ws[a4(w_fl):a4(w_fl) + w3_fl].clone(),
+        call('tvae_conv1_fwd_dft', y, bank, bias, outp, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, 1, 0.01, PARTS)
+        cur = dict(out=outp.clone(), at=at.clone(), W=ws[:w_fl].clone(), W3=ws[a4(w_fl):a4(w_fl) + w3_fl * PARTS // 3].clone(),       # (h3 fills two of the three part arrays)
                    T=ws[a4(w_fl) + a4(w3_fl):a4(w_fl) + a4(w3_fl) + t_fl].clone())
         if os.environ.get('STRESS_FWD_ONLY') != '1':
-            call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, 3)
+            call('tvae_conv1_wgrad_dft', dpre, at, dbank, dbias, ws, ws.numel(), B, Cin, n, k, pad, C, R, PARTS)
             cur.update(dbank=dbank.clone(), dbias=dbias.clone(), Sp=ws[:t_fl].clone())
         if ref is None:
             torch.cuda.synchronize()
