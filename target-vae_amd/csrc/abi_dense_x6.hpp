@@ -40,13 +40,13 @@ TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DEC
         return (int)hipGetLastError();                                                                                \
     }                                                                                                                 \
     }
-// lean-epilogue instances (dense_x6_kernel<XV, NP, EPI>): abi_dense_x6_v2e1{,b,h}.hip (forward without the stored
-// activation) and abi_dense_x6_v5e2{,b,h}.hip (two-valued data gradient from bits with the fused first-layer backward)
+// lean-epilogue instances (dense_x6_kernel<XV, NP, EPI>): abi_dense_x6_v2e1{,b,h}.hip and abi_dense_x6_v0e1{,b,h}.hip (forward
+// without the stored activation: operand recomputed / read from memory) and abi_dense_x6_v5e2{,b,h}.hip (two-valued data gradient from bits with the fused first-layer backward)
 #define TVAE_DX6_DECL_E(XV_, E_)                                              \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p3(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p2(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p1(TVAE_DX6_LAUNCH_ARGS);
-TVAE_DX6_DECL_E(2, 1) TVAE_DX6_DECL_E(5, 2)
+TVAE_DX6_DECL_E(2, 1) TVAE_DX6_DECL_E(5, 2) TVAE_DX6_DECL_E(0, 1)
 #define TVAE_DX6_LAUNCH_DEF_E(XV_, NP_, E_)                                                                           \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_##e##E_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                \
