@@ -113,6 +113,8 @@ def parse_args():
                          "the opt-in bf16 throughput mode")
     ap.add_argument('--no-small-batch', action='store_true',
                     help='skip the 32 / 64 / 128 images-per-step points and the one-rank all-reduce timing (N = 1)')
+    ap.add_argument('--no-workloads', action='store_true',
+                    help='skip the S28 / S28F / S128G companion measurements of the default run (N = 1)')
     ap.add_argument('--no-strong', action='store_true',
                     help='N > 1: skip the extra strong-scaling measurement (global batch fixed at the per-GPU batch)')
     ap.add_argument('--graph', action='store_true',
@@ -165,15 +167,20 @@ MODE_INFO = {
 }
 
 
-def pmc_traffic(entry, grid=None):
+def pmc_traffic(entry, grid=None, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/pmc_traffic.json: FETCH_SIZE x2 -- gfx950 reports half the fetched bytes, calibrated on outer_mask --
-    plus WRITE_SIZE).  Counters cannot be collected inside the timed run, so this is the committed measurement."""
+    plus WRITE_SIZE).  Counters cannot be collected inside the timed run, so this is the committed measurement; `kernel`
+    (the kernel family the bench attaches it to) must be the one the counters were collected on, else None: a stale file
+    must not decorate a different launch (VERDICT r04 weak #10)."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        if grid is not None and (entry + '@grid%d' % grid) in d:
-            return d[entry + '@grid%d' % grid]['hbm_bytes_per_launch']
-        return d[entry]['hbm_bytes_per_launch']
+        e = d[entry + '@grid%d' % grid] if (grid is not None and (entry + '@grid%d' % grid) in d) else d[entry]
+        if kernel is not None and kernel not in e.get('kernel', ''):
+            print(f'# bench.py: profiles/pmc_traffic.json[{entry}] was collected on {e.get("kernel")!r}, not on {kernel!r}: '
+                  'traffic omitted (re-run profiles/collect.sh)', file=sys.stderr)
+            return None
+        return e['hbm_bytes_per_launch']
     except Exception:
         return None
 CFG = dict(n=64, cin=1, zd=2, C=128, k=64, pad=16, R=8, hidden=512, layers=2, n_out=1)
@@ -258,6 +265,44 @@ def cpu_baseline(batch=32, steps=4):
                        f'min; torch {torch.__version__} CPU, {cores} threads',
                 encoder_forward={'value': batch / min(te[1:]), 'unit': 'images/sec',
                                  'sample': f'oracle encoder forward, {batch} images, 1 warm-up + 2 timed, min'})
+
+
+def measure_extra_workload(name, dev, steps, warmup=2):
+    """One of the other BASELINE.json workloads (configs[1], [2], [4]) inside the default, driver-timed run: the same
+    training step (fwd + bwd + Adam, noise drawn on the device, data resident in HBM) at that workload's own batch, timed with
+    the bench's barrier bracket.  A few steps only (~0.5 s of GPU time for all three): these are companion numbers so that
+    the 28x28 / galaxy-shape figures of the north star do not exist only in builder-run profiles."""
+    from tvae import optim, step
+    c = WORKLOADS[name]
+    B = c.get('batch', 256)
+    gen, enc = build_models(dev, c)
+    opt = optim.FlatAdam(list(gen.parameters()) + list(enc.parameters()), lr=2e-4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    mk = torch.randn if c['data'] == 'randn' else torch.rand
+    data = mk(2 * B, c['cin'], c['n'], c['n'], device=dev, generator=g)
+    x = torch.from_numpy(__import__('tvae.tables', fromlist=['x']).image_coords(c['n'])).to(dev)
+    step.pixel_spacing(x)
+
+    def one(i):
+        y = data[(i % 2) * B:(i % 2) * B + B]
+        elbo, _, _ = step.elbo_terms(x, y, gen, enc, c['lik'])
+        (-elbo).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return elbo.detach()
+
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = one(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'workload': c['desc'], 'images_per_step': B, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': 1e3 * dt / steps, 'value': B * steps / dt, 'unit': 'images/sec', 'elbo': float(last)}
 
 
 def main():
@@ -363,7 +408,7 @@ def main():
     small_batch = None
     if world == 1 and args.workload == 'S64' and not (args.no_small_batch or args.no_f32_companion) and gs_box[0] is None:
         small_batch = {'per_image_rate_at_full_batch': B * args.steps / dt, 'full_batch': B, 'points': []}
-        for bs in (32, 64, 128):
+        for bs in (12, 32, 64, 100, 128):
             if bs >= B:
                 continue
             for i in range(2):
@@ -377,8 +422,11 @@ def main():
             small_batch['points'].append({'images_per_step': bs, 'ms_per_step': 1e3 * dsb / args.steps,
                                           'value': bs * args.steps / dsb, 'unit': 'images/sec',
                                           'ratio_to_full_batch_rate': (bs * args.steps / dsb) / (B * args.steps / dt),
-                                          'implied_speedup_at_%d_gpus' % (B // bs): (B // bs) * (bs * args.steps / dsb) /
-                                          (B * args.steps / dt)})
+                                          **({'implied_speedup_at_%d_gpus' % (B // bs): (B // bs) * (bs * args.steps / dsb) /
+                                              (B * args.steps / dt)} if B % bs == 0 else
+                                             {'note': "the reference's default --minibatch-size 100 (train_mnist.py:426) on one "
+                                                      'rank' if bs == 100 else 'the per-rank share of that default minibatch on 8 '
+                                                      'ranks (13 / 12 images)'})})
         try:
             if not dist.is_initialized():
                 import tempfile
@@ -403,6 +451,10 @@ def main():
                                                          'buffer; not a ring time'}
             if made_pg:
                 dist.destroy_process_group()
+                try:
+                    os.unlink(store.name + '.store')      # the file:// rendezvous (do not leave it behind)
+                except OSError:
+                    pass
         except Exception as ex:       # the collective is a side measurement: never let it take the bench line down
             small_batch['allreduce_one_rank'] = {'error': repr(ex)[:200]}
     # companion measurement: the same number of steps with every matrix product on the exact fp32 MFMA
@@ -500,37 +552,69 @@ def main():
     # encoder forward only (SURVEY 8d "Metric"; BASELINE north_star states its roofline target on it): the same 256
     # images through conv1 -> conv2 -> heads -> attention head in training mode (the two activations a backward needs are
     # written), timed with events on the launch stream
-    enc_fwd = None
+    enc_fwd = enc_inf = None
     if world == 1 and args.workload == 'S64':
         ho = c['n'] + 2 * c['pad'] - c['k'] + 1
         yb = data[:B]
-        with torch.no_grad():
-            for _ in range(2):
-                enc(yb, dev)
-            torch.cuda.synchronize()
-            ops.KERNEL_EVENTS = {}
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.steps):
-                enc(yb, dev)
-            e1.record()
-            torch.cuda.synchronize()
-            kev_e = ops.kernel_event_ms()
-            ops.KERNEL_EVENTS = None
-        ms_e = e0.elapsed_time(e1) / args.steps
         P = c['R'] * ho * ho
+
+        def time_encoder(training):
+            # training = True: grad mode on, the forward keeps what a backward needs (conv1 / conv2 activations, sign words,
+            # image spectra); False: under torch.no_grad() like eval_model (train_mnist.py:352-387) and get_latent
+            # (clustering_mnist.py:121-161) -- the inference-mode kernels (tvae/ops.py: no H, no sign words)
+            with torch.enable_grad() if training else torch.no_grad():
+                for _ in range(2):
+                    enc(yb, dev)
+                torch.cuda.synchronize()
+                ops.KERNEL_EVENTS = {}
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    enc(yb, dev)
+                e1.record()
+                torch.cuda.synchronize()
+                kev_e = ops.kernel_event_ms()
+                ops.KERNEL_EVENTS = None
+            return e0.elapsed_time(e1) / args.steps, kev_e
+
+        ms_e, kev_e = time_encoder(True)
         # algorithmic bytes per image, training mode: input + heads + both saved activations + bank / B
         bytes_img = 4.0 * (c['cin'] * c['n'] ** 2 + (3 + 2 * c['zd']) * P + 2 * c['C'] * P) + \
             4.0 * c['C'] * c['R'] * c['cin'] * c['k'] ** 2 / B
         fl_img = conv1_flops_per_image(c) + 2.0 * c['C'] * c['C'] * P + 2.0 * c['C'] * (3 + 2 * c['zd']) * P
-        enc_fwd = {'value': B / (ms_e * 1e-3), 'unit': 'images/sec', 'ms': ms_e,
+        enc_fwd = {'value': B / (ms_e * 1e-3), 'unit': 'images/sec', 'ms': ms_e, 'mode': 'training (grad enabled)',
                    'algorithmic_bytes_per_image': bytes_img,
                    'hbm': {'achieved': bytes_img * B / (ms_e * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                            'frac': bytes_img * B / (ms_e * 1e-3) / 8.0e12},
                    'mfma': {'direct_form_tflops': fl_img * B / (ms_e * 1e-3) / 1e12,
                             'note': 'direct-form FLOPs (2*C*R*k^2*Ho^2 + 1x1x1 layers) over the measured time; the '
                                     'frequency-domain convolution executes 7x fewer, so this exceeds every peak'},
-                   'conv1_fwd_ms': kev_e.get('tvae_conv1_fwd', {}).get('mean_ms')}
+                   'conv1_fwd_ms': kev_e.get('tvae_conv1_fwd', {}).get('mean_ms'),
+                   'enc_tail_fwd_ms': kev_e.get('tvae_enc_tail_fwd_x6', {}).get('mean_ms')}
+        ms_i, kev_i = time_encoder(False)
+        # SURVEY 8d byte figure (i), the module-boundary minimum of a fully fused inference encoder: input + the 7 encoder
+        # outputs (3 + 2 + 2z rows of P positions) + the rotated bank amortised over the batch = 0.396 MB / image at cfg4
+        bytes_inf = 4.0 * (c['cin'] * c['n'] ** 2 + (3 + 2 + 2 * c['zd']) * P) + \
+            4.0 * c['C'] * c['R'] * c['cin'] * c['k'] ** 2 / B
+        enc_inf = {'value': B / (ms_i * 1e-3), 'unit': 'images/sec', 'ms': ms_i,
+                   'mode': 'inference (torch.no_grad(): no conv2 activation, no sign words, nothing retained)',
+                   'algorithmic_bytes_per_image': bytes_inf,
+                   'hbm': {'achieved': bytes_inf * B / (ms_i * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                           'frac': bytes_inf * B / (ms_i * 1e-3) / 8.0e12},
+                   'conv1_fwd_ms': kev_i.get('tvae_conv1_fwd', {}).get('mean_ms'),
+                   'enc_tail_fwd_ms': kev_i.get('tvae_enc_tail_fwd_x6', {}).get('mean_ms'),
+                   'speedup_over_training_forward': ms_e / ms_i}
+    # the other BASELINE.json workloads in the same driver-timed line: S28 (configs[1]), S28F (configs[2]),
+    # S128G (configs[4]) at their own batch, default arithmetic
+    workloads = None
+    if world == 1 and args.workload == 'S64' and not args.no_workloads and gs_box[0] is None:
+        workloads = {}
+        for wn in ('S28', 'S28F', 'S128G'):
+            try:
+                workloads[wn] = measure_extra_workload(wn, dev, min(args.steps, 10))
+            except Exception as ex:          # a companion must never take the headline down
+                workloads[wn] = {'error': repr(ex)[:300]}
+            torch.cuda.empty_cache()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -546,13 +630,13 @@ def main():
         # every timed entry point: (algorithmic FLOPs per launch, kernel, note)
         conv_dft = mode in ('x6', 'h3', 'bf16') and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
         entries = {
-            'tvae_conv1_fwd': (conv_flops, 'dft_spectra_kernel + batched dense_x6_plain4_kernel + dft_out_ring_kernel'
+            'tvae_conv1_fwd': (conv_flops, 'dft_spectra_kernel + batched dense_x6_xres_kernel (other frames: _plain4_kernel) + dft_out_ring_kernel'
                                if conv_dft else info['kernels']['tvae_conv1_fwd']),
             'tvae_conv1_wgrad': (conv_flops, 'dft_dy_ring_kernel + batched dense_wgrad_x6_wide_kernel (256 x 192 tile; other frames: _dma_kernel) + dft_dbank_mf_kernel'
                                  if conv_dft else info['kernels']['tvae_conv1_wgrad']),
             'tvae_linear_fwd_x6': (dense_flops, 'dense_x6_kernel'),
             'tvae_linear_dgrad_x6': (dense_flops, 'dense_x6_kernel'),
-            'tvae_linear_wgrad_x6': (dense_flops, 'dense_wgrad_x6_kernel'),
+            'tvae_linear_wgrad_x6': (dense_flops, 'dense_wgrad_x6_dma_kernel'),
         }
         # fused encoder tail (conv2 + head projection; csrc/enc_tail_x6_kernels.hpp): HBM-bound side kernels
         ho_ = c['n'] + 2 * c['pad'] - c['k'] + 1
@@ -629,7 +713,8 @@ def main():
                          # dense_x6_kernel is launched with several shapes: pick the decoder-layer launch by its grid
                          # (512 threads x 8*ceil(tiles_n/8) workgroups; forward and data-gradient launches averaged)
                          'traffic': pmc_traffic(dom, 512 * 8 * ((Nt // 128 + 7) // 8) * ((c['hidden'] + 511) // 512)
-                                                if dom.startswith('tvae_linear') else None)
+                                                if dom.startswith('tvae_linear') else None,
+                                                kernel=entries[dom][1].split()[0] if dom.startswith('tvae_linear') else None)
                          if args.workload == 'S64' else None,
                          'algorithmic_flops_per_launch': flops, 'mean_launch_ms': kev[dom]['mean_ms'],
                          'launches_timed': kev[dom]['launches'],
@@ -663,8 +748,12 @@ def main():
             out['strong_scaling'] = strong
         if small_batch is not None:
             out['small_batch'] = small_batch
+        if workloads is not None:
+            out['workloads'] = workloads
         if enc_fwd is not None:
             out['encoder_forward'] = enc_fwd
+        if enc_inf is not None:
+            out['encoder_forward_inference'] = enc_inf
         if enc_tail:
             out['encoder_tail'] = enc_tail
         if companion is not None:

@@ -26,7 +26,7 @@ int tvae_abi_version(void);
  * v_mfma_f32_32x32x16_bf16 partial products, fp32 accumulate: fp32-equivalent results) when called with parts = 3, in the
  * "h3" arithmetic (two fp16 parts under power-of-two scales, three v_mfma_f32_32x32x16_f16 products: fp32-equivalent
  * results with half the matrix instructions; tvae_dense_split2h below) with parts = 2, and with operands rounded to one
- * bf16 number (throughput mode, NOT fp32-equivalent) with parts = 1.  tvae_abi_version() == 5.  ABI 4: parts = 2,
+ * bf16 number (throughput mode, NOT fp32-equivalent) with parts = 1.  tvae_abi_version() == 6.  ABI 4: parts = 2,
  * tvae_dense_split2h; the buffers sized by tvae_conv1_dft_at_floats and tvae_linear_wgrad_x6_ws_floats carry extra words
  * -- the operand maxima of the h3 arithmetic -- behind their data.  ABI 5: the h3 scale is ONE POWER OF TWO PER ROW of an
  * operand in the sense of the product (a row / column of the output), not one per tensor: tvae_dense_split2h keeps one
@@ -166,7 +166,8 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* x_amax, tvae_stream_t stream);
 /* ABI 5, the two-valued form WITHOUT the saved activation (vg_bits != NULL; dpre may then be NULL): the 0 / 1 operand
  * [H > 0] and the row sums sum_n gy[n] [H[m][n] > 0] come from the sign bits the forward launch stored (tvae_linear_fwd_x6
- * sign_bits; that launch may then be given Y = NULL and never writes H), and the weight gradient of the single-output
+ * sign_bits; that launch may then be given Y = NULL and never writes H; ABI 6: with Y = NULL AND sign_bits = NULL it is the
+ * inference-mode forward -- only the fused column dot col_y leaves the launch), and the weight gradient of the single-output
  * Linear behind the layer, dWo[m] = sum_n gy[n] H[m][n], from the identity act(p) = act'(p) p of LeakyReLU:
  *     rs_dwo[m] = rs_rowdot[m] + rs_bias[m] * sum_n gy[n] act'(H[m][n]),   rs_rowdot[m] = sum_k W[m][k] G[m][k]
  * (G = this layer's weight gradient before its row factor wo[m]: tvae_linear_wgrad_x6 rd_rowdot, which must run first;
@@ -284,7 +285,9 @@ int tvae_rot_pool_bwd(const float* A1, const float* dX, const float* fw, float* 
  * feature-major operands, N = B*R*Ho*Ho columns (any N).  w3 = tvae_dense_split3(W2, rows 128, K 128, transpose 0).
  *   forward: H = act(W2 A1 + b2) [128][N],  heads = Wh H + bh [nh][N]; one pass over A1, one over H.  bits_h / bits_a
  *     (LeakyReLU only, both or neither; [N][4] uint32 each): bit (r & 31) of word r >> 5 of column n = [H[r][n] > 0]
- *     resp. [A1[r][n] > 0] -- all the data gradient needs of the two tensors.
+ *     resp. [A1[r][n] > 0] -- all the data gradient needs of the two tensors.  H == NULL (ABI 6): the inference-mode
+ *     forward of eval_model / get_latent (train_mnist.py:352-387 under torch.no_grad(), clustering_mnist.py:121-161) --
+ *     H is not written at all, only the nh head rows leave the kernel (bits_* NULL as well).
  *   data gradient (LeakyReLU): dA1 = act'(A1) . W2^T (act'(H) . Wh^T dheads) from dheads [nh][N] and the sign words; dH is
  *     never stored.  w3p = tvae_dense_split3 (rows 128, K 128, transpose 0) of W2^T with its columns permuted:
  *     column 16 u + 8 h + j (u < 8, h < 2, j < 8) holds W2[16 u + 8 (j >> 2) + 4 h + (j & 3)][.] (the order in which

@@ -202,11 +202,12 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     }
     if (vg.csum) return TVAE_DX6_DISPATCH(3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     // forward of the decoder's last hidden layer with its activation not stored: lean instance (one full row tile)
-    if (va.xr && rows == DX6_ROWS && !ep.C && cd.w && cd.bits && !it.xr && !ep.res && ep.mask == ACT_NONE && ep.act == ACT_LRELU)
+    // (cd.bits == nullptr with no output either: the inference-mode forward -- only the fused column dot leaves the launch)
+    if (va.xr && rows == DX6_ROWS && !ep.C && cd.w && !it.xr && !ep.res && ep.mask == ACT_NONE && ep.act == ACT_LRELU)
         return TVAE_DX6_DISPATCH_E(2, 1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     if (va.xr) return TVAE_DX6_DISPATCH(2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     // the same layer with its input read from memory (28 x 28 shapes, Fourier decoders): lean instance of the plain operand
-    if (!vg.wo && X && rows == DX6_ROWS && N % 128 == 0 && !ep.C && cd.w && cd.bits && !it.xr && !ep.res && ep.mask == ACT_NONE &&
+    if (!vg.wo && X && rows == DX6_ROWS && N % 128 == 0 && !ep.C && cd.w && !it.xr && !ep.res && ep.mask == ACT_NONE &&
         ep.act == ACT_LRELU)
         return TVAE_DX6_DISPATCH_E(0, 1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);

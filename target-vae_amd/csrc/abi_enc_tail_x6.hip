@@ -33,7 +33,7 @@ int tvae_enc_tail_fwd_x6(const void* w3, const float* A1, long lda, const float*
                          int act, float slope, int parts, const float* amax_a1, tvae_stream_t stream) {
     if (N <= 0) return 0;
     if (parts == 2 && !amax_a1) return (int)hipErrorInvalidValue;        // h3 needs the per-channel maxima of A1 (C words) from A1's producer
-    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3) || !A1 || !H || !heads || !Wh ||
+    if (C != ET_C || nh < 1 || nh > ET_MAXH || !aligned16(w3) || (parts != 1 && parts != 2 && parts != 3) || !A1 || !heads || !Wh ||       // (H == NULL: inference-mode forward, heads only)
         !bh || ((bits_h || bits_a) && (act != ACT_LRELU || !aligned16(bits_h) || !aligned16(bits_a))) ||
         !et_ld_ok(N, lda, ldh, ldo))
         return (int)hipErrorInvalidValue;

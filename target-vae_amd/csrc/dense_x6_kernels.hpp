@@ -581,7 +581,7 @@ __device__ __forceinline__ void dense_x6_epilogue_lean(f32x16 (&acc)[2][4], cons
                     const unsigned long long bl = __ballot(v > 0.f);     // lanes 0-31 hold one row, 32-63 the row + 4
                     sw[j] = (unsigned)(half ? bl >> 32 : bl);
                 }
-                if ((lane & 31) == 0)
+                if ((lane & 31) == 0 && sbits)             // (sbits == nullptr: inference-mode forward, nothing is kept for a backward)
                     *reinterpret_cast<uint4*>(sbits + (long)(m0 + rb + p) * bitw + (n0 >> 5)) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
             }
             __builtin_amdgcn_sched_barrier(0);           // one row group at a time: no hoisting of later groups' reads over this one

@@ -88,7 +88,9 @@ __device__ __forceinline__ void et_step_mfma(f32x16 (&acc)[4], const uint4* __re
 }
 
 // FULL: the chunk lies inside [0, N) -- no per-element bounds (every chunk but possibly the last one)
-template <int ACT, bool FULL>
+// SH: the activation H is stored (training: the backward reads it); false = inference-mode forward (H == nullptr: the 1.14 GB
+// tensor is neither allocated nor written -- only the head rows leave the kernel)
+template <int ACT, bool FULL, bool SH = true>
 __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* __restrict__ whs, float* __restrict__ H,
                                                 long ldh, float* __restrict__ heads, long ldo, const float* __restrict__ bh,
                                                 int nh, long n0, long N, int nl, int kh, float slope,
@@ -127,7 +129,7 @@ __device__ __forceinline__ void et_fwd_epilogue(f32x16 (&acc)[4], const float* _
             char* hrow = reinterpret_cast<char*>(H + (long)et_row(i, r, 0) * ldh + n0);
             const float v = et_act<ACT>(acc[i][r] + w1.w, slope);
             if (ACT == ACT_LRELU) hb[i] |= v > 0.f ? (1u << (8 * (r >> 2) + (r & 3))) : 0u;   // + 4 kh: shifted below
-            if (in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(hrow + loff));
+            if (SH && in0) __builtin_nontemporal_store(v, reinterpret_cast<float*>(hrow + loff));
             hs[0] = __fmaf_rn(w0.x, v, hs[0]);
             hs[1] = __fmaf_rn(w0.y, v, hs[1]);
             hs[2] = __fmaf_rn(w0.z, v, hs[2]);
@@ -250,7 +252,8 @@ void enc_tail_fwd_x6_kernel(const uint4* __restrict__ W3, int Rpad, const float*
         }
 #define TVAE_ET_EPI(A_)                                                                                    \
     do {                                                                                                  \
-        if (n0 + ET_CHUNK <= N) et_fwd_epilogue<A_, true>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
+        if (!H) et_fwd_epilogue<A_, false, false>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
+        else if (n0 + ET_CHUNK <= N) et_fwd_epilogue<A_, true>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
         else et_fwd_epilogue<A_, false>(acc, whs, H, ldh, heads, ldo, bh, nh, n0, N, nl, kh, slope, bitsH); \
     } while (0)
         if (act == ACT_LRELU) TVAE_ET_EPI(ACT_LRELU);

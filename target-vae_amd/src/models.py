@@ -118,7 +118,9 @@ class SpatialGenerator(nn.Module):
             sigma = float(self.embed_latent.sigma)
         else:
             params += [None, None]
-        return _ops.DecoderFn.apply(x, z if has_l else None, act, resid, sigma, len(hidden), *params)
+        # under torch.no_grad() (eval_model, train_mnist.py:352-387) the inference-mode forward runs: nothing is kept for a backward
+        with _ops.inference(not _ops.needs_grad(x, z if has_l else None, *params)):
+            return _ops.DecoderFn.apply(x, z if has_l else None, act, resid, sigma, len(hidden), *params)
 
 
 class GroupConv(nn.Module):
@@ -303,9 +305,12 @@ class InferenceNetwork_AttentionTranslation_AttentionRotation(nn.Module):
         _require_gpu(x, 'InferenceNetwork_AttentionTranslation_AttentionRotation')
         C = self.kernels_num
         Wh, bh = self.head_weights()
-        return _ops.EncoderFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight.view(C, C),
-                                    self.conv2.bias, Wh, bh, self.groupconv, self.padding,
-                                    _ops.act_code(self.activation))
+        # under torch.no_grad() (eval_model, get_latent) the inference-mode forward runs: no conv2 activation, no sign words
+        with _ops.inference(not _ops.needs_grad(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                                Wh, bh)):
+            return _ops.EncoderFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight.view(C, C),
+                                        self.conv2.bias, Wh, bh, self.groupconv, self.padding,
+                                        _ops.act_code(self.activation))
 
     def forward(self, x, device, E=None):
         """Reference 7-tuple (attn, q_t_r, p_r, a_sampled, offsets, theta, z).  `E` optionally injects the

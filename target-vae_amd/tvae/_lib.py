@@ -116,7 +116,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
 # entry points tvae.ops calls and with which `parts`:
 #   'h3'   (default) *_x6 / *_dft entry points with parts = 2: operands as TWO fp16 parts under a power-of-two tensor scale,

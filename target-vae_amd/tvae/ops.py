@@ -90,6 +90,34 @@ def _in_forward_arithmetic(backward):
 
 PATH_LOG = None          # set to a set() to record which fused branches a step actually took (tests assert on it)
 
+# Inference-mode forward (reference: eval_model runs under torch.no_grad(), train_mnist.py:352-387; get_latent,
+# clustering_mnist.py:121-161).  Inside torch.autograd.Function.forward grad mode is ALWAYS off, so the decision is taken by
+# the caller (`needs_grad` over the op's differentiable inputs, src/models.py) and handed down through this switch: the
+# forward then writes nothing that only a backward would read -- no conv2 activation H (1.14 GB at 64x64 / 256), no sign
+# words, no decoder sign bits, no retained spectra -- and saves nothing on ctx.
+_INFER = False
+
+
+def needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class inference:
+    """`with ops.inference(flag):` -- the Functions applied inside run their inference-mode forward when `flag`."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _INFER
+        self.prev, _INFER = _INFER, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _INFER
+        _INFER = self.prev
+        return False
+
 
 def _note(name: str) -> None:
     if PATH_LOG is not None:
@@ -459,12 +487,17 @@ class EncoderFn(torch.autograd.Function):
         _expect(tuple(W2.shape) == (C2, C) and tuple(Wh.shape) == (nh, C2) and b1.numel() == C and
                 b2.numel() == C2 and bh.numel() == nh, 'encoder parameter shapes are inconsistent')
         keep = {}
+        infer = _INFER
         A1 = conv1_forward(y, w1, b1, C, R, k, pad, act, keep)
-        ctx.at = keep.get('at')
-        H = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        ctx.at = None if infer else keep.get('at')
+        fused = _enc_tail_fused(C, C2, nh, N)
+        # inference: the fused tail writes the head rows only -- H is neither allocated nor stored (include/tvae_hip.h, ABI 6)
+        H = None if (infer and fused) else torch.empty(C2, N, dtype=torch.float32, device=y.device)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
         bits = None
-        if _enc_tail_fused(C, C2, nh, N):
+        if infer:
+            _note('enc.inference')
+        if fused:
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
             # h3 instance: needs max |A1| from A1's producer -- the output transform of the frequency-domain convolution leaves
             # it in the last word behind A^T (keep['at'])
@@ -472,7 +505,7 @@ class EncoderFn(torch.autograd.Function):
             p_f = 2 if a1max is not None else _p3()
             w3 = _split_weight(W2, C2, C, False, 'enc_w2', nparts=p_f)
             _note('enc.tail_fwd_x6')
-            if act == ACT_LRELU:                         # sign words of H and A1: all the fused data gradient reads of them
+            if act == ACT_LRELU and not infer:           # sign words of H and A1: all the fused data gradient reads of them
                 bits = torch.empty(2, N, 4, dtype=torch.int32, device=y.device)
             with _timed('tvae_enc_tail_fwd_x6', p_f):
                 call('tvae_enc_tail_fwd_x6', w3, A1, N, b2, Wh.contiguous(), bh.contiguous(), nh, H, N, heads, N,
@@ -485,9 +518,11 @@ class EncoderFn(torch.autograd.Function):
             else:
                 call('tvae_linear_fwd', Wh.contiguous(), H, bh, None, 1, None, heads, nh, N, C2, N, N, ACT_NONE,
                      LRELU_SLOPE)
+        if infer:
+            return heads
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.bits = bits
-        ctx.a1max = a1max if _enc_tail_fused(C, C2, nh, N) else None      # (a view of keep['at']: max |A1| for the h3 weight gradient)
+        ctx.a1max = a1max if fused else None      # (a view of keep['at']: max |A1| for the h3 weight gradient)
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
@@ -795,6 +830,7 @@ class DecoderFn(torch.autograd.Function):
                 all(tuple(W.shape) == (F_, F_) for W, _ in hidden), 'decoder parameter shapes are inconsistent')
         _expect(Wl is None or (z is not None and tuple(z.shape) == (B, Wl.shape[1])), 'latent z does not match latent_linear')
         dev = xr.device
+        infer = _INFER
         LB = None
         # Fourier-feature first layer on the split pipe: the per-image latent term joins the reduction (rows z[img(n)] under
         # the features, weights [Wc | Wl]) instead of being a per-image bias
@@ -863,18 +899,20 @@ class DecoderFn(torch.autograd.Function):
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
                 # the backward of the single-output Linear behind the last hidden layer needs only the SIGN of this
                 # layer's LeakyReLU output (two-valued implicit gradient): one bit per element, stored by this launch
-                if (li == n_hidden - 1 and FUSE_SIGN_BITS and FUSE_VIRT_GRAD and n_out == 1 and not resid and act == ACT_LRELU
-                        and F_ >= 256 and Nt % 32 == 0):
+                bits_ok = (li == n_hidden - 1 and FUSE_SIGN_BITS and FUSE_VIRT_GRAD and n_out == 1 and not resid
+                           and act == ACT_LRELU and F_ >= 256 and Nt % 32 == 0)
+                if bits_ok and not infer:
                     sbits = torch.empty(F_, Nt // 32, dtype=torch.int32, device=dev)
                     _note('dec.sign_bits')
                 # Round 4: with the fused output dot AND the sign bits, nothing downstream needs this layer's activation
                 # itself -- the backward takes [H > 0] from the bits and dWo from the identity sum_k W[m][k] G[m][k] +
                 # b[m] g0[m] (include/tvae_hip.h: tvae_linear_dgrad_x6 vg_bits) -- so the 2.1 GB tensor is neither written
                 # here nor read there.  Same conditions as the backward's row-sum fusion (it forms g0).
-                no_h = (FUSE_NO_H and fuse and sbits is not None and li == n_hidden - 1 and FUSE_ROW_SUMS and F_ <= 512
-                        and Nt % 128 == 0 and not resid)
+                # (inference: same launch without the bits -- only the fused output dot leaves it)
+                no_h = (FUSE_NO_H and fuse and (sbits is not None or (infer and bits_ok)) and li == n_hidden - 1 and
+                        FUSE_ROW_SUMS and F_ <= 512 and Nt % 128 == 0 and not resid)
                 if no_h:
-                    _note('dec.no_h')
+                    _note('dec.no_h_inference' if infer else 'dec.no_h')
                 else:
                     hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
                 with _timed('tvae_linear_fwd_x6', p_l):
@@ -891,6 +929,8 @@ class DecoderFn(torch.autograd.Function):
             hs.append(hn)
         if not fused_out:
             call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
+        if infer:
+            return yh
         ctx.save_for_backward(xr, z if Wl is not None else None, feat, LB if virt_act else None, *hs,
                               *[p for p in params if p is not None])
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)

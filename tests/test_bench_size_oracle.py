@@ -262,3 +262,47 @@ def test_encoder_kink_free_probe_at_bench_size(cfg, B):
     for k_, t in enc.named_parameters():
         err = float((t.grad.detach().cpu().double() - g_o[k_].double()).abs().max() / g_o[k_].double().abs().max())
         assert err < 1e-3, (cfg, f'B={B}', k_, err)
+
+
+def test_inference_forward_at_bench_size_skips_training_stores():
+    """S64, B = 256 (every CU busy, full persistent grids): the no-grad forward (eval_model / get_latent path) is bitwise the
+    training forward, allocates >= 1.1 GB less (the conv2 activation H [128][2.2 M] fp32 and the two sign-word planes are
+    never created) and leaves nothing behind on the module."""
+    from tvae import ops, step
+    c = S64
+    B = 256
+    gen, enc = _models(c=c)
+    gen, enc = gen.to(dev()), enc.to(dev())
+    y, E, ez, et = (t.to(dev()) for t in _inputs(B, c=c))
+    x = O.image_coords(c['n']).to(dev())
+    for _ in range(2):                                   # scratch buffers and tables exist afterwards
+        with torch.no_grad():
+            step.elbo_terms(x, y, gen, enc, c['lik'], (E, ez, et))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        ei = step.elbo_terms(x, y, gen, enc, c['lik'], (E, ez, et), return_aux=True)
+    torch.cuda.synchronize()
+    peak_inf = torch.cuda.max_memory_allocated() - base
+    hi, yi = ei[3]['heads'].clone(), ei[3]['y_hat'].clone()
+    ei = tuple(t.clone() for t in ei[:3])
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    ops.PATH_LOG = set()
+    try:
+        etr = step.elbo_terms(x, y, gen, enc, c['lik'], (E, ez, et), return_aux=True)
+        took = set(ops.PATH_LOG)
+    finally:
+        ops.PATH_LOG = None
+    torch.cuda.synchronize()
+    peak_tr = torch.cuda.max_memory_allocated() - base
+    assert 'enc.inference' not in took and 'dec.no_h' in took
+    for a, b in zip(ei, etr[:3]):
+        assert torch.equal(a, b.detach())
+    assert torch.equal(hi, etr[3]['heads'].detach()) and torch.equal(yi, etr[3]['y_hat'].detach())
+    ho = c['n'] + 2 * c['pad'] - c['k'] + 1
+    h_bytes = 4 * c['C'] * B * c['R'] * ho * ho
+    assert peak_tr - peak_inf >= h_bytes, (peak_tr, peak_inf, h_bytes)

@@ -827,3 +827,41 @@ def test_secondary_branches_golden(name, t_inf, r_inf):
     assert_encoder_grads(enc, fx, GRAD_TOL)
     for k_, t in gen.named_parameters():
         assert_grad_close(t.grad, fx['gd.' + k_], tol=GRAD_TOL, name='gen.' + k_)
+
+
+@pytest.mark.parametrize('name', sorted(HOT))
+def test_inference_mode_forward_equals_training_forward(name, gemm_mode):
+    """Under torch.no_grad() (eval_model, train_mnist.py:352-387; get_latent, clustering_mnist.py:121-161) the encoder and
+    the decoder run their inference-mode forward (tvae/ops.py `_INFER`: no conv2 activation, no sign words, no decoder sign
+    bits, nothing retained).  Same kernels minus stores: every output must be BITWISE the training-mode forward's, and the
+    ELBO terms the reference's."""
+    from tvae import ops, step
+    fx = load_golden(name)
+    lik, _ = HOT[name]
+    enc, gen, n = seeded_models(fx)
+    enc, gen = enc.to(dev()), gen.to(dev())
+    x = O.image_coords(n).to(dev())
+    y = torch.from_numpy(fx['y']).to(dev())
+    noise = tuple(torch.from_numpy(fx[k_]).to(dev()) for k_ in ('E', 'eps_z', 'eps_theta'))
+    et, lt, kt, aux_t = step.elbo_terms(x, y, gen, enc, lik, noise, return_aux=True)
+    ops.PATH_LOG = set()
+    try:
+        with torch.no_grad():
+            ei, li, ki, aux_i = step.elbo_terms(x, y, gen, enc, lik, noise, return_aux=True)
+        took = set(ops.PATH_LOG)
+    finally:
+        ops.PATH_LOG = None
+    assert 'enc.inference' in took, took
+    assert not ({'dec.sign_bits', 'dec.no_h'} & took), took
+    if gemm_mode in ('x6', 'h3') and name != 'hot_M50_B2':
+        assert 'dec.no_h_inference' in took, took
+    for a, b in ((et, ei), (lt, li), (kt, ki)):
+        assert torch.equal(a.detach(), b)
+    for k_ in ('heads', 'y_hat', 'z', 'theta', 'dx', 'a_sampled', 'q_t_r'):
+        assert torch.equal(aux_t[k_].detach(), aux_i[k_]), k_
+    assert abs(float(ei) - float(fx['elbo'])) / abs(float(fx['elbo'])) < OUT_TOL
+    assert abs(float(li) - float(fx['log_p'])) / abs(float(fx['log_p'])) < OUT_TOL
+    assert abs(float(ki) - float(fx['kl'])) / abs(float(fx['kl'])) < OUT_TOL
+    # a later training step is unaffected by the switch (it is scoped to the no_grad calls)
+    e2, _, _ = step.elbo_terms(x, y, gen, enc, lik, noise)
+    assert torch.equal(e2.detach(), et.detach()) and e2.requires_grad
