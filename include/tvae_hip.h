@@ -108,9 +108,12 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
 
 /* ---- lifting convolution through the frequency domain ("dft") -----------------------------------------------------
  * Same operator as tvae_conv1_fwd / tvae_conv1_wgrad (src/models.py:215) for Cin = 1, evaluated with the circular-
- * correlation theorem on the (n+2*pad)^2 frame: DFT of image and filters by direct sums, the spectral contraction as
- * one batched GEMM per call on the split-bf16 dense kernels (7x fewer matrix FLOPs than the direct form), inverse
- * transform of the 33-wide output rows on the vector ALU.  `at` (tvae_conv1_dft_at_floats floats) receives the image
+ * correlation theorem on an L x L frame -- ABI 6: L = max(n + pad, ksz) rounded up to a multiple of 4 (tvae_conv1_dft_frame),
+ * not the reference's n + 2*pad: the leading and the trailing zero band of the padded image share their storage on the
+ * circle, and the result is still exact (csrc/abi_conv_dft.hip: dft_plan) -- DFT of image and filters by direct sums, the
+ * spectral contraction as one batched GEMM per call on the split-bf16 dense kernels (10x fewer matrix FLOPs than the direct
+ * form at the 64 x 64 shape), the transforms along w on the fp32 matrix pipe.  tvae_conv1_dft_ring: which instance of those
+ * transforms the geometry takes (0 = register-staged / generic, else an LDS-DMA ring kernel).  `at` (tvae_conv1_dft_at_floats floats) receives the image
  * spectra in GEMM-operand form in the forward call and is consumed again by the weight gradient of the same step;
  * ws is scratch (tvae_conv1_dft_ws_floats floats); dbias (C floats, may be NULL) receives the bias gradient
  * sum over (image, rotation, position) of dpre, read off the zero-frequency row.  tvae_conv1_dft_supported: 1 if this geometry is handled
@@ -118,6 +121,8 @@ int tvae_conv1_wgrad_x6(const float* y, const void* d3, float* dbank, float* ws,
 int tvae_conv1_dft_supported(int B, int Cin, int n, int ksz, int pad, int C, int R);
 long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R);
+int tvae_conv1_dft_frame(int B, int Cin, int n, int ksz, int pad, int C, int R);
+int tvae_conv1_dft_ring(int B, int Cin, int n, int ksz, int pad, int C, int R);
 int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, float* out, float* at, float* ws,
                        long ws_floats, int B, int Cin, int n, int ksz, int pad, int C, int R, int act, float slope,
                        int parts, tvae_stream_t stream);

@@ -67,9 +67,24 @@ constexpr size_t DFT_LDS_TARGET = 50 * 1024;       // three workgroups per CU fo
 static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     DftPlan q;
     q.Cin = Cin;
-    q.L = n + 2 * pad;
+    // Frame of the circular correlation (round 5).  The reference pads the image with `pad` zeros on BOTH sides (frame n + 2 pad)
+    // and the correlation theorem was first applied on that frame.  A circular frame of only L = n + pad is already alias free:
+    // with the image at positions [pad, pad + n) of the frame, an index h + u (output row + tap) that runs past L lands on
+    // positions [0, pad) -- the LEADING zeros -- exactly where the linear correlation meets the TRAILING zeros of the padded
+    // image (h + u <= n + 2 pad - 1 < L + pad; one wrap only).  The two zero bands share their storage.  The filter (ksz taps)
+    // must fit the frame as well: L = max(n + pad, ksz), rounded up to a multiple of 4 (radix-4 step of the spectra, whole
+    // octets of the spectral reduction) but never beyond the reference's own n + 2 pad.  64 x 64 / k 64 / p 16: L = 80 instead of
+    // 96 -- Lh 41 instead of 49 frequencies (T and S' 16 % smaller), reduction 2 L = 160 instead of 192 (30 % fewer matrix
+    // FLOPs in both spectral GEMMs); 28 x 28 / k 28 / p 8: 36 instead of 44; the galaxy shape 160 instead of 192.  Exact: nothing
+    // is approximated (tests/test_hip_primitives.py::test_conv1_dft_matches_fp64).  TVAE_DFT_FULL_FRAME=1 restores n + 2 pad.
+    q.Ho = n + 2 * pad - ksz + 1;
+    {
+        static const bool full = getenv("TVAE_DFT_FULL_FRAME") && getenv("TVAE_DFT_FULL_FRAME")[0] == '1';
+        int Lmin = n + pad > ksz ? n + pad : ksz;
+        Lmin = (Lmin + 3) & ~3;
+        q.L = (full || Lmin > n + 2 * pad) ? n + 2 * pad : Lmin;
+    }
     q.Lh = q.L / 2 + 1;
-    q.Ho = q.L - ksz + 1;
     q.M = C * R;
     q.K2 = 2 * q.L * Cin;
     q.NB = (long)B * q.Ho;
@@ -82,10 +97,14 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.gen = q.Lh > 64 || q.Ho > DFT_WROWS;
     // frames of the reference configurations (28x28 k28 p8; 64x64 k64 p16; the 50x50 MNIST-U geometry k28 p8) take the
     // ring kernels (conv_dft_kernels.hpp); every other frame the register-staged / generic ones
-    q.ring = (q.L == 44 && q.Ho == 17) ? 1 : (q.L == 96 && q.Ho == 33) ? 2 : (q.L == 66 && q.Ho == 39) ? 3 : 0;
+    // ring ids: 1 / 2 / 3 = the 28x28, 64x64 and 50x50 (MNIST-U) geometries on the short frame (L = 36 / 80 / 60);
+    //           4 / 5 / 6 = the same on the reference's full frame (L = 44 / 96 / 66; TVAE_DFT_FULL_FRAME=1)
+    q.ring = (q.L == 36 && q.Ho == 17) ? 1 : (q.L == 80 && q.Ho == 33) ? 2 : (q.L == 60 && q.Ho == 39) ? 3 :
+             (q.L == 44 && q.Ho == 17) ? 4 : (q.L == 96 && q.Ho == 33) ? 5 : (q.L == 66 && q.Ho == 39) ? 6 : 0;
     if (q.ring) {              // (LHP, NT, REM1) / (NS, NRT) of the instances: tables sized to match
-        q.LHP = q.Lh; q.NT = q.ring == 3 ? 2 : 1; q.REM1 = q.ring == 2 ? 1 : 0;
-        q.NS = (q.Ho + 1) / 2; q.NRT = q.ring == 1 ? 2 : 3;
+        q.LHP = q.Lh; q.NT = q.Ho > 32 + 1 ? 2 : 1; q.REM1 = q.Ho == 33 ? 1 : 0;
+        q.NS = (q.Ho + 1) / 2;
+        q.NRT = (q.ring == 5) ? 3 : (2 * q.Lh + 31) / 32;      // (the 96-wide frame: 96 real rows + the Nyquist pair on the vector ALU)
     } else if (q.gen) {                                               // whole 32-row tiles, zero rows beyond Ho
         q.LHP = q.Lh; q.NT = (q.Ho + 31) / 32; q.REM1 = 0;
         q.NS = (q.Ho + 1) / 2; q.NRT = (2 * q.Lh + 31) / 32;
@@ -157,6 +176,10 @@ long tvae_conv1_dft_at_floats(int B, int Cin, int n, int ksz, int pad, int C, in
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     return ((q.at_floats + 3) & ~3L) + q.trailer_floats;
 }
+// frame length L of the circular correlation, and which instance of the transforms along w a geometry takes (0: register-staged
+// / generic; 1 .. 6: the LDS-DMA ring kernels, dft_plan)
+int tvae_conv1_dft_frame(int B, int Cin, int n, int ksz, int pad, int C, int R) { return dft_plan(B, Cin, n, ksz, pad, C, R).L; }
+int tvae_conv1_dft_ring(int B, int Cin, int n, int ksz, int pad, int C, int R) { return dft_plan(B, Cin, n, ksz, pad, C, R).ring; }
 long tvae_conv1_dft_ws_floats(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     const DftPlan q = dft_plan(B, Cin, n, ksz, pad, C, R);
     // forward: W + W3 + T + tables; backward: S' (= T) + split-K slabs of G + tables
@@ -186,7 +209,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     // bf16 STORAGE of T (round 4): the one-part throughput mode on a ring geometry with whole 256-row tiles writes and reads T
     // as 2-byte elements (TVAE_BF16_STORE=0 keeps fp32 storage; the fp32-class arithmetics never take this path)
     static const bool bf16_store = !(getenv("TVAE_BF16_STORE") && getenv("TVAE_BF16_STORE")[0] == '0');
-    const bool t16 = bf16_store && parts == 1 && q.ring && q.K2 <= 256 && (2 * q.M) % DX4_ROWS == 0;
+    // (ring 3, the 50 x 50 geometry on its 60-wide frame: a bf16 slot of 4 KB cannot hold the 32 x 39 transposition patch)
+    const bool t16 = bf16_store && parts == 1 && q.ring && q.ring != 3 && q.K2 <= 256 && (2 * q.M) % DX4_ROWS == 0;
     // the maxima are produced in every arithmetic (one small fill and a few atomics): the weight gradient may run in
     // h3 after a forward that did not
     float* amax = at + ((q.at_floats + 3) & ~3L);
@@ -271,8 +295,11 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         if (act == ACT_TANH) { if (t16) TVAE_OUT_RING_ONE(L_, N_, R_, H_, true, true); else TVAE_OUT_RING_ONE(L_, N_, R_, H_, true, false); } \
         else { if (t16) TVAE_OUT_RING_ONE(L_, N_, R_, H_, false, true); else TVAE_OUT_RING_ONE(L_, N_, R_, H_, false, false); } \
     } while (0)
-            if (q.ring == 1) TVAE_OUT_RING(23, 1, false, 17);
-            else if (q.ring == 2) TVAE_OUT_RING(49, 1, true, 33);
+            if (q.ring == 1) TVAE_OUT_RING(19, 1, false, 17);
+            else if (q.ring == 2) TVAE_OUT_RING(41, 1, true, 33);
+            else if (q.ring == 3) { if (act == ACT_TANH) TVAE_OUT_RING_ONE(31, 2, false, 39, true, false); else TVAE_OUT_RING_ONE(31, 2, false, 39, false, false); }
+            else if (q.ring == 4) TVAE_OUT_RING(23, 1, false, 17);
+            else if (q.ring == 5) TVAE_OUT_RING(49, 1, true, 33);
             else TVAE_OUT_RING(34, 2, false, 39);
 #undef TVAE_OUT_RING
 #undef TVAE_OUT_RING_ONE
@@ -356,8 +383,11 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     } while (0)
 #define TVAE_DY_RING(S_, T_, L2_, H_, Q_)                                                                           \
     do { if (s16) TVAE_DY_RING_ONE(S_, T_, L2_, H_, Q_, true); else TVAE_DY_RING_ONE(S_, T_, L2_, H_, Q_, false); } while (0)
-            if (q.ring == 1) TVAE_DY_RING(9, 2, 46, 17, false);
-            else if (q.ring == 2) TVAE_DY_RING(17, 3, 98, 33, true);
+            if (q.ring == 1) TVAE_DY_RING(9, 2, 38, 17, false);
+            else if (q.ring == 2) TVAE_DY_RING(17, 3, 82, 33, false);
+            else if (q.ring == 3) TVAE_DY_RING(20, 2, 62, 39, false);
+            else if (q.ring == 4) TVAE_DY_RING(9, 2, 46, 17, false);
+            else if (q.ring == 5) TVAE_DY_RING(17, 3, 98, 33, true);
             else TVAE_DY_RING(20, 3, 68, 39, false);
 #undef TVAE_DY_RING
 #undef TVAE_DY_RING_ONE

@@ -77,6 +77,8 @@ QUERIES = {
     'tvae_conv1_dft_supported': ('iiiiiii', 'i'),
     'tvae_conv1_dft_at_floats': ('iiiiiii', 'l'),
     'tvae_conv1_dft_ws_floats': ('iiiiiii', 'l'),
+    'tvae_conv1_dft_frame': ('iiiiiii', 'i'),
+    'tvae_conv1_dft_ring': ('iiiiiii', 'i'),
     'tvae_enc_tail_wgrad_x6_ws_floats': ('l', 'l'),
     'tvae_linear_wgrad_x6_ws_floats': ('iii', 'l'),
 }

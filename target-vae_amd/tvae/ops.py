@@ -321,7 +321,6 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
 
 
 CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
-DFT_RING_FRAMES = {(44, 17), (96, 33), (66, 39)}      # (frame, outputs per row) with ring transforms (csrc/abi_conv_dft.hip)
 FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
 FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
 FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
@@ -353,7 +352,7 @@ def conv1_forward(y, weight, bias, C, R, k, pad, act, keep=None, bank=None):
                          device=y.device)
         ws = _scratch(y.device, 'dft_ws', query('tvae_conv1_dft_ws_floats', B, Cin, n, k, pad, C, R))
         _note('conv1.dft')
-        if (n + 2 * pad, n + 2 * pad - k + 1) in DFT_RING_FRAMES:
+        if query('tvae_conv1_dft_ring', B, Cin, n, k, pad, C, R):
             _note('conv1.dft_ring')      # ring (LDS-DMA) transforms along w: abi_conv_dft.hip dft_plan
         with _timed('tvae_conv1_fwd', parts()):
             call('tvae_conv1_fwd_dft', y, bank, bias, out, at, ws, ws.numel(), B, Cin, n, k, pad, C, R, act,

@@ -264,7 +264,11 @@ def test_linear_wgrad_x6(M, N, K, acc):
     # round 4: the spectral GEMM kernels of their own shape at their edges -- one image (a single 128-column panel, two k-steps
     # per reduction slice), 2 M = 512 / 1 024 rows; and the weight gradient's 192-column tiles on a 1 152-column problem
     # (galaxy frame, three channels) with 2 M = 512 rows
-    (1, 64, 64, 16, 32, 8, 1, 1), (2, 64, 64, 16, 32, 16, 1, 1), (3, 128, 64, 32, 16, 16, 1, 3)])
+    (1, 64, 64, 16, 32, 8, 1, 1), (2, 64, 64, 16, 32, 16, 1, 1), (3, 128, 64, 32, 16, 16, 1, 3),
+    # round 5, the short circular frame L = max(n + pad, k) rounded up to 4 (csrc/abi_conv_dft.hip: dft_plan): a filter longer
+    # than n + pad (frame = k), no padding at all (frame = n), odd sizes whose rounding stops at n + 2 pad, padding >= k
+    (3, 20, 40, 12, 4, 4, 1, 1), (2, 24, 9, 0, 4, 4, 0, 1), (2, 21, 7, 3, 4, 4, 1, 1), (2, 19, 5, 1, 4, 4, 1, 2),
+    (2, 16, 6, 8, 4, 4, 0, 1)])
 @pytest.mark.parametrize('nparts', [3, 2])
 def test_conv1_dft_matches_fp64(B, n, k, pad, C, R, act, Cin, nparts):
     """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): fp32-level agreement with fp64, in the exact
