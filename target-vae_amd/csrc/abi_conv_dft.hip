@@ -35,7 +35,9 @@ static int dev_cu_count() {
 
 // Geometry / workspace of the frequency-domain lifting convolution (conv_dft_kernels.hpp).
 struct DftPlan {
-    int L, Lh, Ho, M, K2, Cin; // frame, half spectrum, output size, rows C*R, reduction 2*L*Cin
+    int L, Lh, Ho, M, K2, Cin; // frame, half spectrum, output size, rows C*R, reduction 2*Ky*Cin
+    bool mixed;                // frequency domain along x only, spatial taps along y (Ky = ksz); else both axes (Ky = L)
+    int Ky;
     bool gen;                  // generic transforms along w (Lh > 64 or Ho > 64: no specialised instance)
     int ring;                  // ring (LDS-DMA) transforms along w: 0 = none, 1 / 2 / 3 = the 44- / 96- / 66-wide frame
     int LHP, NT, REM1;         // forward w-transform: frequencies processed, 32-row output tiles, extra row
@@ -60,8 +62,8 @@ struct DftPlan {
     long o_cmax, o_fmax, o_wmax, o_smax, o_a1max, trailer_floats;
     bool ok;
 };
-static size_t dft_lds_spectra(int S, int L, int FXB) {
-    return (size_t)S * FXB * 8 + (size_t)L * FXB * 8 + (size_t)L * 8;
+static size_t dft_lds_spectra(int S, int L, int FXB, bool mixed = false) {
+    return (size_t)S * FXB * 8 + (mixed ? 0 : (size_t)L * FXB * 8) + (size_t)L * 8;
 }
 constexpr size_t DFT_LDS_TARGET = 50 * 1024;       // three workgroups per CU for the latency-bound direct-sum transforms
 static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
@@ -86,7 +88,16 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     }
     q.Lh = q.L / 2 + 1;
     q.M = C * R;
-    q.K2 = 2 * q.L * Cin;
+    // Round 5: the mixed form (conv_dft_kernels.hpp: dft_spectra_x_kernel) -- the DFT runs along x only and the reduction of the
+    // spectral GEMMs is (channel, re | im, tap row u < ksz) instead of (channel, re | im, frequency fy < L): ksz <= L, so it is
+    // never the longer one (128 instead of 160 at the 64 x 64 shape, 384 instead of 960 at the galaxy shape).
+    // TVAE_DFT_YSPECTRAL=1 restores the transform along both axes.
+    {
+        static const bool yspec = getenv("TVAE_DFT_YSPECTRAL") && getenv("TVAE_DFT_YSPECTRAL")[0] == '1';
+        q.mixed = !yspec;
+    }
+    q.Ky = q.mixed ? ksz : q.L;
+    q.K2 = 2 * q.Ky * Cin;
     q.NB = (long)B * q.Ho;
     q.NBpad = (q.NB + 127) / 128 * 128;
     q.Mb = x6_round_up(2 * q.M, DX6_ROWS);
@@ -139,11 +150,11 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     const int S = n > ksz ? n : ksz;
     q.nblk = 1;
     q.FXB = q.Lh;
-    while (q.nblk < 16 && dft_lds_spectra(S, q.L, q.FXB) > DFT_LDS_TARGET) {
+    while (q.nblk < 16 && dft_lds_spectra(S, q.L, q.FXB, q.mixed) > DFT_LDS_TARGET) {
         ++q.nblk;
         q.FXB = (q.Lh + q.nblk - 1) / q.nblk;
     }
-    q.lds_sp = dft_lds_spectra(S, q.L, q.FXB);
+    q.lds_sp = dft_lds_spectra(S, q.L, q.FXB, q.mixed);
     q.FXBd = q.Lh;
     auto lds_db = [&](int f) { return (size_t)q.L * f * 8 + (size_t)ksz * f * 8 + (size_t)q.L * 8 + (size_t)ksz * ksz * 4; };
     // the inverse transform runs one workgroup per (filter, channel): 1 024 of them at the bench shape = FOUR per CU, so its
@@ -151,6 +162,7 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     constexpr size_t DFT_LDS_DBANK = 39 * 1024;
     for (int nb = 1; nb < 16 && lds_db(q.FXBd) > DFT_LDS_DBANK; ++nb) q.FXBd = (q.Lh + nb) / (nb + 1);
     q.lds_db = lds_db(q.FXBd);
+    if (q.mixed) q.lds_db = ((size_t)ksz * q.Lh + q.L) * 8;      // dft_dbank_x_kernel: D [ksz][Lh] complex + twiddles
     q.o_cmax = 0;
     q.o_fmax = q.o_cmax + (long)q.Lh * B;
     q.o_wmax = q.o_fmax + q.Lh;
@@ -222,12 +234,16 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     float* a1max = amax + q.o_a1max;
     float* EO = tab;
     float* ED = EO + ((q.eo_floats + 3) & ~3L);
-    hipError_t e = allow_big_lds(dft_spectra_kernel, q.lds_sp);
+    hipError_t e = q.mixed ? allow_big_lds(dft_spectra_x_kernel, q.lds_sp) : allow_big_lds(dft_spectra_kernel, q.lds_sp);
     if (e != hipSuccess) return (int)e;
     if (q.Mb != 2 * q.M) {                             // rows that pad 2M to the 512-row tile must be zero
         e = dft_zero(W, q.w_floats, st);
         if (e != hipSuccess) return (int)e;
     }
+    if (q.mixed)
+        hipLaunchKernelGGL(dft_spectra_x_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
+                           n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);
+    else
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
                        n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);
     TVAE_CHECK_LAUNCH();
@@ -275,7 +291,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         // contraction over fx on the fp32 matrix pipe
         const int NTT = q.NT + q.REM1;
         hipLaunchKernelGGL(dft_wtab_kernel, dim3(64), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT, NTT, q.NS,
-                           q.NRT);
+                           q.NRT, q.mixed ? 1.f / (float)q.L : 1.f / ((float)q.L * (float)q.L));
         TVAE_CHECK_LAUNCH();
         const long ntiles = (long)q.M * (q.NBpad / 32);
         if (q.ring) {
@@ -366,7 +382,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     float* ED = EO + ((q.eo_floats + 3) & ~3L);
     {
         hipLaunchKernelGGL(dft_wtab_kernel, dim3(64), dim3(256), 0, st, EO, ED, q.L, q.Lh, q.Ho, q.LHP, q.NT,
-                           q.NT + q.REM1, q.NS, q.NRT);
+                           q.NT + q.REM1, q.NS, q.NRT, q.mixed ? 1.f / (float)q.L : 1.f / ((float)q.L * (float)q.L));
         TVAE_CHECK_LAUNCH();
         const long ntiles = (long)q.M * (q.NBpad / 32);
         if (q.ring) {
@@ -450,7 +466,12 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     }
     // both contractions on the fp32 matrix pipe where the tiles are not mostly padding (ksz <= 64, >= 17 frequencies per block)
     static const bool dbank_mf = !(getenv("TVAE_DBANK_MF") && getenv("TVAE_DBANK_MF")[0] == '0');
-    if (dbank_mf && ksz <= 64 && q.FXBd >= 17 && q.FXBd <= 64) {
+    if (q.mixed) {       // the tap rows are spatial already: x stage only
+        hipError_t e = allow_big_lds(dft_dbank_x_kernel, q.lds_db);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(dft_dbank_x_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, nslabs, q.g_floats,
+                           dbank, ksz, q.L, q.Lh, q.M, Cin);
+    } else if (dbank_mf && ksz <= 64 && q.FXBd >= 17 && q.FXBd <= 64) {
         hipError_t e = allow_big_lds(dft_dbank_mf_kernel, q.lds_db);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(dft_dbank_mf_kernel, dim3(q.M * Cin), dim3(256), q.lds_db, st, (const float*)slabs, nslabs,

@@ -53,7 +53,8 @@ bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilo
     // step double and the kernel measured 213 us against dense_x6_plain4_kernel's 195; nine steps (50 x 50) were not measured.
     // Two parts (h3): 1.21 against 1.38 ms; three (x6): 1.76 against 1.80.
     // Round 5 (short frame: reduction 2 L = 160 at the 64 x 64 shape): ten steps take it as well.
-    const bool shape_ok = (parts == 2 || parts == 3) && (nk == 12 || nk == 10);
+    // ... and eight (mixed form: reduction 2 ksz = 128).
+    const bool shape_ok = (parts == 2 || parts == 3) && (nk == 12 || nk == 10 || nk == 8);
     if (!on || !lean || !shape_ok || N % 128 != 0 || Mb < rows_per_problem ||
         lds > X6_LDS_MAX || !aligned16(w3) || (parts == 2 && (!hs.amax_a || !hs.amax_x)))
         return false;
@@ -67,7 +68,8 @@ bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilo
                            ep.ldc, ep.ctile, rows_per_problem, Mb, Rpad, K, nprob, tilesN, nch, x_stride, c_stride, hs);  \
     } while (0)
     if (nk == 12) { if (parts == 3) TVAE_XRES_LAUNCH(3, 12); else TVAE_XRES_LAUNCH(2, 12); }
-    else { if (parts == 3) TVAE_XRES_LAUNCH(3, 10); else TVAE_XRES_LAUNCH(2, 10); }
+    else if (nk == 10) { if (parts == 3) TVAE_XRES_LAUNCH(3, 10); else TVAE_XRES_LAUNCH(2, 10); }
+    else { if (parts == 3) TVAE_XRES_LAUNCH(3, 8); else TVAE_XRES_LAUNCH(2, 8); }
 #undef TVAE_XRES_LAUNCH
     *rc = (int)hipGetLastError();
     return true;

@@ -243,6 +243,104 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: the MIXED form -- frequency domain along x only, the correlation along y stays spatial.
+//     out[b][m][h][w] = 1/L * Re sum_{fx < Lh} c_fx e^{+2 pi i fx w / L}  T[fx][(b,h)][m]
+//     T[fx][(b,h)][m] = sum_{ci} sum_{u < ksz} X[b][ci][h + u - pad][fx] * conj( Kx[m][ci][u][fx] )
+// with X / Kx the 1-D DFTs ALONG x of the image rows (at frame positions x + pad) and of the filter rows.  The reduction of the
+// spectral GEMM is then k = (ci*2 + ri)*ksz + u: K2 = 2 ksz Cin instead of 2 L Cin (128 instead of 160 at the 64 x 64 shape, 384
+// instead of 960 at the galaxy shape) -- ksz <= L always, so it never loses -- T, S' and the transforms along w are unchanged,
+// the spectra need no transform along y and no phase per output row (the GEMM operand is a Toeplitz view of the row spectra:
+// AT[fx][k][(b,h)] = X[b][ci][h + u - pad][fx], zero outside the image), and the inverse transform of the weight gradient
+// needs its x stage only.  Same launch shape as dft_spectra_kernel (a workgroup per (plane, block of frequencies)).
+// LDS: row spectra S*FXB complex + twiddles L complex.
+// ------------------------------------------------------------------------------------------
+static __global__ void dft_spectra_x_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
+                                            int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
+                                            int M, int Mb, int L, int Lh, int FXB, int nblk, DftMax mxp) {
+    extern __shared__ float sm_dft[];
+    const int nimg = B * Cin * nblk;
+    int id = blockIdx.x;
+    const bool is_img = id < nimg;
+    if (!is_img) id -= nimg;
+    const int blk = id % nblk;
+    const int ci = (id / nblk) % Cin;
+    const int outer = id / (nblk * Cin);                 // image b or filter m
+    const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
+    const int S = is_img ? n : ksz, pd = is_img ? pad : 0;
+    const float* pl = is_img ? y + ((long)outer * Cin + ci) * n * n : bank + ((long)outer * Cin + ci) * ksz * ksz;
+    float2* Rw = reinterpret_cast<float2*>(sm_dft);      // [row][f]
+    float2* tw = Rw + S * FXB;
+    fill_twiddles(tw, L);
+    __syncthreads();
+    // Rw[yy][f] = sum_x pl[yy][x] e^{-2 pi i fx (x + pd) / L}  (the plane is read straight from memory: see dft_plane_spectrum)
+    for (int i = threadIdx.x; i < S * nfx; i += blockDim.x) {
+        const int yy = i / nfx, f = i - yy * nfx, fx = fx0 + f;
+        const float* row = pl + yy * S;
+        float re = 0.f, im = 0.f;
+        int ph = (fx * pd) % L;
+#pragma unroll 4
+        for (int x = 0; x < S; ++x) {
+            const float v = row[x];
+            const float2 t = tw[ph];
+            re += v * t.x;
+            im -= v * t.y;
+            ph += fx;
+            if (ph >= L) ph -= L;
+        }
+        Rw[yy * FXB + f] = make_float2(re, im);
+    }
+    __syncthreads();
+    const long rowlen = 2L * ksz * Cin;
+    if (is_img) {
+        // AT[fx][(2 ci + ri) ksz + u][b Ho + h] = Re / Im X[h + u - pad][fx]  (h fastest: coalesced runs of Ho floats)
+        const int total = nfx * ksz * Ho;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int h = i % Ho;
+            const int t2 = i / Ho;
+            const int u = t2 % ksz, f = t2 / ksz;
+            const int r = h + u - pad;
+            const float2 v = (r >= 0 && r < n) ? Rw[r * FXB + f] : make_float2(0.f, 0.f);
+            float* dst = AT + ((long)(fx0 + f) * rowlen + (long)(2 * ci) * ksz + u) * NBpad + (long)outer * Ho + h;
+            dst[0] = v.x;
+            dst[(long)ksz * NBpad] = v.y;
+        }
+        for (int f = threadIdx.x >> 6; f < nfx; f += blockDim.x >> 6) {       // one frequency per wave and turn
+            float q = 0.f;
+            for (int r = threadIdx.x & 63; r < n; r += 64) {
+                const float2 k = Rw[r * FXB + f];
+                q = fmaxf(q, fmaxf(fabsf(k.x), fabsf(k.y)));
+            }
+            q = h3_wave_max(q);
+            if ((threadIdx.x & 63) == 0) dft_max_slot(mxp.cmax + (long)(fx0 + f) * B + outer, q, Cin == 1);
+        }
+    } else {
+        const int m = outer;
+        for (int i = threadIdx.x; i < nfx * ksz; i += blockDim.x) {
+            const int u = i % ksz, f = i / ksz;
+            const float2 k = Rw[u * FXB + f];
+            float* r0 = W + ((long)(fx0 + f) * Mb + m) * rowlen + (long)(2 * ci) * ksz;
+            float* r1 = W + ((long)(fx0 + f) * Mb + M + m) * rowlen + (long)(2 * ci) * ksz;
+            r0[u] = k.x;
+            r0[ksz + u] = k.y;
+            r1[u] = -k.y;
+            r1[ksz + u] = k.x;
+        }
+        for (int f = threadIdx.x >> 6; f < nfx; f += blockDim.x >> 6) {
+            float q = 0.f;
+            for (int u = threadIdx.x & 63; u < ksz; u += 64) {
+                const float2 k = Rw[u * FXB + f];
+                q = fmaxf(q, fmaxf(fabsf(k.x), fabsf(k.y)));
+            }
+            q = h3_wave_max(q);
+            if ((threadIdx.x & 63) == 0) {
+                dft_max_slot(mxp.wmax + (long)(fx0 + f) * Mb + m, q, Cin == 1);
+                dft_max_slot(mxp.wmax + (long)(fx0 + f) * Mb + M + m, q, Cin == 1);
+            }
+        }
+    }
+}
+
 // ==========================================================================================
 // The two transforms along w on the matrix pipe, in plain fp32 (v_mfma_f32_32x32x2_f32: exact products, fp32
 // accumulate -- no operand splitting, so the vector ALU only moves data).  They are small GEMMs with a constant operand,
@@ -259,8 +357,9 @@ constexpr int DFT_WROWS = 64;          // largest output width of the matrix-pip
 //                              t == NT (REM1 only): the same for the single extra row w = 32*NT, identical in all 32 lanes
 // ED[s < NS][rt < NRT][lane]:  E'[kk = 32 rt + (lane & 31)][w = 2s + (lane >> 5)], kk = 2 fx + ri: ri ? -sin : cos
 // Entries outside fx < Lh, w < Ho are zero (they pad the loops of the kernels).
+// norm: 1/L^2 (both axes in the frequency domain) or 1/L (mixed form: x only)
 static __global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict__ ED, int L, int Lh, int Ho, int LHP, int NT,
-                                int NTT, int NS, int NRT) {
+                                int NTT, int NS, int NRT, float norm) {
     const int nEO = LHP * NTT * 64, nED = NS * NRT * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nEO + nED; i += gridDim.x * blockDim.x) {
         int fx, w, ri;
@@ -284,7 +383,7 @@ static __global__ void dft_wtab_kernel(float* __restrict__ EO, float* __restrict
             float sn, cs;
             sincospif(2.0f * (float)((fx * w) % L) / (float)L, &sn, &cs);
             v = ri ? -sn : cs;
-            if (fwd) v *= (((fx == 0) || (2 * fx == L)) ? 1.f : 2.f) / ((float)L * (float)L);
+            if (fwd) v *= (((fx == 0) || (2 * fx == L)) ? 1.f : 2.f) * norm;
         }
         if (i < nEO) EO[i] = v; else ED[i - nEO] = v;
     }
@@ -1186,6 +1285,69 @@ static __global__ __launch_bounds__(256) void dft_dbank_mf_kernel(const float* _
     __syncthreads();
     const float inv = 1.f / ((float)L * (float)L);
     for (int i = threadIdx.x; i < ksz * ksz; i += blockDim.x) dbank[((long)m * Cin + ci) * ksz * ksz + i] = outp[i] * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5, mixed form (dft_spectra_x_kernel): the spectral weight gradient is G[fx][m | M+m][(ci, ri, u)] with the tap row u
+// already spatial, so only the x stage of the inverse transform is left:
+//   D[u][fx] = ( G[m][(0,u)] + G[M+m][(1,u)],  G[m][(1,u)] - G[M+m][(0,u)] )
+//   dbank[m][ci][u][v] = 1/L sum_fx c_fx ( Dr cos(2 pi fx v / L) - Di sin(2 pi fx v / L) ),  u, v < ksz
+// on the fp32 matrix pipe (rows u, columns v, k = pairs of fx), slabs summed in order while they are loaded.  One workgroup
+// per (filter, channel); wave w owns the 32 x 32 output tiles (ut, vt) = w, w + 4, ..  LDS: D ksz*Lh complex + twiddles.
+// ------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void dft_dbank_x_kernel(const float* __restrict__ G, int nsl, long gs,
+                                                                 float* __restrict__ dbank, int ksz, int L, int Lh, int M,
+                                                                 int Cin) {
+    extern __shared__ float sm_dft[];
+    float2* D = reinterpret_cast<float2*>(sm_dft);       // [u][fx]  (pitch Lh)
+    float2* tw = D + ksz * Lh;
+    const int m = blockIdx.x / Cin, ci = blockIdx.x - m * Cin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
+    fill_twiddles(tw, L);
+    const long rowlen = 2L * ksz * Cin;
+    for (int i = threadIdx.x; i < Lh * ksz; i += blockDim.x) {
+        const int u = i % ksz, f = i / ksz;
+        const float* r0 = G + ((long)f * 2 * M + m) * rowlen + (long)(2 * ci) * ksz;
+        const float* r1 = G + ((long)f * 2 * M + M + m) * rowlen + (long)(2 * ci) * ksz;
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+        for (int sl = 0; sl < nsl; ++sl) {
+            a += r0[sl * gs + u];
+            b += r1[sl * gs + ksz + u];
+            c += r0[sl * gs + ksz + u];
+            d += r1[sl * gs + u];
+        }
+        D[u * Lh + f] = make_float2(a + b, c - d);
+    }
+    __syncthreads();
+    const int nt = (ksz + 31) / 32;
+    const float inv = 1.f / (float)L;
+    for (int tile = wave; tile < nt * nt; tile += 4) {
+        const int ut = tile / nt, vt = tile - ut * nt;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        const int v = 32 * vt + li;                      // B column
+        const int ua = min(32 * ut + li, ksz - 1);       // A row (clamped: rows >= ksz are not stored)
+        int ph = (int)(((long)kh * v) % L);              // (fx v) mod L for fx = kh
+        const int dph = (2 * v) % L;
+        for (int t = 0; 2 * t < Lh; ++t) {
+            const int fx = 2 * t + kh;
+            const float2 z = D[ua * Lh + min(fx, Lh - 1)];
+            const float cf = fx < Lh ? (((fx == 0) || (2 * fx == L)) ? 1.f : 2.f) : 0.f;
+            const float2 w = tw[ph];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(z.x, cf * w.x, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(z.y, -cf * w.y, o, 0, 0, 0);
+            ph += dph;
+            if (ph >= L) ph -= L;
+        }
+        if (v < ksz) {                                   // D layout: lane = column v, registers = rows u
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ur = 32 * ut + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (ur < ksz) dbank[((long)m * Cin + ci) * ksz * ksz + ur * ksz + v] = o[r] * inv;
+            }
+        }
+    }
 }
 
 }  // namespace tvae
