@@ -287,7 +287,7 @@ def measure_extra_workload(name, dev, steps, warmup=2):
     def one(i):
         y = data[(i % 2) * B:(i % 2) * B + B]
         elbo, _, _ = step.elbo_terms(x, y, gen, enc, c['lik'])
-        (-elbo).backward()
+        step.backward_neg_elbo(elbo)         # = (-elbo).backward() of the training loop (tvae/step.py)
         opt.step()
         opt.zero_grad(set_to_none=True)
         return elbo.detach()
@@ -357,7 +357,7 @@ def main():
             opt.zero_grad()
             return e_
         elbo, log_p, kl = step.elbo_terms(x, y, gen, enc, c['lik'])
-        (-elbo).backward()
+        step.backward_neg_elbo(elbo)         # = (-elbo).backward() of the training loop (tvae/step.py)
         opt.step()
         opt.zero_grad(set_to_none=True)      # as the training loop (tvae/step.py): gradients gathered by one multi-tensor copy
         return elbo.detach()
@@ -588,7 +588,7 @@ def main():
                            'frac': bytes_img * B / (ms_e * 1e-3) / 8.0e12},
                    'mfma': {'direct_form_tflops': fl_img * B / (ms_e * 1e-3) / 1e12,
                             'note': 'direct-form FLOPs (2*C*R*k^2*Ho^2 + 1x1x1 layers) over the measured time; the '
-                                    'frequency-domain convolution executes 7x fewer, so this exceeds every peak'},
+                                    'frequency-domain convolution executes 13x fewer, so this exceeds every peak'},
                    'conv1_fwd_ms': kev_e.get('tvae_conv1_fwd', {}).get('mean_ms'),
                    'enc_tail_fwd_ms': kev_e.get('tvae_enc_tail_fwd_x6', {}).get('mean_ms')}
         ms_i, kev_i = time_encoder(False)
@@ -630,9 +630,9 @@ def main():
         # every timed entry point: (algorithmic FLOPs per launch, kernel, note)
         conv_dft = mode in ('x6', 'h3', 'bf16') and bool(int(os.environ.get('TVAE_CONV_DFT', '1')))
         entries = {
-            'tvae_conv1_fwd': (conv_flops, 'dft_spectra_kernel + batched dense_x6_xres_kernel (other frames: _plain4_kernel) + dft_out_ring_kernel'
+            'tvae_conv1_fwd': (conv_flops, 'dft_spectra_x_kernel + batched dense_x6_xres_kernel (other frames: _plain4_kernel) + dft_out_ring_kernel'
                                if conv_dft else info['kernels']['tvae_conv1_fwd']),
-            'tvae_conv1_wgrad': (conv_flops, 'dft_dy_ring_kernel + batched dense_wgrad_x6_wide_kernel (256 x 192 tile; other frames: _dma_kernel) + dft_dbank_mf_kernel'
+            'tvae_conv1_wgrad': (conv_flops, 'dft_dy_ring_kernel + batched dense_wgrad_x6_dma_kernel (512 x 128 tile) + dft_dbank_x_kernel'
                                  if conv_dft else info['kernels']['tvae_conv1_wgrad']),
             'tvae_linear_fwd_x6': (dense_flops, 'dense_x6_kernel'),
             'tvae_linear_dgrad_x6': (dense_flops, 'dense_x6_kernel'),
@@ -701,8 +701,15 @@ def main():
                                                   'optimizer step (tvae/optim.py)'}
                                       if world > 1 else None),
                        'arithmetic_mode': mode, 'graph_replay': bool(args.graph),
-                       'lifting_conv': ('frequency domain: DFT + batched split-pipe GEMM (326 GFLOP of matrix work per '
-                                        'launch instead of 2339)' if conv_dft else 'direct implicit GEMM')},
+                       'lifting_conv': (('mixed domain: DFT along x on the short circular frame L = %d (n + pad, not n + 2 pad), tap '
+                                         'rows spatial; batched split-pipe GEMM with reduction 2*k*Cin = %d: %.0f GFLOP of matrix work '
+                                         'per launch instead of %.0f in the direct form') %
+                                        (_lib.query('tvae_conv1_dft_frame', B, c['cin'], c['n'], c['k'], c['pad'], c['C'], c['R']),
+                                         2 * c['k'] * c['cin'],
+                                         2.0 * (_lib.query('tvae_conv1_dft_frame', B, c['cin'], c['n'], c['k'], c['pad'], c['C'], c['R']) // 2 + 1)
+                                         * 2 * c['C'] * c['R'] * 2 * c['k'] * c['cin'] * B * (c['n'] + 2 * c['pad'] - c['k'] + 1) / 1e9,
+                                         conv_flops / 1e9)
+                                        if conv_dft else 'direct implicit GEMM')},
             'roofline': {'kernel': dom + ' (' + entries[dom][1] + ', ' + info['insn'] + ')', 'bound': 'mfma',
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': ach / peak,

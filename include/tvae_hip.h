@@ -354,6 +354,13 @@ int tvae_loglik_fwd(const float* yh, const float* y, float* lp, int B, int L, in
 int tvae_loglik_bwd(const float* yh, const float* y, const float* glp, float* gyh, int B, int L, int kind,
                     tvae_stream_t stream);
 
+/* ELBO scalars of a minibatch (train_mnist.py:282,291-292) in one launch: logp[0] = float32 mean of lp [B], kld[0] = float64
+ * mean of kl [B], elbo[0] = logp - kld (float64); and the chain rule of all three in one more (NULL upstream gradient = 0):
+ * g_lp[b] = (g_elbo + g_logp) / B, g_kl[b] = (g_kld - g_elbo) / B.  (ABI 6) */
+int tvae_elbo_reduce(const float* lp, const float* kl, int B, double* elbo, float* logp, double* kld, tvae_stream_t stream);
+int tvae_elbo_reduce_bwd(const double* g_elbo, const float* g_logp, const double* g_kld, int B, float* g_lp, float* g_kl,
+                         tvae_stream_t stream);
+
 /* ---- particle likelihood tail: train_particles.py:298-338 ----
  * ctf_corr: per-image depthwise cross-correlation out[b] = in[b] (*) ctf[b] with an odd kc x kc filter and zero padding
  * kc/2 (F.conv2d(y_mu.view(1,B,n,n), ctf, padding=pad, groups=B), :298-302); flip = 1 uses the 180-degree rotated

@@ -11,9 +11,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log" > "$OUT/${TAG}_bench.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion > "$OUT/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/write.log" 2>&1
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/qs_${1:-x}
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/stats.log" 2>&1
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 cp "$S" "$OUT/kernel_stats.csv"
 rm -rf "$OUT/stats"

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 TAG=${1:-x}; PAT=${2:-tvae::}; WL=${3:-S64}
 OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/p" -o q -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion > "$OUT/log.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/p" -o q -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/log.txt" 2>&1
 F=$(find "$OUT/p" -name '*counter_collection.csv' | head -1)
 python3 - "$F" "$PAT" <<'PY' | tee "$OUT/sq_counters.txt"
 import csv, re, sys

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 WL=${1:-S64}
 OUT=$PWD/gpurun_out/tl_$WL
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/t" -o k -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-f32-companion --no-small-batch > "$OUT/log.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/t" -o k -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-f32-companion --no-workloads --no-small-batch > "$OUT/log.txt" 2>&1
 F=$(find "$OUT/t" -name '*kernel_trace.csv' | head -1)
 python3 - "$F" > "$PWD/gpurun_out/timeline_$WL.txt" <<'PY'
 import csv, sys

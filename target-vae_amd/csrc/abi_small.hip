@@ -63,8 +63,25 @@ int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int
 }
 
 int tvae_seg_sum(const float* in, int S_, long L, float* out, float scale, int accumulate, tvae_stream_t stream) {
+    if (L <= 64 && S_ >= 32)         // few outputs, many segments: one wave per output
+        hipLaunchKernelGGL(seg_sum_wave_kernel, dim3((unsigned)L), dim3(64), 0, S(stream), in, S_, L, out, scale, accumulate);
+    else
     hipLaunchKernelGGL(seg_sum_kernel, dim3(grid1d(L, 256)), dim3(256), 0, S(stream), in, S_, L, out, scale,
                        accumulate);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int tvae_elbo_reduce(const float* lp, const float* kl, int B, double* elbo, float* logp, double* kld, tvae_stream_t stream) {
+    if (B <= 0 || !lp || !kl || !elbo || !logp || !kld) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, S(stream), lp, kl, B, elbo, logp, kld);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+int tvae_elbo_reduce_bwd(const double* g_elbo, const float* g_logp, const double* g_kld, int B, float* g_lp, float* g_kl,
+                         tvae_stream_t stream) {
+    if (B <= 0 || !g_lp || !g_kl) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(elbo_reduce_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), g_elbo, g_logp, g_kld, B, g_lp, g_kl);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

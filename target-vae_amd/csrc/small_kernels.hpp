@@ -198,6 +198,22 @@ static __global__ void seg_sum_kernel(const float* __restrict__ in, int S, long 
     }
 }
 
+// The same for FEW outputs and many segments (row sums of a head-gradient / output-gradient tensor: L = 1 .. 7 outputs, S = 256
+// segments): the kernel above then runs L threads that each walk S dependent loads (17-23 us for 2 KB of data); here one
+// wave per output, lanes over the segments, a fixed-order butterfly at the end (deterministic).
+static __global__ __launch_bounds__(64) void seg_sum_wave_kernel(const float* __restrict__ in, int S, long L, float* __restrict__ out,
+                                                               float scale, int accumulate) {
+    const long i = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < S; k += 64) s += in[(long)k * L + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        s *= scale;
+        if (accumulate) out[i] += s; else out[i] = s;
+    }
+}
+
 // Column "dot" with a skinny matrix: out[n*NO + o] = b[o] + sum_m W[m*wsm + o*wso] * X[m*ldx + n]
 // (last decoder layer n_out <= 4; coordinate gradient dx'[pix][2]).  Lanes run along n.
 template <int NO>
@@ -966,6 +982,51 @@ static __global__ void adam_flat_kernel(float* __restrict__ p, const float* __re
         v[i] = vv;
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
         p[i] -= (lr / bc1) * (mm / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ELBO scalars of a minibatch in ONE launch (reference train_mnist.py:282,291-292: log_p = mean_b lp (float32), kl_div =
+// mean_b kl (float64), elbo = log_p - kl_div) and their backward in one more -- the ATen form is a dozen 5-us launches
+// (two means, a cast, a subtraction, and the chain rule of each).  One workgroup; fixed summation order.
+// ------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void elbo_reduce_kernel(const float* __restrict__ lp, const float* __restrict__ kl, int B,
+                                                                double* __restrict__ elbo, float* __restrict__ logp,
+                                                                double* __restrict__ kld) {
+    __shared__ double sm[2 * 4];
+    double a = 0.0, k = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        a += (double)lp[b];
+        k += (double)kl[b];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        k += __shfl_xor(k, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sm[2 * (threadIdx.x >> 6)] = a;
+        sm[2 * (threadIdx.x >> 6) + 1] = k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sa = (sm[0] + sm[2]) + (sm[4] + sm[6]), sk = (sm[1] + sm[3]) + (sm[5] + sm[7]);
+        const float lpm = (float)(sa / (double)B);       // the reference's log-likelihood term is a float32 scalar
+        const double klm = sk / (double)B;
+        logp[0] = lpm;
+        kld[0] = klm;
+        elbo[0] = (double)lpm - klm;
+    }
+}
+// g_lp[b] = (g_elbo + g_logp) / B,  g_kl[b] = (g_kld - g_elbo) / B   (NULL upstream gradients count as zero)
+static __global__ void elbo_reduce_bwd_kernel(const double* __restrict__ g_elbo, const float* __restrict__ g_logp,
+                                              const double* __restrict__ g_kld, int B, float* __restrict__ g_lp,
+                                              float* __restrict__ g_kl) {
+    const double ge = g_elbo ? g_elbo[0] : 0.0, gl = g_logp ? (double)g_logp[0] : 0.0, gk = g_kld ? g_kld[0] : 0.0;
+    const float a = (float)((ge + gl) / (double)B), k = (float)((gk - ge) / (double)B);
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        g_lp[b] = a;
+        g_kl[b] = k;
     }
 }
 

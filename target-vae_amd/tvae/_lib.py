@@ -62,6 +62,8 @@ SIGNATURES = {
     'tvae_fourier_bwd': 'pppfplilp',
     'tvae_loglik_fwd': 'pppiii',
     'tvae_loglik_bwd': 'ppppiii',
+    'tvae_elbo_reduce': 'ppippp',
+    'tvae_elbo_reduce_bwd': 'pppipp',
     'tvae_ctf_corr': 'pppiiii',
     'tvae_loglik_masked_fwd': 'pppffiip',
     'tvae_loglik_masked_bwd': 'pppffiipp',
@@ -191,6 +193,9 @@ def query(name, *args) -> int:
     return int(getattr(lib(), name)(*[int(a) for a in args]))
 
 
+_F64_OK = {'tvae_elbo_reduce', 'tvae_elbo_reduce_bwd'}      # entry points with float64 scalars (the reference's ELBO / KL dtype)
+
+
 def _ptr(t, name, pos):
     if t is None:
         return None
@@ -198,7 +203,7 @@ def _ptr(t, name, pos):
         raise TvaeHipError(f'{name} arg {pos}: expected a tensor or None, got {type(t)}')
     if not t.is_cuda:
         raise TvaeHipError(f'{name} arg {pos}: tensor must live on the GPU (no CPU fallback)')
-    if t.dtype not in (torch.float32, torch.int32):
+    if t.dtype not in (torch.float32, torch.int32) and not (t.dtype == torch.float64 and name in _F64_OK):
         raise TvaeHipError(f'{name} arg {pos}: dtype {t.dtype} not supported (fp32 / int32 only)')
     if not t.is_contiguous():
         raise TvaeHipError(f'{name} arg {pos}: tensor must be contiguous')

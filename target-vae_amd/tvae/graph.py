@@ -28,7 +28,7 @@ class GraphedStep:
         self.E = torch.ones(self.B, self.rp, dtype=torch.float32, device=dev)
         self.ez = torch.zeros(self.B, self.zd, dtype=torch.float32, device=dev)
         self.et = torch.zeros(self.B, dtype=torch.float32, device=dev)
-        optim._early_n = 0                 # no collective from inside a captured backward: step() reduces everything
+        optim.disable_early_bucket()       # no collective from inside a captured backward: step() reduces everything
         _step.pixel_spacing(x_coord)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -44,15 +44,30 @@ class GraphedStep:
         # the graph now holds raw pointers into the scratch buffers of tvae.ops: from here on an outgrown buffer is kept
         # alive instead of freed (a larger eager batch later must not hand the graph's blocks back to the allocator)
         from . import ops as _ops
-        _ops.pin_scratch()
+        self._pin = _ops.pin_scratch()
         optim.flat_g.zero_()
+
+    def close(self) -> None:
+        """Drop the graph and release the scratch blocks that were only kept alive for its raw pointers (the
+        pinned list used to be process-global and grew for ever)."""
+        self.graph = None
+        if getattr(self, '_pin', None) is not None:
+            from . import ops as _ops
+            _ops.unpin_scratch(self._pin)
+            self._pin = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _fwd_bwd(self):
         self.opt.flat_g.zero_()
         for p, gv in zip(self.opt._ps, self.opt._gviews):
             p.grad = gv
         elbo, log_p, kl = _step.elbo_terms(self.x, self.y, self.gen, self.enc, self.lik, (self.E, self.ez, self.et))
-        (-elbo).backward()
+        _step.backward_neg_elbo(elbo)
         return torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()])
 
     def draw_noise(self, generator=None):

@@ -149,19 +149,26 @@ _TABLES = {}
 # writes into it on every replay (a later, larger eager batch -- an uneven shard, a test set larger than the captured
 # minibatch -- would trigger exactly that: ADVICE r03).  Once pinned, outgrown buffers are kept alive instead of freed: the
 # graph keeps its blocks, eager calls get the new, larger ones.
-_PINNED = None
+_PINNED = {}             # pin token -> outgrown buffers kept alive for that graph
 
 
-def pin_scratch() -> None:
-    global _PINNED
-    if _PINNED is None:
-        _PINNED = []
+def pin_scratch() -> int:
+    """Called after a capture: returns a token; until `unpin_scratch(token)` every scratch buffer that is outgrown is kept
+    alive (the graph holds raw pointers into the blocks that existed at capture time)."""
+    tok = (max(_PINNED) + 1) if _PINNED else 1
+    _PINNED[tok] = []
+    return tok
+
+
+def unpin_scratch(token: int) -> None:
+    _PINNED.pop(token, None)
 
 
 def _replace_ws(key, new):
     old = _WS.get(key)
-    if old is not None and _PINNED is not None:
-        _PINNED.append(old)
+    if old is not None:
+        for lst in _PINNED.values():
+            lst.append(old)
     _WS[key] = new
 
 
@@ -333,7 +340,7 @@ FUSE_NO_H = os.environ.get('TVAE_FUSE_NO_H', '1') != '0'
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
-    """Frequency-domain lifting convolution (DFT + batched split-pipe GEMM): 7x fewer matrix FLOPs than the direct
+    """Frequency-domain lifting convolution (DFT along x + batched split-pipe GEMM): 13x fewer matrix FLOPs than the direct
     form; same arithmetic mode as 'x6' (TVAE_CONV_DFT=0 keeps the direct x6 kernels)."""
     return CONV_DFT and split_pipe() and bool(query('tvae_conv1_dft_supported', B, Cin, n, k, pad, C, R))
 
@@ -760,6 +767,9 @@ class HeadFn(torch.autograd.Function):
              tb.P, zd, tb.sigma_p, tb.theta_off_scale, attn, q, a, z, th, dx, kl, part, part.numel())
         ctx.save_for_backward(heads, q, a, eps_z, eps_t)
         ctx.tb, ctx.B, ctx.zd = tb, B, zd
+        # outputs nothing differentiates (attn, q_t_r, a_sampled in the training step) reach backward as None, not as three
+        # zero-filled [B][R P] tensors
+        ctx.set_materialize_grads(False)
         return attn, q, a, z, th, dx, kl
 
     @staticmethod
@@ -1117,6 +1127,39 @@ class LogLikFn(torch.autograd.Function):
         gyh = torch.empty_like(yh)
         call('tvae_loglik_bwd', yh, y, g.contiguous(), gyh, B, L, ctx.kind)
         return gyh.view(ctx.shape), None, None
+
+
+class ElboFn(torch.autograd.Function):
+    """(elbo f64, log_p f32, kl f64) of a minibatch from the per-image terms lp [B], kl [B] (train_mnist.py:282,291-292:
+    log_p = lp.mean(), kl_div = kl.double().mean(), elbo = log_p - kl_div) -- one launch forward, one backward, instead of a
+    dozen ATen launches for two means, a cast, a subtraction and their chain rules."""
+
+    @staticmethod
+    def forward(ctx, lp, kl):
+        B = lp.shape[0]
+        _expect(lp.dim() == 1 and tuple(kl.shape) == (B,) and B >= 1, 'per-image ELBO terms must be [B] vectors')
+        dev_ = lp.device
+        elbo = torch.empty((), dtype=torch.float64, device=dev_)
+        logp = torch.empty((), dtype=torch.float32, device=dev_)
+        kld = torch.empty((), dtype=torch.float64, device=dev_)
+        call('tvae_elbo_reduce', lp.contiguous(), kl.contiguous(), B, elbo, logp, kld)
+        ctx.B = B
+        ctx.set_materialize_grads(False)
+        return elbo, logp, kld
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_logp, g_kld):
+        B = ctx.B
+        ref = next(g for g in (g_elbo, g_logp, g_kld) if g is not None)
+        g_lp = torch.empty(B, dtype=torch.float32, device=ref.device)
+        g_kl = torch.empty(B, dtype=torch.float32, device=ref.device)
+
+        def as_(g, dt):
+            return None if g is None else g.to(dt).contiguous()
+
+        call('tvae_elbo_reduce_bwd', as_(g_elbo, torch.float64), as_(g_logp, torch.float32), as_(g_kld, torch.float64), B, g_lp,
+             g_kl)
+        return g_lp, g_kl
 
 
 class CtfFn(torch.autograd.Function):

@@ -19,6 +19,16 @@ ALIGN = 64      # floats
 
 
 class FlatAdam(torch.optim.Optimizer):
+    """Adam over one flat parameter / gradient buffer (module docstring).
+
+    Contract with a data-parallel reducer that posts an early bucket (`early_params`, two-bucket all-reduce): exactly ONE
+    backward per `step()`.  The hook of the early parameters posts the all-reduce of their segment from inside that backward;
+    a second backward before `step()` (gradient accumulation, a probe backward) would add into a buffer the collective is
+    reducing, so it raises RuntimeError instead (tests/test_host_cpu.py::test_flat_adam_second_backward_raises).
+    `TVAE_DP_EARLY=0` restores the single collective at `step()`, under which any number of backwards accumulate as with
+    torch.optim.Adam.  `disable_early_bucket()` (tvae/graph.py: a captured backward must not post collectives) switches the
+    hooks off for good."""
+
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, update_fn=None, early_params=None):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -64,7 +74,16 @@ class FlatAdam(torch.optim.Optimizer):
             for p in self._ps[:self._early_n]:
                 p.register_post_accumulate_grad_hook(self._early_hook)
 
+    def disable_early_bucket(self) -> None:
+        """No collective from inside the backward any more: step() reduces the whole buffer (the hooks stay registered but
+        return at once, so nothing drifts: ADVICE r04)."""
+        self._early_n = 0
+        self._early_seen = 0
+        self._early_posted = False
+
     def _early_hook(self, _p):
+        if self._early_n == 0:
+            return
         # Contract: ONE backward per optimizer step.  Once the early segment has been posted, the collective is reading and
         # writing flat_g[:early_end] on its own stream; a second backward before step() (gradient accumulation, a probe)
         # would accumulate into it underneath the all-reduce and produce wrong gradients without an error (ADVICE r03).

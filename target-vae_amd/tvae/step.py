@@ -82,13 +82,27 @@ def elbo_terms(x, y, generator_model, encoder_model, likelihood='bce', noise=Non
             lp = ops.LogLikFn.apply(y_mu, y, ops.LIK_KIND['gauss'])
     else:
         lp = ops.LogLikFn.apply(y_hat, y, ops.LIK_KIND[likelihood])
-    log_p = lp.mean()                       # mean over the batch (train_mnist.py:291: BCE mean * size)
-    kl_div = kl_b.double().mean()           # float64 like the reference (its prior grid is float64)
-    elbo = log_p - kl_div
+    # log_p = lp.mean() (float32: train_mnist.py:291), kl_div = kl_b.double().mean() (float64 like the reference, whose prior
+    # grid is float64), elbo = log_p - kl_div -- one launch (ops.ElboFn)
+    elbo, log_p, kl_div = ops.ElboFn.apply(lp, kl_b)
     if return_aux:
         return elbo, log_p, kl_div, dict(attn=attn, q_t_r=q, a_sampled=a, z=z, theta=theta, dx=dx, x_rot=xr,
                                          y_hat=y_hat, kl_per_image=kl_b, heads=heads)
     return elbo, log_p, kl_div
+
+
+_NEG_ONE = {}
+
+
+def backward_neg_elbo(elbo: torch.Tensor) -> None:
+    """`(-elbo).backward()` of the reference's training loop (train_mnist.py:320-321: loss = -elbo; loss.backward()) without
+    the negation, its backward and the ones-fill: the seed gradient d(-elbo)/d(elbo) = -1 is a cached constant."""
+    key = (elbo.device.type, elbo.device.index, elbo.dtype)
+    g = _NEG_ONE.get(key)
+    if g is None:
+        g = torch.full((), -1.0, dtype=elbo.dtype, device=elbo.device)
+        _NEG_ONE[key] = g
+    elbo.backward(gradient=g)
 
 
 def _check_branch(t_inf, r_inf):
@@ -164,7 +178,7 @@ def train_epoch(iterator, x_coord, generator_model, encoder_model, optim, t_inf,
             else:
                 elbo, log_p, kl = eval_minibatch(x_coord, y, generator_model, encoder_model, t_inf, r_inf, epoch, device,
                                                  theta_prior, groupconv, image_dim, likelihood, noise)
-            (-elbo).backward()
+            backward_neg_elbo(elbo)
             optim.step()
             optim.zero_grad(set_to_none=True)
             stats = torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()]).tolist()

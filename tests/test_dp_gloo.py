@@ -31,11 +31,11 @@ def _make_params():
     return gen, enc
 
 
-def _data_and_noise():
+def _data_and_noise(n_img=N_IMG):
     g = torch.Generator().manual_seed(11)
-    data = torch.rand(N_IMG, 1, NPIX, NPIX, generator=g)
-    E = torch.empty(N_IMG, 4 * HO * HO).exponential_(generator=g)
-    return data, E, torch.randn(N_IMG, ZD, generator=g), torch.randn(N_IMG, generator=g)
+    data = torch.rand(n_img, 1, NPIX, NPIX, generator=g)
+    E = torch.empty(n_img, 4 * HO * HO).exponential_(generator=g)
+    return data, E, torch.randn(n_img, ZD, generator=g), torch.randn(n_img, generator=g)
 
 
 def _torch_adam(p, g, m, v, step, lr, b1, b2, eps, scale):
@@ -43,7 +43,7 @@ def _torch_adam(p, g, m, v, step, lr, b1, b2, eps, scale):
     O.adam_update([p], [g * scale], [m], [v], step, lr, b1, b2, eps)
 
 
-def _train(rank, world, epochs=2):
+def _train(rank, world, epochs=2, N_IMG=N_IMG, GB=GB):
     from oracle import tvae_oracle as O
     from tvae import dp, optim
     gen, enc = _make_params()
@@ -51,7 +51,7 @@ def _train(rank, world, epochs=2):
     reducer = dp.GradReducer() if world > 1 else None
     opt = optim.FlatAdam(params, lr=1e-2, reducer=reducer, update_fn=_torch_adam,
                           early_params=len(list(gen.parameters())))
-    data, E, ez, et = _data_and_noise()
+    data, E, ez, et = _data_and_noise(N_IMG)
     x = O.image_coords(NPIX)
     batches = dp.ShardedBatches(data, GB, rank, world, shuffle=True, seed=5, reducer=reducer)
     stats = [0.0, 0.0]
@@ -61,6 +61,10 @@ def _train(rank, world, epochs=2):
         for (y,), (lo, hi, g) in zip(batches, dp.shard_slices(N_IMG, GB, rank, world)):
             idx = perm[lo:hi]
             assert torch.equal(y, data[idx])
+            if hi == lo:        # no image of this global minibatch on this rank: still in both collectives, weight 0 (tvae/step.py)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                continue
             encp = dict(enc.named_parameters())
             genp = dict(gen.named_parameters())
             elbo, _, _ = O.elbo_step(x, y, encp, genp, likelihood='bce', E=E[idx], eps_z=ez[idx],
@@ -78,7 +82,7 @@ def _train(rank, world, epochs=2):
     return named, stats
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, kw=None):
     for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -88,7 +92,7 @@ def _worker(rank, world, port, out_dir):
     from tvae import dp
     r, w, _ = dp.init_from_env(backend='gloo')
     assert (r, w) == (rank, world)
-    flat, stats = _train(rank, world)
+    flat, stats = _train(rank, world, **(kw or {}))
     torch.save(dict(flat=flat, stats=stats), os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
@@ -115,6 +119,30 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert rel_err(r0['flat'][k_], flat1[k_]) < 2e-4, k_          # == the single-process global-batch run
     assert r0['stats'][1] == stats1[1] == 2 * N_IMG
     assert abs(r0['stats'][0] - stats1[0]) / abs(stats1[0]) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_gloo_reference_minibatch_matches_single_process(tmp_path):
+    """EIGHT ranks (the node the north star names) over gloo with the reference's default minibatch of
+    100 images (train_mnist.py:426): every global minibatch splits 13 / 12 over the ranks, the ragged tail (205 = 2 x 100 + 5
+    images) leaves three ranks with NO image -- they still join both buckets of the all-reduce with weight 0 and take the
+    same Adam step -- and all eight replicas must stay bit-identical and equal the single process on the global batches."""
+    kw = dict(epochs=1, N_IMG=205, GB=100)
+    torch.set_num_threads(4)
+    flat1, stats1 = _train(0, 1, **kw)
+    from tvae import dp
+    sizes = [[hi - lo for lo, hi, _ in dp.shard_slices(205, 100, r, 8)] for r in range(8)]
+    assert sorted(s_[0] for s_ in sizes) == [12] * 4 + [13] * 4 and [s_[2] for s_ in sizes].count(0) == 3
+    mp.spawn(_worker, args=(8, _free_port(), str(tmp_path), kw), nprocs=8, join=True)
+    rs = [torch.load(tmp_path / f'rank{r}.pt') for r in range(8)]
+    for k_ in flat1:
+        for r in range(1, 8):
+            assert torch.equal(rs[0]['flat'][k_], rs[r]['flat'][k_]), (k_, r)
+        if k_ == 'e.conv_a.bias':
+            continue
+        assert rel_err(rs[0]['flat'][k_], flat1[k_]) < 2e-4, k_
+    assert rs[0]['stats'][1] == stats1[1] == 205
+    assert abs(rs[0]['stats'][0] - stats1[0]) / abs(stats1[0]) < 1e-5
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -382,31 +382,70 @@ def test_shape_validation_happens_before_any_launch():
 
 def test_scratch_buffers_outlive_a_captured_graph():
     """once a hipGraph has been captured (tvae/graph.py -> ops.pin_scratch), growing a scratch buffer
-    or the shared workspace must not free the block the graph still points to."""
+    or the shared workspace must not free the block the graph still points to.  ADVICE r04: the pin belongs to the graph
+    (a token), and releasing it (GraphedStep.close) lets the outgrown blocks go."""
     import torch
     from tvae import ops
     cpu = torch.device('cpu')
-    saved = dict(ops._WS), ops._PINNED
+    saved = dict(ops._WS), dict(ops._PINNED)
     try:
         ops._WS.clear()
-        ops._PINNED = None
+        ops._PINNED.clear()
         a = ops._scratch(cpu, 'k', 16)
         w = ops.workspace(cpu, 8)
         ops._scratch(cpu, 'k', 32)                       # before pinning: plain replacement
-        assert ops._PINNED is None
+        assert not ops._PINNED
         b = ops._scratch(cpu, 'k', 32)
-        ops.pin_scratch()
+        tok = ops.pin_scratch()
         c = ops._scratch(cpu, 'k', 64)
         w2 = ops.workspace(cpu, 64)
         assert c.numel() >= 64 and w2.numel() == 64
-        kept = {t.data_ptr() for t in ops._PINNED}
+        kept = {t.data_ptr() for t in ops._PINNED[tok]}
         assert b.data_ptr() in kept and w.data_ptr() in kept and a.data_ptr() not in kept
         assert ops._scratch(cpu, 'k', 8) is c            # no growth: same buffer, nothing new pinned
-        assert len(ops._PINNED) == 2
+        assert len(ops._PINNED[tok]) == 2
+        tok2 = ops.pin_scratch()                         # a second graph: both keep what is outgrown from now on
+        ops._scratch(cpu, 'k', 128)
+        assert len(ops._PINNED[tok]) == 3 and len(ops._PINNED[tok2]) == 1
+        ops.unpin_scratch(tok)
+        assert tok not in ops._PINNED and tok2 in ops._PINNED
+        ops.unpin_scratch(tok2)
+        assert not ops._PINNED
     finally:
         ops._WS.clear()
         ops._WS.update(saved[0])
-        ops._PINNED = saved[1]
+        ops._PINNED.clear()
+        ops._PINNED.update(saved[1])
+
+
+def test_flat_adam_second_backward_raises():
+    """with the two-bucket reducer active exactly one backward per step() is supported -- a second one reaching the
+    early bucket after it was posted raises; after disable_early_bucket() (captured-graph path) the hooks are inert."""
+    import pytest
+    from tvae import optim
+
+    class Reducer:
+        active = True
+
+        def begin(self, seg):
+            pass
+
+        def __call__(self, flat_g, start=0):
+            return 1.0
+
+    ps = [torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(2))]
+    opt = optim.FlatAdam(ps, lr=1e-2, update_fn=lambda *a: None, reducer=Reducer(), early_params=1)
+    opt.zero_grad(set_to_none=True)
+    sum((p ** 2).sum() for p in ps).backward()
+    with pytest.raises(RuntimeError, match='second backward'):
+        sum((p ** 2).sum() for p in ps).backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    opt.disable_early_bucket()
+    for _ in range(2):                                   # hooks inert: gradient accumulation is allowed again
+        sum((p ** 2).sum() for p in ps).backward()
+    assert opt._early_seen == 0 and not opt._early_posted
+    opt.step()
 
 
 def test_hand_counted_kernels_use_no_scratch_and_no_packed_fp32():
