@@ -177,6 +177,11 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
  *     rs_dwo[m] = rs_rowdot[m] + rs_bias[m] * sum_n gy[n] act'(H[m][n]),   rs_rowdot[m] = sum_k W[m][k] G[m][k]
  * (G = this layer's weight gradient before its row factor wo[m]: tvae_linear_wgrad_x6 rd_rowdot, which must run first;
  * rs_bias = the layer's bias or NULL).  Requires vg_csum, rs_part .. rs_dwo, N % 32 == 0. */
+/* ABI 6: with rs_db = rs_dwo = NULL tvae_linear_dgrad_x6 leaves only the per-tile partial sums in rs_part; the caller totals
+ * them with tvae_dgrad_rowsum_total (ntiles = N / 128; rs_rowdot / rs_bias as above, NULL for the form that summed H itself) --
+ * on another stream if it likes: the totals are the only part of the data-gradient launch that waits for the weight gradient. */
+int tvae_dgrad_rowsum_total(const float* rs_part, int ntiles, int M, const float* rs_wo, const float* rs_gysum, float slope,
+                            float* rs_db, float* rs_dwo, const float* rs_rowdot, const float* rs_bias, tvae_stream_t stream);
 /* Row sums of the streamed activation (ABI 3; two-valued form only, i.e. vg_csum given; M <= 512): with rs_part
  * [M][N/128][2] (workspace), rs_wo [M] (the single-output Linear's weight, src/models.py:121-123), rs_gysum [1] = sum_n
  * vg_gy[n], the launch also returns rs_db [M] = wo[m] sum_n gy[n] act'(H[m][n]) (bias gradient of the layer that produced

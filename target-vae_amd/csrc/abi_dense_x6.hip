@@ -250,11 +250,13 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
     } else if (!dX) {
         return (int)hipErrorInvalidValue;
     }
-    if (vg_bits && !(vg_csum && rs_part && rs_rowdot && N % 32 == 0))     // the bits form: two-valued, with its row sums and
-        return (int)hipErrorInvalidValue;                                // dWo from the weight-gradient identity
+    if (vg_bits && !(vg_csum && rs_part && (rs_rowdot || !rs_db) && N % 32 == 0))     // the bits form: two-valued, with its row sums
+        return (int)hipErrorInvalidValue;                                // and dWo from the weight-gradient identity
     if (rs_rowdot && !vg_bits) return (int)hipErrorInvalidValue;
     if (rs_part) {       // row sums of the streamed activation (two-valued form only; M = rows of H <= 512)
-        if (!vg_csum || !vg_gy || !rs_wo || !rs_gysum || !rs_db || !rs_dwo || M > DX6_ROWS || N % 128 != 0 ||
+        // (rs_db == rs_dwo == NULL: partial sums only -- the caller totals them later with tvae_dgrad_rowsum_total, e.g. on the
+        //  stream that also runs the weight gradient whose rd_rowdot the totals need: tvae/ops.py side stream)
+        if (!vg_csum || !vg_gy || !rs_wo || !rs_gysum || (!rs_db != !rs_dwo) || M > DX6_ROWS || N % 128 != 0 ||
             rs_part_floats < (long)(N / 128) * M * 2 || (reinterpret_cast<size_t>(rs_part) & 7))
             return (int)hipErrorInvalidValue;
     }
@@ -262,9 +264,19 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                              InTail{in_xr, in_wc, in_gxr, in_part, in_bc, in_lb, in_np > 0 ? in_np : 1},
                              VirtGrad{vg_wo, vg_gy, mask, slope, vg_csum, (const unsigned*)vg_bits, rs_part, 0},
                              VirtAct{nullptr, nullptr, nullptr, nullptr, 1, 0, 0.f}, x_amax);
-    if (rc || !rs_part || N <= 0 || K <= 0) return rc;
+    if (rc || !rs_part || !rs_db || N <= 0 || K <= 0) return rc;
     hipLaunchKernelGGL(dgrad_rowsum_total_kernel, dim3(M), dim3(256), 0, S(stream), (const float*)rs_part, N / 128, M, rs_wo,
                        rs_gysum, slope, rs_db, rs_dwo, rs_rowdot, rs_bias);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+// The totals of tvae_linear_dgrad_x6's row sums as an entry point of their own (ABI 6): rs_part [M][ntiles][2] as that launch
+// left it (called with rs_db = rs_dwo = NULL), everything else as there.  from_bits != 0: the bits form (dwo from rs_rowdot).
+int tvae_dgrad_rowsum_total(const float* rs_part, int ntiles, int M, const float* rs_wo, const float* rs_gysum, float slope,
+                            float* rs_db, float* rs_dwo, const float* rs_rowdot, const float* rs_bias, tvae_stream_t stream) {
+    if (!rs_part || !rs_wo || !rs_gysum || !rs_db || !rs_dwo || ntiles <= 0 || M <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dgrad_rowsum_total_kernel, dim3(M), dim3(256), 0, S(stream), rs_part, ntiles, M, rs_wo, rs_gysum, slope,
+                       rs_db, rs_dwo, rs_rowdot, rs_bias);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -32,6 +32,7 @@ SIGNATURES = {
     'tvae_linear_fwd_x6': 'pppppiiillifpppppppipip',
     'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppipppp',
     'tvae_dec_in_total': 'piiippp',
+    'tvae_dgrad_rowsum_total': 'piippfpppp',
     'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplppp',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',

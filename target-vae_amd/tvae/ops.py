@@ -41,6 +41,42 @@ def act_code(activation) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# side stream of the backward (round 5): the decoder's hidden-layer weight gradient produces parameter gradients only -- nothing
+# in the backward reads them before the optimizer -- so it is issued on a second stream and runs under the encoder's backward
+# (HBM-bound transforms, the frequency-domain convolution).  Everything it reads is kept alive until the join (the caching
+# allocator would otherwise hand a freed block to the next main-stream allocation while the side kernel still reads it), and
+# it has its own split-K workspace.  `join_side()` runs as an autograd-engine callback at the end of the backward pass that
+# issued side work, and before that wherever gradients are consumed mid-pass (tvae/optim.py: _gather, i.e. the early
+# all-reduce bucket).  Nothing is issued on the side stream while a hipGraph is being captured.
+# ---------------------------------------------------------------------------------------------
+# MEASURED (round 5, same box, two runs each): 9.49 / 9.55 ms per step overlapped against 9.53 / 9.57 serial -- nothing: the two
+# streams do run concurrently (kernel time per step 11.2 ms inside a 9.55 ms span) but slow each other down by what they gain;
+# the weight gradient holds 130 KB of LDS and two 256-register waves per SIMD, so no other workgroup fits beside it on a CU
+# and the overlap is a partition of the CUs, not a use of idle issue slots.  Correct (bitwise the serial gradients:
+# tests/test_bench_size_oracle.py::test_side_stream_backward_is_bitwise_the_serial_backward), therefore kept, but OFF by
+# default: TVAE_OVERLAP=1 switches it on.
+OVERLAP = os.environ.get('TVAE_OVERLAP', '0') == '1'
+_SIDE = {}
+_SIDE_PENDING = []       # (event recorded on the side stream, device, tensors kept alive until the join)
+
+
+def side_stream(device):
+    k = (device.type, device.index)
+    s_ = _SIDE.get(k)
+    if s_ is None:
+        s_ = torch.cuda.Stream(device=device)
+        _SIDE[k] = s_
+    return s_
+
+
+def join_side() -> None:
+    """The current stream waits for every piece of work issued on a side stream since the last join."""
+    while _SIDE_PENDING:
+        ev, device, _keep = _SIDE_PENDING.pop()
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
+# ---------------------------------------------------------------------------------------------
 # optional in-run kernel timing (bench.py): events are recorded on the stream the kernels are launched on
 # ---------------------------------------------------------------------------------------------
 KERNEL_EVENTS = None     # set to {} to record (start, end) torch.cuda.Event pairs per entry point
@@ -178,13 +214,13 @@ def _replace_ws(key, new):
 POISON_WS = os.environ.get('TVAE_POISON_WS', '0') == '1'
 
 
-def workspace(device, floats: int) -> torch.Tensor:
+def workspace(device, floats: int, key: str = '') -> torch.Tensor:
     """Split-K scratch (grown on demand, reused across calls on the same stream).  The caller gets a view of EXACTLY the
     size it asked for: several entry points cap their number of reduction slices by the workspace they are handed, so
     passing "whatever the shared buffer has grown to" would make the summation order of a step depend on which other call
     had run before it (the first step of a process differed from every later one by 2e-7 on one tensor: round 3)."""
-    key = (device.type, device.index)
-    t = _WS.get(key)
+    key = (device.type, device.index) if not key else ('ws_' + key, device.type, device.index)      # key: a second, independent
+    t = _WS.get(key)                                                                              # workspace (side stream)
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
         _replace_ws(key, t)
@@ -259,7 +295,7 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None):
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None, ws_key=''):
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only).
     bits: [H > 0] as stored sign bits (dpre may then be None).  rowdot_w = the layer's own weight [M][K]: also returns
@@ -268,7 +304,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
     dW = torch.empty(M, K, dtype=torch.float32, device=dev_)
     need = 64 * max(M, 128) * max(K, 128)
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
-        ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
+        ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24), ws_key)
         # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
         # ... or (round 4) against an operand from memory whose bound the caller supplies (x_amax), or two plain operands
         # from memory with both bounds (a_amax, x_amax)
@@ -1005,7 +1041,17 @@ class DecoderFn(torch.autograd.Function):
             xg_amax = None
             if parts() == 2 and use_vg and sbits is not None and va is None and li == 0 and ctx.h_bound is not None:
                 xg_amax = ctx.h_bound * _inf_norm(vg[1])
-            if from_bits:                                # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
+            # Round 5: the bits form's weight gradient on the side stream (its only consumer inside the backward, the totals of
+            # the row sums, moves there with it): issued AFTER the data gradient below
+            # (only when autograd will ADOPT the returned gradient tensors -- p.grad is None for the three parameters whose
+            #  gradients come from the side stream: with an existing .grad it would add them in place on the main stream the
+            #  moment this function returns, before the side stream has produced them)
+            side = (OVERLAP and from_bits and fuse_rs and act == ACT_LRELU and _dense_x6_ok(F_, Nt) and
+                    not torch.cuda.is_current_stream_capturing() and
+                    all(getattr(t_, 'grad', None) is None for t_ in (W, b, Wo)))
+            if side:
+                dW = rowdot = None
+            elif from_bits:                              # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
                 dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax)
             else:
                 dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits, x_amax=xg_amax), None
@@ -1037,8 +1083,27 @@ class DecoderFn(torch.autograd.Function):
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
                          bc if va else None, LB if va else None, Np if va else 0,
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
-                         tot[0] if rs else None, tot[1] if rs else None, p_d,
-                         sbits if from_bits else None, rowdot, b if from_bits else None)
+                         tot[0] if (rs and not side) else None, tot[1] if (rs and not side) else None, p_d,
+                         sbits if from_bits else None, rowdot, b if (from_bits and not side) else None)
+                if side:
+                    _note('dec.wgrad_side_stream')
+                    cur, ss = torch.cuda.current_stream(dev), side_stream(dev)
+                    ev0 = cur.record_event()             # everything the weight gradient and the totals read is complete here
+                    with torch.cuda.stream(ss):          # (dW / rowdot come from the side stream's pool: every later use of
+                        ss.wait_event(ev0)               #  that pool is ordered behind the next step's ev0, i.e. behind the
+                        dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax,      # gather)
+                                            ws_key='side')
+                        call('tvae_dgrad_rowsum_total', rs_part, Nt // 128, F_, vg[0], dbo, LRELU_SLOPE, tot[0], tot[1], rowdot, b)
+                        ev1 = ss.record_event()
+                    # kept alive until the join: what the side kernels READ and nothing else holds (sign bits, upstream gradient,
+                    # coordinates ..).  NOT the returned gradients (dW, the views of `tot`, dbo): an extra reference makes
+                    # autograd's AccumulateGrad CLONE them on the main stream -- before the side stream has written them --
+                    # instead of adopting the tensor; they stay alive through p.grad until the optimizer has gathered them.
+                    _SIDE_PENDING.append((ev1, dev, (rowdot, sbits, vg[1], va, xg_amax)))
+                    # whoever reads the gradients after this backward pass (plain autograd users included) finds them complete:
+                    # the engine runs the join on the backward's stream when the whole pass has finished (the early all-reduce
+                    # bucket, which fires in the middle of the pass, joins by itself: tvae/optim.py _gather)
+                    torch.autograd.Variable._execution_engine.queue_callback(join_side)
                 if two_val and li == 0 and n_hidden == 1 and has_f and parts() == 2:
                     # bound of the gradient this launch leaves in `dprev` (read again by the Fourier first layer's backward):
                     # |dX[k][n]| <= max |gy| * sum_m |wo[m] W[m][k]|
