@@ -34,7 +34,8 @@ ENTRY = {'conv1_fwd_img_kernel': 'tvae_conv1_fwd', 'conv1_wgrad_img_kernel': 'tv
          'dense_x6_plain4_kernel': 'tvae_spectral_fwd', 'dense_x6_xres_kernel': 'tvae_spectral_fwd',
          'dft_out_ring_kernel': 'tvae_dft_out', 'dft_dy_ring_kernel': 'tvae_dft_dy',
          'enc_tail_wgrad_x6_kernel': 'tvae_enc_tail_wgrad_x6', 'dft_dbank_kernel': 'tvae_dft_dbank',
-         'dft_spectra_kernel': 'tvae_dft_spectra',
+         'dft_spectra_kernel': 'tvae_dft_spectra', 'dft_spectra_x_kernel': 'tvae_dft_spectra', 'dft_dbank_x_kernel': 'tvae_dft_dbank',
+         'dft_dbank_mf_kernel': 'tvae_dft_dbank',
          'dense_wgrad_x6_dma_kernel<true': 'tvae_linear_wgrad_x6', 'dense_wgrad_x6_dma_kernel<false': 'tvae_spectral_wgrad', 'dense_wgrad_x6_wide_kernel': 'tvae_spectral_wgrad',
          'dft_out_mf_kernel': 'tvae_dft_out', 'dft_dy_mf_kernel': 'tvae_dft_dy',
          'dft_out_gen_kernel': 'tvae_dft_out', 'dft_dy_gen_kernel': 'tvae_dft_dy',
