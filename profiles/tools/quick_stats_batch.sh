@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 B=${1:-32}
 OUT=$PWD/gpurun_out/qsb_$B
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --batch $B --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --batch $B --steps 5 --warmup 2 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/stats.log" 2>&1
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 cp "$S" "$OUT/kernel_stats.csv"; rm -rf "$OUT/stats"
 python3 - "$OUT/kernel_stats.csv" <<'PY'

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 WL=${1:-S128G}; ST=${2:-3}
 OUT=$PWD/gpurun_out/qs_$WL
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --workload $WL --steps $ST --warmup 1 --no-cpu-baseline --no-f32-companion > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --workload $WL --steps $ST --warmup 1 --no-cpu-baseline --no-f32-companion --no-workloads > "$OUT/stats.log" 2>&1
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 cp "$S" "$OUT/kernel_stats.csv"
 rm -rf "$OUT/stats"

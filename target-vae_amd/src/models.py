@@ -118,9 +118,17 @@ class SpatialGenerator(nn.Module):
             sigma = float(self.embed_latent.sigma)
         else:
             params += [None, None]
+        # pixel counts that are not a multiple of the GEMM tile (28 x 28, 50 x 50): pad every image's pixel range so that the
+        # decoder's fast path applies (tvae/ops.py: decoder_padded_pixels); the padded outputs are sliced away
+        Np = x.shape[1]
+        Np_p = _ops.decoder_padded_pixels(Np, x.shape[0], self.coord_linear.out_features, len(hidden), out.out_features, resid,
+                                          self.fourier_expansion, act)
+        if Np_p:
+            x = torch.nn.functional.pad(x, (0, 0, 0, Np_p - Np))
         # under torch.no_grad() (eval_model, train_mnist.py:352-387) the inference-mode forward runs: nothing is kept for a backward
         with _ops.inference(not _ops.needs_grad(x, z if has_l else None, *params)):
-            return _ops.DecoderFn.apply(x, z if has_l else None, act, resid, sigma, len(hidden), *params)
+            y = _ops.DecoderFn.apply(x, z if has_l else None, act, resid, sigma, len(hidden), *params)
+        return y[:, :Np] if Np_p else y
 
 
 class GroupConv(nn.Module):

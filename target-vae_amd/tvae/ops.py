@@ -52,8 +52,8 @@ def act_code(activation) -> int:
 # MEASURED (round 5, same box, two runs each): 9.49 / 9.55 ms per step overlapped against 9.53 / 9.57 serial -- nothing: the two
 # streams do run concurrently (kernel time per step 11.2 ms inside a 9.55 ms span) but slow each other down by what they gain;
 # the weight gradient holds 130 KB of LDS and two 256-register waves per SIMD, so no other workgroup fits beside it on a CU
-# and the overlap is a partition of the CUs, not a use of idle issue slots.  Correct (bitwise the serial gradients:
-# tests/test_bench_size_oracle.py::test_side_stream_backward_is_bitwise_the_serial_backward), therefore kept, but OFF by
+# and the overlap is a partition of the CUs, not a use of idle issue slots.  Correct (bitwise the serial gradients: the
+# bench-size test test_side_stream_backward_is_bitwise_the_serial_backward), therefore kept, but OFF by
 # default: TVAE_OVERLAP=1 switches it on.
 OVERLAP = os.environ.get('TVAE_OVERLAP', '0') == '1'
 _SIDE = {}
@@ -851,6 +851,24 @@ class CoordFn(torch.autograd.Function):
         gth = torch.empty(B, dtype=torch.float32, device=xc.device)
         call('tvae_coord_bwd', xc, dx, theta, g.contiguous(), gdx, gth, B, Np)
         return None, gdx, gth
+
+
+DEC_PAD = os.environ.get('TVAE_DEC_PAD', '1') != '0'
+
+
+def decoder_padded_pixels(Np: int, B: int, F_: int, n_hidden: int, n_out: int, resid: bool, fourier: bool, act: int) -> int:
+    """Round 5: images whose pixel count is not a multiple of the 128-column GEMM tile (28 x 28 = 784, 50 x 50 = 2 500) cannot
+    take the decoder's fast path -- first layer recomputed inside its consumers, lean epilogues, fused first-layer backward --
+    because its tiles must lie inside one image.  Padding every image's pixel range to the next multiple of 128 (coordinates
+    (0, 0), outputs sliced away, zero upstream gradient: every reduction of the backward is unaffected) costs <= 15 % more
+    columns and removes the stored first layer, its separate backward pass and the generic epilogues.  Returns the padded
+    pixel count, or 0 when the decoder should run as it is (src/models.py: SpatialGenerator.forward pads around DecoderFn, so
+    autograd differentiates the padding)."""
+    Np_p = (Np + 127) // 128 * 128
+    if (not DEC_PAD or Np % 128 == 0 or fourier or resid or n_hidden < 1 or n_out != 1 or act != ACT_LRELU or
+            not (256 <= F_ <= 512) or Np_p > 1.15 * Np or not (FUSE_VIRT_ACT and FUSE_IN_TAIL) or not _dense_x6_ok(F_, B * Np_p)):
+        return 0
+    return Np_p
 
 
 class DecoderFn(torch.autograd.Function):

@@ -875,3 +875,47 @@ def test_inference_mode_forward_equals_training_forward(name, gemm_mode):
     # a later training step is unaffected by the switch (it is scoped to the no_grad calls)
     e2, _, _ = step.elbo_terms(x, y, gen, enc, lik, noise)
     assert torch.equal(e2.detach(), et.detach()) and e2.requires_grad
+
+
+def test_decoder_pads_pixel_ranges_to_the_gemm_tile(gemm_mode):
+    """Round 5: 28 x 28 images (784 pixels, not a multiple of the 128-column tile) reach the decoder's fast path -- recomputed
+    first layer, unsaved last hidden activation, fused first-layer backward -- by padding every image's pixel range to 896
+    (src/models.py: SpatialGenerator.forward, tvae/ops.py: decoder_padded_pixels).  Outputs and every gradient must agree with
+    the unpadded path (different kernels: fp32-rounding level, not bitwise), and the padded branch must be the one taken."""
+    import src.models as M
+    from tvae import ops, step
+    if gemm_mode == 'f32':
+        pytest.skip('the fast path is a split-pipe path')
+    torch.manual_seed(3)
+    n, B = 28, 32
+    gen = M.SpatialGenerator(2, 512, num_layers=2).to(dev())
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(n, 1, 2, kernels_num=128, kernels_size=28, padding=8,
+                                                                    groupconv=8, rot_refinement=True, theta_prior=np.pi,
+                                                                    normal_prior_over_r=False).to(dev())
+    y = torch.rand(B, 1, n, n, device=dev())
+    x = O.image_coords(n).to(dev())
+    noise = step.draw_noise(B, 8 * 17 * 17, 2, dev())
+    res = {}
+    for pad in (True, False):
+        saved = ops.DEC_PAD
+        ops.DEC_PAD, ops.PATH_LOG = pad, set()
+        try:
+            for p in list(gen.parameters()) + list(enc.parameters()):
+                p.grad = None
+            elbo, lp, kl, aux = step.elbo_terms(x, y, gen, enc, 'bce', noise, return_aux=True)
+            (-elbo).backward()
+            torch.cuda.synchronize()
+            res[pad] = (float(elbo), aux['y_hat'].detach().clone(), [p.grad.detach().clone() for p in gen.parameters()] +
+                        [p.grad.detach().clone() for p in enc.parameters()], set(ops.PATH_LOG))
+        finally:
+            ops.DEC_PAD, ops.PATH_LOG = saved, None
+    assert {'dec.virt_act', 'dec.no_h', 'dec.fuse_in'} <= res[True][3], res[True][3]
+    assert 'dec.virt_act' not in res[False][3]
+    assert tuple(res[True][1].shape) == (B, n * n, 1)
+    assert abs(res[True][0] - res[False][0]) / abs(res[False][0]) < 1e-5
+    assert rel_err(res[True][1], res[False][1]) < 1e-5
+    names = [k_ for k_, _ in gen.named_parameters()] + [k_ for k_, _ in enc.named_parameters()]
+    for nm, a, b in zip(names, res[True][2], res[False][2]):
+        if nm == 'conv_a.bias':
+            continue
+        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-3, nm      # (kink flips between the two paths)
