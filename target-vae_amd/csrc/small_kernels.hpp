@@ -411,7 +411,10 @@ static __global__ void fourier_bwd_kernel(const float* __restrict__ xr, const fl
         if (live)
             for (int q = 0; q < fe; ++q) {
                 const float w0 = wsm[q][0], w1 = wsm[q][1];
-                const float t = -sinf(x0 * w0 + x1 * w1 + wsm[q][2]) * dfeat[(long)(f0 + q) * ld + n];
+                // v_sin_f32 (arguments here stay below ~10^3 rad: inside the instruction's +-256-revolution domain; absolute
+                // error ~1e-6, far below the gradient's own rounding) instead of the ~40-instruction libm routine: this loop is
+                // F sines per pixel and was 0.58 ms of the 7.2 ms 28 x 28 Fourier step -- round 5
+                const float t = -__sinf(x0 * w0 + x1 * w1 + wsm[q][2]) * dfeat[(long)(f0 + q) * ld + n];
                 g0 += t * w0;
                 g1 += t * w1;
             }
