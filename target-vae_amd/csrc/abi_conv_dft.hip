@@ -322,6 +322,31 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             TVAE_CHECK_LAUNCH();
             return 0;
         }
+        static const bool wide_gen = !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0');
+        // large frames (galaxy shape): a workgroup per tile, its waves split the output rows (dft_out_wide_kernel); the single
+        // last column of Ho = 32 k + 1 outputs goes to the vector ALU instead of a whole wave
+        const int NTW = (q.Ho % 32 == 1 && q.NT > 1) ? q.NT - 1 : q.NT;
+        if (q.gen && wide_gen && q.Lh <= DFT_WIDE_LH && NTW <= 8 && q.REM1 == 0 && q.Lh * 16 <= 8 * 64 * NTW) {
+            const size_t lds_w = ((size_t)2 * q.Lh * 64 + (size_t)NTW * 32 * 33 + 2 * q.Lh) * 4;
+            if (lds_w <= 150 * 1024) {
+                const int cus = dev_cu_count();
+                const long fit = (long)(150 * 1024 / lds_w);
+                const long wg_per_cu = fit < 2 ? fit : 2;
+                const int grid = (int)(ntiles < wg_per_cu * cus ? ntiles : wg_per_cu * cus);
+#define TVAE_OUT_WIDE(LHR_, NLD_)                                                                                    \
+    do {                                                                                                            \
+        e = allow_big_lds(dft_out_wide_kernel<LHR_, NLD_>, lds_w);                                                  \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((dft_out_wide_kernel<LHR_, NLD_>), dim3(grid), dim3(64 * NTW), lds_w, st, (const float*)T, \
+                           (const float*)EO, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, q.NT, NTW, act, slope, a1max); \
+    } while (0)
+                const int nld = cdiv(16 * q.Lh, 64 * NTW);            // float4 pieces per thread and tile
+                if (q.Lh <= 82 && nld <= 6) TVAE_OUT_WIDE(82, 6); else TVAE_OUT_WIDE(DFT_WIDE_LH, 8);
+#undef TVAE_OUT_WIDE
+                TVAE_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (q.gen) {
             const int grid = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
 #define TVAE_OUT_GEN(N_)                                                                                            \
@@ -407,6 +432,25 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
             else TVAE_DY_RING(20, 3, 68, 39, false);
 #undef TVAE_DY_RING
 #undef TVAE_DY_RING_ONE
+            TVAE_CHECK_LAUNCH();
+        } else if (q.gen && !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0') && q.NS <= DFT_WIDE_NS &&
+                   q.NRT <= 8 && 32 * q.Ho <= 16 * 64 * q.NRT && (size_t)2 * (32 * (q.Ho | 1) + 1) * 4 <= 150 * 1024) {
+            // large frames (galaxy shape): a workgroup per tile, its waves split the rows of S' (dft_dy_wide_kernel)
+            const size_t lds_w = (size_t)2 * (32 * (q.Ho | 1) + 1) * 4;
+            const int cus = dev_cu_count();
+            const long fit = (long)(150 * 1024 / lds_w);
+            const long wg_per_cu = fit < 2 ? fit : 2;
+            const int gridw = (int)(ntiles < wg_per_cu * cus ? ntiles : wg_per_cu * cus);
+            hipError_t ew = hipSuccess;
+#define TVAE_DY_WIDE(NSR_)                                                                                           \
+    do {                                                                                                            \
+        ew = allow_big_lds(dft_dy_wide_kernel<NSR_>, lds_w);                                                        \
+        if (ew != hipSuccess) return (int)ew;                                                                       \
+        hipLaunchKernelGGL(dft_dy_wide_kernel<NSR_>, dim3(gridw), dim3(64 * q.NRT), lds_w, st, dpre, (const float*)ED, Sp, \
+                           q.M, R, B, q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, smax);                                      \
+    } while (0)
+            if (q.NS <= 50) TVAE_DY_WIDE(50); else if (q.NS <= 66) TVAE_DY_WIDE(66); else TVAE_DY_WIDE(DFT_WIDE_NS);
+#undef TVAE_DY_WIDE
             TVAE_CHECK_LAUNCH();
         } else if (q.gen) {
             const size_t lds_g = (size_t)4 * 32 * ((2 * q.NS) | 1) * 4;

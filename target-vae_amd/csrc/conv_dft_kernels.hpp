@@ -1086,6 +1086,245 @@ static __global__ __launch_bounds__(256) void dft_dy_gen_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: "wide" forms of the two generic transforms for LARGE frames (galaxy shape: L = 160, Lh = 81, Ho = 129), where the
+// kernels above are latency bound (0.6 / 1.0 TB/s: a dependent global load of the constant operand per matrix instruction,
+// integer divisions in a serial staging loop, one wave per tile).  Here a WORKGROUP owns a tile (filter row m, 32 columns) and
+// its waves split the OUTPUT rows: wave q holds the constant operand of ITS 32 output rows in registers for the whole kernel
+// (Ho / 2 resp. Lh values per lane) and all waves read the tile's streamed values from one shared LDS image, staged by all
+// threads together with coalesced loads one tile ahead (two slots, one barrier per tile).  Plain loads and __syncthreads:
+// nothing is hand counted.  Workgroups walk contiguous tile ranges (a filter row stays with a workgroup for many tiles).
+// ------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS only: __syncthreads() also drains the vector-memory counter, i.e. every tile would wait for
+// the acknowledgement of its own output stores
+__device__ __forceinline__ void dft_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int DFT_WIDE_NS = 80;        // k-steps (pairs of w) the dY form keeps in registers: Ho <= 160
+constexpr int DFT_WIDE_LH = 96;        // frequencies the out form keeps in registers: L <= 190
+
+// S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]; blockDim = 64 * NRT (wave rt = 32-row tile of (fx, ri) pairs).
+// LDS: two slots of 32 * PW + 1 floats, PW = Ho | 1 (odd pitch: conflict-free operand reads).  NSR >= NS: register array size.
+template <int NSR>
+static __global__ __launch_bounds__(512) void dft_dy_wide_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+                                                                 float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
+                                                                 long NBpad, int NS, int NRT, float* __restrict__ amax) {
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    const int lane = threadIdx.x & 63, j = lane & 31, kh = lane >> 5;
+    const int rt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int PW = Ho | 1, SLOT = 32 * PW + 1, nthr = blockDim.x;
+    float areg[NSR];
+#pragma unroll
+    for (int s_ = 0; s_ < NSR; ++s_) areg[s_] = s_ < NS ? ED[((long)s_ * NRT + rt) * 64 + lane] : 0.f;
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
+    const int P = Ho * Ho;
+    const long jump = (long)(R - 1) * P;
+    const long per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long t_beg = (long)blockIdx.x * per, t_end = min(ntiles, t_beg + per);
+    if (t_beg >= t_end) return;
+    constexpr int NLD = 16;                              // staged values per thread and tile (host: 32 Ho <= 16 * 64 NRT)
+    const int nel = 32 * Ho;
+    const int nld = (nel + nthr - 1) / nthr;             // ... of which this many are real (wave uniform)
+    float stage[NLD];
+    // element e = i * nthr + tid of a tile is the same (column, w) in every tile: its destination offset is computed ONCE (an
+    // integer division per element and tile in the staging code cost as many issue cycles as the tile's matrix instructions)
+    int dsto[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = i * nthr + (int)threadIdx.x;
+        dsto[i] = e + (e / Ho) * (PW - Ho);
+    }
+    auto tile_load = [&](long tile) {                    // the tile's 32 * Ho values into registers (zeros past the batch)
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const int c = m / R, r_ = m - c * R;
+        const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+        const float* base = dY + ((((long)c * B + b0) * R + r_) * P + (long)h0 * Ho);
+        const long cnt = n0 < NB ? (NB - n0 < 32 ? NB - n0 : 32) * Ho : 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (i < nld) {
+                const int e = i * nthr + (int)threadIdx.x;
+                float v = 0.f;
+                if (e < nel && e < cnt) {
+                    const int x = h0 * Ho + e;           // image boundaries before this element: at most one when Ho >= 32
+                    const int nb = Ho >= 32 ? (x >= P ? 1 : 0) : x / P;
+                    v = base[e + nb * jump];
+                }
+                stage[i] = v;
+            }
+        }
+    };
+    auto tile_put = [&](int slot) {
+        float* dst = sm_w + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (i < nld) {
+                const int e = i * nthr + (int)threadIdx.x;
+                if (e < nel) dst[dsto[i]] = stage[i];
+            }
+        }
+    };                                                   // (index 32 PW and the pad element of every column are never written)
+    // (the pad element of each column row -- w = Ho when Ho is even -- only ever meets a zero of the constant operand, but it
+    //  must be finite: zero the slots once)
+    for (int i = threadIdx.x; i < 2 * SLOT; i += nthr) sm_w[i] = 0.f;
+    __syncthreads();
+    tile_load(t_beg);
+    tile_put(0);
+    __syncthreads();
+    float mx = 0.f;
+    int m_prev = -1;
+    for (long tile = t_beg; tile < t_end; ++tile) {
+        const int slot = (int)((tile - t_beg) & 1);
+        if (tile + 1 < t_end) tile_load(tile + 1);       // in flight under this tile's matrix instructions
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const float* bs = sm_w + slot * SLOT + j * PW + kh;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NSR; s_ += 2) {            // two independent chains
+            if (s_ < NS) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_], bs[2 * s_], acc0, 0, 0, 0);
+            if (s_ + 1 < NS && s_ + 1 < NSR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_ + 1 < NSR ? s_ + 1 : s_], bs[2 * s_ + 2], acc1, 0, 0, 0);
+        }
+        if (m != m_prev && m_prev >= 0) h3_tile_flush_rd(mx, amax + m_prev, lane);
+        m_prev = m;
+        // the next tile into its slot BEFORE this tile's stores are issued: the wait for its loads then covers only operations
+        // older than them (slot ^ 1 was last read before the previous barrier)
+        if (tile + 1 < t_end) tile_put(slot ^ 1);
+        float* p0 = Sp + dft_t_off(n0 + j, m, 2 * M, Lh);
+        float* p1 = Sp + dft_t_off(n0 + j, M + m, 2 * M, Lh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                   // row kk = 2 fx + ri = 32 rt + (r & 3) + 8 (r >> 2) + 4 kh
+            const int kk = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int fx = kk >> 1;
+            const float v = acc0[r] + acc1[r];
+            if (fx < Lh) {
+                ((kk & 1) ? p1 : p0)[(long)fx * 128] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        }
+        dft_lds_barrier();
+    }
+    if (m_prev >= 0) h3_tile_flush_rd(mx, amax + m_prev, lane);
+}
+
+// out[c][b][r][h][w] = act(bias[c] + sum_k E[w][k] T[k][(m,n)]); blockDim = 64 * NTW: wave t = 32 output columns w on the
+// matrix pipe; with XROW (Ho = 32 NTW + 1: 129 at the galaxy shape) the single last column is a dot product on the vector ALU
+// of wave 0, its table row taken from tile NTW of EO (NT = NTW + 1 tiles were tabulated).
+// LDS: two slots of Lh * 64 floats ([fx][re | im][32 columns]: the B-operand order), one 32 x 33 patch per wave, Lh * 2 floats.
+template <int LHR, int NLD>
+static __global__ __launch_bounds__(512) void dft_out_wide_kernel(const float* __restrict__ T, const float* __restrict__ EO,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int M, int R, int B, int Ho, int Lh, long NBpad, int NT,
+                                                                  int NTW, int act, float slope, float* __restrict__ amax) {
+    extern __shared__ __attribute__((aligned(16))) float sm_w[];
+    const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
+    const int wt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int SLOT = Lh * 64, nthr = blockDim.x;
+    const bool xrow = NT > NTW;                          // one extra output column w = 32 NTW
+    float* patch = sm_w + 2 * SLOT + wt * (32 * 33);
+    float* ex = sm_w + 2 * SLOT + NTW * (32 * 33);       // [fx][ri]: E[w = 32 NTW][(fx, ri)]
+    float eo[LHR];
+#pragma unroll
+    for (int fx = 0; fx < LHR; ++fx) eo[fx] = fx < Lh ? EO[((long)fx * NT + wt) * 64 + lane] : 0.f;
+    if (xrow)
+        for (int i = threadIdx.x; i < 2 * Lh; i += nthr) ex[i] = EO[((long)(i >> 1) * NT + NTW) * 64 + (i & 1) * 32];
+    const long tiles_n = NBpad / 32, ntiles = (long)M * tiles_n, NB = (long)B * Ho;
+    const int P = Ho * Ho;
+    const long per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long t_beg = (long)blockIdx.x * per, t_end = min(ntiles, t_beg + per);
+    if (t_beg >= t_end) return;
+    // NLD float4 pieces per thread and tile (host: 16 Lh <= NLD * 64 NTW; a compile-time count keeps `stage` in registers)
+    const int npc = Lh * 16;                             // pieces of a tile: (fx, ri) rows x 8 float4
+    float4 stage[NLD];
+    auto tile_load = [&](long tile) __attribute__((always_inline)) {
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const float* t0 = T + dft_t_off(n0, m, 2 * M, Lh);
+        const float* t1 = T + dft_t_off(n0, M + m, 2 * M, Lh);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int pc = min(i * nthr + (int)threadIdx.x, npc - 1);        // (past the end: the last piece again)
+            const int q4 = pc & 7, rr = pc >> 3, fx = rr >> 1;
+            stage[i] = *reinterpret_cast<const float4*>(((rr & 1) ? t1 : t0) + (long)fx * 128 + 4 * q4);
+        }
+    };
+    auto tile_put = [&](int slot) __attribute__((always_inline)) {
+        float4* dst = reinterpret_cast<float4*>(sm_w + slot * SLOT);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int pc = i * nthr + (int)threadIdx.x;
+            if (pc < npc) dst[pc] = stage[i];            // piece pc = ((fx * 2 + ri) * 8 + q4): [fx][ri][32] floats, linear
+        }
+    };
+    tile_load(t_beg);
+    tile_put(0);
+    __syncthreads();
+    float amx = 0.f;
+    int c_prev = -1;
+    for (long tile = t_beg; tile < t_end; ++tile) {
+        const int slot = (int)((tile - t_beg) & 1);
+        if (tile + 1 < t_end) tile_load(tile + 1);
+        const int m = (int)(tile / tiles_n);
+        const long n0 = (tile - (long)m * tiles_n) * 32;
+        const float* vs = sm_w + slot * SLOT + lane;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int fx = 0; fx < LHR; fx += 2) {            // two independent chains
+            if (fx < Lh) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx], vs[fx * 64], acc0, 0, 0, 0);
+            if (fx + 1 < Lh && fx + 1 < LHR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx + 1 < LHR ? fx + 1 : fx], vs[(fx + 1) * 64], acc1, 0, 0, 0);
+        }
+        float racc = 0.f;
+        if (xrow && wt == 0) {                           // the single last column on the vector ALU (wave uniform)
+            for (int fx = 0; fx < Lh; ++fx) racc = __fmaf_rn(ex[2 * fx + ri], vs[fx * 64], racc);
+            racc += __shfl_xor(racc, 32, 64);
+        }
+        const int c = m / R, r_ = m - c * R;
+        if (c != c_prev && c_prev >= 0) h3_tile_flush_rd(amx, amax + c_prev, lane);
+        c_prev = c;
+        if (tile + 1 < t_end) tile_put(slot ^ 1);        // before this tile's output stores (see dft_dy_wide_kernel)
+        if (n0 < NB) {                                   // (a tile of pure padding columns has no outputs)
+            const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc0[r] + acc1[r] + bv;
+                if (act == ACT_LRELU) x = x > 0.f ? x : x * slope;
+                else if (act == ACT_TANH) x = tanhf(x);
+                patch[j * 33 + (r & 3) + 8 * (r >> 2) + 4 * ri] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int tmax = (int)(NB - n0 < 32 ? NB - n0 : 32);
+            const int wn = min(32, Ho - 32 * wt);        // valid output columns of this wave's tile
+            const int w = lane & 31;
+            const int b0 = (int)(n0 / Ho), h0 = (int)(n0 - (long)b0 * Ho);
+            float* obase = out + (((long)c * B + b0) * R + r_) * P + (long)h0 * Ho + 32 * wt + w;
+            const long jump = (long)(R - 1) * P;
+#pragma unroll 4
+            for (int col = lane >> 5; col < tmax; col += 2) {
+                if (w < wn) {
+                    const int nb = Ho >= 32 ? (h0 + col >= Ho ? 1 : 0) : (h0 + col) / Ho;      // image boundaries before this column
+                    const float sv = patch[col * 33 + w];
+                    amx = fmaxf(amx, fabsf(sv));
+                    obase[(long)col * Ho + nb * jump] = sv;
+                }
+            }
+            if (xrow && wt == 0 && ri == 0 && j < tmax) {
+                float x = racc + bv;
+                if (act == ACT_LRELU) x = x > 0.f ? x : x * slope;
+                else if (act == ACT_TANH) x = tanhf(x);
+                const int nb = Ho >= 32 ? (h0 + j >= Ho ? 1 : 0) : (h0 + j) / Ho;
+                amx = fmaxf(amx, fabsf(x));
+                out[(((long)c * B + b0) * R + r_) * P + (long)h0 * Ho + (long)j * Ho + nb * jump + 32 * NTW] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        dft_lds_barrier();
+    }
+    if (c_prev >= 0) h3_tile_flush_rd(amx, amax + c_prev, lane);
+}
+
 // Bias gradient of the lifting convolution for free: the fx = 0 real row of S' is sum_w dY[m][n][w], so
 // db[c] = sum_{r, n} S'[c*R + r][fx = 0][n]  (reads M*NB floats instead of a pass over dY).  Two stages: one workgroup per
 // filter row m (1 024 of them: the single-stage version had 128 workgroups walking 51 MB-strided runs), then R sums.
