@@ -327,7 +327,8 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         // last column of Ho = 32 k + 1 outputs goes to the vector ALU instead of a whole wave
         const int NTW = (q.Ho % 32 == 1 && q.NT > 1) ? q.NT - 1 : q.NT;
         if (q.gen && wide_gen && q.Lh <= DFT_WIDE_LH && NTW <= 8 && q.REM1 == 0 && q.Lh * 16 <= 8 * 64 * NTW) {
-            const size_t lds_w = ((size_t)2 * q.Lh * 64 + (size_t)NTW * 32 * 33 + 2 * q.Lh) * 4;
+            const int LHR = (q.Lh <= 82 && cdiv(16 * q.Lh, 64 * NTW) <= 6) ? 82 : DFT_WIDE_LH;      // the instance's padded slot
+            const size_t lds_w = ((size_t)2 * LHR * 64 + (size_t)NTW * 32 * 33 + 2 * q.Lh) * 4;
             if (lds_w <= 150 * 1024) {
                 const int cus = dev_cu_count();
                 const long fit = (long)(150 * 1024 / lds_w);
@@ -436,20 +437,23 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         } else if (q.gen && !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0') && q.NS <= DFT_WIDE_NS &&
                    q.NRT <= 8 && 32 * q.Ho <= 16 * 64 * q.NRT && (size_t)2 * (32 * (q.Ho | 1) + 1) * 4 <= 150 * 1024) {
             // large frames (galaxy shape): a workgroup per tile, its waves split the rows of S' (dft_dy_wide_kernel)
-            const size_t lds_w = (size_t)2 * (32 * (q.Ho | 1) + 1) * 4;
+            const int NSR = q.NS <= 50 ? 50 : (q.NS <= 66 ? 66 : DFT_WIDE_NS);      // the instance's padded slot
+            const size_t lds_w = (size_t)2 * (32 * (q.Ho | 1) + 2 * NSR + 2) * 4;
             const int cus = dev_cu_count();
             const long fit = (long)(150 * 1024 / lds_w);
             const long wg_per_cu = fit < 2 ? fit : 2;
             const int gridw = (int)(ntiles < wg_per_cu * cus ? ntiles : wg_per_cu * cus);
             hipError_t ew = hipSuccess;
-#define TVAE_DY_WIDE(NSR_)                                                                                           \
+#define TVAE_DY_WIDE(NSR_, NLD_, WPE_)                                                                               \
     do {                                                                                                            \
-        ew = allow_big_lds(dft_dy_wide_kernel<NSR_>, lds_w);                                                        \
+        ew = allow_big_lds(dft_dy_wide_kernel<NSR_, NLD_, WPE_>, lds_w);                                            \
         if (ew != hipSuccess) return (int)ew;                                                                       \
-        hipLaunchKernelGGL(dft_dy_wide_kernel<NSR_>, dim3(gridw), dim3(64 * q.NRT), lds_w, st, dpre, (const float*)ED, Sp, \
-                           q.M, R, B, q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, smax);                                      \
+        hipLaunchKernelGGL((dft_dy_wide_kernel<NSR_, NLD_, WPE_>), dim3(gridw), dim3(64 * q.NRT), lds_w, st, dpre,  \
+                           (const float*)ED, Sp, q.M, R, B, q.Ho, q.Lh, q.NBpad, q.NS, q.NRT, smax);                \
     } while (0)
-            if (q.NS <= 50) TVAE_DY_WIDE(50); else if (q.NS <= 66) TVAE_DY_WIDE(66); else TVAE_DY_WIDE(DFT_WIDE_NS);
+            // (an instance at three waves per SIMD -- two of the galaxy shape's six-wave workgroups per CU, 168 registers with 17
+            //  spilled -- measured 2.17 ms against 2.05 for this one)
+            if (q.NS <= 50) TVAE_DY_WIDE(50, 16, 2); else if (q.NS <= 66) TVAE_DY_WIDE(66, 16, 2); else TVAE_DY_WIDE(DFT_WIDE_NS, 16, 2);
 #undef TVAE_DY_WIDE
             TVAE_CHECK_LAUNCH();
         } else if (q.gen) {

@@ -1103,14 +1103,17 @@ constexpr int DFT_WIDE_LH = 96;        // frequencies the out form keeps in regi
 
 // S'[(fx,ri)][(m,n)] = sum_w E'[(fx,ri)][w] dY[(m,n)][w]; blockDim = 64 * NRT (wave rt = 32-row tile of (fx, ri) pairs).
 // LDS: two slots of 32 * PW + 1 floats, PW = Ho | 1 (odd pitch: conflict-free operand reads).  NSR >= NS: register array size.
-template <int NSR>
-static __global__ __launch_bounds__(512) void dft_dy_wide_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
+template <int NSR, int NLD, int WPE>
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dft_dy_wide_kernel(const float* __restrict__ dY, const float* __restrict__ ED,
                                                                  float* __restrict__ Sp, int M, int R, int B, int Ho, int Lh,
                                                                  long NBpad, int NS, int NRT, float* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, kh = lane >> 5;
     const int rt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int PW = Ho | 1, SLOT = 32 * PW + 1, nthr = blockDim.x;
+    // (slot: the tile's 32 columns at pitch PW, then 2 NSR zeros: the chain below runs NSR steps unconditionally -- steps beyond
+    //  NS meet a zero of the constant operand and read finite padding; a run-time guard per matrix instruction would put every
+    //  one of them, with its LDS read, into a basic block of its own and serialise the read latencies)
+    const int PW = Ho | 1, SLOT = 32 * PW + 2 * NSR + 2, nthr = blockDim.x;
     float areg[NSR];
 #pragma unroll
     for (int s_ = 0; s_ < NSR; ++s_) areg[s_] = s_ < NS ? ED[((long)s_ * NRT + rt) * 64 + lane] : 0.f;
@@ -1120,7 +1123,7 @@ static __global__ __launch_bounds__(512) void dft_dy_wide_kernel(const float* __
     const long per = (ntiles + gridDim.x - 1) / gridDim.x;
     const long t_beg = (long)blockIdx.x * per, t_end = min(ntiles, t_beg + per);
     if (t_beg >= t_end) return;
-    constexpr int NLD = 16;                              // staged values per thread and tile (host: 32 Ho <= 16 * 64 NRT)
+    // NLD staged values per thread and tile (host: 32 Ho <= NLD * 64 NRT)
     const int nel = 32 * Ho;
     const int nld = (nel + nthr - 1) / nthr;             // ... of which this many are real (wave uniform)
     float stage[NLD];
@@ -1182,9 +1185,9 @@ static __global__ __launch_bounds__(512) void dft_dy_wide_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < NSR; s_ += 2) {            // two independent chains
-            if (s_ < NS) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_], bs[2 * s_], acc0, 0, 0, 0);
-            if (s_ + 1 < NS && s_ + 1 < NSR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_ + 1 < NSR ? s_ + 1 : s_], bs[2 * s_ + 2], acc1, 0, 0, 0);
+        for (int s_ = 0; s_ < NSR; s_ += 2) {            // two independent chains, no branches
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_], bs[2 * s_], acc0, 0, 0, 0);
+            if (s_ + 1 < NSR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s_ + 1 < NSR ? s_ + 1 : s_], bs[2 * s_ + 2], acc1, 0, 0, 0);
         }
         if (m != m_prev && m_prev >= 0) h3_tile_flush_rd(mx, amax + m_prev, lane);
         m_prev = m;
@@ -1220,7 +1223,7 @@ static __global__ __launch_bounds__(512) void dft_out_wide_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) float sm_w[];
     const int lane = threadIdx.x & 63, j = lane & 31, ri = lane >> 5;
     const int wt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int SLOT = Lh * 64, nthr = blockDim.x;
+    const int SLOT = LHR * 64, nthr = blockDim.x;        // (rows Lh .. LHR - 1 stay zero: the chain runs LHR steps unconditionally)
     const bool xrow = NT > NTW;                          // one extra output column w = 32 NTW
     float* patch = sm_w + 2 * SLOT + wt * (32 * 33);
     float* ex = sm_w + 2 * SLOT + NTW * (32 * 33);       // [fx][ri]: E[w = 32 NTW][(fx, ri)]
@@ -1257,6 +1260,8 @@ static __global__ __launch_bounds__(512) void dft_out_wide_kernel(const float* _
             if (pc < npc) dst[pc] = stage[i];            // piece pc = ((fx * 2 + ri) * 8 + q4): [fx][ri][32] floats, linear
         }
     };
+    for (int i = threadIdx.x; i < 2 * SLOT; i += nthr) sm_w[i] = 0.f;
+    __syncthreads();
     tile_load(t_beg);
     tile_put(0);
     __syncthreads();
@@ -1272,9 +1277,9 @@ static __global__ __launch_bounds__(512) void dft_out_wide_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-        for (int fx = 0; fx < LHR; fx += 2) {            // two independent chains
-            if (fx < Lh) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx], vs[fx * 64], acc0, 0, 0, 0);
-            if (fx + 1 < Lh && fx + 1 < LHR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx + 1 < LHR ? fx + 1 : fx], vs[(fx + 1) * 64], acc1, 0, 0, 0);
+        for (int fx = 0; fx < LHR; fx += 2) {            // two independent chains, no branches
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx], vs[fx * 64], acc0, 0, 0, 0);
+            if (fx + 1 < LHR) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(eo[fx + 1 < LHR ? fx + 1 : fx], vs[(fx + 1) * 64], acc1, 0, 0, 0);
         }
         float racc = 0.f;
         if (xrow && wt == 0) {                           // the single last column on the vector ALU (wave uniform)
