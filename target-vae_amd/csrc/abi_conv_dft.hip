@@ -146,6 +146,14 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     // shape: 6 tiles instead of 9, i.e. S' read and split 6 times instead of 9).
     q.wsplits = ((2 * q.M) % WW_ROWS == 0 && q.K2 > 128 &&
                  (q.K2 <= 192 || cdiv(q.K2, 192) * 192 <= cdiv(q.K2, 128) * 128)) ? q.splits : 0;
+    // Round 5: its slices are free in number, and every slice writes a whole slab of G that the inverse transform reads back.
+    // Where a slab is as large as the operand (galaxy shape: 8 images, slab 0.51 GB against S' 1.53 GB) eight slices moved
+    // 2 x 4 GB to read 1.5: as many slices as keep the slab traffic below the operand's, at least one, at most the 8 above.
+    if (q.wsplits > 0) {
+        const long by_bytes = q.t_floats / (2 * q.g_floats);
+        const int cap = (int)(by_bytes < 1 ? 1 : (by_bytes > 8 ? 8 : by_bytes));
+        if (q.wsplits > cap) q.wsplits = cap;
+    }
     // spectra: as few frequency blocks per plane as LDS allows (images and filters share one launch)
     const int S = n > ksz ? n : ksz;
     q.nblk = 1;
