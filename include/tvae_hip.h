@@ -161,7 +161,10 @@ int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const 
  * (the h3 scale of the streamed operand); the same argument of tvae_linear_dgrad_x6 (plain form: X = dpre) and a_amax /
  * x_amax of tvae_linear_wgrad_x6 (plain form: max |dpre|, max |X|; two-valued form from sign bits against an operand from
  * memory: x_amax >= max |gy[n] X[k][n]|).  A bound that is 2^j too large costs j of the 16 bits by which an element may lie
- * below its group's maximum before its low part goes subnormal (csrc/conv_x6_kernels.hpp). */
+ * below its group's maximum before its low part goes subnormal (csrc/conv_x6_kernels.hpp).  ABI 6: x_amax_rows != 0 of
+ * tvae_linear_wgrad_x6 -- x_amax then holds K words, one bound per ROW of X (a row of X is a column of dW: a hidden unit far
+ * below the others -- dead, or not yet trained -- keeps the full two-part precision relative to ITSELF, as the recomputed form
+ * does through dec_l0_bound_kernel's per-unit words). */
 int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, const float* aux, float* dX, int M,
                          int N, int K, long ldd, long ldx, int mask, float slope, const float* in_xr,
                          const float* in_wc, float* in_gxr, float* in_part, long in_part_floats, const float* vg_wo,
@@ -201,7 +204,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
                          int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
-                         const float* a_amax, const float* x_amax, tvae_stream_t stream);
+                         const float* a_amax, const float* x_amax, int x_amax_rows, tvae_stream_t stream);
 /* rd_rowdot (optional, ABI 5; two-valued LeakyReLU form, accumulate = 0): also returns rd_rowdot[m] = sum_k rd_w[m][k] G[m][k]
  * with G[m][k] = dW[m][k] / wo[m] taken BEFORE the multiplication (exact for wo[m] = 0); rd_w = the layer's weight, [M][K]
  * with row stride rd_ldw. */

@@ -75,7 +75,7 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
                          long ldd, long ldx, int accumulate, const float* vg_wo, const float* vg_gy, int vg_act,
                          float vg_slope, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
                          int va_np, const void* vg_bits, int parts, const float* rd_w, long rd_ldw, float* rd_rowdot,
-                         const float* a_amax, const float* x_amax, tvae_stream_t stream) {
+                         const float* a_amax, const float* x_amax, int x_amax_rows, tvae_stream_t stream) {
     // dW[m][k] = sum_n dpre[m][n] X[k][n]  (output M x K, reduction N), exact-split bf16 arithmetic
     if (M <= 0 || K <= 0) return 0;
     if (parts != 1 && parts != 2 && parts != 3) return (int)hipErrorInvalidValue;
@@ -110,7 +110,9 @@ int tvae_linear_wgrad_x6(const float* dpre, const float* X, float* dW, float* ws
     int rc;
     if (parts == 2 && !h3_recomp) {
         rc = dense_wgrad_x6_launch_p2(variant, dpre, ldd, X, ldx, ws, M, K, N, nchunk, tmk, DenseBatch{0, 0, 0}, 0L, vgs, vas,
-                                      ATILE_PLAIN, S(stream), H3Scale{a_amax, x_amax, 0, 0, 0, 0, 0});
+                                      ATILE_PLAIN, S(stream),
+                                      // x_amax_rows: one bound per ROW of X (= per column of dW) instead of one for the tensor
+                                      H3Scale{a_amax, x_amax, 0, 0, 0, x_amax_rows ? 1 : 0, x_amax_rows ? K : 0});
     } else if (parts == 2) {
         float* slots = ws + (long)splits * per;
         hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, S(stream), slots, 4 + K);

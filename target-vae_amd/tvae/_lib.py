@@ -33,7 +33,7 @@ SIGNATURES = {
     'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppipppp',
     'tvae_dec_in_total': 'piiippp',
     'tvae_dgrad_rowsum_total': 'piippfpppp',
-    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplppp',
+    'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplpppi',
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
@@ -87,7 +87,7 @@ QUERIES = {
 }
 
 # trailing arguments a caller may leave out (beyond all-pointer tails, which are always optional)
-OPTIONAL_TAIL = {'tvae_linear_wgrad_x6': 5}      # rd_w, rd_ldw, rd_rowdot, a_amax, x_amax (ABI 5)
+OPTIONAL_TAIL = {'tvae_linear_wgrad_x6': 6}      # rd_w, rd_ldw, rd_rowdot, a_amax, x_amax (ABI 5), x_amax_rows (ABI 6)
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

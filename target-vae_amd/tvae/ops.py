@@ -317,7 +317,8 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
                  *(va if va else (None, None, None, None, 0)), bits, p,
                  rowdot_w.contiguous() if rowdot_w is not None else None, K, rowdot,
-                 a_amax if p == 2 else None, x_amax if p == 2 else None)
+                 a_amax if p == 2 else None, x_amax if p == 2 else None,
+                 1 if (p == 2 and x_amax is not None and x_amax.numel() == K and K > 1) else 0)      # one bound per row of X
         return dW if rowdot_w is None else (dW, rowdot)
     _expect(virt is None and va is None and rowdot_w is None, 'implicit operands need the split-pipe weight gradient')
     ws = workspace(dev_, max(need, 1 << 24))
@@ -905,7 +906,7 @@ class DecoderFn(torch.autograd.Function):
             LB = torch.empty(B, F_, dtype=torch.float32, device=dev)
             call('tvae_latent_bias', Wl.contiguous(), z, LB, B, F_, zd)
         feat = None
-        feat_amax = h_bound = None       # h3 bounds of operands that are streamed from memory (include/tvae_hip.h: x_amax)
+        feat_amax = h_bound = h_rows = None       # h3 bounds of operands that are streamed from memory (include/tvae_hip.h: x_amax)
         # without Fourier features the coordinate layer's output is two FMAs and an activation per element: the layers
         # that consume it (first hidden layer: forward, mask of the data gradient, weight gradient) recompute it and the
         # [hid][B*n^2] tensor is never written or read
@@ -931,7 +932,10 @@ class DecoderFn(torch.autograd.Function):
                 p_c = parts() if parts() != 2 else 2
                 if p_c == 2:
                     feat_amax = torch.clamp(_inf_norm(z), min=1.0) if zx else torch.ones(1, dtype=torch.float32, device=dev)
-                    h_bound = Wfull.detach().abs().sum(1).amax().reshape(1) * feat_amax + _inf_norm(bc)
+                    # per-unit bound of this layer's output (the weight gradient of the layer BEHIND it takes one
+                    # scale per row of its X operand = per unit here), and its maximum for the forward of that layer
+                    h_rows = Wfull.detach().abs().sum(1) * feat_amax + bc.detach().abs()
+                    h_bound = h_rows.amax().reshape(1)
                     _note('dec.four_h3')
                 w3c = _split_weight(Wfull, F_, Ff + zx, False, 'x6_dense_wc', nparts=p_c)
                 with _timed('tvae_linear_fwd_x6', p_c):
@@ -942,8 +946,9 @@ class DecoderFn(torch.autograd.Function):
         else:
             call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
             if parts() == 2 and _dense_x6_ok(F_, Nt):      # the stored coordinate layer: |act(pre)| <= |pre| <= this bound
-                h_bound = _inf_norm(xr) * Wc.detach().abs().sum(1).amax().reshape(1) + \
-                    (_inf_norm(bc.detach()[None, :] + LB) if LB is not None else _inf_norm(bc))
+                h_rows = _inf_norm(xr) * Wc.detach().abs().sum(1) + \
+                    ((bc.detach()[None, :] + LB).abs().amax(0) if LB is not None else bc.detach().abs())      # per unit
+                h_bound = h_rows.amax().reshape(1)
         hs = [h]
         yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
         fused_out = False
@@ -999,7 +1004,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.meta = (act, resid, sigma, n_hidden, Wl is not None, Wf is not None, B, Np)
         ctx.arith = get_gemm_mode()
         ctx.sbits = sbits
-        ctx.h_bound, ctx.feat_amax = h_bound, feat_amax
+        ctx.h_bound, ctx.feat_amax, ctx.h_rows = h_bound, feat_amax, h_rows
         return yh
 
     @staticmethod
@@ -1058,7 +1063,8 @@ class DecoderFn(torch.autograd.Function):
             # times max |gy| (the operand of the two-valued form is gy[n] X[k][n])
             xg_amax = None
             if parts() == 2 and use_vg and sbits is not None and va is None and li == 0 and ctx.h_bound is not None:
-                xg_amax = ctx.h_bound * _inf_norm(vg[1])
+                # one bound per unit (row of the X operand) where the forward formed them, else the tensor's
+                xg_amax = (ctx.h_rows if ctx.h_rows is not None else ctx.h_bound) * _inf_norm(vg[1])
             # Round 5: the bits form's weight gradient on the side stream (its only consumer inside the backward, the totals of
             # the row sums, moves there with it): issued AFTER the data gradient below
             # (only when autograd will ADOPT the returned gradient tensors -- p.grad is None for the three parameters whose

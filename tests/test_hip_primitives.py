@@ -614,6 +614,20 @@ def test_h3_row_dynamic_range_decoder(e):
     ref_dW = d @ H0.t()
     assert row_rel_err(dW, ref_dW, dim=1) < ROW_TOL      # per COLUMN of dW = per row of the X operand
     assert float(ref_dW[:, u0].abs().max()) < 1e4 * s
+    # ADVICE r04 / ABI 6: the same weight gradient with its X operand read from MEMORY (Fourier decoders, stored first layers):
+    # one bound per ROW of X -- (|w0| + |w1|) max |x'| + max_b |bc + lb|, times max |gy| -- keeps the small unit's column
+    # exact to itself; with ONE bound for the tensor it loses the bits the unit lies below the others (measured here)
+    rows = ((Wc.abs().sum(1) * xr.abs().max() + (bc[None, :] + LB).abs().amax(0)) * gy.abs().max()).contiguous()
+    dWm = torch.empty(M, F_, device=dev())
+    call('tvae_linear_wgrad_x6', None, h0, dWm, ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, wo.to(dev()), gy.to(dev()), 1, SLOPE,
+         None, None, None, None, 0, bits, 2, None, 0, None, None, rows, 1)
+    assert row_rel_err(dWm, ref_dW, dim=1) < ROW_TOL
+    if e >= 24:
+        dW1 = torch.empty(M, F_, device=dev())
+        call('tvae_linear_wgrad_x6', None, h0, dW1, ws, ws.numel(), M, Nt, F_, Nt, Nt, 0, wo.to(dev()), gy.to(dev()), 1, SLOPE,
+             None, None, None, None, 0, bits, 2, None, 0, None, None, rows.amax().reshape(1), 0)
+        err1 = float(((dW1.double().cpu() - ref_dW)[:, u0]).abs().max() / ref_dW[:, u0].abs().max())
+        assert err1 > 10 * ROW_TOL, err1                  # (the per-tensor bound really is the weaker form: the reason for the rows)
 
 
 @pytest.mark.parametrize('e', [16, 24, 32])
