@@ -43,6 +43,7 @@ struct DftPlan {
     int LHP, NT, REM1;         // forward w-transform: frequencies processed, 32-row output tiles, extra row
     int NS, NRT;               // backward w-transform: k2-steps (pairs of w), 32-row tiles of (fx, ri)
     int FXB, nblk;             // spectra: frequencies per workgroup, blocks per plane
+    int FXBf, nblkf;           // ... of the FILTER planes (mixed form: the images may take more, smaller blocks)
     int FXBd;                  // inverse transform of the weight gradient: frequencies per pass
     int splits;                // reduction slices of the weight-gradient GEMM
     int wsplits;               // the same for its exact-fit tile (dense_wgrad_x6_wide_kernel), 0: geometry not eligible
@@ -162,7 +163,22 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
         ++q.nblk;
         q.FXB = (q.Lh + q.nblk - 1) / q.nblk;
     }
-    q.lds_sp = dft_lds_spectra(S, q.L, q.FXB, q.mixed);
+    // mixed form: an image's workgroup writes FXB * ksz * Ho operand values as 132-byte runs 33 KB apart; with all Lh frequencies
+    // in one block that loop, not the transform, sets the kernel's duration (0.11 ms at the 64 x 64 shape, at ANY batch size: one
+    // workgroup per image is the longest pole); more, smaller frequency blocks per plane spread it over more workgroups
+    // (measured at the 64 x 64 shape: one block 114 us at any batch; four blocks 130 us at 256 images -- more workgroups than the
+    //  write stream needs -- but 69 us at 32: as many blocks as give the IMAGES a workgroup per CU, at most 8)
+    q.nblkf = q.nblk;
+    q.FXBf = q.FXB;
+    if (q.mixed) {
+        int want = (256 + B * Cin - 1) / (B * Cin);
+        if (want > 8) want = 8;
+        while (q.nblk < want && q.nblk < q.Lh) {
+            ++q.nblk;
+            q.FXB = (q.Lh + q.nblk - 1) / q.nblk;
+        }
+    }
+    q.lds_sp = dft_lds_spectra(S, q.L, q.FXBf, q.mixed);       // (the larger of the two block sizes: FXBf >= FXB)
     q.FXBd = q.Lh;
     auto lds_db = [&](int f) { return (size_t)q.L * f * 8 + (size_t)ksz * f * 8 + (size_t)q.L * 8 + (size_t)ksz * ksz * 4; };
     // the inverse transform runs one workgroup per (filter, channel): 1 024 of them at the bench shape = FOUR per CU, so its
@@ -248,9 +264,23 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         e = dft_zero(W, q.w_floats, st);
         if (e != hipSuccess) return (int)e;
     }
-    if (q.mixed)
-        hipLaunchKernelGGL(dft_spectra_x_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
-                           n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);
+    static const bool spectra_mf = !(getenv("TVAE_SPECTRA_MF") && getenv("TVAE_SPECTRA_MF")[0] == '0');
+    const int smax_ = n > ksz ? n : ksz;
+    if (q.mixed && spectra_mf && smax_ <= 128) {         // row transform on the fp32 matrix pipe (dft_spectra_x_mf_kernel)
+#define TVAE_SPX_MF(KSR_)                                                                                            \
+    do {                                                                                                            \
+        e = allow_big_lds(dft_spectra_x_mf_kernel<KSR_>, q.lds_sp);                                                 \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL(dft_spectra_x_mf_kernel<KSR_>, dim3((unsigned)(B * Cin * q.nblk + q.M * Cin * q.nblkf)), dim3(256), \
+                           q.lds_sp, st, y, at, B, Cin, n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, \
+                           q.FXBf, q.nblkf, mxp);                                                                   \
+    } while (0)
+        if (smax_ <= 32) TVAE_SPX_MF(16); else if (smax_ <= 64) TVAE_SPX_MF(32); else TVAE_SPX_MF(64);
+#undef TVAE_SPX_MF
+    } else if (q.mixed)
+        hipLaunchKernelGGL(dft_spectra_x_kernel, dim3((unsigned)(B * Cin * q.nblk + q.M * Cin * q.nblkf)), dim3(256), q.lds_sp, st,
+                           y, at, B, Cin, n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, q.FXBf, q.nblkf,
+                           mxp);
     else
     hipLaunchKernelGGL(dft_spectra_kernel, dim3((unsigned)((B + q.M) * Cin * q.nblk)), dim3(256), q.lds_sp, st, y, at, B, Cin,
                        n, pad, q.Ho, q.NBpad, bank, W, ksz, q.M, q.Mb, q.L, q.Lh, q.FXB, q.nblk, mxp);

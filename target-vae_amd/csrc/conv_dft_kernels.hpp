@@ -255,55 +255,30 @@ static __global__ void dft_spectra_kernel(const float* __restrict__ y, float* __
 // needs its x stage only.  Same launch shape as dft_spectra_kernel (a workgroup per (plane, block of frequencies)).
 // LDS: row spectra S*FXB complex + twiddles L complex.
 // ------------------------------------------------------------------------------------------
-static __global__ void dft_spectra_x_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
-                                            int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
-                                            int M, int Mb, int L, int Lh, int FXB, int nblk, DftMax mxp) {
-    extern __shared__ float sm_dft[];
-    const int nimg = B * Cin * nblk;
-    int id = blockIdx.x;
-    const bool is_img = id < nimg;
-    if (!is_img) id -= nimg;
-    const int blk = id % nblk;
-    const int ci = (id / nblk) % Cin;
-    const int outer = id / (nblk * Cin);                 // image b or filter m
-    const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
-    const int S = is_img ? n : ksz, pd = is_img ? pad : 0;
-    const float* pl = is_img ? y + ((long)outer * Cin + ci) * n * n : bank + ((long)outer * Cin + ci) * ksz * ksz;
-    float2* Rw = reinterpret_cast<float2*>(sm_dft);      // [row][f]
-    float2* tw = Rw + S * FXB;
-    fill_twiddles(tw, L);
-    __syncthreads();
-    // Rw[yy][f] = sum_x pl[yy][x] e^{-2 pi i fx (x + pd) / L}  (the plane is read straight from memory: see dft_plane_spectrum)
-    for (int i = threadIdx.x; i < S * nfx; i += blockDim.x) {
-        const int yy = i / nfx, f = i - yy * nfx, fx = fx0 + f;
-        const float* row = pl + yy * S;
-        float re = 0.f, im = 0.f;
-        int ph = (fx * pd) % L;
-#pragma unroll 4
-        for (int x = 0; x < S; ++x) {
-            const float v = row[x];
-            const float2 t = tw[ph];
-            re += v * t.x;
-            im -= v * t.y;
-            ph += fx;
-            if (ph >= L) ph -= L;
-        }
-        Rw[yy * FXB + f] = make_float2(re, im);
-    }
-    __syncthreads();
+// tail shared by both forms of the row transform: GEMM operands and operand maxima from the row spectra Rw [row][f]
+__device__ __forceinline__ void dft_spectra_x_tail(const float2* Rw, bool is_img, int outer, int ci, int fx0, int nfx, int FXB,
+                                                   float* __restrict__ AT, int B, int Cin, int n, int pad, int Ho, long NBpad,
+                                                   float* __restrict__ W, int ksz, int M, int Mb, DftMax mxp) {
     const long rowlen = 2L * ksz * Cin;
     if (is_img) {
         // AT[fx][(2 ci + ri) ksz + u][b Ho + h] = Re / Im X[h + u - pad][fx]  (h fastest: coalesced runs of Ho floats)
-        const int total = nfx * ksz * Ho;
-        for (int i = threadIdx.x; i < total; i += blockDim.x) {
-            const int h = i % Ho;
-            const int t2 = i / Ho;
-            const int u = t2 % ksz, f = t2 / ksz;
+        // element i = (f * ksz + u) * Ho + h, h fastest (consecutive threads write consecutive addresses); the indices advance
+        // incrementally: two integer divisions per element made this loop, not the transform, the kernel's critical path
+        const int total = nfx * ksz * Ho, nth = blockDim.x;
+        const int dh = nth % Ho, dt = nth / Ho;          // i += nth:  h += dh (carry into t2), t2 += dt
+        int h = threadIdx.x % Ho, t2 = threadIdx.x / Ho;
+        int u = t2 % ksz, f = t2 / ksz;
+        for (int i = threadIdx.x; i < total; i += nth) {
             const int r = h + u - pad;
             const float2 v = (r >= 0 && r < n) ? Rw[r * FXB + f] : make_float2(0.f, 0.f);
             float* dst = AT + ((long)(fx0 + f) * rowlen + (long)(2 * ci) * ksz + u) * NBpad + (long)outer * Ho + h;
             dst[0] = v.x;
             dst[(long)ksz * NBpad] = v.y;
+            h += dh;
+            int du = dt;
+            if (h >= Ho) { h -= Ho; ++du; }
+            u += du;
+            while (u >= ksz) { u -= ksz; ++f; }
         }
         for (int f = threadIdx.x >> 6; f < nfx; f += blockDim.x >> 6) {       // one frequency per wave and turn
             float q = 0.f;
@@ -339,6 +314,130 @@ static __global__ void dft_spectra_x_kernel(const float* __restrict__ y, float* 
             }
         }
     }
+}
+
+static __global__ void dft_spectra_x_kernel(const float* __restrict__ y, float* __restrict__ AT, int B, int Cin, int n, int pad,
+                                            int Ho, long NBpad, const float* __restrict__ bank, float* __restrict__ W, int ksz,
+                                            int M, int Mb, int L, int Lh, int FXB, int nblk, int FXBf, int nblkf, DftMax mxp) {
+    extern __shared__ float sm_dft[];
+    // images and filters have their own number of frequency blocks per plane (a filter's workgroup is cheap and there are
+    // C R Cin of them: splitting those as well only multiplies fixed costs)
+    const int nimg = B * Cin * nblk;
+    int id = blockIdx.x;
+    const bool is_img = id < nimg;
+    if (!is_img) {
+        id -= nimg;
+        nblk = nblkf;
+        FXB = FXBf;
+    }
+    const int blk = id % nblk;
+    const int ci = (id / nblk) % Cin;
+    const int outer = id / (nblk * Cin);                 // image b or filter m
+    const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
+    const int S = is_img ? n : ksz, pd = is_img ? pad : 0;
+    const float* pl = is_img ? y + ((long)outer * Cin + ci) * n * n : bank + ((long)outer * Cin + ci) * ksz * ksz;
+    float2* Rw = reinterpret_cast<float2*>(sm_dft);      // [row][f]
+    float2* tw = Rw + S * FXB;
+    fill_twiddles(tw, L);
+    __syncthreads();
+    // Rw[yy][f] = sum_x pl[yy][x] e^{-2 pi i fx (x + pd) / L}  (the plane is read straight from memory: see dft_plane_spectrum)
+    for (int i = threadIdx.x; i < S * nfx; i += blockDim.x) {
+        const int yy = i / nfx, f = i - yy * nfx, fx = fx0 + f;
+        const float* row = pl + yy * S;
+        float re = 0.f, im = 0.f;
+        int ph = (fx * pd) % L;
+#pragma unroll 4
+        for (int x = 0; x < S; ++x) {
+            const float v = row[x];
+            const float2 t = tw[ph];
+            re += v * t.x;
+            im -= v * t.y;
+            ph += fx;
+            if (ph >= L) ph -= L;
+        }
+        Rw[yy * FXB + f] = make_float2(re, im);
+    }
+    __syncthreads();
+    dft_spectra_x_tail(Rw, is_img, outer, ci, fx0, nfx, FXB, AT, B, Cin, n, pad, Ho, NBpad, W, ksz, M, Mb, mxp);
+}
+
+// The same with the row transform on the fp32 matrix pipe (round 5): Rw[yy][(f, re | im)] = sum_x pl[yy][x] E[x][(f, re | im)] is
+// a small GEMM per plane (64 x 64 x 82 at the 64 x 64 shape: 192 v_mfma_f32_32x32x2_f32 per plane, spread over four waves) where the
+// direct sums above walk a dependent twiddle index per tap (0.11 ms of FIXED cost per step -- the 1 024 filter planes do not
+// shrink with the batch).  A wave owns (row tile, column tile) pairs: its 32 plane rows sit in registers (KSR pairs of taps,
+// zero padded: the chain is branch free), the twiddle operand comes from the LDS table with a running phase per lane.
+template <int KSR>
+static __global__ __launch_bounds__(256) void dft_spectra_x_mf_kernel(const float* __restrict__ y, float* __restrict__ AT, int B,
+                                                                      int Cin, int n, int pad, int Ho, long NBpad,
+                                                                      const float* __restrict__ bank, float* __restrict__ W,
+                                                                      int ksz, int M, int Mb, int L, int Lh, int FXB, int nblk, int FXBf, int nblkf,
+                                                                      DftMax mxp) {
+    extern __shared__ float sm_dft[];
+    // images and filters have their own number of frequency blocks per plane (a filter's workgroup is cheap and there are
+    // C R Cin of them: splitting those as well only multiplies fixed costs)
+    const int nimg = B * Cin * nblk;
+    int id = blockIdx.x;
+    const bool is_img = id < nimg;
+    if (!is_img) {
+        id -= nimg;
+        nblk = nblkf;
+        FXB = FXBf;
+    }
+    const int blk = id % nblk;
+    const int ci = (id / nblk) % Cin;
+    const int outer = id / (nblk * Cin);                 // image b or filter m
+    const int fx0 = blk * FXB, nfx = min(FXB, Lh - fx0);
+    const int S = is_img ? n : ksz, pd = is_img ? pad : 0;
+    const float* pl = is_img ? y + ((long)outer * Cin + ci) * n * n : bank + ((long)outer * Cin + ci) * ksz * ksz;
+    float2* Rw = reinterpret_cast<float2*>(sm_dft);      // [row][f]
+    float* Rwf = sm_dft;                                 // the same as floats: [(row * FXB + f) * 2 + (re | im)]
+    float2* tw = Rw + S * FXB;
+    fill_twiddles(tw, L);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int MT = (S + 31) / 32, NC = (2 * nfx + 31) / 32;
+    int mt_have = -1;
+    float a[KSR];
+    for (int pair = wave; pair < MT * NC; pair += 4) {   // (wave uniform)
+        const int mt = pair % MT, nt = pair / MT;
+        if (mt != mt_have) {                             // this lane's plane row, taps 2 t + kh
+            const int row = 32 * mt + li;
+            const float* rp = pl + (long)min(row, S - 1) * S;
+            const float ok = row < S ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < KSR; ++t) {
+                const int x = 2 * t + kh;
+                a[t] = x < S ? rp[x] * ok : 0.f;
+            }
+            mt_have = mt;
+        }
+        const int ncol = 32 * nt + li, f = ncol >> 1, ri = ncol & 1;
+        const int fx = fx0 + min(f, nfx - 1);
+        const float bs = f < nfx ? 1.f : 0.f;
+        int ph = (int)(((long)fx * (kh + pd)) % L);
+        const int dph = (2 * fx) % L;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KSR; ++t) {
+            const float2 w = tw[ph];
+            const float bv = (ri ? -w.y : w.x) * bs;     // e^{-i theta}: (cos, -sin)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc, 0, 0, 0);
+            ph += dph;
+            if (ph >= L) ph -= L;
+        }
+        if (f < nfx) {                                   // D: lane = column (f, ri), registers = rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int yy = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (yy < S) Rwf[((long)yy * FXB + f) * 2 + ri] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    dft_spectra_x_tail(Rw, is_img, outer, ci, fx0, nfx, FXB, AT, B, Cin, n, pad, Ho, NBpad, W, ksz, M, Mb, mxp);
 }
 
 // ==========================================================================================
