@@ -141,6 +141,10 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.splits = (int)(cdiv(q.K2, 128) >= 8 ? q.NBpad / 1024 : q.NBpad / 32);
     if (q.splits < 1) q.splits = 1;
     if (q.splits > 8) q.splits = 8;
+    {
+        static const int force = getenv("TVAE_DFT_SPLITS") ? atoi(getenv("TVAE_DFT_SPLITS")) : 0;      // experiments
+        if (force > 0 && force < q.splits) q.splits = force;
+    }
     // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles.  (Its slices are not pinned to XCDs, so
     // their number is free: 9 slices, whose groups fill 7 whole rounds of the 256 CUs where 8 run 6.125, measured the same.)
     // Wider problems take it in 192-column tiles when those pad no more than the 128-wide ones (1 152 columns at the galaxy
