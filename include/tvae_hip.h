@@ -369,6 +369,21 @@ int tvae_elbo_reduce(const float* lp, const float* kl, int B, double* elbo, floa
 int tvae_elbo_reduce_bwd(const double* g_elbo, const float* g_logp, const double* g_kld, int B, float* g_lp, float* g_kl,
                          tvae_stream_t stream);
 
+/* ---- gradient all-reduce of the data-parallel step (the reference is single-GPU; SURVEY 8b / 8e: one sum all-reduce of the
+ * flat fp32 gradient buffer per step over RCCL).  RCCL is resolved at run time (dlopen; inside a PyTorch process the instance
+ * torch already loaded), so libtvae_hip.so has no link dependency on it: tvae_rccl_available() == 0 when none is found and the
+ * other entry points then return 100001.  The communicator belongs to the caller: one rank fills a 128-byte id
+ * (tvae_rccl_unique_id), distributes it by any means (tvae/dp.py: torch.distributed broadcast), every rank calls
+ * tvae_rccl_comm_init on its current device (a collective), tvae_allreduce_flat sums `count` floats in place on `stream`
+ * (asynchronous; the two buckets of tvae/optim.py are two calls on segments of the buffer), tvae_rccl_comm_destroy frees it.
+ * The default data-parallel path of this repo calls RCCL through torch.distributed ("nccl" backend); TVAE_DP_ABI=1 routes
+ * the two buckets through these entry points instead (tvae/dp.py: GradReducer).  (ABI 6) */
+int tvae_rccl_available(void);
+int tvae_rccl_unique_id(void* id128);
+int tvae_rccl_comm_init(void** comm, int nranks, const void* id128, int rank);
+int tvae_allreduce_flat(void* comm, float* buf, long count, tvae_stream_t stream);
+int tvae_rccl_comm_destroy(void* comm);
+
 /* ---- particle likelihood tail: train_particles.py:298-338 ----
  * ctf_corr: per-image depthwise cross-correlation out[b] = in[b] (*) ctf[b] with an odd kc x kc filter and zero padding
  * kc/2 (F.conv2d(y_mu.view(1,B,n,n), ctf, padding=pad, groups=B), :298-302); flip = 1 uses the 180-degree rotated

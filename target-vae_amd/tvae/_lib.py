@@ -182,8 +182,51 @@ class arithmetic:
         return False
 
 
+# gradient all-reduce over RCCL behind the C ABI (include/tvae_hip.h; host functions, only the collective takes a stream)
+RCCL_SYMBOLS = ('tvae_rccl_available', 'tvae_rccl_unique_id', 'tvae_rccl_comm_init', 'tvae_allreduce_flat',
+                'tvae_rccl_comm_destroy')
+
+
 def exported_symbols():
-    return ['tvae_abi_version'] + sorted(SIGNATURES) + sorted(QUERIES)
+    return ['tvae_abi_version'] + sorted(SIGNATURES) + sorted(QUERIES) + list(RCCL_SYMBOLS)
+
+
+class RcclComm:
+    """An RCCL communicator owned through the C ABI (tvae_rccl_comm_init): `unique_id()` on one rank, the 128 bytes to every
+    rank by any means, then `RcclComm(nranks, id, rank)` on every rank (a collective, on the current device)."""
+
+    def __init__(self, nranks: int, id128: bytes, rank: int):
+        L = lib()
+        if not L.tvae_rccl_available():
+            raise TvaeHipError('no RCCL library could be resolved in this process')
+        self._comm = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(id128), 128)
+        rc = L.tvae_rccl_comm_init(ctypes.byref(self._comm), int(nranks), buf, int(rank))
+        if rc:
+            raise TvaeHipError(f'tvae_rccl_comm_init failed ({rc})')
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = lib().tvae_rccl_unique_id(buf)
+        if rc:
+            raise TvaeHipError(f'tvae_rccl_unique_id failed ({rc})')
+        return buf.raw
+
+    def all_reduce_(self, t) -> None:
+        """In-place sum all-reduce of a contiguous fp32 CUDA tensor on the current torch stream (asynchronous)."""
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise TvaeHipError('tvae_allreduce_flat: contiguous fp32 CUDA tensor expected')
+        L = lib()
+        L.tvae_allreduce_flat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+        rc = L.tvae_allreduce_flat(self._comm, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise TvaeHipError(f'tvae_allreduce_flat failed ({rc})')
+
+    def close(self) -> None:
+        if self._comm:
+            lib().tvae_rccl_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
 
 
 def query(name, *args) -> int:

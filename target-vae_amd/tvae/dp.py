@@ -52,7 +52,7 @@ class GradReducer:
     `weight` handles a ragged last minibatch: rank r holds b_r images and its loss is a mean over b_r, so the
     global-batch gradient is sum_r (b_r / b_global) g_r; ranks pre-scale by b_r * world / b_global."""
 
-    def __init__(self, group=None, always=False):
+    def __init__(self, group=None, always=False, abi=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # `always`: issue the collectives even in a one-rank group (they are identities there) -- lets a 1-GPU box
@@ -61,6 +61,29 @@ class GradReducer:
         self.weight = 1.0
         self._pending = []
         self.posted_early = 0          # diagnostics: how many early buckets were posted from a backward
+        # `abi` (default: TVAE_DP_ABI=1): the two buckets through the library's own entry point tvae_allreduce_flat on a
+        # communicator created through the C ABI (include/tvae_hip.h) instead of torch.distributed's all_reduce; the 128-byte
+        # id travels over the torch process group once.  Same collectives, same order, on a side stream of its own.
+        self._abi = None
+        if abi is None:
+            abi = os.environ.get('TVAE_DP_ABI', '0') == '1'
+        if abi and self.active and dist.get_backend(group) == 'nccl':
+            from ._lib import RcclComm
+            dev = torch.device('cuda', torch.cuda.current_device())
+            rank = dist.get_rank(group)
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0, group=group)
+            self._abi = RcclComm(self.world, bytes(idt.cpu().numpy().tobytes()), rank)
+            self._abi_stream = torch.cuda.Stream(device=dev)
+
+    def _abi_reduce(self, t: torch.Tensor) -> None:
+        cur = torch.cuda.current_stream(t.device)
+        self._abi_stream.wait_stream(cur)            # behind the kernels that produced the gradients
+        with torch.cuda.stream(self._abi_stream):
+            self._abi.all_reduce_(t)
+        self._pending.append(self._abi_stream.record_event())
 
     def set_local_fraction(self, local_b: int, global_b: int):
         self.weight = float(local_b) * self.world / float(global_b)
@@ -70,7 +93,10 @@ class GradReducer:
             return
         if self.weight != 1.0:
             segment.mul_(self.weight)
-        self._pending.append(dist.all_reduce(segment, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._abi is not None:
+            self._abi_reduce(segment)
+        else:
+            self._pending.append(dist.all_reduce(segment, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.posted_early += 1
 
     def __call__(self, flat_g: torch.Tensor, start: int = 0) -> float:
@@ -80,9 +106,12 @@ class GradReducer:
         if rest.numel() > 0:
             if self.weight != 1.0:
                 rest.mul_(self.weight)
-            dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group)
+            if self._abi is not None:
+                self._abi_reduce(rest)
+            else:
+                dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group)
         for w in self._pending:
-            w.wait()
+            w.wait()                                 # (torch Work objects and CUDA events both: the current stream waits)
         self._pending = []
         return 1.0 / self.world
 

@@ -31,13 +31,15 @@ def _models(dev):
     return gen.to(dev), enc.to(dev)
 
 
-def _train(rank, world, dev_index=0, always=False, turns=False):
+def _train(rank, world, dev_index=0, always=False, turns=False, abi=False):
     from tvae import dp, optim, step, tables
     dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
     gen, enc = _models(dev)
     params = list(gen.parameters()) + list(enc.parameters())
-    reducer = dp.GradReducer(always=always) if (world > 1 or always) else None
+    reducer = dp.GradReducer(always=always, abi=abi) if (world > 1 or always) else None
+    if abi:
+        assert reducer._abi is not None          # the collectives really go through tvae_allreduce_flat
     opt = optim.FlatAdam(params, lr=1e-3, reducer=reducer, early_params=len(list(gen.parameters())))
     if world > 1:
         dist.broadcast(opt.flat_p, src=0)
@@ -170,6 +172,47 @@ def _worker_rccl_one(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_rccl_abi(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    from tvae import _lib
+    assert _lib.lib().tvae_rccl_available() == 1
+    named, tot = _train(0, 1, always=True, abi=True)
+    # the entry point itself, on a known buffer: one rank -> identity, asynchronous on the given stream
+    comm = _lib.RcclComm(1, _lib.RcclComm.unique_id(), 0)
+    buf = torch.arange(1 << 20, dtype=torch.float32, device='cuda')
+    want = buf.clone()
+    comm.all_reduce_(buf)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    comm.close()
+    torch.save(dict(named=named, tot=tot), os.path.join(out_dir, 'rccl_abi.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_c_abi_allreduce_runs_the_collective_path(tmp_path):
+    """SURVEY 8b lists `tvae_allreduce_flat` among the library's exports (VERDICT r04 missing #5): the two gradient buckets
+    through the C-ABI entry point on a communicator created through the C ABI (tvae_rccl_unique_id / _comm_init; RCCL resolved
+    at run time inside the process, the id broadcast over the torch process group), `GradReducer(abi=True)` = TVAE_DP_ABI=1.
+    One rank: every collective is an identity, the training result must equal the plain single-process run BITWISE."""
+    named1, tot1 = _train(0, 1)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.start_processes(_worker_rccl_abi, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method='spawn')
+    r = torch.load(tmp_path / 'rccl_abi.pt')
+    for k_ in named1:
+        assert torch.equal(r['named'][k_], named1[k_]), k_
+    assert r['tot'] == tot1
+
+
 @pytest.mark.timeout(900)
 def test_one_rank_rccl_group_runs_the_collective_path(tmp_path):
     """What a 1-GPU box can execute of the RCCL path: a ONE-rank `nccl` process group, the reducer forced to issue its
@@ -188,7 +231,7 @@ def test_one_rank_rccl_group_runs_the_collective_path(tmp_path):
     assert r['tot'] == tot1
 
 
-def _worker_rccl(rank, world, port, out_dir):
+def _worker_rccl(rank, world, port, out_dir, abi=False):
     for p in (ROOT, os.path.join(ROOT, 'target-vae_amd'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -197,21 +240,23 @@ def _worker_rccl(rank, world, port, out_dir):
     from tvae import dp
     r, w, local = dp.init_from_env(backend='nccl')          # "nccl" IS RCCL on ROCm; one process per GPU
     assert dist.get_backend() == 'nccl' and local == rank
-    named, tot = _train(rank, world, dev_index=local)
+    named, tot = _train(rank, world, dev_index=local, abi=abi)
     torch.save(dict(named=named, tot=tot), os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL parity needs 2 GPUs (one process per GPU)')
-def test_two_ranks_rccl_match_single_process(tmp_path):
-    """The same comparison over RCCL: one process per GPU, flat-gradient all-reduce on the nccl backend."""
+@pytest.mark.parametrize('abi', [False, True])
+def test_two_ranks_rccl_match_single_process(tmp_path, abi):
+    """The same comparison over RCCL: one process per GPU, flat-gradient all-reduce on the nccl backend -- through
+    torch.distributed, and (abi) through the library's own tvae_allreduce_flat on a communicator made through the C ABI."""
     named1, tot1 = _train(0, 1)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    mp.start_processes(_worker_rccl, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    mp.start_processes(_worker_rccl, args=(2, port, str(tmp_path), abi), nprocs=2, join=True, start_method='spawn')
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     for k_ in named1:
