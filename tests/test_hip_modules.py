@@ -270,7 +270,7 @@ def test_step_hot_widths_golden(name, gemm_mode):
         assert_grad_close(t.grad, fx['gd.' + k_], tol=max(GRAD_TOL, 2 * float(fx['kd.' + k_])), name='gen.' + k_)
 
 
-@pytest.mark.parametrize('cfg', ['small', 'small_fourier', 'S28', 'S28F', 'S64', 'S64x', 'M28', 'M28r', 'M50', 'M50x'])
+@pytest.mark.parametrize('cfg', ['small', 'small_fourier', 'S28', 'S28F', 'S64', 'S64x', 'M28', 'M28r', 'M50', 'M50x', 'G96'])
 def test_step_does_not_read_out_of_bounds(cfg):
     """Out-of-bounds READ detector.  Every float tensor the step allocates (torch.empty / torch.zeros, workspaces
     included) becomes a view into the middle of a larger allocation; ELBO and every gradient must be bitwise independent
@@ -293,7 +293,10 @@ def test_step_does_not_read_out_of_bounds(cfg):
                                          # transforms; M28r: a batch whose last 32-column tile is ragged
                                          'M28': (28, 2, 8, 32, 128, 512, 28, 8, False),
                                          'M28r': (28, 2, 8, 5, 128, 512, 28, 8, False),
-                                         'M50': (50, 2, 8, 4, 128, 512, 28, 8, False)}[cfg]
+                                         'M50': (50, 2, 8, 4, 128, 512, 28, 8, False),
+                                         # round 5: a large frame (L = 112, Ho = 97 = 3 x 32 + 1): the WIDE generic transforms
+                                         # along w (workgroup per tile, extra output column on the vector ALU), ragged batch
+                                         'G96': (96, 2, 8, 3, 16, 64, 32, 16, False)}[cfg]
     torch.manual_seed(0)
     gen = M.SpatialGenerator(zd, hid, num_layers=2, fourier_expansion=four, sigma=2.0 / (n - 1)).to(dev())
     enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(
