@@ -156,8 +156,13 @@ int tvae_dense_split2h(const float* W, long ldw, void* a3, long a3_bytes, int ro
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, void* sign_bits, int parts, const float* x_amax, tvae_stream_t stream);
-/* x_amax (optional, ABI 5): with parts = 2 and X read from memory, ONE device word holding max |X| or an upper bound of it
+                       int va_np, void* sign_bits, int parts, const float* x_amax, float* y_amax, tvae_stream_t stream);
+/* y_amax (optional, ABI 7; also the last argument of tvae_linear_dgrad_x6): ONE device word, zeroed by the caller, that
+ * receives max |Y| (max |dX|) of what the launch stores, by atomic max from its epilogue -- the measured h3 bound x_amax of the
+ * launch that streams this output next, so that every hidden layer of a deep decoder runs the two-part arithmetic, not only
+ * the one whose input has an analytic bound.  Needs the output stored and nothing fused behind it (no col_w / sign_bits;
+ * data gradient: no in_xr).
+ * x_amax (optional, ABI 5): with parts = 2 and X read from memory, ONE device word holding max |X| or an upper bound of it
  * (the h3 scale of the streamed operand); the same argument of tvae_linear_dgrad_x6 (plain form: X = dpre) and a_amax /
  * x_amax of tvae_linear_wgrad_x6 (plain form: max |dpre|, max |X|; two-valued form from sign bits against an operand from
  * memory: x_amax >= max |gy[n] X[k][n]|).  A bound that is 2^j too large costs j of the 16 bits by which an element may lie
@@ -171,7 +176,7 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
                          float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
-                         const float* x_amax, tvae_stream_t stream);
+                         const float* x_amax, float* y_amax, tvae_stream_t stream);
 /* ABI 5, the two-valued form WITHOUT the saved activation (vg_bits != NULL; dpre may then be NULL): the 0 / 1 operand
  * [H > 0] and the row sums sum_n gy[n] [H[m][n] > 0] come from the sign bits the forward launch stored (tvae_linear_fwd_x6
  * sign_bits; that launch may then be given Y = NULL and never writes H; ABI 6: with Y = NULL AND sign_bits = NULL it is the

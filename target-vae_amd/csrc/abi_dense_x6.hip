@@ -220,9 +220,13 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,
                        int K, long ldx, long ldy, int act, float slope, const float* col_w, const float* col_b,
                        float* col_y, const float* va_xr, const float* va_wc, const float* va_bc, const float* va_lb,
-                       int va_np, void* sign_bits, int parts, const float* x_amax, tvae_stream_t stream) {
+                       int va_np, void* sign_bits, int parts, const float* x_amax, float* y_amax, tvae_stream_t stream) {
     Epilogue ep;
     ep.C = Y; ep.ldc = ldy;
+    // y_amax (ABI 7): max |Y| of what this launch stores, by atomic max into a word the caller has zeroed (generic epilogue only:
+    // the launch must store its output and fuse nothing behind it)
+    if (y_amax && (!Y || col_w || sign_bits)) return (int)hipErrorInvalidValue;
+    ep.amax_out = y_amax;
     if (sign_bits && (act != ACT_LRELU || N % 32 != 0)) return (int)hipErrorInvalidValue;
     ep.bias = bias;
     ep.res = res; ep.ldres = ldy;
@@ -237,10 +241,12 @@ int tvae_linear_dgrad_x6(const void* w3t, const float* dpre, const float* add, c
                          const float* vg_gy, const float* vg_csum, const float* in_bc, const float* in_lb, int in_np,
                          float* rs_part, long rs_part_floats, const float* rs_wo, const float* rs_gysum, float* rs_db,
                          float* rs_dwo, int parts, const void* vg_bits, const float* rs_rowdot, const float* rs_bias,
-                         const float* x_amax, tvae_stream_t stream) {
+                         const float* x_amax, float* y_amax, tvae_stream_t stream) {
     // dX[k][n] = act'(aux[k][n]) * (add[k][n] + sum_m W[m][k] dpre[m][n]): rows = K, reduction = M; w3t = split of W^T
     Epilogue ep;
     ep.C = dX; ep.ldc = ldx;                             // dX may be NULL when the fused first-layer backward consumes it
+    if (y_amax && (!dX || in_xr)) return (int)hipErrorInvalidValue;      // y_amax (ABI 7): max |dX| as stored, see tvae_linear_fwd_x6
+    ep.amax_out = y_amax;
     ep.res = add; ep.ldres = ldx;
     ep.aux = aux; ep.ldaux = ldx;
     ep.mask = (aux || in_bc) ? mask : ACT_NONE; ep.slope = slope;

@@ -21,7 +21,7 @@ static void launch_heads_bwd(const float* W, const float* dY, long ldy, const fl
 
 extern "C" {
 
-int tvae_abi_version(void) { return 6; }
+int tvae_abi_version(void) { return 7; }
 
 int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* tap_w, float* bank, int C, int Cin,
                          int ksz, int R, tvae_stream_t stream) {

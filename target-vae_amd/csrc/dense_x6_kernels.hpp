@@ -445,7 +445,8 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                                                   int n0, int M, int wave, int lane, const float* wsm,
                                                   float (&ysum)[4], const InTail& it, const float* wc2,
                                                   float (&gsum)[4][2], int tile_n, const float* cbm,
-                                                  const float (&gyv)[4], float oms, unsigned* sbits, long bitw) {
+                                                  const float (&gyv)[4], float oms, unsigned* sbits, long bitw,
+                                                  float& vmax) {
     // direct from the accumulator layout: 32 consecutive n (128 contiguous bytes) per row and instruction.  The
     // optional mask / residual operands are fetched 32 at a time (8 rows x 4 column tiles) before any of them is
     // consumed: 4 global round trips per wave tile instead of one per row, within the 256-register budget of two
@@ -515,6 +516,7 @@ __device__ __forceinline__ void dense_x6_epilogue(f32x16 (&acc)[2][4], const Epi
                         sw[j] = (unsigned)(lane < 32 ? bl : bl >> 32);
                     }
                     if (m < M) {
+                        vmax = fmaxf(vmax, fabsf(v));            // (Epilogue.amax_out)
                         if (crow && !(TVAE_ABL & 4)) __builtin_nontemporal_store(v, crow + j * 32);     // written once, read by a later launch: no reuse in L2
                         if (wsm && !(TVAE_ABL & 2)) ysum[j] += wsm[row] * v;        // fused column dot (next, skinny layer)
                         if (it.xr) {                             // fused first-layer backward (see InTail)
@@ -973,9 +975,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
         for (int j = 0; j < 4; ++j) gyv[j] = vg.gy[n0 + j * 32 + (lane & 31)];
     }
     const float oms = 1.f - vg.slope;
+    float vmax = 0.f;
 #define TVAE_DX6_EPI(A_, M_, R_, V_)                                                                                    \
     dense_x6_epilogue<A_, M_, R_, V_, MASKB>(acc, ep, bsm, m0, n0, M, wave, lane, wsm, ysum, it, wsm_, gsum, tile_n, cbm_, \
-                                             gyv, oms, cd.bits, (long)(N >> 5))
+                                             gyv, oms, cd.bits, (long)(N >> 5), vmax)
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
     if (EPI == 2) {
@@ -1012,6 +1015,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     }
 #undef TVAE_DX6_EPI_R
 #undef TVAE_DX6_EPI
+    if (EPI == 0 && ep.amax_out) {                       // one atomic per wave at most (most find a larger value already there)
+        const float m_ = h3_wave_max(vmax);
+        if (lane == 0) h3_atomic_amax(ep.amax_out, m_);
+    }
     if (it.xr) {
         float* cds = reinterpret_cast<float*>(Bs);          // [wave][128][2]
 #pragma unroll
@@ -1253,6 +1260,7 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
     float gsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float gyv[4] = {0.f, 0.f, 0.f, 0.f};
     const InTail it{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    float vmax_ = 0.f;                                   // (Epilogue.amax_out is not wired for this instance)
     if (TVAE_ABL & 8) {                                  // ablation: no epilogue (keep the accumulators alive)
         float t_ = 0.f;
 #pragma unroll
@@ -1265,13 +1273,13 @@ void dense_x6_plain4_kernel(const uint4* __restrict__ A3, const float* __restric
     } else
     if (ep.act == ACT_LRELU)
         dense_x6_epilogue<ACT_LRELU, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
-                                                                     gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+                                                                     gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0, vmax_);
     else if (ep.act == ACT_TANH)
         dense_x6_epilogue<ACT_TANH, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
-                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0, vmax_);
     else
         dense_x6_epilogue<ACT_NONE, ACT_NONE, false, false, false>(acc, ep, bsm, m0, n0, M, wave, lane, nullptr, ysum, it, nullptr,
-                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0);
+                                                                    gsum, tile_n, nullptr, gyv, 0.f, nullptr, 0, vmax_);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -55,6 +55,8 @@ struct Epilogue {
     float slope = 0.01f;
     int accumulate = 0;            // C += instead of C =
     long ctile = 0;                // dense_x6_kernel only: != 0 -> column tile t (128 columns) starts at C + t*ctile
+    float* amax_out = nullptr;     // dense_x6_kernel (generic epilogue) only: atomic max |stored value| into this (zeroed) word --
+                                   // the h3 bound of the launch that streams this output next (round 6)
     // conv1 output remap: column n = img*convP + p, row m = c*convR + r  ->  C[c*ldc + img*convR*convP + r*convP + p]
     int convR = 0;                 // power of two (reference allows R in {4,8,16})
     int conv_shift = 0;            // log2(convR)

@@ -29,8 +29,8 @@ SIGNATURES = {
     'tvae_conv1_wgrad_dft': 'pppppliiiiiiii',
     'tvae_dense_split3': 'plpliiipp',
     'tvae_dense_split2h': 'plpliiipp',
-    'tvae_linear_fwd_x6': 'pppppiiillifpppppppipip',
-    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppipppp',
+    'tvae_linear_fwd_x6': 'pppppiiillifpppppppipipp',
+    'tvae_linear_dgrad_x6': 'pppppiiillifpppplpppppiplppppippppp',
     'tvae_dec_in_total': 'piiippp',
     'tvae_dgrad_rowsum_total': 'piippfpppp',
     'tvae_linear_wgrad_x6': 'ppppliiillippifppppipiplpppi',
@@ -121,7 +121,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # Arithmetic of the matrix products.  The C ABI is stateless: the mode is host-side ROUTING only -- it decides which
 # entry points tvae.ops calls and with which `parts`:
 #   'h3'   (default) *_x6 / *_dft entry points with parts = 2: operands as TWO fp16 parts under a power-of-two tensor scale,

@@ -68,8 +68,6 @@ class GraphedStep:
             p.grad = gv
         elbo, log_p, kl = _step.elbo_terms(self.x, self.y, self.gen, self.enc, self.lik, (self.E, self.ez, self.et))
         _step.backward_neg_elbo(elbo)
-        from . import ops as _ops
-        _ops.join_side()                   # (no side-stream work is issued while capturing; this is for the warm-up calls)
         return torch.stack([elbo.detach().double(), log_p.detach().double(), kl.detach().double()])
 
     def draw_noise(self, generator=None):

@@ -41,42 +41,6 @@ def act_code(activation) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
-# side stream of the backward (round 5): the decoder's hidden-layer weight gradient produces parameter gradients only -- nothing
-# in the backward reads them before the optimizer -- so it is issued on a second stream and runs under the encoder's backward
-# (HBM-bound transforms, the frequency-domain convolution).  Everything it reads is kept alive until the join (the caching
-# allocator would otherwise hand a freed block to the next main-stream allocation while the side kernel still reads it), and
-# it has its own split-K workspace.  `join_side()` runs as an autograd-engine callback at the end of the backward pass that
-# issued side work, and before that wherever gradients are consumed mid-pass (tvae/optim.py: _gather, i.e. the early
-# all-reduce bucket).  Nothing is issued on the side stream while a hipGraph is being captured.
-# ---------------------------------------------------------------------------------------------
-# MEASURED (round 5, same box, two runs each): 9.49 / 9.55 ms per step overlapped against 9.53 / 9.57 serial -- nothing: the two
-# streams do run concurrently (kernel time per step 11.2 ms inside a 9.55 ms span) but slow each other down by what they gain;
-# the weight gradient holds 130 KB of LDS and two 256-register waves per SIMD, so no other workgroup fits beside it on a CU
-# and the overlap is a partition of the CUs, not a use of idle issue slots.  Correct (bitwise the serial gradients: the
-# bench-size test test_side_stream_backward_is_bitwise_the_serial_backward), therefore kept, but OFF by
-# default: TVAE_OVERLAP=1 switches it on.
-OVERLAP = os.environ.get('TVAE_OVERLAP', '0') == '1'
-_SIDE = {}
-_SIDE_PENDING = []       # (event recorded on the side stream, device, tensors kept alive until the join)
-
-
-def side_stream(device):
-    k = (device.type, device.index)
-    s_ = _SIDE.get(k)
-    if s_ is None:
-        s_ = torch.cuda.Stream(device=device)
-        _SIDE[k] = s_
-    return s_
-
-
-def join_side() -> None:
-    """The current stream waits for every piece of work issued on a side stream since the last join."""
-    while _SIDE_PENDING:
-        ev, device, _keep = _SIDE_PENDING.pop()
-        torch.cuda.current_stream(device).wait_event(ev)
-
-
-# ---------------------------------------------------------------------------------------------
 # optional in-run kernel timing (bench.py): events are recorded on the stream the kernels are launched on
 # ---------------------------------------------------------------------------------------------
 KERNEL_EVENTS = None     # set to {} to record (start, end) torch.cuda.Event pairs per entry point
@@ -214,13 +178,13 @@ def _replace_ws(key, new):
 POISON_WS = os.environ.get('TVAE_POISON_WS', '0') == '1'
 
 
-def workspace(device, floats: int, key: str = '') -> torch.Tensor:
+def workspace(device, floats: int) -> torch.Tensor:
     """Split-K scratch (grown on demand, reused across calls on the same stream).  The caller gets a view of EXACTLY the
     size it asked for: several entry points cap their number of reduction slices by the workspace they are handed, so
     passing "whatever the shared buffer has grown to" would make the summation order of a step depend on which other call
     had run before it (the first step of a process differed from every later one by 2e-7 on one tensor: round 3)."""
-    key = (device.type, device.index) if not key else ('ws_' + key, device.type, device.index)      # key: a second, independent
-    t = _WS.get(key)                                                                              # workspace (side stream)
+    key = (device.type, device.index)
+    t = _WS.get(key)
     if t is None or t.numel() < floats:
         t = torch.empty(int(floats), dtype=torch.float32, device=device)
         _replace_ws(key, t)
@@ -295,7 +259,7 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None, ws_key=''):
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None):
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only).
     bits: [H > 0] as stored sign bits (dpre may then be None).  rowdot_w = the layer's own weight [M][K]: also returns
@@ -304,7 +268,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
     dW = torch.empty(M, K, dtype=torch.float32, device=dev_)
     need = 64 * max(M, 128) * max(K, 128)
     if split_pipe() and M >= 256 and K >= 128 and N % 16 == 0 and N >= 32:
-        ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24), ws_key)
+        ws = workspace(dev_, max(query('tvae_linear_wgrad_x6_ws_floats', M, N, K), 1 << 24))
         # h3 instance: the two-valued form from sign bits against the recomputed first-layer operand (two products per block)
         # ... or (round 4) against an operand from memory whose bound the caller supplies (x_amax), or two plain operands
         # from memory with both bounds (a_amax, x_amax)
@@ -374,6 +338,7 @@ FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
 FUSE_ROW_SUMS = os.environ.get('TVAE_FUSE_ROW_SUMS', '1') != '0'
 FUSE_ENC_WGRAD = os.environ.get('TVAE_FUSE_ENC_WGRAD', '1') != '0'
 FUSE_NO_H = os.environ.get('TVAE_FUSE_NO_H', '1') != '0'
+H3_DEEP = os.environ.get('TVAE_H3_DEEP', '1') != '0'      # round 6: measured bounds -> h3 for every hidden decoder layer
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:
@@ -953,15 +918,27 @@ class DecoderFn(torch.autograd.Function):
         yh = torch.empty(B, Np, n_out, dtype=torch.float32, device=dev)
         fused_out = False
         sbits = None
+        # Round 6: every hidden layer whose input is a STORED activation runs h3 -- the launch that stores hs[l] also leaves
+        # max |hs[l]| in a word (tvae_linear_fwd_x6 y_amax, atomic max from its epilogue), the measured bound of the launch that
+        # streams it next (forward here, weight gradient in the backward).  An analytic row-sum chain would lose ~5 bits of
+        # fp16's exponent headroom per layer; a measured maximum loses none, whatever the depth.
+        meas_words = torch.zeros(max(n_hidden, 1), dtype=torch.float32, device=dev) if (
+            H3_DEEP and parts() == 2 and n_hidden >= 2 and _dense_x6_ok(F_, Nt)) else None
+        h_meas = [None] * (n_hidden + 1)          # h_meas[l]: measured max |hs[l]| (one device word) or None
+        rows_l = h_rows                           # per-unit bound of hs[l] by the row-sum chain (None: not available)
+        rows_all = [rows_l]
         for li, (W, b) in enumerate(hidden):
             hn = None
             if _dense_x6_ok(F_, Nt):
                 # h3 instances: the layer whose streamed operand is the recomputed first-layer activation, or (round 4) the
-                # stored output of the first layer under its bound (deeper layers have no bound worth the name: x6)
-                h3_mem = parts() == 2 and li == 0 and not va and h_bound is not None and not resid
+                # stored output of the first layer under its bound, or (round 6) a deeper layer's stored input under its
+                # measured maximum
+                h3_mem = parts() == 2 and not (va and li == 0) and (
+                    (li == 0 and h_bound is not None and not resid) or (li > 0 and h_meas[li] is not None))
+                x_bound = (h_bound if li == 0 else h_meas[li]) if h3_mem else None
                 p_l = 2 if (parts() == 2 and ((va and li == 0) or h3_mem)) else _p3()
                 if h3_mem:
-                    _note('dec.hidden_h3_mem')
+                    _note('dec.hidden_h3_mem' if li == 0 else 'dec.hidden_h3_meas')
                 w3 = _split_weight(W, F_, F_, False, 'x6_dense_w', nparts=p_l)
                 # the last hidden layer also applies the single-output Linear that follows it (one pass less over h)
                 fuse = FUSE_COLDOT and li == n_hidden - 1 and n_out == 1 and F_ <= 512
@@ -983,17 +960,28 @@ class DecoderFn(torch.autograd.Function):
                     _note('dec.no_h_inference' if infer else 'dec.no_h')
                 else:
                     hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+                # this layer's output feeds another hidden layer: leave its maximum for that launch
+                emit = (meas_words[li:li + 1] if (meas_words is not None and li + 1 < n_hidden and hn is not None and not fuse)
+                        else None)
                 with _timed('tvae_linear_fwd_x6', p_l):
                     call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
-                         p_l, h_bound if h3_mem else None)
+                         p_l, x_bound, emit)
+                h_meas[li + 1] = emit
+                if rows_l is not None and parts() == 2:      # |act(W h + b [+ h])| <= |W| rows + |b| [+ rows], unit by unit
+                    rows_l = torch.addmv(b.detach().abs(), W.detach().abs(), rows_l) + (rows_l if resid else 0.0)
+                else:
+                    rows_l = None
+                rows_all.append(rows_l)
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
                 hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
                      Nt, Nt, act, LRELU_SLOPE)
+                rows_l = None
+                rows_all.append(None)
             hs.append(hn)
         if not fused_out:
             call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
@@ -1005,6 +993,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.arith = get_gemm_mode()
         ctx.sbits = sbits
         ctx.h_bound, ctx.feat_amax, ctx.h_rows = h_bound, feat_amax, h_rows
+        ctx.h_meas, ctx.rows_all = h_meas, rows_all
         return yh
 
     @staticmethod
@@ -1051,6 +1040,14 @@ class DecoderFn(torch.autograd.Function):
         dWo, drow = tot[1:], tot[0]
         grads_hidden = []
         fused_in = False
+        # Round 6 (h3 for every hidden layer): one bound word per stored gradient tensor -- the top one analytically
+        # (|d[m][n]| <= max_m sum_o |Wo[o][m]| max |gy|: act' <= 1), every later one measured by the data-gradient launch that
+        # stores it (tvae_linear_dgrad_x6 y_amax)
+        h3_deep = H3_DEEP and parts() == 2 and _dense_x6_ok(F_, Nt)
+        dmeas = torch.zeros(n_hidden + 1, dtype=torch.float32, device=dev) if h3_deep else None
+        d_bnd = None                                     # bound word of the stored gradient `d` (None: none / not stored)
+        if h3_deep and not virt:
+            d_bnd = (_inf_norm(gy) * Wo.detach().abs().sum(0).amax()).reshape(1)
         for li in range(n_hidden - 1, -1, -1):
             W, b = hidden[li]
             hprev = hs[li]
@@ -1065,18 +1062,25 @@ class DecoderFn(torch.autograd.Function):
             if parts() == 2 and use_vg and sbits is not None and va is None and li == 0 and ctx.h_bound is not None:
                 # one bound per unit (row of the X operand) where the forward formed them, else the tensor's
                 xg_amax = (ctx.h_rows if ctx.h_rows is not None else ctx.h_bound) * _inf_norm(vg[1])
-            # Round 5: the bits form's weight gradient on the side stream (its only consumer inside the backward, the totals of
-            # the row sums, moves there with it): issued AFTER the data gradient below
-            # (only when autograd will ADOPT the returned gradient tensors -- p.grad is None for the three parameters whose
-            #  gradients come from the side stream: with an existing .grad it would add them in place on the main stream the
-            #  moment this function returns, before the side stream has produced them)
-            side = (OVERLAP and from_bits and fuse_rs and act == ACT_LRELU and _dense_x6_ok(F_, Nt) and
-                    not torch.cuda.is_current_stream_capturing() and
-                    all(getattr(t_, 'grad', None) is None for t_ in (W, b, Wo)))
-            if side:
-                dW = rowdot = None
-            elif from_bits:                              # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
+            elif parts() == 2 and use_vg and sbits is not None and va is None and li > 0 and ctx.h_meas[li] is not None:
+                # (round 6) a deeper layer's stored input under its measured maximum, capped per unit by the row-sum chain
+                xb_ = ctx.h_meas[li] if ctx.rows_all[li] is None else torch.minimum(ctx.rows_all[li], ctx.h_meas[li])
+                xg_amax = xb_ * _inf_norm(vg[1])
+            # plain form (both operands stored tensors) in h3: bound of d (one word) and of the layer's input -- the first
+            # layer's analytic per-unit bound, or a deeper layer's measured maximum (capped unit by unit by the row-sum chain
+            # where the forward formed it: a unit far below the others keeps its own scale)
+            plain_h3 = h3_deep and not use_vg and d_bnd is not None and va is None
+            xw_amax = None
+            if plain_h3:
+                if li == 0:
+                    xw_amax = ctx.h_rows if ctx.h_rows is not None else ctx.h_bound
+                elif ctx.h_meas[li] is not None:
+                    xw_amax = ctx.h_meas[li] if ctx.rows_all[li] is None else torch.minimum(ctx.rows_all[li], ctx.h_meas[li])
+            if from_bits:                              # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
                 dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax)
+            elif plain_h3 and xw_amax is not None:
+                _note('dec.wgrad_h3_meas')
+                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, None, None, act, None, a_amax=d_bnd, x_amax=xw_amax), None
             else:
                 dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits, x_amax=xg_amax), None
             db = drow if drow is not None else _rowsum(d, F_, Nt)
@@ -1089,12 +1093,16 @@ class DecoderFn(torch.autograd.Function):
             if _dense_x6_ok(F_, Nt):
                 # LeakyReLU: the implicit gradient in its two-valued form (3 MFMAs per block instead of 6)
                 two_val = use_vg and act == ACT_LRELU
-                p_d = 2 if (parts() == 2 and two_val) else _p3()      # h3 instance: the exact 0 / 1 operand (two products)
+                # h3 instances: the exact 0 / 1 operand (two products), or (round 6) a stored gradient under its bound word
+                p_d = 2 if (parts() == 2 and (two_val or (not use_vg and d_bnd is not None))) else _p3()
+                if p_d == 2 and not two_val:
+                    _note('dec.dgrad_h3_meas')
+                emit = dmeas[li:li + 1] if (dmeas is not None and not fuse_in) else None      # max |dprev| for its consumers
                 if two_val:
                     w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt', scale=vg[0], nparts=p_d)
                     _note('dec.virt_grad_2val')
                 else:
-                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt'), None
+                    w3t, csum = _split_weight(W, F_, F_, True, 'x6_dense_wt', nparts=p_d), None
                 if fuse_in:
                     gxr_f = torch.empty(B, Np, 2, dtype=torch.float32, device=dev)
                     part_f = workspace(dev, (Nt // 128) * F_ * 3)
@@ -1107,27 +1115,9 @@ class DecoderFn(torch.autograd.Function):
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
                          bc if va else None, LB if va else None, Np if va else 0,
                          rs_part, rs_part.numel() if rs else 0, vg[0] if rs else None, dbo if rs else None,
-                         tot[0] if (rs and not side) else None, tot[1] if (rs and not side) else None, p_d,
-                         sbits if from_bits else None, rowdot, b if (from_bits and not side) else None)
-                if side:
-                    _note('dec.wgrad_side_stream')
-                    cur, ss = torch.cuda.current_stream(dev), side_stream(dev)
-                    ev0 = cur.record_event()             # everything the weight gradient and the totals read is complete here
-                    with torch.cuda.stream(ss):          # (dW / rowdot come from the side stream's pool: every later use of
-                        ss.wait_event(ev0)               #  that pool is ordered behind the next step's ev0, i.e. behind the
-                        dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax,      # gather)
-                                            ws_key='side')
-                        call('tvae_dgrad_rowsum_total', rs_part, Nt // 128, F_, vg[0], dbo, LRELU_SLOPE, tot[0], tot[1], rowdot, b)
-                        ev1 = ss.record_event()
-                    # kept alive until the join: what the side kernels READ and nothing else holds (sign bits, upstream gradient,
-                    # coordinates ..).  NOT the returned gradients (dW, the views of `tot`, dbo): an extra reference makes
-                    # autograd's AccumulateGrad CLONE them on the main stream -- before the side stream has written them --
-                    # instead of adopting the tensor; they stay alive through p.grad until the optimizer has gathered them.
-                    _SIDE_PENDING.append((ev1, dev, (rowdot, sbits, vg[1], va, xg_amax)))
-                    # whoever reads the gradients after this backward pass (plain autograd users included) finds them complete:
-                    # the engine runs the join on the backward's stream when the whole pass has finished (the early all-reduce
-                    # bucket, which fires in the middle of the pass, joins by itself: tvae/optim.py _gather)
-                    torch.autograd.Variable._execution_engine.queue_callback(join_side)
+                         tot[0] if rs else None, tot[1] if rs else None, p_d,
+                         sbits if from_bits else None, rowdot, b if from_bits else None,
+                         d_bnd if (p_d == 2 and not two_val) else None, emit)
                 if two_val and li == 0 and n_hidden == 1 and has_f and parts() == 2:
                     # bound of the gradient this launch leaves in `dprev` (read again by the Fourier first layer's backward):
                     # |dX[k][n]| <= max |gy| * sum_m |wo[m] W[m][k]|
@@ -1135,9 +1125,11 @@ class DecoderFn(torch.autograd.Function):
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
+                d_bnd = emit
             else:
                 call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
                      act, LRELU_SLOPE)
+                d_bnd = None
             d = dprev
             grads_hidden.append((dW, db))
         grads_hidden.reverse()
@@ -1168,6 +1160,8 @@ class DecoderFn(torch.autograd.Function):
             # h3 for the Fourier first layer's backward (round 4): both operands come from memory with known bounds -- the
             # features are cosines (<= 1), d is bounded by the two-valued data gradient that produced it (ctx.d_bound)
             d_bound = getattr(ctx, 'd_bound', None) if parts() == 2 else None
+            if d_bound is None and parts() == 2:
+                d_bound = d_bnd                          # (round 6) measured by the launch that stored d
             one = torch.ones(1, dtype=torch.float32, device=dev) if d_bound is not None else None
             dWc = _wgrad(d, feat, F_, Nt, Ff, a_amax=d_bound, x_amax=one)
             dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)

@@ -117,7 +117,6 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def _gather(self, lo: int, hi: int) -> None:
         """Gradients of parameters lo .. hi-1 into their slices of the flat buffer; `p.grad` becomes the view again."""
-        ops.join_side()      # gradients produced on the backward's side stream (tvae/ops.py) are complete from here on
         dst, src = [], []
         for p, gv in zip(self._ps[lo:hi], self._gviews[lo:hi]):
             if p.grad is None:

@@ -378,67 +378,3 @@ def test_bf16_mode_matches_oracle_at_bench_size(cfg, B):
     assert rep['y_hat'] < gate['yhat'], (cfg, rep['y_hat'])
     for k_, v in grads.items():
         assert v['l2'] < gate['grad_l2'] and v['cos'] > gate['cos'], (cfg, k_, v)
-
-
-def test_side_stream_backward_is_bitwise_the_serial_backward():
-    """Round 5: the decoder's hidden-layer weight gradient (+ the totals of the row sums that need its row
-    dot products) runs on a side stream under the encoder's backward.  Same kernels, same operands: every gradient must be
-    BITWISE what the one-stream order gives, at the full batch (every CU busy on both streams), repeatedly, and also when the
-    gradients are consumed through FlatAdam (gather + Adam on the main stream right behind the backward)."""
-    from tvae import ops, optim, step
-    c, B = S64, 256
-    gen, enc = _models(c=c)
-    gen, enc = gen.to(dev()), enc.to(dev())
-    y, E, ez, et = (t.to(dev()) for t in _inputs(B, c=c))
-    x = O.image_coords(c['n']).to(dev())
-    params = list(gen.parameters()) + list(enc.parameters())
-
-    def grads(overlap):
-        saved = ops.OVERLAP
-        ops.OVERLAP = overlap
-        ops.PATH_LOG = set()
-        try:
-            for p in params:
-                p.grad = None
-            elbo, _, _ = step.elbo_terms(x, y, gen, enc, c['lik'], (E, ez, et))
-            step.backward_neg_elbo(elbo)
-            took = set(ops.PATH_LOG)
-            out = [p.grad.detach().clone() for p in params]      # (main stream: ordered behind the engine's join callback)
-            torch.cuda.synchronize()
-        finally:
-            ops.OVERLAP, ops.PATH_LOG = saved, None
-        return out, took
-
-    g0, took0 = grads(False)
-    assert 'dec.wgrad_side_stream' not in took0
-    for rep in range(3):
-        g1, took1 = grads(True)
-        assert 'dec.wgrad_side_stream' in took1, took1
-        for a, b, p in zip(g0, g1, params):
-            assert torch.equal(a, b), (rep, tuple(p.shape))
-    # through the optimizer: two Adam steps from the same start, serial vs overlapped
-    start = [p.detach().clone() for p in params]
-    res = []
-    for overlap in (False, True):
-        with torch.no_grad():
-            for p, s_ in zip(params, start):
-                p.copy_(s_)
-        opt = optim.FlatAdam(params, lr=1e-3)
-        saved = ops.OVERLAP
-        ops.OVERLAP = overlap
-        try:
-            for _ in range(2):
-                elbo, _, _ = step.elbo_terms(x, y, gen, enc, c['lik'], (E, ez, et))
-                step.backward_neg_elbo(elbo)
-                opt.step()
-                opt.zero_grad(set_to_none=True)
-            torch.cuda.synchronize()
-        finally:
-            ops.OVERLAP = saved
-        res.append([p.detach().clone() for p in params])
-        # detach the parameters from this optimizer's flat buffer before the next one is built
-        with torch.no_grad():
-            for p in params:
-                p.data = p.data.clone()
-    for a, b in zip(*res):
-        assert torch.equal(a, b)

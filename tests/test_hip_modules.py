@@ -922,3 +922,79 @@ def test_decoder_pads_pixel_ranges_to_the_gemm_tile(gemm_mode):
         if nm == 'conv_a.bias':
             continue
         assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-3, nm      # (kink flips between the two paths)
+
+
+@pytest.mark.parametrize('fourier,n_out,resid', [(False, 1, False), (True, 3, False), (False, 3, True), (True, 1, False)])
+def test_deep_decoder_runs_h3_on_measured_bounds(fourier, n_out, resid, gemm_mode):
+    """Round 6: every hidden layer of a deep decoder (galaxy configuration: 4 layers, reference
+    train_galaxy.py:412-420, src/models.py:84-93) runs the two-part h3 arithmetic -- the launch that stores a hidden activation
+    (or a hidden gradient) leaves its measured maximum for the launch that streams it next (tvae_linear_fwd_x6 /
+    tvae_linear_dgrad_x6 y_amax).  Against float64 on the CPU: outputs 1e-5, gradients 2e-4 of max-norm; the h3 instances
+    must be the ones that ran (no silent x6), also for a hidden unit 2^-20 below its layer."""
+    import src.models as M
+    from tvae import ops
+    if gemm_mode != 'h3':
+        pytest.skip('h3 routing test')
+    torch.manual_seed(11)
+    zd, hid, L, B, Np = 4, 512, 4, 4, 256
+    sigma = 2.0 / 15
+    gen = M.SpatialGenerator(zd, hid, n_out=n_out, num_layers=L, resid=resid, fourier_expansion=fourier, sigma=sigma)
+    with torch.no_grad():                                # a hidden unit far below the others (dead / untrained), layer 2
+        lin = gen.layers[3].linear if resid else gen.layers[3]
+        lin.weight[7].mul_(2.0 ** -20)
+        lin.bias[7].mul_(2.0 ** -20)
+    sd64 = {k_: v.detach().double().clone().requires_grad_(v.dtype.is_floating_point and 'embed' not in k_)
+            for k_, v in gen.state_dict().items()}
+    x = (torch.rand(B, Np, 2) * 2 - 1)
+    z = torch.randn(B, zd)
+    gy = torch.randn(B, Np, n_out)
+    x64, z64 = x.double().requires_grad_(True), z.double().requires_grad_(True)
+    import torch.nn.functional as F_nn
+
+    def ref():                                           # oracle.generator_forward in float64 (same formulas, reference lines there)
+        h = x64.reshape(B * Np, 2)
+        if fourier:
+            h = torch.cos(F_nn.linear(h, sd64['embed_latent.weight'] / sigma, sd64['embed_latent.bias']))
+        h = F_nn.linear(h, sd64['coord_linear.weight'], sd64['coord_linear.bias']).view(B, Np, -1)
+        h = (h + F_nn.linear(z64, sd64['latent_linear.weight']).unsqueeze(1)).view(B * Np, -1)
+        h = F_nn.leaky_relu(h, 0.01)
+        li = 1
+        for _ in range(1, L):
+            if resid:
+                h = F_nn.leaky_relu(F_nn.linear(h, sd64[f'layers.{li}.linear.weight'], sd64[f'layers.{li}.linear.bias']) + h, 0.01)
+                li += 1
+            else:
+                h = F_nn.leaky_relu(F_nn.linear(h, sd64[f'layers.{li}.weight'], sd64[f'layers.{li}.bias']), 0.01)
+                li += 2
+        return F_nn.linear(h, sd64[f'layers.{li}.weight'], sd64[f'layers.{li}.bias']).view(B, Np, n_out)
+
+    y64 = ref()
+    (y64 * gy.double()).sum().backward()
+    gen = gen.to(dev())
+    xg, zg = x.to(dev()).requires_grad_(True), z.to(dev()).requires_grad_(True)
+    ops.PATH_LOG, ops.PARTS_LOG = set(), {}
+    try:
+        yh = gen(xg, zg)
+        (yh * gy.to(dev())).sum().backward()
+        torch.cuda.synchronize()
+        took, plog = set(ops.PATH_LOG), dict(ops.PARTS_LOG)
+    finally:
+        ops.PATH_LOG, ops.PARTS_LOG = None, None
+    assert {'dec.hidden_h3_meas', 'dec.dgrad_h3_meas', 'dec.wgrad_h3_meas'} <= took, took
+    # every split-pipe launch of the decoder ran a two-part instance (the recomputed / two-valued forms included); the only
+    # three-part launch left is a residual first hidden layer behind a stored coordinate layer (no h3 instance: x6)
+    # (without Fourier features the first hidden layer's weight gradient meets a stored gradient with the RECOMPUTED coordinate
+    #  layer: that operand pair has no h3 instance)
+    for ep_ in ('tvae_linear_fwd_x6', 'tvae_linear_dgrad_x6', 'tvae_linear_wgrad_x6'):
+        ps = [p_ for p_, _ in plog[ep_]]
+        allowed3 = (1 if resid else 0) + (1 if (ep_ == 'tvae_linear_wgrad_x6' and not fourier and not resid) else 0)
+        assert ps.count(3) <= allowed3 and set(ps) <= {2, 3}, (ep_, ps)
+    assert rel_err(yh, y64.detach()) < 1e-5
+    assert_grad_close(xg.grad.reshape(-1, 2), x64.grad.reshape(-1, 2), tol=2e-4, name='gx')
+    assert_grad_close(zg.grad, z64.grad, tol=2e-4, name='gz')
+    for k_, t in gen.named_parameters():
+        assert_grad_close(t.grad, sd64[k_].grad, tol=2e-4, name=k_)
+    # the dead unit's own gradient row, relative to ITSELF (its scale group is its row / its bound)
+    wname = 'layers.3.linear.weight' if resid else 'layers.3.weight'
+    g_dead, r_dead = dict(gen.named_parameters())[wname].grad[7].double().cpu(), sd64[wname].grad[7]
+    assert float((g_dead - r_dead).abs().max() / r_dead.abs().max()) < 1e-3, 'dead unit row'

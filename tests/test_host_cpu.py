@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.tvae_abi_version() == _lib.ABI_VERSION == 6
+    assert L.tvae_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_signature_arity_matches_header():
