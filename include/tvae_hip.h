@@ -69,12 +69,13 @@ int tvae_linear_wgrad(const float* dpre, const float* X, float* dW, float* ws, l
                       long ldd, long ldx, int accumulate, tvae_stream_t stream);
 
 /* ---- reductions / skinny products used by bias grads, coordinate layer, last decoder layer ----
- * rowdot_seg: out[seg][m][o] = sum_{n in seg} X[m][n] * V[n][o]   (V NULL -> ones, no = 1; no in {1,2,3,4})
+ * rowdot_seg: out[seg][m][o] = sum_{n in seg} X[m][n] * V[n][o]   (V NULL -> ones, no = 1; no in {1,2,3,4});
+ *             amax (optional, ABI 7): one ZEROED device word that also receives max |X| (the h3 bound of X's consumer)
  * seg_sum:    out[i] (+)= scale * sum_s in[s][i]
  * coldot:     out[n][o] = b[o] + sum_m W[m*wsm + o*wso] X[m][n]
  * outer_mask: D[m][n] = (sum_o W[m*wsm + o*wso] dy[n][o]) * act'(H[m][n])
  * act_bwd:    dpre[i] = dY[i] * act'(Y[i]) */
-int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out,
+int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out, float* amax,
                     tvae_stream_t stream);
 int tvae_seg_sum(const float* in, int S, long L, float* out, float scale, int accumulate, tvae_stream_t stream);
 int tvae_coldot(const float* X, long ldx, int M, int N, const float* W, int wsm, int wso, const float* bias, int no,
@@ -333,6 +334,23 @@ long tvae_enc_tail_wgrad_x6_ws_floats(long N);
 int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long ldd, int nh, const void* bits_h,
                            const float* Wh, float* dW2, float* ws, long ws_floats, int C, long N, float slope, int parts, const float* amax_a1,
                            tvae_stream_t stream);
+/* ---- encoder tail with MANY head rows (ABI 7; 8 <= nh <= 128, e.g. the galaxy configuration's z_dim = 50 -> 103 rows:
+ * reference train_galaxy.py:412-420, src/models.py:347-358,390-392): both directions as two chained 128 x 128 split-pipe
+ * GEMMs per 32-column chunk with a register hand-off (csrc/enc_tail_wide_kernels.hpp); parts = 2 (h3) or 1 (bf16) -- both
+ * weights stay in LDS, which the exact three-part split does not fit.  C = 128.
+ *   forward: w3 = cells of W2 (tvae_dense_split2h / split3 with one part used, rows = K = 128); wh3 = cells of Wh with its K
+ *     columns in the order slot 16 u + 8 h + j <- row 16 u + 8 (j >> 2) + 4 h + (j & 3) (rows = nh, K = 128); H may be NULL
+ *     (inference); bits_h / bits_a (LeakyReLU, both or neither): the sign words tvae_enc_tail_fwd_x6 writes; amax_a1 as there.
+ *   data gradient (LeakyReLU): wht3 = cells of Wh^T (transpose = 1: rows = 128, K = nh); w3p = cells of W2^T with the same
+ *     K order (as tvae_enc_tail_dgrad_x6); dH (optional) receives act'(H) . Wh^T dheads for the weight gradients
+ *     (dW2 = dH A1^T, db2 = rowsum dH); amax_dheads (parts = 2): ONE word >= max |dheads| (tvae_rowdot_seg amax). */
+int tvae_enc_tail_wide_max_rows(void);
+int tvae_enc_tail_fwd_wide(const void* w3, const void* wh3, const float* A1, long lda, const float* b2, const float* bh, int nh,
+                           float* H, long ldh, float* heads, long ldo, void* bits_h, void* bits_a, int C, long N, int act,
+                           float slope, int parts, const float* amax_a1, tvae_stream_t stream);
+int tvae_enc_tail_dgrad_wide(const void* wht3, const void* w3p, const float* dheads, long ldd, int nh, const void* bits_h,
+                             const void* bits_a, float* dH, long ldh, float* dA1, long lda, int C, long N, float slope,
+                             int parts, const float* amax_dheads, tvae_stream_t stream);
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

@@ -45,17 +45,17 @@ int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_
     TVAE_CHECK_LAUNCH();
     return 0;
 }
-int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out,
+int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int N, int seglen, float* out, float* amax,
                     tvae_stream_t stream) {
     if (seglen <= 0 || M <= 0) return (int)hipErrorInvalidValue;
     const int nseg = (N + seglen - 1) / seglen;
     dim3 grid(M, nseg), block(256);
     if (!V) no = 1;
     switch (no) {
-        case 1: hipLaunchKernelGGL(rowdot_seg_kernel<1>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
-        case 2: hipLaunchKernelGGL(rowdot_seg_kernel<2>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
-        case 3: hipLaunchKernelGGL(rowdot_seg_kernel<3>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
-        case 4: hipLaunchKernelGGL(rowdot_seg_kernel<4>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M); break;
+        case 1: hipLaunchKernelGGL(rowdot_seg_kernel<1>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M, amax); break;
+        case 2: hipLaunchKernelGGL(rowdot_seg_kernel<2>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M, amax); break;
+        case 3: hipLaunchKernelGGL(rowdot_seg_kernel<3>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M, amax); break;
+        case 4: hipLaunchKernelGGL(rowdot_seg_kernel<4>, grid, block, 0, S(stream), X, ldx, V, N, seglen, out, M, amax); break;
         default: return (int)hipErrorInvalidValue;
     }
     TVAE_CHECK_LAUNCH();

@@ -162,7 +162,7 @@ static __global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, c
 // ------------------------------------------------------------------------------------------
 template <int NO>
 static __global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ V, int N,
-                                  int seglen, float* __restrict__ out, int M) {
+                                  int seglen, float* __restrict__ out, int M, float* __restrict__ amax) {
     __shared__ float sm[NO * 16];
     const int m = blockIdx.x, seg = blockIdx.y;
     const int nbeg = seg * seglen;
@@ -170,9 +170,11 @@ static __global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, 
     float acc[NO];
 #pragma unroll
     for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+    float mx = 0.f;                                      // amax (optional): max |X| by the way -- the h3 bound of X's consumer
     const float* xr = X + (long)m * ldx;
     for (int n = nbeg + threadIdx.x; n < nend; n += blockDim.x) {
         const float x = xr[n];
+        mx = fmaxf(mx, fabsf(x));
         if (V) {
 #pragma unroll
             for (int o = 0; o < NO; ++o) acc[o] += x * V[(long)n * NO + o];
@@ -184,6 +186,13 @@ static __global__ void rowdot_seg_kernel(const float* __restrict__ X, long ldx, 
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int o = 0; o < NO; ++o) out[((long)seg * M + m) * NO + o] = acc[o];
+    }
+    if (amax) {                                          // one atomic per workgroup, and only when it brings something new
+        mx = block_max(mx, sm);
+        if (threadIdx.x == 0) {
+            const unsigned b = __float_as_uint(mx);
+            if (b > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(amax))) atomicMax(reinterpret_cast<unsigned*>(amax), b);
+        }
     }
 }
 

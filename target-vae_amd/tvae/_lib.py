@@ -37,7 +37,7 @@ SIGNATURES = {
     'tvae_linear_fwd': 'ppppippiiillif',
     'tvae_linear_dgrad': 'pppppiiillif',
     'tvae_linear_wgrad': 'ppppliiilli',
-    'tvae_rowdot_seg': 'plpiiiip',
+    'tvae_rowdot_seg': 'plpiiiipp',
     'tvae_seg_sum': 'pilpfi',
     'tvae_coldot': 'pliipiipip',
     'tvae_outer_mask': 'pipiiplpliiif',
@@ -52,6 +52,8 @@ SIGNATURES = {
     'tvae_enc_tail_fwd_x6': 'pplpppiplplppilifip',
     'tvae_enc_tail_dgrad_x6': 'ppplippplilfi',
     'tvae_enc_tail_wgrad_x6': 'plplipppplilfip',
+    'tvae_enc_tail_fwd_wide': 'ppplppiplplppilifip',
+    'tvae_enc_tail_dgrad_wide': 'ppplippplplilfip',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',
@@ -83,6 +85,7 @@ QUERIES = {
     'tvae_conv1_dft_frame': ('iiiiiii', 'i'),
     'tvae_conv1_dft_ring': ('iiiiiii', 'i'),
     'tvae_enc_tail_wgrad_x6_ws_floats': ('l', 'l'),
+    'tvae_enc_tail_wide_max_rows': ('', 'i'),
     'tvae_linear_wgrad_x6_ws_floats': ('iii', 'l'),
 }
 

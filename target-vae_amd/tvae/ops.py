@@ -217,12 +217,12 @@ def _seglen(N: int) -> int:
     return max(2048, (N + 255) // 256)
 
 
-def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[m] = sum_n X[m][n] (deterministic two-level reduction)."""
+def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = sum_n X[m][n] (deterministic two-level reduction).  amax (a zeroed device word): also receives max |X|."""
     sl = _seglen(N)
     nseg = (N + sl - 1) // sl
     tmp = torch.empty(nseg, M, dtype=torch.float32, device=X.device)
-    call('tvae_rowdot_seg', X, N, None, 1, M, N, sl, tmp)
+    call('tvae_rowdot_seg', X, N, None, 1, M, N, sl, tmp, amax)
     if out is None:
         out = torch.empty(M, dtype=torch.float32, device=X.device)
     call('tvae_seg_sum', tmp, nseg, M, out, 1.0, 0)
@@ -474,6 +474,14 @@ def _enc_tail_fused(C: int, C2: int, nh: int, N: int = 0) -> bool:
     return FUSE_ENC_TAIL and split_pipe() and C == 128 and C2 == 128 and nh <= 7 and N < ENC_TAIL_MAX_COLS
 
 
+def _enc_tail_wide(C: int, C2: int, nh: int, N: int, have_a1max: bool) -> bool:
+    """Round 6: the encoder tail with 8 .. 128 head rows (z_dim > 2: the galaxy configuration's z_dim = 50 gives 103) as two
+    chained split-pipe GEMMs per direction (enc_tail_wide_kernels.hpp) instead of separate fp32-MFMA GEMMs.  h3 or bf16
+    arithmetic (both weights stay in LDS; the exact three-part split does not fit), the reference's 128 channels."""
+    return (FUSE_ENC_TAIL and split_pipe() and parts() in (1, 2) and C == 128 and C2 == 128 and SKINNY_MAX <= nh <= 128 and
+            N < ENC_TAIL_MAX_COLS and (parts() == 1 or have_a1max))
+
+
 class EncoderFn(torch.autograd.Function):
     """conv1 -> act -> conv2 (1x1x1) -> act -> {conv_a, conv_r, conv_z} (src/models.py:354-358,390-392).
 
@@ -499,13 +507,28 @@ class EncoderFn(torch.autograd.Function):
         A1 = conv1_forward(y, w1, b1, C, R, k, pad, act, keep)
         ctx.at = None if infer else keep.get('at')
         fused = _enc_tail_fused(C, C2, nh, N)
+        wide = not fused and _enc_tail_wide(C, C2, nh, N, keep.get('out_max') is not None)
         # inference: the fused tail writes the head rows only -- H is neither allocated nor stored (include/tvae_hip.h, ABI 6)
-        H = None if (infer and fused) else torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        H = None if (infer and (fused or wide)) else torch.empty(C2, N, dtype=torch.float32, device=y.device)
         heads = torch.empty(nh, N, dtype=torch.float32, device=y.device)
         bits = None
+        a1max = None
         if infer:
             _note('enc.inference')
-        if fused:
+        if wide:
+            # conv2 + the stacked head projection as two chained GEMMs per 32-column chunk (H handed over in registers)
+            p_f = parts()
+            a1max = keep.get('out_max') if p_f == 2 else None
+            w3 = _split_weight(W2, C2, C, False, 'enc_w2', nparts=p_f)
+            whp = _split_weight(Wh[:, _enc_tail_perm(y.device)], nh, C2, False, 'enc_whp', nparts=p_f)
+            _note('enc.tail_fwd_wide')
+            if act == ACT_LRELU and not infer:
+                bits = torch.empty(2, N, 4, dtype=torch.int32, device=y.device)
+            with _timed('tvae_enc_tail_fwd_wide', p_f):
+                call('tvae_enc_tail_fwd_wide', w3, whp, A1, N, b2, bh.contiguous(), nh, H, N, heads, N,
+                     bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act, LRELU_SLOPE,
+                     p_f, a1max)
+        elif fused:
             # conv2 + the stacked head projection in one pass over A1 and one over H, on the split pipe
             # h3 instance: needs max |A1| from A1's producer -- the output transform of the frequency-domain convolution leaves
             # it in the last word behind A^T (keep['at'])
@@ -530,6 +553,7 @@ class EncoderFn(torch.autograd.Function):
             return heads
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.bits = bits
+        ctx.wide = wide
         ctx.a1max = a1max if fused else None      # (a view of keep['at']: max |A1| for the h3 weight gradient)
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
@@ -543,9 +567,24 @@ class EncoderFn(torch.autograd.Function):
         N = B * R * Ho * Ho
         C2, nh = W2.shape[0], Wh.shape[0]
         dheads = dheads.contiguous()
-        dbh = _rowsum(dheads, nh, N)
+        wide_bw = ctx.wide and ctx.bits is not None
+        dmax = torch.zeros(1, dtype=torch.float32, device=y.device) if (wide_bw and parts() == 2) else None
+        dbh = _rowsum(dheads, nh, N, amax=dmax)          # (+ max |dheads| by the way: the h3 bound of the wide data gradient)
         dA1 = None
-        if ctx.bits is not None:
+        dH = None
+        if wide_bw:
+            # dH = act'(H) . Wh^T dheads and dA1 = act'(A1) . W2^T dH in one launch (dH handed over in registers and stored
+            # once for the two weight gradients below)
+            p_e = parts()
+            wht = _split_weight(Wh, C2, nh, True, 'enc_wht', nparts=p_e)
+            w3p = _split_weight(W2.t()[:, _enc_tail_perm(y.device)], C, C2, False, 'enc_w2p', nparts=p_e)
+            dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+            dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)
+            _note('enc.tail_dgrad_wide')
+            with _timed('tvae_enc_tail_dgrad_wide', p_e):
+                call('tvae_enc_tail_dgrad_wide', wht, w3p, dheads, N, nh, ctx.bits[0], ctx.bits[1], dH, N, dA1, N, C, N,
+                     LRELU_SLOPE, p_e, dmax)
+        elif ctx.bits is not None:
             # dA1 straight from the head gradients and the sign words (dH is formed in registers, never stored)
             p_e = 2 if parts() == 2 else _p3()      # h3 instance: 128 x 128 GEMM on two fp16 parts, scale per 32-column chunk
             w3p = _split_weight(W2.t()[:, _enc_tail_perm(y.device)], C, C2, False, 'enc_w2p', nparts=p_e)
@@ -558,9 +597,13 @@ class EncoderFn(torch.autograd.Function):
                      LRELU_SLOPE, p_e)
         # conv2's weight gradient in one pass from A1, the head gradients and the sign words of H (dH is formed inside the
         # GEMM's operand build and never written); dWh / db2 from a sums-only pass over H
-        fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0
-        dH = None if fuse_w else torch.empty(C2, N, dtype=torch.float32, device=y.device)
-        if nh <= SKINNY_MAX:
+        fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0 and not wide_bw
+        if not fuse_w and dH is None:
+            dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
+        if wide_bw:
+            dWh = _wgrad(dheads, H, nh, N, C2)
+            db2 = _rowsum(dH, C2, N)
+        elif nh <= SKINNY_MAX:
             # one pass over H: masked dgrad + dWh + the row sums of dH (= db2)
             npan = (N + 511) // 512
             part = workspace(y.device, npan * C2 * (nh + 1) + 4 + 64 * C2 * (nh + 1))      # + room for the two-stage total

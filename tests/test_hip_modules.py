@@ -998,3 +998,65 @@ def test_deep_decoder_runs_h3_on_measured_bounds(fourier, n_out, resid, gemm_mod
     wname = 'layers.3.linear.weight' if resid else 'layers.3.weight'
     g_dead, r_dead = dict(gen.named_parameters())[wname].grad[7].double().cpu(), sd64[wname].grad[7]
     assert float((g_dead - r_dead).abs().max() / r_dead.abs().max()) < 1e-3, 'dead unit row'
+
+
+@pytest.mark.parametrize('zd', [10, 50])
+def test_encoder_with_many_head_rows_takes_the_wide_tail(zd, gemm_mode):
+    """Round 6: z_dim > 2 gives 3 + 2 z_dim > 7 head rows (galaxy: 103, reference
+    train_galaxy.py:412-420); conv2 + the stacked heads then run as two chained split-pipe GEMMs per direction
+    (tvae_enc_tail_fwd_wide / _dgrad_wide) instead of five fp32-MFMA GEMMs.  The 7-tuple and every parameter gradient against
+    the exact fp32-MFMA arithmetic of the same modules; the wide branch must be the one taken (h3), under no_grad too."""
+    import src.models as M
+    from tvae import ops
+    from tvae._lib import arithmetic
+    if gemm_mode != 'h3':
+        pytest.skip('h3 routing test')
+    torch.manual_seed(5)
+    n, B, R, k, pad = 20, 3, 4, 20, 4
+    enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(n, 1, zd, kernels_num=128, kernels_size=k, padding=pad,
+                                                                    groupconv=R, rot_refinement=True, theta_prior=np.pi,
+                                                                    normal_prior_over_r=False).to(dev())
+    with torch.no_grad():
+        for m in (enc.conv_a, enc.conv_r, enc.conv_z):
+            m.weight.mul_(8.0)
+    y = torch.rand(B, 1, n, n, device=dev())
+    Ho = n + 2 * pad - k + 1
+    gen = torch.Generator(device=dev()).manual_seed(1)
+    wts = [torch.randn(B, R, Ho, Ho, device=dev(), generator=gen), torch.randn(B, 2, R, Ho, Ho, device=dev(), generator=gen),
+           torch.randn(B, 2 * zd, R, Ho, Ho, device=dev(), generator=gen)]
+
+    def run(mode):
+        for p in enc.parameters():
+            p.grad = None
+        ops.PATH_LOG = set()
+        try:
+            with arithmetic(mode):
+                torch.manual_seed(77)                    # the encoder draws its Gumbel noise itself (reference models.py:387)
+                out = enc(y, dev())
+                attn, q, p_r, a, off, theta, z = out
+                ((q * wts[0]).sum() + (theta * wts[1]).sum() + (z * wts[2]).sum()).backward()
+            torch.cuda.synchronize()
+            return [t.detach().clone() for t in (attn, q, a, theta, z)], {k_: p.grad.clone() for k_, p in enc.named_parameters()}, set(ops.PATH_LOG)
+        finally:
+            ops.PATH_LOG = None
+
+    o1, g1, took = run('h3')
+    o0, g0, took0 = run('f32')
+    assert {'enc.tail_fwd_wide', 'enc.tail_dgrad_wide'} <= took, took
+    assert 'enc.tail_fwd_wide' not in took0
+    for a_, b_ in zip(o1, o0):
+        assert rel_err(a_, b_) < 2e-5
+    for k_ in g0:
+        if k_ == 'conv_a.bias':
+            continue                                     # analytically zero (the log-softmax is shift invariant): rounding noise
+        assert_grad_close(g1[k_], g0[k_], tol=GRAD_TOL, name=k_)
+    ops.PATH_LOG = set()
+    try:
+        with torch.no_grad():
+            torch.manual_seed(77)
+            oi = enc(y, dev())
+        took_i = set(ops.PATH_LOG)
+    finally:
+        ops.PATH_LOG = None
+    assert {'enc.tail_fwd_wide', 'enc.inference'} <= took_i, took_i
+    assert torch.equal(oi[5], o1[3]) and torch.equal(oi[6], o1[4])

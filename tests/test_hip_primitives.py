@@ -1256,3 +1256,88 @@ def test_implicit_wgrad_and_multi_tile_dft_fp64():
     torch.cuda.synchronize()
 
     assert max(e1, e2, e3) < GEMM_TOL['f32'], (e1, e2, e3)
+
+
+@pytest.mark.parametrize('N,nh,act,parts', [(4096, 103, 1, 2), (1000, 8, 1, 2), (2080, 23, 1, 2), (4128, 128, 1, 2), (999, 64, 2, 2),
+                                            (1024, 65, 0, 2), (4096, 103, 1, 1)])
+def test_enc_tail_wide(N, nh, act, parts):
+    """Round 6: the encoder tail with 8 .. 128 head rows (galaxy: z_dim = 50 -> 103 rows; reference src/models.py:347-358,
+    390-392) as two chained split-pipe GEMMs per direction -- tvae_enc_tail_fwd_wide / tvae_enc_tail_dgrad_wide against
+    float64: H, the head rows, the sign words, dH and dA1; ragged N (not a multiple of the 32-column chunk), head-row counts
+    that leave partial k-steps (nh % 16 != 0) and partial row tiles, a row of every operand 2^-20 below the rest (h3: per
+    row relative error), and the bf16 throughput arithmetic at its own tolerance."""
+    from tvae._lib import query
+    C = 128
+    s = 2.0 ** -20
+    W2, b2 = rnd(C, C, seed=1, scale=C ** -0.5), rnd(C, seed=2)
+    Wh, bh = rnd(nh, C, seed=3, scale=C ** -0.5), rnd(nh, seed=4)
+    A1 = rnd(C, N, seed=5)
+    W2[5] *= s; b2[5] *= s                                # a row of W2 (row of H), a head row, a column of Wh (row of dH)
+    Wh[nh - 2] *= s; bh[nh - 2] *= s
+    Wh[:, 19] *= s
+    perm = _enc_tail_perm().cpu()
+    split = 'tvae_dense_split2h' if parts == 2 else 'tvae_dense_split3'
+
+    def cells(W, rows, K, transpose):
+        a3 = torch.empty(query('tvae_dense_x6_bytes', rows, K) // 4, device=dev())
+        call(split, W.contiguous().to(dev()), W.shape[1], a3, a3.numel() * 4, rows, K, transpose, None, None)
+        return a3
+
+    a1max = A1.abs().amax(dim=1).contiguous().to(dev()) if parts == 2 else None
+    w3, whp = cells(W2, C, C, 0), cells(Wh[:, perm], nh, C, 0)
+    H = torch.full((C, N), float('nan'), device=dev())
+    heads = torch.full((nh, N), float('nan'), device=dev())
+    bits = torch.zeros(2, N, 4, dtype=torch.int32, device=dev()) if act == 1 else None
+    call('tvae_enc_tail_fwd_wide', w3, whp, A1.to(dev()), N, b2.to(dev()), bh.to(dev()), nh, H, N, heads, N,
+         bits[0] if bits is not None else None, bits[1] if bits is not None else None, C, N, act, SLOPE, parts, a1max)
+    Hr = act_ref(W2.double() @ A1.double() + b2.double()[:, None], act)
+    hr = Wh.double() @ Hr + bh.double()[:, None]
+    tol = ROW_TOL if parts == 2 else 2e-2
+    assert row_rel_err(H, Hr) < tol
+    assert row_rel_err(heads, hr) < (tol if parts == 2 else 3e-2)
+    # inference form: no H, no sign words, the same head rows bit for bit
+    h2 = torch.full((nh, N), float('nan'), device=dev())
+    call('tvae_enc_tail_fwd_wide', w3, whp, A1.to(dev()), N, b2.to(dev()), bh.to(dev()), nh, None, N, h2, N, None, None, C, N,
+         act, SLOPE, parts, a1max)
+    assert torch.equal(h2, heads)
+    if act != 1:
+        return
+    # sign words: bit (row & 31) of word (row >> 5) of column n (the layout tvae_enc_tail_fwd_x6 writes)
+    Hs = H.double().cpu()
+    for t, ref in ((bits[0], Hs), (bits[1], A1.double())):
+        w = t.cpu().numpy().astype(np.uint32)             # [N][4]
+        got = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(N, 128).T
+        assert np.array_equal(got.astype(bool), (ref > 0).numpy())
+    dheads = rnd(nh, N, seed=6)
+    dheads[3] *= s
+    dmax = dheads.abs().max().reshape(1).to(dev()) if parts == 2 else None
+    wht, w3p = cells(Wh, C, nh, 1), cells(W2.t()[:, perm], C, C, 0)
+    dH = torch.full((C, N), float('nan'), device=dev())
+    dA1 = torch.full((C, N), float('nan'), device=dev())
+    call('tvae_enc_tail_dgrad_wide', wht, w3p, dheads.to(dev()), N, nh, bits[0], bits[1], dH, N, dA1, N, C, N, SLOPE, parts, dmax)
+    dHr = (Wh.double().t() @ dheads.double()) * dact_ref(Hs, 1)
+    dAr = (W2.double().t() @ dHr) * dact_ref(A1.double(), 1)
+    assert row_rel_err(dH, dHr) < tol
+    assert row_rel_err(dA1, dAr) < tol
+    # without the dH output: the same dA1 bit for bit
+    dA2 = torch.full((C, N), float('nan'), device=dev())
+    call('tvae_enc_tail_dgrad_wide', wht, w3p, dheads.to(dev()), N, nh, bits[0], bits[1], None, N, dA2, N, C, N, SLOPE, parts, dmax)
+    assert torch.equal(dA2, dA1)
+    with pytest.raises(Exception):                       # more head rows than the kernel's 128
+        call('tvae_enc_tail_fwd_wide', w3, whp, A1.to(dev()), N, b2.to(dev()), bh.to(dev()), 129, H, N, heads, N, None, None, C, N,
+             act, SLOPE, parts, a1max)
+    if parts == 2:
+        with pytest.raises(Exception):                   # h3 without the operand bound
+            call('tvae_enc_tail_dgrad_wide', wht, w3p, dheads.to(dev()), N, nh, bits[0], bits[1], dH, N, dA1, N, C, N, SLOPE, 2, None)
+
+
+def test_rowdot_seg_amax():
+    """tvae_rowdot_seg's optional by-product (ABI 7): max |X| into a zeroed word, next to the segment sums."""
+    M, N = 9, 70001
+    X = rnd(M, N, seed=3)
+    X[4, 12345] = -77.5
+    tmp = torch.empty(35, M, device=dev())
+    amax = torch.zeros(1, device=dev())
+    call('tvae_rowdot_seg', X.to(dev()), N, None, 1, M, N, 2048, tmp, amax)
+    assert float(amax) == 77.5
+    assert rel_err(tmp.sum(0), X.double().sum(1)) < 1e-5
