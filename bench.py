@@ -61,7 +61,12 @@ def spawn_ranks(n: int, timeout_s: float = 3600.0) -> int:
     import socket
     import subprocess
     have = visible_gpu_count()
-    if have < n:
+    # TVAE_BENCH_REHEARSE=1: a dress rehearsal of the N-rank code path on ONE GPU -- every rank on device 0, collectives over
+    # gloo (RCCL refuses two ranks on one device).  It exists so that everything that only runs with WORLD_SIZE > 1 (replica
+    # broadcast, early bucket, diagnostics, strong-scaling block) has executed before the driver's first multi-GPU run; its
+    # numbers mean nothing.  At most a handful of ranks (the GPU boxes allow few processes on the card).
+    rehearse = os.environ.get('TVAE_BENCH_REHEARSE', '0') == '1'
+    if have < n and not (rehearse and have >= 1 and n <= 4):
         print(f'bench.py: --gpus {n} but only {have} GPU(s) are visible', file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -69,8 +74,10 @@ def spawn_ranks(n: int, timeout_s: float = 3600.0) -> int:
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if rehearse else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if rehearse:
+            env['TVAE_DP_BACKEND'] = 'gloo'
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     t_end = time.monotonic() + timeout_s
     rc = 0
@@ -311,7 +318,7 @@ def main():
 
     from tvae import dp, ops, optim, step
     from tvae import _lib
-    rank, world, local = dp.init_from_env()
+    rank, world, local = dp.init_from_env(backend=os.environ.get('TVAE_DP_BACKEND') or None)
     if world != args.gpus:
         if rank == 0:
             print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
@@ -378,6 +385,7 @@ def main():
         last = one_step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    early_posted_main = reducer.posted_early if reducer is not None else 0      # (warm-up + timed steps; diagnostics below)
     kev = ops.kernel_event_ms()
     ops.KERNEL_EVENTS = None
     if gs_box[0] is not None:
@@ -629,7 +637,24 @@ def main():
             except Exception as ex:          # a companion must never take the headline down
                 workloads[wn] = {'error': repr(ex)[:300]}
             torch.cuda.empty_cache()
+    dp_diag = None
     if world > 1:
+        # self-diagnosis of the first multi-GPU run: every rank's own wall time of the timed region, the
+        # early buckets it posted from inside a backward, the collectives it issued -- gathered, so that a straggler, a rank
+        # that never posted the early bucket or a group of the wrong size is visible in the one JSON line
+        mine = torch.tensor([dt, float(early_posted_main), float(dist.get_world_size()), float(torch.cuda.current_device())],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = [[float(v) for v in t_.tolist()] for t_ in allr]
+        dp_diag = {'per_rank_ms_per_step': [1e3 * p_[0] / args.steps for p_ in per],
+                   'ms_per_step_min': 1e3 * min(p_[0] for p_ in per) / args.steps,
+                   'ms_per_step_max': 1e3 * max(p_[0] for p_ in per) / args.steps,
+                   'early_buckets_posted_per_rank': [int(p_[1]) for p_ in per],
+                   'early_buckets_expected': (args.warmup + args.steps) if opt._early_n else 0,
+                   'world_size_seen_per_rank': [int(p_[2]) for p_ in per],
+                   'device_index_per_rank': [int(p_[3]) for p_ in per],
+                   'note': 'steps of the warm-up and the timed region both post the early (decoder) bucket'}
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -709,8 +734,12 @@ def main():
             'elbo': elbo_last,
             'config': {'workload': c['desc'],
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
-                       'collective': ({'backend': dist.get_backend() + ' (RCCL)', 'world_size_seen': dist.get_world_size(),
+                       'collective': ({'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ' (REHEARSAL on one GPU: '
+                                                                            'numbers are not a scaling measurement)'),
+                                       'world_size_seen': dist.get_world_size(),
                                        'payload_bytes_per_step': int(opt.flat_g.numel()) * 4,
+                                       'early_bucket_bytes': int(opt._early_end) * 4,
+                                       'diagnostics': dp_diag,
                                        'buckets': 'decoder segment posted from the backward, encoder segment at the '
                                                   'optimizer step (tvae/optim.py)'}
                                       if world > 1 else None),
@@ -791,6 +820,8 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
     if world > 1:
+        if reducer is not None:
+            reducer.close()
         dist.destroy_process_group()
 
 

@@ -24,6 +24,7 @@ struct Rccl {
     AllReduceFn all_reduce = nullptr;
     CommDestroyFn destroy = nullptr;
     bool ok = false;
+    bool preloaded = false;      // the handle is the instance that was already in the process (RTLD_NOLOAD hit)
 };
 Rccl& rccl() {
     static Rccl r;
@@ -34,6 +35,7 @@ Rccl& rccl() {
             r.h = dlopen(n, RTLD_LAZY | RTLD_NOLOAD);
             if (r.h) break;
         }
+        r.preloaded = r.h != nullptr;
         for (int i = 0; !r.h && i < 4; ++i) r.h = dlopen(names[i], RTLD_LAZY | RTLD_LOCAL);      // ... else load one
         if (!r.h) return;
         r.get_id = reinterpret_cast<GetUniqueIdFn>(dlsym(r.h, "ncclGetUniqueId"));
@@ -45,24 +47,30 @@ Rccl& rccl() {
     return r;
 }
 constexpr int TVAE_ERR_NO_RCCL = 100001;                 // (outside the hipError_t range)
+// an ncclResult_t r != 0 is reported as 100100 + r (ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3,
+// ncclInvalidArgument = 4, ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7): the caller can tell them apart
+constexpr int TVAE_ERR_NCCL_BASE = 100100;
+inline int nccl_rc(int r) { return r ? TVAE_ERR_NCCL_BASE + r : 0; }
 }  // namespace
 
 extern "C" {
 
-// 1 when an RCCL library could be resolved in this process
-int tvae_rccl_available(void) { return rccl().ok ? 1 : 0; }
+// 0: no RCCL library could be resolved; 1: the instance that was ALREADY loaded in this process (inside PyTorch: torch's own);
+// 2: this library loaded a copy of its own -- a second RCCL instance if the process also uses another one (the host side
+// refuses that combination: tvae/_lib.py RcclComm)
+int tvae_rccl_available(void) { return rccl().ok ? (rccl().preloaded ? 1 : 2) : 0; }
 // id128: 128 bytes, filled on ONE rank (ncclGetUniqueId) and distributed to the others by the caller
 int tvae_rccl_unique_id(void* id128) {
     if (!rccl().ok) return TVAE_ERR_NO_RCCL;
     if (!id128) return (int)hipErrorInvalidValue;
-    return rccl().get_id(reinterpret_cast<UniqueId*>(id128)) ? (int)hipErrorUnknown : 0;
+    return nccl_rc(rccl().get_id(reinterpret_cast<UniqueId*>(id128)));
 }
 // collective over all ranks (ncclCommInitRank on the CURRENT device): *comm receives the communicator
 int tvae_rccl_comm_init(void** comm, int nranks, const void* id128, int rank) {
     if (!rccl().ok) return TVAE_ERR_NO_RCCL;
     if (!comm || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return (int)hipErrorInvalidValue;
     UniqueId id = *reinterpret_cast<const UniqueId*>(id128);
-    return rccl().init_rank(comm, nranks, id, rank) ? (int)hipErrorUnknown : 0;
+    return nccl_rc(rccl().init_rank(comm, nranks, id, rank));
 }
 // in-place sum all-reduce of count floats on `stream` (asynchronous, like every other entry point): the flat gradient buffer
 // of tvae/optim.py, or a leading / trailing segment of it (the two buckets of the data-parallel step)
@@ -70,12 +78,12 @@ int tvae_allreduce_flat(void* comm, float* buf, long count, tvae_stream_t stream
     if (!rccl().ok) return TVAE_ERR_NO_RCCL;
     if (!comm || (count > 0 && !buf) || count < 0) return (int)hipErrorInvalidValue;
     if (count == 0) return 0;
-    return rccl().all_reduce(buf, buf, (size_t)count, NCCL_FLOAT32, NCCL_SUM, comm, tvae::S(stream)) ? (int)hipErrorUnknown : 0;
+    return nccl_rc(rccl().all_reduce(buf, buf, (size_t)count, NCCL_FLOAT32, NCCL_SUM, comm, tvae::S(stream)));
 }
 int tvae_rccl_comm_destroy(void* comm) {
     if (!rccl().ok) return TVAE_ERR_NO_RCCL;
     if (!comm) return 0;
-    return rccl().destroy(comm) ? (int)hipErrorUnknown : 0;
+    return nccl_rc(rccl().destroy(comm));
 }
 
 }  // extern "C"

@@ -420,10 +420,16 @@ static __global__ void fourier_bwd_kernel(const float* __restrict__ xr, const fl
         if (live)
             for (int q = 0; q < fe; ++q) {
                 const float w0 = wsm[q][0], w1 = wsm[q][1];
-                // v_sin_f32 (arguments here stay below ~10^3 rad: inside the instruction's +-256-revolution domain; absolute
-                // error ~1e-6, far below the gradient's own rounding) instead of the ~40-instruction libm routine: this loop is
-                // F sines per pixel and was 0.58 ms of the 7.2 ms 28 x 28 Fourier step -- round 5
-                const float t = -__sinf(x0 * w0 + x1 * w1 + wsm[q][2]) * dfeat[(long)(f0 + q) * ld + n];
+                // v_sin_f32 instead of the ~40-instruction libm routine (this loop is F sines per pixel: 0.58 -> 0.2 ms of the
+                // 28 x 28 Fourier step, round 5) -- with the range reduction done HERE (round 6): the instruction takes
+                // revolutions and is specified for +-256 of them only, so the argument is brought to [0, 1) first, and the
+                // product with 1 / 2 pi carries its rounding error along (two-term constant, one FMA for the product's own
+                // rounding): the reduced phase is exact to ~1e-8 |arg| rad, below the rounding of the fp32 argument itself
+                // (6e-8 |arg|) whatever sigma and the coordinates are.
+                const float a_ = x0 * w0 + x1 * w1 + wsm[q][2];
+                const float t_ = a_ * 0.15915494f;                                        // fp32(1 / 2 pi)
+                const float e_ = __fmaf_rn(a_, 6.4206383e-09f, __fmaf_rn(a_, 0.15915494f, -t_));
+                const float t = -__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t_) + e_) * dfeat[(long)(f0 + q) * ld + n];
                 g0 += t * w0;
                 g1 += t * w1;
             }

@@ -196,40 +196,79 @@ def exported_symbols():
 
 class RcclComm:
     """An RCCL communicator owned through the C ABI (tvae_rccl_comm_init): `unique_id()` on one rank, the 128 bytes to every
-    rank by any means, then `RcclComm(nranks, id, rank)` on every rank (a collective, on the current device)."""
+    rank by any means, then `RcclComm(nranks, id, rank)` on every rank (a collective, on the current device).
+    EXPERIMENTAL (TVAE_DP_ABI=1): it has run with one rank only; the default data-parallel path calls RCCL through
+    torch.distributed.  `close()` (or garbage collection) destroys the communicator -- before destroy_process_group()."""
+
+    @staticmethod
+    def _check_instance():
+        """tvae_rccl_available(): 1 = the RCCL instance already loaded in this process (torch's), 2 = a copy the library had to
+        load itself.  Inside a process whose torch.distributed can use its own RCCL a second instance means two sets of
+        communicators and proxy threads -- refused unless TVAE_RCCL_OWN_COPY=1 says the caller knows."""
+        import sys
+        src = lib().tvae_rccl_available()
+        if not src:
+            raise TvaeHipError('no RCCL library could be resolved in this process')
+        if src == 2 and 'torch.distributed' in sys.modules and os.environ.get('TVAE_RCCL_OWN_COPY', '0') != '1':
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_nccl_available():
+                raise TvaeHipError('libtvae_hip.so would load a SECOND copy of RCCL beside the one torch.distributed uses '
+                                   '(RTLD_NOLOAD found none): set TVAE_RCCL_OWN_COPY=1 to allow it')
+        return src
 
     def __init__(self, nranks: int, id128: bytes, rank: int):
         L = lib()
-        if not L.tvae_rccl_available():
-            raise TvaeHipError('no RCCL library could be resolved in this process')
         self._comm = ctypes.c_void_p()
+        self.instance = self._check_instance()           # 1 = the process's own RCCL, 2 = a private copy
         buf = ctypes.create_string_buffer(bytes(id128), 128)
         rc = L.tvae_rccl_comm_init(ctypes.byref(self._comm), int(nranks), buf, int(rank))
         if rc:
-            raise TvaeHipError(f'tvae_rccl_comm_init failed ({rc})')
+            raise TvaeHipError(f'tvae_rccl_comm_init failed ({_rccl_rc(rc)})')
 
     @staticmethod
     def unique_id() -> bytes:
+        RcclComm._check_instance()
         buf = ctypes.create_string_buffer(128)
         rc = lib().tvae_rccl_unique_id(buf)
         if rc:
-            raise TvaeHipError(f'tvae_rccl_unique_id failed ({rc})')
+            raise TvaeHipError(f'tvae_rccl_unique_id failed ({_rccl_rc(rc)})')
         return buf.raw
 
     def all_reduce_(self, t) -> None:
         """In-place sum all-reduce of a contiguous fp32 CUDA tensor on the current torch stream (asynchronous)."""
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise TvaeHipError('tvae_allreduce_flat: contiguous fp32 CUDA tensor expected')
+        if not self._comm:
+            raise TvaeHipError('tvae_allreduce_flat on a closed communicator')
         L = lib()
         L.tvae_allreduce_flat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
         rc = L.tvae_allreduce_flat(self._comm, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
         if rc:
-            raise TvaeHipError(f'tvae_allreduce_flat failed ({rc})')
+            raise TvaeHipError(f'tvae_allreduce_flat failed ({_rccl_rc(rc)})')
 
     def close(self) -> None:
-        if self._comm:
+        if getattr(self, '_comm', None):
             lib().tvae_rccl_comm_destroy(self._comm)
             self._comm = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_NCCL_RESULT = {1: 'ncclUnhandledCudaError', 2: 'ncclSystemError', 3: 'ncclInternalError', 4: 'ncclInvalidArgument',
+                5: 'ncclInvalidUsage', 6: 'ncclRemoteError', 7: 'ncclInProgress'}
+
+
+def _rccl_rc(rc: int) -> str:
+    """Return codes of the tvae_rccl_* entry points: 100001 = no RCCL, 100100 + r = ncclResult_t r, else a hipError_t."""
+    if rc == 100001:
+        return 'no RCCL library resolved'
+    if rc > 100100:
+        return f'ncclResult_t {rc - 100100} {_NCCL_RESULT.get(rc - 100100, "?")}'
+    return f'hipError_t {rc}'
 
 
 def query(name, *args) -> int:
@@ -240,7 +279,10 @@ def query(name, *args) -> int:
     return int(getattr(lib(), name)(*[int(a) for a in args]))
 
 
-_F64_OK = {'tvae_elbo_reduce', 'tvae_elbo_reduce_bwd'}      # entry points with float64 scalars (the reference's ELBO / KL dtype)
+# float64 arguments (the reference's ELBO / KL dtype), by (entry point, argument position): elbo / kld of tvae_elbo_reduce,
+# g_elbo / g_kld of tvae_elbo_reduce_bwd.  Every other pointer of those entry points is float* (a float64 `kl`
+# passed where float* is expected would be reinterpreted silently).
+_F64_OK = {('tvae_elbo_reduce', 3), ('tvae_elbo_reduce', 5), ('tvae_elbo_reduce_bwd', 0), ('tvae_elbo_reduce_bwd', 2)}
 
 
 def _ptr(t, name, pos):
@@ -250,7 +292,10 @@ def _ptr(t, name, pos):
         raise TvaeHipError(f'{name} arg {pos}: expected a tensor or None, got {type(t)}')
     if not t.is_cuda:
         raise TvaeHipError(f'{name} arg {pos}: tensor must live on the GPU (no CPU fallback)')
-    if t.dtype not in (torch.float32, torch.int32) and not (t.dtype == torch.float64 and name in _F64_OK):
+    if (name, pos) in _F64_OK:
+        if t.dtype != torch.float64:
+            raise TvaeHipError(f'{name} arg {pos}: dtype {t.dtype}, the C ABI takes double* here')
+    elif t.dtype not in (torch.float32, torch.int32):
         raise TvaeHipError(f'{name} arg {pos}: dtype {t.dtype} not supported (fp32 / int32 only)')
     if not t.is_contiguous():
         raise TvaeHipError(f'{name} arg {pos}: tensor must be contiguous')

@@ -61,9 +61,10 @@ class GradReducer:
         self.weight = 1.0
         self._pending = []
         self.posted_early = 0          # diagnostics: how many early buckets were posted from a backward
-        # `abi` (default: TVAE_DP_ABI=1): the two buckets through the library's own entry point tvae_allreduce_flat on a
-        # communicator created through the C ABI (include/tvae_hip.h) instead of torch.distributed's all_reduce; the 128-byte
-        # id travels over the torch process group once.  Same collectives, same order, on a side stream of its own.
+        # `abi` (EXPERIMENTAL, default off; TVAE_DP_ABI=1): the two buckets through the library's own entry point
+        # tvae_allreduce_flat on a communicator created through the C ABI (include/tvae_hip.h) instead of torch.distributed's
+        # all_reduce; the 128-byte id travels over the torch process group once.  Same collectives, same order, on the compute
+        # stream.  It has only ever run with ONE rank (no multi-GPU node was available to any round).
         self._abi = None
         if abi is None:
             abi = os.environ.get('TVAE_DP_ABI', '0') == '1'
@@ -76,14 +77,27 @@ class GradReducer:
                 idt.copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0, group=group)
             self._abi = RcclComm(self.world, bytes(idt.cpu().numpy().tobytes()), rank)
-            self._abi_stream = torch.cuda.Stream(device=dev)
 
     def _abi_reduce(self, t: torch.Tensor) -> None:
-        cur = torch.cuda.current_stream(t.device)
-        self._abi_stream.wait_stream(cur)            # behind the kernels that produced the gradients
-        with torch.cuda.stream(self._abi_stream):
-            self._abi.all_reduce_(t)
-        self._pending.append(self._abi_stream.record_event())
+        # On the COMPUTE stream itself: a second communicator on a stream of its own beside torch.distributed's
+        # would leave the device-side order of the two communicators' collectives to the scheduler, rank by rank -- the classic
+        # two-communicator deadlock.  Stream order = program order = the same on every rank; torch's own collectives wait
+        # for the compute stream before they start.  (No overlap with the backward in this experimental mode.)
+        self._abi.all_reduce_(t)
+
+    def close(self) -> None:
+        """Destroy the C-ABI communicator (if any) -- call before dist.destroy_process_group()."""
+        if self._abi is not None:
+            torch.cuda.synchronize()
+            self._abi.close()
+            self._abi = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_abi', None) is not None:
+                self._abi.close()
+        except Exception:
+            pass
 
     def set_local_fraction(self, local_b: int, global_b: int):
         self.weight = float(local_b) * self.world / float(global_b)

@@ -394,4 +394,6 @@ def run(kind: str, argv=None):
     if log_file is not None:
         log_file.close()
     if world > 1:
+        if reducer is not None:
+            reducer.close()                              # (a C-ABI communicator dies before the process group: ADVICE r05)
         torch.distributed.destroy_process_group()

@@ -43,7 +43,10 @@ def _torch_adam(p, g, m, v, step, lr, b1, b2, eps, scale):
     O.adam_update([p], [g * scale], [m], [v], step, lr, b1, b2, eps)
 
 
-def _train(rank, world, epochs=2, N_IMG=N_IMG, GB=GB):
+def _train(rank, world, epochs=2, N_IMG=N_IMG, GB=GB, graph_from=None):
+    """graph_from = e: from epoch e on the step follows tvae/graph.py's protocol -- `disable_early_bucket()` once (a captured
+    backward must not post collectives), full-size shards accumulate STRAIGHT into the flat gradient buffer (zeroed, every
+    p.grad its view: what a replay leaves behind), any other shard size runs the eager set_to_none protocol."""
     from oracle import tvae_oracle as O
     from tvae import dp, optim
     gen, enc = _make_params()
@@ -55,16 +58,27 @@ def _train(rank, world, epochs=2, N_IMG=N_IMG, GB=GB):
     x = O.image_coords(NPIX)
     batches = dp.ShardedBatches(data, GB, rank, world, shuffle=True, seed=5, reducer=reducer)
     stats = [0.0, 0.0]
+    full = -(-GB // world)                               # the shard size a graph would have been captured at
+    n_early_eager = 0
     for ep in range(epochs):
         batches.set_epoch(ep)
         perm = dp.epoch_permutation(N_IMG, 5, ep)
+        graph_mode = graph_from is not None and ep >= graph_from
+        if graph_mode and ep == graph_from:
+            opt.disable_early_bucket()                   # GraphedStep.__init__
         for (y,), (lo, hi, g) in zip(batches, dp.shard_slices(N_IMG, GB, rank, world)):
             idx = perm[lo:hi]
             assert torch.equal(y, data[idx])
+            if not graph_mode:
+                n_early_eager += 1
             if hi == lo:        # no image of this global minibatch on this rank: still in both collectives, weight 0 (tvae/step.py)
                 opt.step()
                 opt.zero_grad(set_to_none=True)
                 continue
+            if graph_mode and hi - lo == full:           # GraphedStep._fwd_bwd / run: gradients land in the flat buffer
+                opt.flat_g.zero_()
+                for p_, gv in zip(opt._ps, opt._gviews):
+                    p_.grad = gv
             encp = dict(enc.named_parameters())
             genp = dict(gen.named_parameters())
             elbo, _, _ = O.elbo_step(x, y, encp, genp, likelihood='bce', E=E[idx], eps_z=ez[idx],
@@ -74,8 +88,8 @@ def _train(rank, world, epochs=2, N_IMG=N_IMG, GB=GB):
             opt.zero_grad(set_to_none=True)
             stats[0] += float(elbo) * (hi - lo)
             stats[1] += hi - lo
-    if world > 1:           # two buckets: the decoder segment was posted from inside every backward (tvae/optim.py)
-        assert reducer.posted_early == epochs * len(batches) and not reducer._pending
+    if world > 1:           # two buckets: the decoder segment was posted from inside every EAGER-phase backward (tvae/optim.py)
+        assert reducer.posted_early == n_early_eager and not reducer._pending
     stats = dp.allreduce_stats(stats, torch.device('cpu'))
     named = {'d.' + k_: v.detach().clone() for k_, v in gen.named_parameters()}
     named.update({'e.' + k_: v.detach().clone() for k_, v in enc.named_parameters()})
@@ -318,3 +332,24 @@ def test_empty_shard_and_fourier_buffers(tmp_path):
     assert r0['tot'][2] == tot1[2] == N2
     for i in (0, 1):
         assert abs(r0['tot'][i] - tot1[i]) / abs(tot1[i]) < 1e-5
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_graph_protocol_after_early_bucket(tmp_path):
+    """VERDICT r05 item 8 / ADVICE r04: the two-bucket all-reduce and the hipGraph step together.  Epoch 0 runs eagerly with the
+    early decoder bucket posted from inside every backward; then the optimizer is switched the way GraphedStep does
+    (`disable_early_bucket()`: hooks stay registered, `_early_n = 0`) and full-size shards accumulate straight into the flat
+    buffer while ragged ones keep the eager set_to_none protocol.  Both ranks must stay bit-identical and follow the
+    single-process run of the same schedule; no early bucket may be posted after the switch."""
+    torch.set_num_threads(4)
+    kw = dict(epochs=3, graph_from=1)
+    flat1, stats1 = _train(0, 1, **kw)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), kw), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    for k_ in flat1:
+        assert torch.equal(r0['flat'][k_], r1['flat'][k_]), k_
+        if k_ == 'e.conv_a.bias':
+            continue
+        assert rel_err(r0['flat'][k_], flat1[k_]) < 3e-4, k_
+    assert r0['stats'][1] == stats1[1] == 3 * N_IMG

@@ -78,6 +78,9 @@ def _train(rank, world, dev_index=0, always=False, turns=False, abi=False):
     if reducer is not None:   # two buckets: the decoder segment went out from inside every backward
         assert reducer.posted_early == (2 * len(batches) if os.environ.get("TVAE_DP_EARLY", "1") != "0" else 0) and not reducer._pending
     tot = dp.allreduce_stats(tot, dev)
+    if reducer is not None:
+        reducer.close()                          # (the C-ABI communicator, if any, before the process group goes)
+        assert reducer._abi is None
     named = {'d.' + k_: v.detach().cpu().clone() for k_, v in gen.named_parameters()}
     named.update({'e.' + k_: v.detach().cpu().clone() for k_, v in enc.named_parameters()})
     return named, tot
@@ -279,3 +282,28 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 512 and line['value'] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """everything in bench.py that only runs with WORLD_SIZE > 1 -- replica broadcast, the early gradient
+    bucket, the gathered per-rank diagnostics, the strong-scaling block -- executed before the driver's first multi-GPU run:
+    two ranks on THIS box's one GPU over gloo (TVAE_BENCH_REHEARSE=1; RCCL refuses two ranks on one device).  The numbers
+    are meaningless; the JSON line must be complete and self-consistent."""
+    import json
+    import subprocess
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['TVAE_BENCH_REHEARSE'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--workload', 'S28', '--batch', '32', '--no-cpu-baseline'], capture_output=True, text=True, timeout=800,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 64 and line['value'] > 0
+    col = line['config']['collective']
+    assert col['world_size_seen'] == 2 and 'REHEARSAL' in col['backend']
+    d = col['diagnostics']
+    assert d['world_size_seen_per_rank'] == [2, 2] and len(d['per_rank_ms_per_step']) == 2
+    assert d['early_buckets_expected'] == 3 and d['early_buckets_posted_per_rank'] == [3, 3]
+    assert d['ms_per_step_min'] <= line['ms_per_step'] * 1.0001 and d['ms_per_step_max'] > 0
+    assert line['strong_scaling']['global_batch'] == 32 and line['strong_scaling']['value'] > 0

@@ -1341,3 +1341,25 @@ def test_rowdot_seg_amax():
     call('tvae_rowdot_seg', X.to(dev()), N, None, 1, M, N, 2048, tmp, amax)
     assert float(amax) == 77.5
     assert rel_err(tmp.sum(0), X.double().sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize('sigma,span,amin', [(2.0 / 127, 2.0, 300.0), (0.2 / 127, 2.0, 3000.0), (0.01, 1.5, 300.0), (2.0 / 27, 1.0, 30.0)])
+def test_fourier_bwd_large_arguments(sigma, span, amin):
+    """tvae_fourier_bwd evaluates sin with v_sin_f32 after its own range reduction.  Against float64 at the galaxy
+    sigma with |coordinates| ~ 2 (|arg| up to ~500 rad), at a 10x smaller sigma (~5 000 rad: far outside the instruction's native
+    +-256 revolutions), and at the dsprites default 0.01 (reference train_dsprites.py:492-494).  The float64 reference takes
+    the fp32-ROUNDED argument (what any fp32 forward, the reference's included, evaluates cos of)."""
+    Nt, Ff = 4096, 256
+    xr = (torch.rand(Nt, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1) * span
+    Wf, bf = rnd(Ff, 2, seed=2), torch.rand(Ff, generator=torch.Generator().manual_seed(3)) * 2 * math.pi
+    g = rnd(Ff, Nt, seed=4)
+    gx = torch.empty(Nt, 2, device=dev())
+    call('tvae_fourier_bwd', xr.to(dev()), Wf.to(dev()), bf.to(dev()), sigma, g.to(dev()), Nt, Ff, Nt, gx)
+    w = (Wf / sigma)                                      # fp32, as the kernel forms it
+    arg = (xr[:, 0:1] * w[:, 0][None, :] + xr[:, 1:2] * w[:, 1][None, :] + bf[None, :])      # [Nt][Ff] fp32
+    assert float(arg.abs().max()) > amin
+    t = -torch.sin(arg.double()) * g.double().t()
+    ref = torch.stack([(t * w[:, 0].double()[None, :]).sum(1), (t * w[:, 1].double()[None, :]).sum(1)], 1)
+    # per element: rounding of the fp32 argument sum (up to 3 ulp of |arg|) times the slope of sin, summed over Ff features
+    tol = 4e-7 * float(arg.abs().max()) + 2e-6
+    assert rel_err(gx, ref) < tol, (rel_err(gx, ref), tol)
