@@ -280,8 +280,11 @@ def measure_extra_workload(name, dev, steps, warmup=2):
     the bench's barrier bracket.  A few steps only (~0.5 s of GPU time for all three): these are companion numbers so that
     the 28x28 / galaxy-shape figures of the north star do not exist only in builder-run profiles."""
     from tvae import optim, step
+    # 'S128G@32': the galaxy workload at 32 images per step next to its 8 (VERDICT r05 item 3d: 136 MB of lifted activations per
+    # image is 4.4 GB at 32 -- nothing in 288 GB -- and the per-launch fixed costs are shared by four times the images)
+    name, _, b_over = name.partition('@')
     c = WORKLOADS[name]
-    B = c.get('batch', 256)
+    B = int(b_over) if b_over else c.get('batch', 256)
     gen, enc = build_models(dev, c)
     opt = optim.FlatAdam(list(gen.parameters()) + list(enc.parameters()), lr=2e-4)
     g = torch.Generator(device=dev)
@@ -631,7 +634,7 @@ def main():
     workloads = None
     if world == 1 and args.workload == 'S64' and not args.no_workloads and gs_box[0] is None:
         workloads = {}
-        for wn in ('S28', 'S28F', 'S128G'):
+        for wn in ('S28', 'S28F', 'S128G', 'S128G@32'):
             try:
                 workloads[wn] = measure_extra_workload(wn, dev, min(args.steps, 10))
             except Exception as ex:          # a companion must never take the headline down

@@ -3,6 +3,7 @@
 // along w on the fp32 matrix pipe, inverse transform of the weight gradient.
 #include "abi_dense_x6.hpp"
 #include "conv_dft_kernels.hpp"
+#include "conv_dft_h3_kernels.hpp"
 
 using namespace tvae;
 
@@ -54,6 +55,10 @@ struct DftPlan {
     long w3_floats;            // split cells of W
     long t_floats;             // T / S' [Lh][2M][NBpad]
     long eo_floats, ed_floats, tab_floats;
+    // round 6: the transforms along w of LARGE frames on the 16-bit matrix pipe (conv_dft_h3_kernels.hpp; h3 arithmetic only):
+    // k-steps / output tiles of the two GEMMs, their cell tables behind the fp32 tables, 0 = not this geometry
+    int h3w, KS, NWT, WS, NKT;
+    long eoc_floats, edc_floats;
     long g_floats;             // one split-K slab of G [Lh][2M][K2]
     size_t lds_sp, lds_db;
     // operand maxima of the h3 arithmetic, behind A^T (offsets in floats from the 16-byte aligned end of A^T):
@@ -130,7 +135,14 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     }
     q.eo_floats = (long)q.LHP * (q.NT + q.REM1) * 64;
     q.ed_floats = (long)q.NS * q.NRT * 64;
-    q.tab_floats = ((q.eo_floats + 3) & ~3L) + ((q.ed_floats + 3) & ~3L) + q.M;   // EO + ED + per-row bias-gradient sums
+    // the h3 instances of the wide transforms: the galaxy frame (L = 160: Lh = 81, Ho = 129) and every other generic frame whose
+    // step / tile counts they cover
+    q.KS = (2 * q.Lh + 15) / 16; q.NWT = (q.Ho + 31) / 32; q.WS = (q.Ho + 15) / 16; q.NKT = (2 * q.Lh + 31) / 32;
+    q.h3w = (q.gen && q.KS <= 11 && q.NWT <= 5 && q.WS <= 9 && q.NKT <= 6 && q.Ho >= 32) ? 1 : 0;
+    q.eoc_floats = q.h3w ? (long)5 * 11 * 2 * 64 * 4 : 0;
+    q.edc_floats = q.h3w ? (long)6 * 9 * 2 * 64 * 4 : 0;
+    // EO + ED + per-row bias-gradient sums (+ the h3 cell tables, 16-byte aligned)
+    q.tab_floats = ((q.eo_floats + 3) & ~3L) + ((q.ed_floats + 3) & ~3L) + ((q.M + 3) & ~3L) + q.eoc_floats + q.edc_floats;
     q.g_floats = (long)q.Lh * 2 * q.M * q.K2;
     // 8 reduction slices deal one to each XCD (TileMap: a slice lives on ONE XCD).  Round 4: also for short reductions --
     // with NBpad / 1024 slices a 32-image step (the per-GPU share of a 256-image global batch on 8 GPUs) ran its 392 tiles on
@@ -365,6 +377,27 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             return 0;
         }
         static const bool wide_gen = !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0');
+        static const bool wide_h3 = !(getenv("TVAE_DFT_WIDE_H3") && getenv("TVAE_DFT_WIDE_H3")[0] == '0');
+        if (q.h3w && h3 && wide_h3 && !t16) {
+            // round 6: large frames in the h3 arithmetic leave the fp32 matrix pipe (which bounds them: conv_dft_h3_kernels.hpp)
+            uint4* EOc = reinterpret_cast<uint4*>(ED + ((q.ed_floats + 3) & ~3L) + ((q.M + 3) & ~3L));
+            uint4* EDc = EOc + q.eoc_floats / 4;
+            const float norm = q.mixed ? 1.f / (float)q.L : 1.f / ((float)q.L * (float)q.L);
+            hipLaunchKernelGGL(dft_wtab_h3_kernel, dim3(64), dim3(256), 0, st, EOc, EDc, q.L, q.Lh, q.Ho, 11, 5, 9, 6, norm);
+            TVAE_CHECK_LAUNCH();
+            int ex = 0;
+            frexpf(2.f * norm, &ex);                     // 2 norm in [2^(ex-1), 2^ex): h3_scale = 2^(15 - ex)
+            const float eo_inv = ldexpf(1.f, ex - 15);
+            constexpr size_t lds_h = ((size_t)16 * 11 * 32 + 2 * 2 * 11 * 32 * 4 + 32 + 5 * 32 * 33) * 4;
+            e = allow_big_lds(dft_out_h3_kernel<11, 5, 5>, lds_h);
+            if (e != hipSuccess) return (int)e;
+            const int cus = dev_cu_count();
+            const int grid = (int)(ntiles < 2L * cus ? ntiles : 2L * cus);
+            hipLaunchKernelGGL((dft_out_h3_kernel<11, 5, 5>), dim3(grid), dim3(320), lds_h, st, (const float*)T,
+                               (const uint4*)EOc, bias, out, q.M, R, B, q.Ho, q.Lh, q.NBpad, act, slope, eo_inv, a1max);
+            TVAE_CHECK_LAUNCH();
+            return 0;
+        }
         // large frames (galaxy shape): a workgroup per tile, its waves split the output rows (dft_out_wide_kernel); the single
         // last column of Ho = 32 k + 1 outputs goes to the vector ALU instead of a whole wave
         const int NTW = (q.Ho % 32 == 1 && q.NT > 1) ? q.NT - 1 : q.NT;
@@ -476,6 +509,21 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
 #undef TVAE_DY_RING
 #undef TVAE_DY_RING_ONE
             TVAE_CHECK_LAUNCH();
+        } else if (q.h3w && parts == 2 && !(getenv("TVAE_DFT_WIDE_H3") && getenv("TVAE_DFT_WIDE_H3")[0] == '0')) {
+            // round 6: the same transform on the 16-bit matrix pipe (conv_dft_h3_kernels.hpp)
+            uint4* EOc = reinterpret_cast<uint4*>(ED + ((q.ed_floats + 3) & ~3L) + ((q.M + 3) & ~3L));
+            uint4* EDc = EOc + q.eoc_floats / 4;
+            hipLaunchKernelGGL(dft_wtab_h3_kernel, dim3(64), dim3(256), 0, st, EOc, EDc, q.L, q.Lh, q.Ho, 11, 5, 9, 6,
+                               q.mixed ? 1.f / (float)q.L : 1.f / ((float)q.L * (float)q.L));
+            TVAE_CHECK_LAUNCH();
+            const size_t lds_h = ((size_t)((32 * (q.Ho | 1) + 3) & ~3) + 2 * 2 * 9 * 32 * 4 + 32) * 4;
+            hipError_t eh = allow_big_lds(dft_dy_h3_kernel<9, 6, 11>, lds_h);
+            if (eh != hipSuccess) return (int)eh;
+            const int cus = dev_cu_count();
+            const int gridh = (int)(ntiles < 2L * cus ? ntiles : 2L * cus);
+            hipLaunchKernelGGL((dft_dy_h3_kernel<9, 6, 11>), dim3(gridh), dim3(384), lds_h, st, dpre, (const uint4*)EDc, Sp, q.M,
+                               R, B, q.Ho, q.Lh, q.NBpad, ldexpf(1.f, -14), smax);
+            TVAE_CHECK_LAUNCH();
         } else if (q.gen && !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0') && q.NS <= DFT_WIDE_NS &&
                    q.NRT <= 8 && 32 * q.Ho <= 16 * 64 * q.NRT && (size_t)2 * (32 * (q.Ho | 1) + 1) * 4 <= 150 * 1024) {
             // large frames (galaxy shape): a workgroup per tile, its waves split the rows of S' (dft_dy_wide_kernel)
@@ -527,7 +575,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         }
     }
     if (dbias) {
-        float* dbpart = ED + ((q.ed_floats + 3) & ~3L);           // M floats behind the transform tables
+        float* dbpart = ED + ((q.ed_floats + 3) & ~3L);           // M floats behind the transform tables (then the h3 cell tables)
         hipLaunchKernelGGL(dft_dbias_rows_kernel, dim3(q.M), dim3(256), 0, st, (const float*)Sp, dbpart, q.Lh, q.NB, q.M,
                            s16 ? 1 : 0);
         TVAE_CHECK_LAUNCH();
