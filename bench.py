@@ -444,7 +444,29 @@ def main():
                 one_step(args.warmup + i, bs)
             barrier()
             dsb = time.perf_counter() - tsb
+            # ... and as the training CLIs run it since round 6: forward + backward replayed from a captured hipGraph
+            # (tvae/graph.py; bitwise the eager step).  The launch count, not the arithmetic, is what a step of this size costs.
+            g_ms = None
+            if bs in (12, 32):
+                try:
+                    from tvae import graph as _graph
+                    gsb = _graph.GraphedStep(x, gen, enc, opt, c['lik'], bs, (c['cin'], c['n'], c['n']), dev)
+                    saved_g, gs_box[0] = gs_box[0], gsb
+                    for i in range(2):
+                        one_step(i, bs)
+                    barrier()
+                    tg = time.perf_counter()
+                    for i in range(args.steps):
+                        one_step(args.warmup + i, bs)
+                    barrier()
+                    g_ms = 1e3 * (time.perf_counter() - tg) / args.steps
+                    gs_box[0] = saved_g
+                    gsb.close()
+                    opt.zero_grad(set_to_none=True)
+                except Exception as ex:                  # a companion must never take the headline down
+                    g_ms = repr(ex)[:200]
             small_batch['points'].append({'images_per_step': bs, 'ms_per_step': 1e3 * dsb / args.steps,
+                                          'ms_per_step_graph_replay': g_ms,
                                           'value': bs * args.steps / dsb, 'unit': 'images/sec',
                                           'ratio_to_full_batch_rate': (bs * args.steps / dsb) / (B * args.steps / dt),
                                           **({'implied_speedup_at_%d_gpus' % (B // bs): (B // bs) * (bs * args.steps / dsb) /
@@ -549,7 +571,7 @@ def main():
         companion_bf16 = {'value': B * args.steps / dt2, 'unit': 'images/sec', 'ms_per_step': 1e3 * dt2 / args.steps,
                           'arithmetic': 'TVAE_GEMM=bf16: operands of the convolution and decoder GEMMs rounded to one bf16 '
                                         'number, fp32 accumulate; since round 4 the two large intermediates of the frequency-'
-                                        'domain convolution, T and S\', are also STORED as bf16 (TVAE_BF16_STORE=0: fp32 storage) '
+                                        'domain convolution, T and S\', are also STORED as bf16 '
                                         '(tolerance 2e-2 on the ELBO terms, tests/test_hip_modules.py::test_bf16_throughput_mode; '
                                         '1.5e-2 on the convolution, tests/test_hip_primitives.py::test_conv1_dft_bf16_mode); not '
                                         'fp32-equivalent, not the headline',

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of one environment switch on one bench workload:
-#   gpurun -- 'bash profiles/tools/ab_wl_env.sh S128G TVAE_H3_DEEP "0 1" [batch]'
+#   gpurun -- 'bash profiles/tools/ab_wl_env.sh S128G TVAE_CONV_DFT "0 1" [batch]'
 WL=$1; VAR=$2; VALS=$3; BATCH=${4:-}
 for rep in 1 2; do
   for v in $VALS; do

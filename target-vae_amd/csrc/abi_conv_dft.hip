@@ -153,10 +153,6 @@ static DftPlan dft_plan(int B, int Cin, int n, int ksz, int pad, int C, int R) {
     q.splits = (int)(cdiv(q.K2, 128) >= 8 ? q.NBpad / 1024 : q.NBpad / 32);
     if (q.splits < 1) q.splits = 1;
     if (q.splits > 8) q.splits = 8;
-    {
-        static const int force = getenv("TVAE_DFT_SPLITS") ? atoi(getenv("TVAE_DFT_SPLITS")) : 0;      // experiments
-        if (force > 0 && force < q.splits) q.splits = force;
-    }
     // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles.  (Its slices are not pinned to XCDs, so
     // their number is free: 9 slices, whose groups fill 7 whole rounds of the 256 CUs where 8 run 6.125, measured the same.)
     // Wider problems take it in 192-column tiles when those pad no more than the 128-wide ones (1 152 columns at the galaxy
@@ -260,7 +256,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
     const bool h3 = parts == 2;
     // bf16 STORAGE of T (round 4): the one-part throughput mode on a ring geometry with whole 256-row tiles writes and reads T
     // as 2-byte elements (TVAE_BF16_STORE=0 keeps fp32 storage; the fp32-class arithmetics never take this path)
-    static const bool bf16_store = !(getenv("TVAE_BF16_STORE") && getenv("TVAE_BF16_STORE")[0] == '0');
+    constexpr bool bf16_store = true;
     // (ring 3, the 50 x 50 geometry on its 60-wide frame: a bf16 slot of 4 KB cannot hold the 32 x 39 transposition patch)
     const bool t16 = bf16_store && parts == 1 && q.ring && q.ring != 3 && q.K2 <= 256 && (2 * q.M) % DX4_ROWS == 0;
     // the maxima are produced in every arithmetic (one small fill and a few atomics): the weight gradient may run in
@@ -280,7 +276,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
         e = dft_zero(W, q.w_floats, st);
         if (e != hipSuccess) return (int)e;
     }
-    static const bool spectra_mf = !(getenv("TVAE_SPECTRA_MF") && getenv("TVAE_SPECTRA_MF")[0] == '0');
+    constexpr bool spectra_mf = true;
     const int smax_ = n > ksz ? n : ksz;
     if (q.mixed && spectra_mf && smax_ <= 128) {         // row transform on the fp32 matrix pipe (dft_spectra_x_mf_kernel)
 #define TVAE_SPX_MF(KSR_)                                                                                            \
@@ -376,8 +372,7 @@ int tvae_conv1_fwd_dft(const float* y, const float* bank, const float* bias, flo
             TVAE_CHECK_LAUNCH();
             return 0;
         }
-        static const bool wide_gen = !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0');
-        static const bool wide_h3 = !(getenv("TVAE_DFT_WIDE_H3") && getenv("TVAE_DFT_WIDE_H3")[0] == '0');
+        constexpr bool wide_gen = true, wide_h3 = true;
         if (q.h3w && h3 && wide_h3 && !t16) {
             // round 6: large frames in the h3 arithmetic leave the fp32 matrix pipe (which bounds them: conv_dft_h3_kernels.hpp)
             uint4* EOc = reinterpret_cast<uint4*>(ED + ((q.ed_floats + 3) & ~3L) + ((q.M + 3) & ~3L));
@@ -472,7 +467,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     float* amax = const_cast<float*>(at) + ((q.at_floats + 3) & ~3L);
     float* smax = amax + q.o_smax;
     // bf16 STORAGE of S' (round 4): one-part mode on a ring geometry (see tvae_conv1_fwd_dft)
-    static const bool bf16_store = !(getenv("TVAE_BF16_STORE") && getenv("TVAE_BF16_STORE")[0] == '0');
+    constexpr bool bf16_store = true;
     const bool s16 = bf16_store && parts == 1 && q.ring;
     hipLaunchKernelGGL(h3_zero_slots_kernel, dim3(1), dim3(256), 0, st, smax, q.M);
     TVAE_CHECK_LAUNCH();
@@ -509,7 +504,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
 #undef TVAE_DY_RING
 #undef TVAE_DY_RING_ONE
             TVAE_CHECK_LAUNCH();
-        } else if (q.h3w && parts == 2 && !(getenv("TVAE_DFT_WIDE_H3") && getenv("TVAE_DFT_WIDE_H3")[0] == '0')) {
+        } else if (q.h3w && parts == 2) {
             // round 6: the same transform on the 16-bit matrix pipe (conv_dft_h3_kernels.hpp)
             uint4* EOc = reinterpret_cast<uint4*>(ED + ((q.ed_floats + 3) & ~3L) + ((q.M + 3) & ~3L));
             uint4* EDc = EOc + q.eoc_floats / 4;
@@ -524,7 +519,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
             hipLaunchKernelGGL((dft_dy_h3_kernel<9, 6, 11>), dim3(gridh), dim3(384), lds_h, st, dpre, (const uint4*)EDc, Sp, q.M,
                                R, B, q.Ho, q.Lh, q.NBpad, ldexpf(1.f, -14), smax);
             TVAE_CHECK_LAUNCH();
-        } else if (q.gen && !(getenv("TVAE_DFT_WIDE_GEN") && getenv("TVAE_DFT_WIDE_GEN")[0] == '0') && q.NS <= DFT_WIDE_NS &&
+        } else if (q.gen && q.NS <= DFT_WIDE_NS &&
                    q.NRT <= 8 && 32 * q.Ho <= 16 * 64 * q.NRT && (size_t)2 * (32 * (q.Ho | 1) + 1) * 4 <= 150 * 1024) {
             // large frames (galaxy shape): a workgroup per tile, its waves split the rows of S' (dft_dy_wide_kernel)
             const int NSR = q.NS <= 50 ? 50 : (q.NS <= 66 ? 66 : DFT_WIDE_NS);      // the instance's padded slot
@@ -584,7 +579,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
     }
     // G[fx][m'][k] = sum_n S'[fx][m'][n] A^T[fx][k][n]: batched split-pipe weight-gradient GEMM into reduction-slice slabs
     // exact-fit tile where the 2 L Cin columns are one and a half of the 128-wide tiles (dense_wgrad_x6_wide_kernel)
-    static const bool wide_on = !(getenv("TVAE_WG_WIDE") && getenv("TVAE_WG_WIDE")[0] == '0');
+    constexpr bool wide_on = true;
     const bool wide = wide_on && parts != 1 && q.wsplits > 0;       // (the one-part mode keeps its bf16-stored S' path)
     const int nslabs = wide ? q.wsplits : q.splits;
     {
@@ -603,7 +598,7 @@ int tvae_conv1_wgrad_dft(const float* dpre, const float* at, float* dbank, float
         if (rc) return rc;
     }
     // both contractions on the fp32 matrix pipe where the tiles are not mostly padding (ksz <= 64, >= 17 frequencies per block)
-    static const bool dbank_mf = !(getenv("TVAE_DBANK_MF") && getenv("TVAE_DBANK_MF")[0] == '0');
+    constexpr bool dbank_mf = true;
     if (q.mixed) {       // the tap rows are spatial already: x stage only
         hipError_t e = allow_big_lds(dft_dbank_x_kernel, q.lds_db);
         if (e != hipSuccess) return (int)e;

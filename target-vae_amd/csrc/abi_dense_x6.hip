@@ -44,7 +44,7 @@ int dense_x6_batched4(const void* w3, const float* X, long ldx, const Epilogue& 
 // (the caller then takes dense_x6_batched4).  ep as for the lean store epilogue; Mb = rows per problem in the cell array.
 bool dense_x6_batched_xres(const void* w3, const float* X, long ldx, const Epilogue& ep, int rows_per_problem, int Mb, int nprob,
                            int N, int K, long x_stride, long c_stride, int parts, hipStream_t st, H3Scale hs, int* rc) {
-    static const bool on = !(getenv("TVAE_FWD_XRES") && getenv("TVAE_FWD_XRES")[0] == '0');
+    constexpr bool on = true;
     const int K8pad = dense_k8pad(K), nk = K8pad / 2;
     const size_t lds = (size_t)nk * parts * 256 * 16 + (size_t)(Mb + 128) * 4;
     const bool lean = !ep.bias && !ep.res && !ep.aux && ep.act == ACT_NONE && ep.mask == ACT_NONE && ep.ctile > 0 && ep.C &&

@@ -82,9 +82,14 @@ def build_parser(kind: str) -> argparse.ArgumentParser:
     p.add_argument('--seed', type=int, default=None, help='seed for init / shuffling / noise (reference: unseeded)')
     p.add_argument('--synthetic', type=int, default=0, metavar='N',
                    help='train on N synthetic images of the dataset shape instead of loading files')
+    # Round 6: ON BY DEFAULT wherever it applies (the attention branch without CTF filters / mask: every BASELINE configuration).
+    # The minibatch shape of a run is fixed, the replay is bitwise the eager result
+    # (tests/test_driver_gpu.py::test_graphed_step_bitwise_equals_eager) and the ~70 launches of a step are most of its cost at
+    # small per-GPU batches (12 images: 1.68 -> 1.43 ms).  --graph insists (error where it cannot apply), --no-graph runs eagerly.
     p.add_argument('--graph', action='store_true',
-                   help='replay a captured hipGraph of forward + backward for full-size minibatches (tvae/graph.py; '
-                        'bitwise the eager result, fewer launches: pays on the 28x28 workloads)')
+                   help='insist on replaying a captured hipGraph of forward + backward for full-size minibatches '
+                        '(tvae/graph.py); without this flag the graph is used wherever it applies')
+    p.add_argument('--no-graph', action='store_true', help='run every step eagerly (no hipGraph capture)')
     return p
 
 
@@ -310,9 +315,12 @@ def run(kind: str, argv=None):
                          '(train_particles.py:303-307,330-333) and is not built')
     step_dim = args.encoder_padding if kind == 'particles' else image_dim   # reference positional argument
     graphed = None
-    if args.graph:
-        if not (t_inf == 'attention' and r_inf != 'unimodal') or isinstance(train_src, tuple) or (mask_radius or 0) > 0:
-            raise SystemExit('--graph captures the TARGET-VAE attention branch without CTF filters / mask')
+    graph_ok = (t_inf == 'attention' and r_inf != 'unimodal') and not isinstance(train_src, tuple) and not (mask_radius or 0) > 0
+    if args.graph and args.no_graph:
+        raise SystemExit('--graph and --no-graph exclude each other')
+    if args.graph and not graph_ok:
+        raise SystemExit('--graph captures the TARGET-VAE attention branch without CTF filters / mask')
+    if graph_ok and not args.no_graph and os.environ.get('TVAE_GRAPH', '1') != '0':
         from . import graph as _graph
         b_cap = train_it.plan[0][rank] if train_it.plan else 0
         if b_cap > 0:

@@ -328,17 +328,17 @@ def _scratch(device, key, floats: int) -> torch.Tensor:
     return t
 
 
+# Routing switches.  Two can be set from the environment (each is kept alive by a test): TVAE_CONV_DFT=0 -- the direct split-pipe
+# convolution instead of the frequency-domain one (bench.py's conv_direct_form line; tests/test_hip_modules.py runs the direct
+# kernels through geometries the DFT plan rejects); TVAE_DEC_PAD=0 -- no padding of 28 x 28 / 50 x 50 pixel ranges to the GEMM
+# tile (test_decoder_pads_pixel_ranges_to_the_gemm_tile flips it).  The FUSE_* names below were environment switches while
+# their fusions were being A/B'd (rounds 2-5; profiles/README.md has every measurement); all of them won and are plain
+# constants now -- the unfused branches they guard remain as the paths of shapes the fused kernels do not cover, and
+# FUSE_ENC_TAIL is still flipped by tests/test_hip_modules.py::test_encoder_tail_paths_agree.
 CONV_DFT = os.environ.get('TVAE_CONV_DFT', '1') != '0'
-FUSE_COLDOT = os.environ.get('TVAE_FUSE_COLDOT', '1') != '0'
-FUSE_IN_TAIL = os.environ.get('TVAE_FUSE_IN_TAIL', '1') != '0'
-FUSE_VIRT_GRAD = os.environ.get('TVAE_FUSE_VIRT_GRAD', '1') != '0'
-FUSE_VIRT_ACT = os.environ.get('TVAE_FUSE_VIRT_ACT', '1') != '0'
-FUSE_SIGN_BITS = os.environ.get('TVAE_FUSE_SIGN_BITS', '1') != '0'
-FUSE_ENC_TAIL = os.environ.get('TVAE_FUSE_ENC_TAIL', '1') != '0'
-FUSE_ROW_SUMS = os.environ.get('TVAE_FUSE_ROW_SUMS', '1') != '0'
-FUSE_ENC_WGRAD = os.environ.get('TVAE_FUSE_ENC_WGRAD', '1') != '0'
-FUSE_NO_H = os.environ.get('TVAE_FUSE_NO_H', '1') != '0'
-H3_DEEP = os.environ.get('TVAE_H3_DEEP', '1') != '0'      # round 6: measured bounds -> h3 for every hidden decoder layer
+FUSE_COLDOT = FUSE_IN_TAIL = FUSE_VIRT_GRAD = FUSE_VIRT_ACT = FUSE_SIGN_BITS = FUSE_ENC_TAIL = True
+FUSE_ROW_SUMS = FUSE_ENC_WGRAD = FUSE_NO_H = True
+H3_DEEP = True           # round 6: measured bounds -> h3 for every hidden decoder layer (test_deep_decoder_runs_h3_on_measured_bounds)
 
 
 def _use_dft(B, Cin, n, k, pad, C, R) -> bool:

@@ -208,12 +208,13 @@ def test_graphed_step_bitwise_equals_eager():
 
 
 def test_cli_graph_flag_same_log_as_eager(tmp_path):
-    """`train_mnist.py --graph` prints the same TSV lines as the eager run under the same seed."""
+    """`train_mnist.py` with the hipGraph step (the default since round 6, and with --graph insisting on it) prints the same
+    TSV lines as the eager run (--no-graph) under the same seed."""
     outs = []
-    for extra in ([], ['--graph']):
+    for extra in (['--no-graph'], [], ['--graph']):
         cmd = [sys.executable, os.path.join(PKG, 'train_mnist.py')] + SMALL + CASES['train_mnist'][0] + extra + \
             ['--seed', '7', '--log-root', str(tmp_path / ('logs' + ''.join(extra)))]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append([ln for ln in r.stdout.splitlines() if '\t' in ln])
-    assert outs[0] == outs[1] and len(outs[0]) == 5
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 5

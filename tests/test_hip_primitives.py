@@ -1,6 +1,7 @@
 """GPU parity of every C-ABI entry point of libtvae_hip.so against plain torch fp64/fp32 math.
 These call through the C ABI (tvae._lib.call -> ctypes) on cuda:0."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1363,3 +1364,19 @@ def test_fourier_bwd_large_arguments(sigma, span, amin):
     # per element: rounding of the fp32 argument sum (up to 3 ulp of |arg|) times the slope of sin, summed over Ff features
     tol = 4e-7 * float(arg.abs().max()) + 2e-6
     assert rel_err(gx, ref) < tol, (rel_err(gx, ref), tol)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('var', ['TVAE_DFT_FULL_FRAME', 'TVAE_DFT_YSPECTRAL'])
+def test_conv1_dft_alternative_formulations(var):
+    """The two round-4 formulations of the frequency-domain convolution that the library still carries behind a switch -- the
+    reference's full zero-padded frame n + 2 pad (its own ring instances 4-6) and the transform along BOTH axes -- run the whole
+    fp64 comparison above in a process of their own (the switches are read once per process).  This test is what keeps them
+    alive (every remaining switch names its test)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, **{var: '1'})
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'conv1_dft_matches_fp64',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout

@@ -304,7 +304,7 @@ def test_cli_flags_match_reference():
             assert (list(a.choices) if a.choices else None) == spec['choices'], (script, dest)
             assert getattr(a.type, '__name__', None) == spec['type'], (script, dest)
             assert (a.nargs == 0) == spec['nargs0'], (script, dest)
-        assert set(mine) - set(flags) == {'seed', 'synthetic', 'graph'}, script      # this framework's own additions
+        assert set(mine) - set(flags) == {'seed', 'synthetic', 'graph', 'no_graph'}, script      # this framework's own additions
 
 
 def test_ctf_filter_matches_reference_golden():
