@@ -215,6 +215,12 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
         ep.act == ACT_LRELU)
         return TVAE_DX6_DISPATCH_E(0, 1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     if (vg.wo) return TVAE_DX6_DISPATCH(1, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+    // plain hidden layer that stores its output (round 6): whole 512-row tiles, bias + LeakyReLU | none (forward) or the
+    // LeakyReLU mask of the saved activation (data gradient), nothing fused behind it: lean store epilogue
+    if (X && rows % DX6_ROWS == 0 && ep.C && !ep.res && !cd.w && !cd.bits && !it.xr && !ep.ctile && !ep.accumulate && !ep.gbias &&
+        ((ep.mask == ACT_NONE && (ep.act == ACT_LRELU || ep.act == ACT_NONE)) || (ep.mask == ACT_LRELU && ep.aux && ep.act == ACT_NONE && !ep.bias)) &&
+        ep.ldc * 8 * 4 < (1L << 31) && ep.ldaux * 8 * 4 < (1L << 31))
+        return TVAE_DX6_DISPATCH_E(0, 3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     return TVAE_DX6_DISPATCH(0, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
 }
 int tvae_linear_fwd_x6(const void* w3, const float* X, const float* bias, const float* res, float* Y, int M, int N,

@@ -670,6 +670,58 @@ __device__ __forceinline__ void dense_x6_epilogue_lean_in(f32x16 (&acc)[2][4], c
     }
 }
 
+// Lean epilogue of a PLAIN hidden layer that stores its output (round 6): forward  Y = act(W X + b)  and data gradient
+// dX = act'(aux) . (W^T dpre)  of every hidden decoder layer that is not one of the fused special cases above -- the layers of
+// deep decoders (galaxy: four), of Fourier decoders, of residual-free stacks with n_out > 1.  The generic epilogue took 203 us of
+// a 492 us launch at the galaxy shape (ablations -DTVAE_ABL=8 / =4: 89 us of vector work around 114 us of stores); here: row
+// constants four at a time (ds_read_b128), the h3 factors folded into the bias FMA, wave-uniform row pointers + one 32-bit lane
+// offset, no per-element option tests.  Full 512-row tiles only (M % 512 == 0).  MASKA: multiply by LeakyReLU'(aux) (the data
+// gradient's saved activation); ACT: LeakyReLU on the result (forward).  vmax: max |stored value| (Epilogue.amax_out).
+template <int NP, bool ACT, bool MASKA>
+__device__ __forceinline__ void dense_x6_epilogue_lean_store(f32x16 (&acc)[2][4], float* __restrict__ C, long ldc,
+                                                             const float* __restrict__ aux, long ldaux, long n0, const float* bsm,
+                                                             const float* h3a, const float* h3x, float slope, int wave, int lane,
+                                                             int m0, float& vmax) {
+    float ixv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ixv[j] = NP == 2 ? h3x[j * 32 + (lane & 31)] : 1.f;
+    const int half = lane >> 5;
+    const unsigned loff = (unsigned)((4 * half * ldc + (lane & 31)) * 4);          // bytes (host: 8 ldc floats fit 2^31 bytes)
+    const unsigned aoff = (unsigned)((4 * half * ldaux + (lane & 31)) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rb = wave * 64 + i * 32 + 8 * q;                   // rows rb + 4 half + p <-> registers r = 4 q + p
+            const float4 b4 = *reinterpret_cast<const float4*>(bsm + rb + 4 * half);
+            float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (NP == 2) a4 = *reinterpret_cast<const float4*>(h3a + rb + 4 * half);
+            const float bq[4] = {b4.x, b4.y, b4.z, b4.w}, aq[4] = {a4.x, a4.y, a4.z, a4.w};
+            float av[4][4];
+            if (MASKA) {                                 // the 16 mask values of this row group before any of its stores
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const char* arow = reinterpret_cast<const char*>(aux + (long)(m0 + rb + p) * ldaux + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[p][j] = __builtin_nontemporal_load(reinterpret_cast<const float*>(arow + aoff) + j * 32);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                char* rowp = reinterpret_cast<char*>(C + (long)(m0 + rb + p) * ldc + n0);        // wave uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = NP == 2 ? __fmaf_rn(acc[i][j][4 * q + p] * ixv[j], aq[p], bq[p]) : acc[i][j][4 * q + p] + bq[p];
+                    if (ACT) v = fmaxf(v, v * slope);
+                    if (MASKA) v *= av[p][j] > 0.f ? 1.f : slope;
+                    vmax = fmaxf(vmax, fabsf(v));
+                    __builtin_nontemporal_store(v, reinterpret_cast<float*>(rowp + loff) + j * 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);           // one row group at a time
+        }
+}
+
 // Tile 512 x 128: eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step), two per
 // SIMD, so one wave's split arithmetic, LDS traffic and load waits run under the other's MFMAs.  Every k-value of X is
 // split once per 512 output rows (4 per thread per step).
@@ -691,6 +743,8 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 //   0 = generic epilogue (every option a uniform run-time branch)
 //   1 = dense_x6_epilogue_lean: output not stored, fused column dot + sign bits, LeakyReLU, ONE full 512-row tile (M == 512)
 //   2 = dense_x6_epilogue_lean_in: two-valued data gradient, fused first-layer backward with the recomputed mask, M == 512
+//   3 = dense_x6_epilogue_lean_store: plain stored output, bias + LeakyReLU | none (forward) or the LeakyReLU mask of a saved
+//       activation (data gradient), whole 512-row tiles; Epilogue.amax_out supported
 // The host picks the instance (abi_dense_x6.hip: launch_dense_x6) when the call has exactly that shape.
 template <int XV, int NP, int EPI = 0>
 static __global__ __launch_bounds__(DX6_THREADS, 2)
@@ -981,6 +1035,14 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
                                              gyv, oms, cd.bits, (long)(N >> 5), vmax)
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
+    if (EPI == 3) {
+        if (ep.mask == ACT_LRELU)
+            dense_x6_epilogue_lean_store<NP, false, true>(acc, ep.C, ep.ldc, ep.aux, ep.ldaux, n0, bsm, h3a_, h3x_, ep.slope, wave, lane, m0, vmax);
+        else if (ep.act == ACT_LRELU)
+            dense_x6_epilogue_lean_store<NP, true, false>(acc, ep.C, ep.ldc, nullptr, 0, n0, bsm, h3a_, h3x_, ep.slope, wave, lane, m0, vmax);
+        else
+            dense_x6_epilogue_lean_store<NP, false, false>(acc, ep.C, ep.ldc, nullptr, 0, n0, bsm, h3a_, h3x_, ep.slope, wave, lane, m0, vmax);
+    } else
     if (EPI == 2) {
         float x0_[4], x1_[4];
 #pragma unroll
@@ -1015,7 +1077,7 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     }
 #undef TVAE_DX6_EPI_R
 #undef TVAE_DX6_EPI
-    if (EPI == 0 && ep.amax_out) {                       // one atomic per wave at most (most find a larger value already there)
+    if ((EPI == 0 || EPI == 3) && ep.amax_out) {         // one atomic per wave at most (most find a larger value already there)
         const float m_ = h3_wave_max(vmax);
         if (lane == 0) h3_atomic_amax(ep.amax_out, m_);
     }

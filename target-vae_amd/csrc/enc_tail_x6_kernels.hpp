@@ -573,7 +573,19 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
             mfma_np<NP>(acc[0], af, bf[0]);
             mfma_np<NP>(acc[1], af, bf[1]);
         }
-        if (ch + 1 < c_end) build(cb ^ 1, cb ^ 1);       // (the MFMAs above are independent of it: they overlap)
+        // (unconditional: in the last iteration it rebuilds the clamped re-fetch of the last chunk into the cell set nobody reads
+        //  any more -- under `if` the build was a basic block of its own BEHIND the twelve back-to-back MFMAs, i.e. the wave
+        //  first stalled at every dependent MFMA issue and only then started ~190 vector instructions with the matrix pipe idle;
+        //  in one block the scheduler spreads them between the dependent matrix instructions)
+        build(cb ^ 1, cb ^ 1);
+        // ask for the interleaving explicitly: one matrix instruction, then a slice of the build's vector / LDS work
+#pragma unroll
+        for (int g_ = 0; g_ < 4 * NP; ++g_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);       // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail DMAs still target this workgroup's LDS
     // slab [workgroup][c2][c]: lane (c = 32 (tj + j) + li), register r -> row c2 = et_row(ti, r, kh)

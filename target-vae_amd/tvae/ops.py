@@ -214,7 +214,8 @@ SKINNY_MAX = 8          # head projections with <= 8 output rows use the streami
 
 
 def _seglen(N: int) -> int:
-    return max(2048, (N + 255) // 256)
+    # (a multiple of 4: every segment of a 16-byte aligned row then starts 16-byte aligned -- the float4 path of rowdot_seg)
+    return max(2048, ((N + 255) // 256 + 3) // 4 * 4)
 
 
 def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
