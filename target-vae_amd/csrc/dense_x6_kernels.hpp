@@ -722,6 +722,11 @@ __device__ __forceinline__ void dense_x6_epilogue_lean_store(f32x16 (&acc)[2][4]
         }
 }
 
+// (defined with dense_x6_plain4_kernel below: scale + store of a column-tiled output, whole row tiles)
+template <int NP>
+__device__ __forceinline__ void dense_x6_epilogue_store(f32x16 (&acc)[2][4], float* C, long ldc, long coff, const float* h3a,
+                                                        const float* h3x, int wave, int lane, int m0);
+
 // Tile 512 x 128: eight waves stacked along the rows (64 x 128 each: 2 x 4 MFMA tiles, 48 MFMAs per 16-k step), two per
 // SIMD, so one wave's split arithmetic, LDS traffic and load waits run under the other's MFMAs.  Every k-value of X is
 // split once per 512 output rows (4 per thread per step).
@@ -743,6 +748,8 @@ struct DenseBatch {        // batched launch: row tile t belongs to problem t / 
 //   0 = generic epilogue (every option a uniform run-time branch)
 //   1 = dense_x6_epilogue_lean: output not stored, fused column dot + sign bits, LeakyReLU, ONE full 512-row tile (M == 512)
 //   2 = dense_x6_epilogue_lean_in: two-valued data gradient, fused first-layer backward with the recomputed mask, M == 512
+//   4 = dense_x6_epilogue_store: the spectral contraction's lean store (no bias / activation, column-tiled output, whole row tiles)
+//       for the problems that take THIS tile (reductions > 256: several input channels, wide frames) -- round 6
 //   3 = dense_x6_epilogue_lean_store: plain stored output, bias + LeakyReLU | none (forward) or the LeakyReLU mask of a saved
 //       activation (data gradient), whole 512-row tiles; Epilogue.amax_out supported
 // The host picks the instance (abi_dense_x6.hip: launch_dense_x6) when the call has exactly that shape.
@@ -1035,6 +1042,9 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
                                              gyv, oms, cd.bits, (long)(N >> 5), vmax)
 #define TVAE_DX6_EPI_R(A_, M_, V_) \
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
+    if (EPI == 4) {      // (M is a multiple of the tile: a tile is all real rows, or all rows that pad the stacked problems to 512)
+        if (m0 < M) dense_x6_epilogue_store<NP>(acc, ep.C, ep.ldc, (long)tile_n * ep.ctile, h3a_, h3x_, wave, lane, m0);
+    } else
     if (EPI == 3) {
         if (ep.mask == ACT_LRELU)
             dense_x6_epilogue_lean_store<NP, false, true>(acc, ep.C, ep.ldc, ep.aux, ep.ldaux, n0, bsm, h3a_, h3x_, ep.slope, wave, lane, m0, vmax);
