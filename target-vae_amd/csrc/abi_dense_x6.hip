@@ -208,6 +208,10 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
         // recomputed LeakyReLU mask, nothing else switched on
         if (rows == DX6_ROWS && !ep.C && it.xr && it.bc && !ep.res && ep.mask == ACT_LRELU && !cd.w && !cd.bits)
             return TVAE_DX6_DISPATCH_E(5, 2, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
+        // ... its result stored under the LeakyReLU mask of a saved activation (Fourier decoders), whole row tiles: lean store
+        if (rows % DX6_ROWS == 0 && ep.C && !it.xr && !ep.res && ep.mask == ACT_LRELU && ep.aux && !cd.w && !cd.bits && !ep.ctile &&
+            ep.ldc * 8 * 4 < (1L << 31) && ep.ldaux * 8 * 4 < (1L << 31))
+            return TVAE_DX6_DISPATCH_E(5, 3, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
         return TVAE_DX6_DISPATCH(5, parts, (const uint4*)a3, X, ldx, ep, rows, Rpad, N, K, K8pad, tm, nb, cd, it, vg, va, st, hs);
     }
     if (vg.csum && vg.rpart) {

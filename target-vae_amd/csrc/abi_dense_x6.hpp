@@ -46,7 +46,7 @@ TVAE_DX6_DECL(0) TVAE_DX6_DECL(1) TVAE_DX6_DECL(2) TVAE_DX6_DECL(3) TVAE_DX6_DEC
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p3(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p2(TVAE_DX6_LAUNCH_ARGS); \
     TVAE_INTERNAL int dense_x6_launch_v##XV_##e##E_##_p1(TVAE_DX6_LAUNCH_ARGS);
-TVAE_DX6_DECL_E(2, 1) TVAE_DX6_DECL_E(5, 2) TVAE_DX6_DECL_E(0, 1) TVAE_DX6_DECL_E(0, 3) TVAE_DX6_DECL_E(0, 4)
+TVAE_DX6_DECL_E(2, 1) TVAE_DX6_DECL_E(5, 2) TVAE_DX6_DECL_E(0, 1) TVAE_DX6_DECL_E(0, 3) TVAE_DX6_DECL_E(0, 4) TVAE_DX6_DECL_E(5, 3)
 #define TVAE_DX6_LAUNCH_DEF_E(XV_, NP_, E_)                                                                           \
     namespace tvae {                                                                                                  \
     int dense_x6_launch_v##XV_##e##E_##_p##NP_(TVAE_DX6_LAUNCH_ARGS) {                                                \

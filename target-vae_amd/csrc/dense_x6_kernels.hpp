@@ -677,14 +677,16 @@ __device__ __forceinline__ void dense_x6_epilogue_lean_in(f32x16 (&acc)[2][4], c
 // constants four at a time (ds_read_b128), the h3 factors folded into the bias FMA, wave-uniform row pointers + one 32-bit lane
 // offset, no per-element option tests.  Full 512-row tiles only (M % 512 == 0).  MASKA: multiply by LeakyReLU'(aux) (the data
 // gradient's saved activation); ACT: LeakyReLU on the result (forward).  vmax: max |stored value| (Epilogue.amax_out).
-template <int NP, bool ACT, bool MASKA>
+// MB: the two-valued implicit gradient (VirtGrad.csum; dense_x6_kernel<5>: the 0 / 1 operand has no column scale):
+// value = gy[n] (oms acc + slope csum[m]), bsm = slope csum.
+template <int NP, bool ACT, bool MASKA, bool MB = false>
 __device__ __forceinline__ void dense_x6_epilogue_lean_store(f32x16 (&acc)[2][4], float* __restrict__ C, long ldc,
                                                              const float* __restrict__ aux, long ldaux, long n0, const float* bsm,
                                                              const float* h3a, const float* h3x, float slope, int wave, int lane,
-                                                             int m0, float& vmax) {
+                                                             int m0, float& vmax, const float* gyv = nullptr, float oms = 0.f) {
     float ixv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ixv[j] = NP == 2 ? h3x[j * 32 + (lane & 31)] : 1.f;
+    for (int j = 0; j < 4; ++j) ixv[j] = (NP == 2 && !MB) ? h3x[j * 32 + (lane & 31)] : 1.f;
     const int half = lane >> 5;
     const unsigned loff = (unsigned)((4 * half * ldc + (lane & 31)) * 4);          // bytes (host: 8 ldc floats fit 2^31 bytes)
     const unsigned aoff = (unsigned)((4 * half * ldaux + (lane & 31)) * 4);
@@ -711,7 +713,9 @@ __device__ __forceinline__ void dense_x6_epilogue_lean_store(f32x16 (&acc)[2][4]
                 char* rowp = reinterpret_cast<char*>(C + (long)(m0 + rb + p) * ldc + n0);        // wave uniform
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = NP == 2 ? __fmaf_rn(acc[i][j][4 * q + p] * ixv[j], aq[p], bq[p]) : acc[i][j][4 * q + p] + bq[p];
+                    float v;
+                    if (MB) v = gyv[j] * __fmaf_rn(oms, NP == 2 ? acc[i][j][4 * q + p] * aq[p] : acc[i][j][4 * q + p], bq[p]);
+                    else v = NP == 2 ? __fmaf_rn(acc[i][j][4 * q + p] * ixv[j], aq[p], bq[p]) : acc[i][j][4 * q + p] + bq[p];
                     if (ACT) v = fmaxf(v, v * slope);
                     if (MASKA) v *= av[p][j] > 0.f ? 1.f : slope;
                     vmax = fmaxf(vmax, fabsf(v));
@@ -1044,6 +1048,10 @@ void dense_x6_kernel(const uint4* __restrict__ A3, const float* __restrict__ X, 
     do { if (res) TVAE_DX6_EPI(A_, M_, true, V_); else TVAE_DX6_EPI(A_, M_, false, V_); } while (0)
     if (EPI == 4) {      // (M is a multiple of the tile: a tile is all real rows, or all rows that pad the stacked problems to 512)
         if (m0 < M) dense_x6_epilogue_store<NP>(acc, ep.C, ep.ldc, (long)tile_n * ep.ctile, h3a_, h3x_, wave, lane, m0);
+    } else
+    if (EPI == 3 && MASKB) {     // two-valued data gradient whose result is stored (Fourier decoders: no fused first-layer backward)
+        dense_x6_epilogue_lean_store<NP, false, true, true>(acc, ep.C, ep.ldc, ep.aux, ep.ldaux, n0, bsm, h3a_, h3x_, ep.slope, wave, lane,
+                                                            m0, vmax, gyv, oms);
     } else
     if (EPI == 3) {
         if (ep.mask == ACT_LRELU)
