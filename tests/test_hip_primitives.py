@@ -1380,3 +1380,49 @@ def test_conv1_dft_alternative_formulations(var):
                         '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+@pytest.mark.parametrize('M,K', [(512, 384), (1024, 512)])
+@pytest.mark.parametrize('parts', [3, 2, 1])
+def test_linear_x6_lean_store_epilogue_and_measured_maximum(M, K, parts):
+    """Round 6: plain hidden-layer launches that store their output take the lean store epilogue (dense_x6_kernel<0, NP, 3>: whole
+    512-row tiles -- one and two row tiles here) and can leave max |stored value| in a zeroed word (y_amax, ABI 7): forward with
+    bias + LeakyReLU and without activation, data gradient under the LeakyReLU mask of a saved activation, in all three split
+    arithmetics against float64; the word must hold EXACTLY the maximum of what was stored."""
+    from tvae._lib import query
+    N = 640
+    W, X, b = rnd(M, K, seed=1, scale=K ** -0.5), rnd(K, N, seed=2), rnd(M, seed=3)
+    split = 'tvae_dense_split2h' if parts == 2 else 'tvae_dense_split3'
+    tol = {3: GEMM_TOL['f32'], 2: GEMM_TOL['f32'], 1: 2e-2}[parts]
+
+    def cells(Wm, rows, Kk, tr):
+        a3 = torch.empty(query('tvae_dense_x6_bytes', rows, Kk) // 4, device=dev())
+        call(split, Wm.to(dev()), Wm.shape[1], a3, a3.numel() * 4, rows, Kk, tr, None, None)
+        return a3
+
+    xmax = X.abs().max().reshape(1).to(dev()) if parts == 2 else None
+    w3 = cells(W, M, K, 0)
+    for act in (1, 0):
+        Y = torch.full((M, N), float('nan'), device=dev())
+        amax = torch.zeros(1, device=dev())
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, Y, M, N, K, N, N, act, SLOPE, None, None, None, None, None, None,
+             None, 0, None, parts, xmax, amax)
+        ref = act_ref(W.double() @ X.double() + b.double()[:, None], act)
+        assert rel_err(Y, ref) < tol
+        assert float(amax) == float(Y.abs().max())
+    d = rnd(K, N, seed=6)                                 # gradient of this layer's OUTPUT rows ... transposed problem: rows = K
+    aux = rnd(M, N, seed=7).clamp(-0.9, 0.9)
+    # dX[m][n] = act'(aux[m][n]) * sum_k Wt[k][m] d[k][n] with Wt = W^T (K x M): reuse W as the (K = rows of d) x (M = outputs) weight
+    Wt = rnd(K, M, seed=8, scale=K ** -0.5)
+    w3t = cells(Wt, M, K, 1)
+    dmax = d.abs().max().reshape(1).to(dev()) if parts == 2 else None
+    dX = torch.full((M, N), float('nan'), device=dev())
+    amax = torch.zeros(1, device=dev())
+    call('tvae_linear_dgrad_x6', w3t, d.to(dev()), None, aux.to(dev()), dX, K, N, M, N, N, 1, SLOPE, None, None, None, None, 0, None,
+         None, None, None, None, 0, None, 0, None, None, None, None, parts, None, None, None, dmax, amax)
+    refg = (Wt.double().t() @ d.double()) * dact_ref(aux.double(), 1)
+    assert rel_err(dX, refg) < tol
+    assert float(amax) == float(dX.abs().max())
+    with pytest.raises(Exception):                       # y_amax needs a stored output with nothing fused behind it
+        call('tvae_linear_fwd_x6', w3, X.to(dev()), b.to(dev()), None, None, M, N, K, N, N, 1, SLOPE, None, None, None, None, None, None,
+             None, 0, None, parts, xmax, amax)
