@@ -1088,7 +1088,9 @@ class DecoderFn(torch.autograd.Function):
         # (|d[m][n]| <= max_m sum_o |Wo[o][m]| max |gy|: act' <= 1), every later one measured by the data-gradient launch that
         # stores it (tvae_linear_dgrad_x6 y_amax)
         h3_deep = H3_DEEP and parts() == 2 and _dense_x6_ok(F_, Nt)
-        dmeas = torch.zeros(n_hidden + 1, dtype=torch.float32, device=dev) if h3_deep else None
+        # (words for the measured maxima: only where a stored gradient is streamed again -- a second hidden layer, or the Fourier
+        #  first layer behind the first one; the single-hidden-layer configurations need none and launch no fill)
+        dmeas = torch.zeros(n_hidden + 1, dtype=torch.float32, device=dev) if (h3_deep and (n_hidden >= 2 or has_f)) else None
         d_bnd = None                                     # bound word of the stored gradient `d` (None: none / not stored)
         if h3_deep and not virt:
             d_bnd = (_inf_norm(gy) * Wo.detach().abs().sum(0).amax()).reshape(1)
