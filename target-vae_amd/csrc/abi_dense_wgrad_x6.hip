@@ -59,7 +59,10 @@ extern "C" {
 // order than every later step: 2.4e-7 relative on one tensor; round 3, profiles/tools/graph_replay_probe.py)
 static int wgrad_x6_splits(int M, int N, int K) {
     const int tilesM = cdiv(M, DX6_ROWS), tilesK = cdiv(K, 128);
-    int splits = (2 * 256 + tilesM * tilesK - 1) / (tilesM * tilesK);     // ~2 workgroups per CU
+    // two rounds of one workgroup per CU, and NEVER one workgroup more (round 6: the Fourier first layer's K = 1 026 is 9 column
+    // tiles; rounding UP gave 57 slices = 513 workgroups -- a third round of the 256 CUs for a single workgroup, 480 us where two
+    // full rounds take 330)
+    int splits = (2 * 256) / (tilesM * tilesK);
     if (splits > N / 16) splits = N / 16;
     if (splits < 2) splits = 2;                        // TileMap groups by reduction slice only when there are >= 2
     const int nchunk = cdiv(cdiv(N, splits), 16) * 16;
