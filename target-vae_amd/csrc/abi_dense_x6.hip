@@ -171,7 +171,8 @@ static int launch_dense_x6(const void* a3, const float* X, long ldx, const Epilo
     if (rows <= 0 || N <= 0) return 0;
     if (N % 128 != 0 || !aligned16(a3) || (parts != 1 && parts != 2 && parts != 3)) return (int)hipErrorInvalidValue;
     const int Rpad = x6_round_up(rows, DX6_ROWS), K8pad = dense_k8pad(K);
-    const TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
+    TileMap tm{Rpad / DX6_ROWS, N / 128, 1};
+    tm.pack = 1;                                         // eight adjacent column tiles per XCD (TileMap: the sign-bit lines)
     H3Scale hs = H3_NONE;
     if (parts == 2) {
         // h3 instances: the recomputed first-layer activation (its bound is formed here) and the exact 0 / 1 operand of the

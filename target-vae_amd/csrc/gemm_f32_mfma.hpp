@@ -437,12 +437,20 @@ struct TileMap {
     // (problem, column chunk): the problem's A cells stay in ONE L2 while its column tiles stream, and the bt row tiles
     // of a column panel are adjacent so the panel is fetched once.
     int bt = 0, nch = 1;
+    // pack (round 6; plain tiles only: bt == 0, splits <= 1): EIGHT CONSECUTIVE column tiles on one XCD instead of one in eight.
+    // The decoder's sign bits are one 128-byte line per row and 1 024 columns = eight column tiles; dealt round robin, the eight
+    // tiles that share every line ran on eight different XCDs and each L2 fetched it (0.73 GB fetched by the data gradient for
+    // 0.08 GB of bits, PMC round 6) and wrote its 16-byte piece of it separately.
+    int pack = 0;
     __host__ __device__ int chunk() const { return (tilesN + nch - 1) / nch; }
     __host__ __device__ int groups() const { return bt > 0 ? (tilesM / bt) * nch : (splits > 1 ? splits : tilesN); }
     __host__ __device__ int group_size() const {
         return bt > 0 ? bt * chunk() : (splits > 1 ? tilesM * tilesN : tilesM);
     }
-    __host__ __device__ unsigned grid() const { return (unsigned)(8 * ((groups() + 7) / 8) * group_size()); }
+    __host__ __device__ unsigned grid() const {
+        if (pack && bt == 0 && splits <= 1) return (unsigned)(64 * ((tilesN + 63) / 64) * tilesM);
+        return (unsigned)(8 * ((groups() + 7) / 8) * group_size());
+    }
     __device__ __forceinline__ bool decode(int bid, int& tile_m, int& tile_n, int& split) const {
         const int xcd = bid & 7, j = bid >> 3;
         if (bt > 0) {
@@ -464,6 +472,11 @@ struct TileMap {
         }
         split = 0;
         tile_m = j % tilesM;
+        if (pack) {                                      // workgroups 64 g .. 64 g + 63 (x tilesM): XCD x takes tiles 64 g + 8 x .. + 7
+            const int jn = j / tilesM;
+            tile_n = (jn >> 3) * 64 + xcd * 8 + (jn & 7);
+            return tile_n < tilesN;
+        }
         tile_n = (j / tilesM) * 8 + xcd;
         return tile_n < tilesN;
     }
