@@ -351,6 +351,13 @@ int tvae_enc_tail_fwd_wide(const void* w3, const void* wh3, const float* A1, lon
 int tvae_enc_tail_dgrad_wide(const void* wht3, const void* w3p, const float* dheads, long ldd, int nh, const void* bits_h,
                              const void* bits_a, float* dH, long ldh, float* dA1, long lda, int C, long N, float slope,
                              int parts, const float* amax_dheads, tvae_stream_t stream);
+/* tvae_enc_tail_wgrad_wide (ABI 7): the two weight gradients of that tail, dW2 = dH A1^T and dWh = dheads H^T (autograd of the
+ * 1x1x1 convolutions, src/models.py:347-358,390-392), as ONE cooperative reduction over the columns each:
+ * dW[r][c] = sum_n D[r][n] A[c][n], D [rows_d <= 128][N], A [128][N], both stored tensors streamed by LDS-DMA, h3 arithmetic
+ * (amax_d: one word >= max |D|; amax_a: 128 floats, one bound per row of A).  dW is [128][128] (rows >= rows_d unspecified);
+ * ws as tvae_enc_tail_wgrad_x6_ws_floats(N); N % 32 == 0, C == 128. */
+int tvae_enc_tail_wgrad_wide(const float* D, long ldd, int rows_d, const float* A, long lda, float* dW, float* ws,
+                             long ws_floats, int C, long N, const float* amax_d, const float* amax_a, tvae_stream_t stream);
 /* ---- inference epilogue: get_latent, clustering_mnist.py:123-161 (argmax over (r,h,w) of attn, gather of
  * (z_mu, exp(z_logstd)) and theta_mu there, softmax-expected translation).  zc [B][2*zd], theta_mu [B], dx [B][2]. */
 int tvae_get_latent(const float* heads, long ldh, const float* p_r, const float* off, const float* grid, int B, int R,

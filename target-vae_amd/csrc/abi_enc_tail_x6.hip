@@ -143,4 +143,25 @@ int tvae_enc_tail_wgrad_x6(const float* A1, long lda, const float* dheads, long 
     return 0;
 }
 
+/* Round 6: dW[r][c] = sum_n D[r][n] A[c][n] for two STORED operands (encoder tail with many head rows: dW2 = dH A1^T and
+ * dWh = dheads H^T).  dW is [128][128]; rows >= rows_d are unspecified. */
+int tvae_enc_tail_wgrad_wide(const float* D, long ldd, int rows_d, const float* A, long lda, float* dW, float* ws, long ws_floats,
+                             int C, long N, const float* amax_d, const float* amax_a, tvae_stream_t stream) {
+    if (N <= 0) return 0;
+    if (C != ET_C || rows_d < 1 || rows_d > ET_C || N % EW_NC != 0 || !D || !A || !dW || !ws || !amax_d || !amax_a ||
+        !aligned16(D) || !aligned16(A) || lda % 4 != 0 || ldd % 4 != 0 || lda < N || ldd < N ||
+        ws_floats < tvae_enc_tail_wgrad_x6_ws_floats(N))
+        return (int)hipErrorInvalidValue;
+    const long nchunks = N / EW_NC;
+    const int grid = (int)(nchunks < cu_count() ? nchunks : cu_count());
+    hipError_t e = allow_big_lds(enc_tail_wgrad_plain_kernel, PW_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(enc_tail_wgrad_plain_kernel, dim3(grid), dim3(ET_THREADS), PW_LDS, S(stream), D, ldd, rows_d, A, lda, ws, N,
+                       amax_d, amax_a);
+    TVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(enc_tail_wgrad_total_kernel, dim3(ET_C * ET_C / 64), dim3(256), 0, S(stream), (const float*)ws, grid, dW);
+    TVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // extern "C"

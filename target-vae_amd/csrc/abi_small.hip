@@ -65,9 +65,11 @@ int tvae_rowdot_seg(const float* X, long ldx, const float* V, int no, int M, int
 int tvae_seg_sum(const float* in, int S_, long L, float* out, float scale, int accumulate, tvae_stream_t stream) {
     if (L <= 64 && S_ >= 32)         // few outputs, many segments: one wave per output
         hipLaunchKernelGGL(seg_sum_wave_kernel, dim3((unsigned)L), dim3(64), 0, S(stream), in, S_, L, out, scale, accumulate);
+    else if (S_ >= 64 && L <= 65536)      // many outputs, many segments: 64 outputs x 16 segment lanes per workgroup
+        hipLaunchKernelGGL(seg_sum_tile_kernel, dim3((unsigned)((L + 63) / 64)), dim3(1024), 0, S(stream), in, S_, L, out, scale,
+                           accumulate);
     else
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(grid1d(L, 256)), dim3(256), 0, S(stream), in, S_, L, out, scale,
-                       accumulate);
+        hipLaunchKernelGGL(seg_sum_kernel, dim3(grid1d(L, 256)), dim3(256), 0, S(stream), in, S_, L, out, scale, accumulate);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

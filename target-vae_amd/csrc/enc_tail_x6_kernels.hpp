@@ -598,6 +598,144 @@ static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_x6_kernel
                 NP == 2 ? (acc[j][r] * is_sm[et_row(ti, r, kh)]) * is_sm[ET_C + 32 * (tj + j) + li] : acc[j][r];
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: the same cooperative reduction for TWO STORED operands -- dW[r][c] = sum_n D[r][n] A[c][n], D with <= 128 rows, A
+// with 128 -- the two weight gradients of the encoder tail with many head rows (dW2 = dH A1^T, dWh = dheads H^T; galaxy
+// configuration: 103 head rows, 2.1 M columns at 8 images), which ran as fp32-MFMA GEMMs (0.66 + 0.75 ms for 2 x 2.2 GB).
+// h3 arithmetic only (two fp16 parts per operand: the exact three-part split would need 160 KB of cells and stages):
+// D under one scale from the word amax_d (max |D|, left by the row-sum pass that reads D anyway), A under one scale per row
+// from amax_a[128].  Per chunk and wave four LDS-DMAs (two 1 KB pieces of each operand).  Rows of D beyond rows_d re-read
+// row rows_d - 1: they only reach rows of dW nobody reads.  LDS 128 KB.
+// ------------------------------------------------------------------------------------------
+constexpr int PW_STAGE = 2 * EW_RAW;                   // raw A chunk + raw D chunk
+constexpr int PW_CELLS = 2 * 4 * ET_C * 16;            // one operand of one chunk as cells [part < 2][octet < 4][row]: 16 KB
+constexpr int PW_LDS = 2 * PW_STAGE + 4 * PW_CELLS;    // two stages, two sets of (D cells, A cells)
+
+static __global__ __launch_bounds__(ET_THREADS, 2) void enc_tail_wgrad_plain_kernel(
+    const float* __restrict__ D, long ldd, int rows_d, const float* __restrict__ A, long lda, float* __restrict__ slabs, long N,
+    const float* __restrict__ amax_d, const float* __restrict__ amax_a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ew_sm[];
+    __shared__ float is_sm[2 * ET_C];                    // [0 .. 128): 1 / sD, [128 .. 256): 1 / sA[row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ew_sm;
+    uint4* cellsD = reinterpret_cast<uint4*>(ew_sm + 2 * PW_STAGE);              // [set][D cells | A cells]
+    uint4* cellsA = reinterpret_cast<uint4*>(ew_sm + 2 * PW_STAGE + PW_CELLS);
+    const long nchunks = N / EW_NC;
+    const long per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const long c_beg = (long)blockIdx.x * per;
+    const long c_end = c_beg + per < nchunks ? c_beg + per : nchunks;
+    const int row = tid & 127, oct = tid >> 7;
+    const float sA = h3_scale(amax_a[row]);
+    const float sD = h3_scale(amax_d[0]);
+    if (oct == 0) {
+        is_sm[row] = h3_inv(sD);
+        is_sm[ET_C + row] = h3_inv(sA);
+    }
+    __syncthreads();
+    // DMA role: piece g = 2 wave + q of each operand: rows 8 g .. 8 g + 7, lane -> (row, 16-byte piece (lane & 7)), pieces of a row
+    // stored XOR-swizzled by (row >> 1) & 7 (conflict-free 16-byte reads in the cell build)
+    const float* a_src[2];
+    const float* d_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r_ = 8 * (2 * wave + q) + (lane >> 3);
+        const int rd = r_ < rows_d ? r_ : rows_d - 1;
+        a_src[q] = A + (long)r_ * lda + 4 * ((lane & 7) ^ ((r_ >> 1) & 7));
+        d_src[q] = D + (long)rd * ldd + 4 * ((lane & 7) ^ ((r_ >> 1) & 7));
+    }
+    auto dma_chunk = [&](long ch, int stage) {
+        const long n0 = ch * EW_NC;
+        const unsigned st = lds0 + (unsigned)(stage * PW_STAGE);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* src = a_src[q] + n0;
+            const unsigned dst = st + (unsigned)((2 * wave + q) * 1024);
+            TVAE_EW_DMA_X4(dst, src);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* src = d_src[q] + n0;
+            const unsigned dst = st + (unsigned)(EW_RAW + (2 * wave + q) * 1024);
+            TVAE_EW_DMA_X4(dst, src);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int ti = wave >> 1, tj = 2 * (wave & 1), kh = lane >> 5, li = lane & 31;
+    auto build = [&](int stage, int cb) {
+        const unsigned char* sb = ew_sm + stage * PW_STAGE;
+        uint4* cD = cellsD + cb * (2 * PW_CELLS / 16);
+        uint4* cA = cellsA + cb * (2 * PW_CELLS / 16);
+        const int sw = (row >> 1) & 7;
+        {
+            const float4* rp = reinterpret_cast<const float4*>(sb + row * (EW_NC * 4));
+            const float4 v0 = rp[(2 * oct) ^ sw], v1 = rp[(2 * oct + 1) ^ sw];
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            Cell16 c3[3];
+            et_split2h(x, sA, c3);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) cA[(p * 4 + oct) * ET_C + row] = c3[p].u;
+        }
+        {
+            const float4* rp = reinterpret_cast<const float4*>(sb + EW_RAW + row * (EW_NC * 4));
+            const float4 v0 = rp[(2 * oct) ^ sw], v1 = rp[(2 * oct + 1) ^ sw];
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            Cell16 c3[3];
+            et_split2h(x, sD, c3);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) cD[(p * 4 + oct) * ET_C + row] = c3[p].u;
+        }
+    };
+    // (the pipeline of enc_tail_wgrad_x6_kernel: one barrier per chunk, cells and stages double buffered)
+    if (c_beg < c_end) {
+        dma_chunk(c_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_chunk(c_beg + 1 < c_end ? c_beg + 1 : c_beg, 1);
+        build(0, 0);
+    }
+    for (long ch = c_beg; ch < c_end; ++ch) {
+        const int cb = (int)((ch - c_beg) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_chunk(ch + 2 < c_end ? ch + 2 : c_end - 1, cb);
+        const uint4* cD = cellsD + cb * (2 * PW_CELLS / 16);
+        const uint4* cA = cellsA + cb * (2 * PW_CELLS / 16);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Cell16 af[3], bf[2][3];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                af[p].u = cD[(p * 4 + 2 * ks + kh) * ET_C + 32 * ti + li];
+                bf[0][p].u = cA[(p * 4 + 2 * ks + kh) * ET_C + 32 * tj + li];
+                bf[1][p].u = cA[(p * 4 + 2 * ks + kh) * ET_C + 32 * (tj + 1) + li];
+            }
+            mfma_np<2>(acc[0], af, bf[0]);
+            mfma_np<2>(acc[1], af, bf[1]);
+        }
+        build(cb ^ 1, cb ^ 1);                           // (unconditional, as in enc_tail_wgrad_x6_kernel)
+#pragma unroll
+        for (int g_ = 0; g_ < 8; ++g_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* slab = slabs + (long)blockIdx.x * ET_C * ET_C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            slab[(long)et_row(ti, r, kh) * ET_C + 32 * (tj + j) + li] =
+                (acc[j][r] * is_sm[et_row(ti, r, kh)]) * is_sm[ET_C + 32 * (tj + j) + li];
+}
+
 // dW2[e] = sum over workgroups of slabs[g][e], in workgroup order
 static __global__ void enc_tail_wgrad_total_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dW2) {
     // thread (element e, slab group q < 4): eight loads in flight per thread, fixed summation order

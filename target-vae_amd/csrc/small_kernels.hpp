@@ -249,6 +249,36 @@ static __global__ __launch_bounds__(64) void seg_sum_wave_kernel(const float* __
     }
 }
 
+// ... and for MANY outputs and many segments (the per-image sums of a Fourier decoder's first-layer gradient: L = 512 features,
+// S = 256 images -- seg_sum_kernel ran 512 threads that each walked 256 dependent loads: 70 us for 512 KB): 64 outputs x 16
+// segment lanes per workgroup, four independent partial sums per lane, a fixed-order reduction through LDS (deterministic).
+static __global__ __launch_bounds__(1024) void seg_sum_tile_kernel(const float* __restrict__ in, int S, long L,
+                                                                   float* __restrict__ out, float scale, int accumulate) {
+    __shared__ float sm[16][64];
+    const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + li;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < L) {
+        int k = sl;
+        for (; k + 48 < S; k += 64) {
+            s0 += in[(long)k * L + i];
+            s1 += in[(long)(k + 16) * L + i];
+            s2 += in[(long)(k + 32) * L + i];
+            s3 += in[(long)(k + 48) * L + i];
+        }
+        for (; k < S; k += 16) s0 += in[(long)k * L + i];
+    }
+    sm[sl][li] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < L) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += sm[j][li];
+        s *= scale;
+        if (accumulate) out[i] += s; else out[i] = s;
+    }
+}
+
 // Column "dot" with a skinny matrix: out[n*NO + o] = b[o] + sum_m W[m*wsm + o*wso] * X[m*ldx + n]
 // (last decoder layer n_out <= 4; coordinate gradient dx'[pix][2]).  Lanes run along n.
 template <int NO>

@@ -54,6 +54,7 @@ SIGNATURES = {
     'tvae_enc_tail_wgrad_x6': 'plplipppplilfip',
     'tvae_enc_tail_fwd_wide': 'ppplppiplplppilifip',
     'tvae_enc_tail_dgrad_wide': 'ppplippplplilfip',
+    'tvae_enc_tail_wgrad_wide': 'pliplpplilpp',
     'tvae_rot_pool_fwd': 'ppppiiii',
     'tvae_rot_pool_bwd': 'ppppplpiiiiif',
     'tvae_coord_fwd': 'ppppii',

@@ -555,7 +555,9 @@ class EncoderFn(torch.autograd.Function):
         ctx.save_for_backward(y, W2, Wh, A1, H)
         ctx.bits = bits
         ctx.wide = wide
-        ctx.a1max = a1max if fused else None      # (a view of keep['at']: max |A1| for the h3 weight gradient)
+        ctx.a1max = a1max if (fused or wide) else None      # (a view of keep['at']: max |A1| per channel for the h3 weight gradients)
+        # wide tail, h3: bound per row of H = act(W2 A1 + b2) for the weight gradient that streams H (|act(x)| <= |x|)
+        ctx.hrows = torch.addmv(b2.detach().abs(), W2.detach().abs(), a1max) if (wide and a1max is not None) else None
         ctx.arith = get_gemm_mode()
         ctx.cfg = (C, Cin, k, R, pad, B, Ho, act)
         return heads
@@ -569,7 +571,8 @@ class EncoderFn(torch.autograd.Function):
         C2, nh = W2.shape[0], Wh.shape[0]
         dheads = dheads.contiguous()
         wide_bw = ctx.wide and ctx.bits is not None
-        dmax = torch.zeros(1, dtype=torch.float32, device=y.device) if (wide_bw and parts() == 2) else None
+        words = torch.zeros(2, dtype=torch.float32, device=y.device) if (wide_bw and parts() == 2) else None
+        dmax, dhmax = (words[0:1], words[1:2]) if words is not None else (None, None)
         dbh = _rowsum(dheads, nh, N, amax=dmax)          # (+ max |dheads| by the way: the h3 bound of the wide data gradient)
         dA1 = None
         dH = None
@@ -601,7 +604,20 @@ class EncoderFn(torch.autograd.Function):
         fuse_w = ctx.bits is not None and FUSE_ENC_WGRAD and nh <= SKINNY_MAX and N % 32 == 0 and not wide_bw
         if not fuse_w and dH is None:
             dH = torch.empty(C2, N, dtype=torch.float32, device=y.device)
-        if wide_bw:
+        # wide tail in h3: both weight gradients as cooperative reductions over two stored operands (enc_tail_wgrad_plain_kernel)
+        wide_w = wide_bw and dmax is not None and ctx.hrows is not None and ctx.a1max is not None and N % 32 == 0
+        if wide_w:
+            _note('enc.tail_wgrad_wide')
+            wsw = _scratch(y.device, 'enc_wgrad_slabs', query('tvae_enc_tail_wgrad_x6_ws_floats', N))
+            dWf = torch.empty(2, C2, C, dtype=torch.float32, device=y.device)
+            with _timed('tvae_enc_tail_wgrad_wide', 2):
+                call('tvae_enc_tail_wgrad_wide', dheads, N, nh, H, N, dWf[0], wsw, wsw.numel(), C2, N, dmax, ctx.hrows)
+            dWh = dWf[0, :nh]
+            db2 = _rowsum(dH, C2, N, amax=dhmax)         # (+ max |dH|: the bound of the launch below)
+            with _timed('tvae_enc_tail_wgrad_wide', 2):
+                call('tvae_enc_tail_wgrad_wide', dH, N, C2, A1, N, dWf[1], wsw, wsw.numel(), C, N, dhmax, ctx.a1max)
+            dW2 = dWf[1]
+        elif wide_bw:
             dWh = _wgrad(dheads, H, nh, N, C2)
             db2 = _rowsum(dH, C2, N)
         elif nh <= SKINNY_MAX:
@@ -624,7 +640,7 @@ class EncoderFn(torch.autograd.Function):
             with _timed('tvae_enc_tail_wgrad_x6', p_w):
                 call('tvae_enc_tail_wgrad_x6', A1, N, dheads, N, nh, ctx.bits[0], Wh.contiguous(), dW2, wsw, wsw.numel(), C,
                      N, LRELU_SLOPE, p_w, ctx.a1max if p_w == 2 else None)
-        else:
+        elif not wide_w:
             dW2 = _wgrad(dH, A1, C2, N, C)
         if dA1 is None:
             dA1 = torch.empty(C, N, dtype=torch.float32, device=y.device)

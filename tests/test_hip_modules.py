@@ -1000,19 +1000,22 @@ def test_deep_decoder_runs_h3_on_measured_bounds(fourier, n_out, resid, gemm_mod
     assert float((g_dead - r_dead).abs().max() / r_dead.abs().max()) < 1e-3, 'dead unit row'
 
 
+@pytest.mark.parametrize('geom', [(20, 20, 4, 3), (21, 20, 3, 2)])
 @pytest.mark.parametrize('zd', [10, 50])
-def test_encoder_with_many_head_rows_takes_the_wide_tail(zd, gemm_mode):
+def test_encoder_with_many_head_rows_takes_the_wide_tail(zd, geom, gemm_mode):
     """Round 6: z_dim > 2 gives 3 + 2 z_dim > 7 head rows (galaxy: 103, reference
     train_galaxy.py:412-420); conv2 + the stacked heads then run as two chained split-pipe GEMMs per direction
     (tvae_enc_tail_fwd_wide / _dgrad_wide) instead of five fp32-MFMA GEMMs.  The 7-tuple and every parameter gradient against
-    the exact fp32-MFMA arithmetic of the same modules; the wide branch must be the one taken (h3), under no_grad too."""
+    the exact fp32-MFMA arithmetic of the same modules; the wide branch must be the one taken (h3), under no_grad too.
+    Second geometry: a column count that is a multiple of 32 -- the two weight gradients then run as cooperative reductions
+    (tvae_enc_tail_wgrad_wide) instead of fp32-MFMA GEMMs."""
     import src.models as M
     from tvae import ops
     from tvae._lib import arithmetic
     if gemm_mode != 'h3':
         pytest.skip('h3 routing test')
     torch.manual_seed(5)
-    n, B, R, k, pad = 20, 3, 4, 20, 4
+    (n, k, pad, B), R = geom, 4
     enc = M.InferenceNetwork_AttentionTranslation_AttentionRotation(n, 1, zd, kernels_num=128, kernels_size=k, padding=pad,
                                                                     groupconv=R, rot_refinement=True, theta_prior=np.pi,
                                                                     normal_prior_over_r=False).to(dev())
@@ -1043,6 +1046,7 @@ def test_encoder_with_many_head_rows_takes_the_wide_tail(zd, gemm_mode):
     o1, g1, took = run('h3')
     o0, g0, took0 = run('f32')
     assert {'enc.tail_fwd_wide', 'enc.tail_dgrad_wide'} <= took, took
+    assert ('enc.tail_wgrad_wide' in took) == ((B * R * Ho * Ho) % 32 == 0), took
     assert 'enc.tail_fwd_wide' not in took0
     for a_, b_ in zip(o1, o0):
         assert rel_err(a_, b_) < 2e-5

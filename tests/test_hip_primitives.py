@@ -785,6 +785,75 @@ def test_reductions():
     assert rel_err(tot, 2.0 + 0.5 * X.double().sum(1)) < TOL
 
 
+@pytest.mark.parametrize('N,rows_d,ldpad', [(32 * 700, 103, 0), (32 * 3, 128, 0), (32 * 1031, 8, 64), (32, 1, 0)])
+def test_enc_tail_wgrad_wide(N, rows_d, ldpad):
+    """Round 6: dW[r][c] = sum_n D[r][n] A[c][n] for two stored operands (the encoder tail's weight gradients with many head rows:
+    autograd of the 1x1x1 convolutions, reference src/models.py:347-358,390-392) against float64 -- fewer chunks than
+    workgroups, one chunk, padded leading dimensions, rows of both operands 2^-20 below the rest (per-row relative error of dW's
+    rows AND columns), loose bounds (8x the true maxima), repeatable bit for bit."""
+    from tvae._lib import query
+    C = 128
+    s = 2.0 ** -20
+    D, A = rnd(rows_d, N, seed=1), rnd(C, N, seed=2)
+    A[7] *= s
+    if rows_d > 2:
+        D[1] *= 2.0 ** -10
+    ld = N + ldpad
+    Dp = torch.full((rows_d, ld), float('nan')); Dp[:, :N] = D
+    Ap = torch.full((C, ld), float('nan')); Ap[:, :N] = A
+    if ldpad:
+        Dp[:, N:] = 1e30; Ap[:, N:] = 1e30               # (never read)
+    amax_d = (8.0 * D.abs().max()).reshape(1).to(dev())
+    amax_a = (8.0 * A.abs().amax(dim=1)).contiguous().to(dev())
+    ws = torch.empty(query('tvae_enc_tail_wgrad_x6_ws_floats', N), device=dev())
+    out = [torch.full((C, C), float('nan'), device=dev()) for _ in range(2)]
+    for o in out:
+        call('tvae_enc_tail_wgrad_wide', Dp.to(dev()), ld, rows_d, Ap.to(dev()), ld, o, ws, ws.numel(), C, N, amax_d, amax_a)
+    assert torch.equal(out[0][:rows_d], out[1][:rows_d])
+    ref = D.double() @ A.double().t()
+    got = out[0][:rows_d].double().cpu()
+    assert torch.isfinite(got).all()
+    assert row_rel_err(got, ref) < ROW_TOL
+    assert row_rel_err(got.t(), ref.t()) < ROW_TOL
+    # argument checks: ragged N, too many rows, missing bounds
+    for bad in ((N + 1, rows_d, amax_d), (N, 129, amax_d), (N, rows_d, None)):
+        with pytest.raises(Exception):
+            call('tvae_enc_tail_wgrad_wide', Dp.to(dev()), ld, bad[1], Ap.to(dev()), ld, out[0], ws, ws.numel(), C, bad[0], bad[2], amax_a)
+
+
+def test_enc_tail_wgrad_wide_galaxy_size():
+    """The same entry point at the galaxy configuration's column count (8 images x 16 rotations x 129^2 positions, 103 head
+    rows; BASELINE.json configs[4]) against a float64 product formed on the GPU, bounds as the product path forms them
+    (max |D| measured; per-row analytic bounds of A loose by the row-sum factor)."""
+    from tvae._lib import query
+    C, rows_d, N = 128, 103, 8 * 16 * 129 * 129
+    g = torch.Generator(device=dev()).manual_seed(3)
+    D = torch.randn(rows_d, N, device=dev(), generator=g) * torch.logspace(-6, 0, rows_d, device=dev())[:, None]
+    A = torch.nn.functional.leaky_relu(torch.randn(C, N, device=dev(), generator=g), SLOPE)
+    amax_d = D.abs().max().reshape(1)
+    amax_a = (11.0 * A.abs().amax(dim=1)).contiguous()
+    ws = torch.empty(query('tvae_enc_tail_wgrad_x6_ws_floats', N), device=dev())
+    out = torch.full((C, C), float('nan'), device=dev())
+    call('tvae_enc_tail_wgrad_wide', D, N, rows_d, A, N, out, ws, ws.numel(), C, N, amax_d, amax_a)
+    ref = D.double() @ A.double().t()
+    assert row_rel_err(out[:rows_d], ref) < ROW_TOL
+    assert rel_err(out[:rows_d], ref) < 2e-6
+
+
+@pytest.mark.parametrize('S,L', [(256, 512), (100, 130), (67, 65), (64, 7), (5, 300), (256, 3)])
+def test_seg_sum_instances(S, L):
+    """tvae_seg_sum picks one of three kernels by shape (one thread per output / one wave per output / 64 outputs x 16 segment
+    lanes): all agree with the fp64 sum, with scaling and accumulation, and repeat bit for bit."""
+    X = rnd(S, L, seed=S + L).to(dev())
+    out = torch.full((L,), 3.0, device=dev())
+    call('tvae_seg_sum', X, S, L, out, 0.25, 1)
+    assert rel_err(out, 3.0 + 0.25 * X.double().sum(0)) < TOL
+    o1, o2 = torch.empty(L, device=dev()), torch.empty(L, device=dev())
+    call('tvae_seg_sum', X, S, L, o1, 1.0, 0)
+    call('tvae_seg_sum', X, S, L, o2, 1.0, 0)
+    assert torch.equal(o1, o2) and rel_err(o1, X.double().sum(0)) < TOL
+
+
 @pytest.mark.parametrize('no', [1, 2, 3])
 def test_coldot_outer_mask(no):
     M, N = 64, 1500
