@@ -2,6 +2,7 @@
 // transform, skinny decoder / encoder ends, likelihoods, Adam) behind their C-ABI entry points (include/tvae_hip.h).
 #include "abi_common.hpp"
 #include "small_kernels.hpp"
+#include "rotate_bank_kernels.hpp"
 #include "fused_tail_kernels.hpp"
 
 using namespace tvae;
@@ -28,8 +29,11 @@ int tvae_rotate_bank_fwd(const float* weight, const int* tap_idx, const float* t
     const int k2 = ksz * ksz;
     const long total = (long)C * R * Cin * k2;
     if (total >= 2147483647L || !aligned16(tap_idx) || !aligned16(tap_w)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), weight, tap_idx,
-                       tap_w, bank, C, Cin, k2, R);
+    const long npair = (long)C * Cin;
+    if ((npair + RB_CH - 1) / RB_CH > 65535) return (int)hipErrorInvalidValue;
+    const int npx32 = (ksz + 31) / 32, npy8 = (ksz + 7) / 8;
+    hipLaunchKernelGGL(rotate_bank_fwd_kernel, dim3((unsigned)(R * npx32 * npy8), (unsigned)((npair + RB_CH - 1) / RB_CH)),
+                       dim3(256), 0, S(stream), weight, tap_idx, tap_w, bank, C, Cin, ksz, R);
     TVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -40,8 +44,20 @@ int tvae_rotate_bank_bwd(const float* dbank, const int* csr_ptr, const int* csr_
     const int k2 = ksz * ksz;
     const long total = (long)C * Cin * k2;
     if (total * R >= 2147483647L) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(rotate_bank_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, S(stream), dbank, csr_ptr,
-                       csr_r, csr_dst, csr_w, dweight, C, Cin, k2, R, accumulate);
+    const long npair = (long)C * Cin;
+    if (k2 > (1 << 24) || R > 127) return (int)hipErrorInvalidValue;
+    // pairs per thread: four where that still leaves >= 2 workgroups per CU, else two
+    const int npx = (ksz + 7) / 8;
+    const bool big = (long)npx * npx * ((npair + 15) / 16) >= 512;                 // (2 x the 256 CUs of an MI355X)
+    const int ppw = big ? 16 : 8;
+    if ((npair + ppw - 1) / ppw > 65535) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)(npx * npx), (unsigned)((npair + ppw - 1) / ppw));
+    if (big)
+        hipLaunchKernelGGL(rotate_bank_bwd_kernel<4>, grid, dim3(256), 0, S(stream), dbank, csr_ptr, csr_r, csr_dst, csr_w, dweight,
+                           C, Cin, ksz, R, accumulate);
+    else
+        hipLaunchKernelGGL(rotate_bank_bwd_kernel<2>, grid, dim3(256), 0, S(stream), dbank, csr_ptr, csr_r, csr_dst, csr_w, dweight,
+                           C, Cin, ksz, R, accumulate);
     TVAE_CHECK_LAUNCH();
     return 0;
 }

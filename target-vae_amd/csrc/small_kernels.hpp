@@ -101,60 +101,7 @@ __device__ __forceinline__ float act_deriv_from_out(float y, int act, float slop
     return 1.f;
 }
 
-// ------------------------------------------------------------------------------------------
-// Rotated filter bank (reference GroupConv.trans_filter, src/models.py:174-197).
-// The R fixed rotations are a constant sparse interpolation operator: 4 taps per output pixel.
-// bank[(c*R + r)][ci*k2 + d] = sum_t w[r][d][t] * weight[(c*Cin + ci)*k2 + idx[r][d][t]]
-// ------------------------------------------------------------------------------------------
-static __global__ void rotate_bank_fwd_kernel(const float* __restrict__ weight, const int* __restrict__ tap_idx,
-                                       const float* __restrict__ tap_w, float* __restrict__ bank, int C, int Cin,
-                                       int k2, int R) {
-    // 32-bit index arithmetic (total < 2^31, checked by the caller) and one 16-byte load per tap table entry
-    const unsigned total = (unsigned)C * R * Cin * k2;
-    const int4* ti4 = reinterpret_cast<const int4*>(tap_idx);
-    const float4* tw4 = reinterpret_cast<const float4*>(tap_w);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned d = i % (unsigned)k2;
-        unsigned t = i / (unsigned)k2;
-        const unsigned ci = t % (unsigned)Cin; t /= (unsigned)Cin;
-        const unsigned r = t % (unsigned)R;
-        const unsigned c = t / (unsigned)R;
-        const float* wsrc = weight + (c * Cin + ci) * (unsigned)k2;
-        const int4 id = ti4[r * (unsigned)k2 + d];
-        const float4 tw = tw4[r * (unsigned)k2 + d];
-        float s = 0.f;
-        if (id.x >= 0) s += tw.x * wsrc[id.x];
-        if (id.y >= 0) s += tw.y * wsrc[id.y];
-        if (id.z >= 0) s += tw.z * wsrc[id.z];
-        if (id.w >= 0) s += tw.w * wsrc[id.w];
-        bank[i] = s;
-    }
-}
-
-// Transposed operator in gather (CSR) form: deterministic, no atomics.
-// dweight[(c*Cin+ci)*k2 + s] = sum_{e in [ptr[s],ptr[s+1])} w[e] * dbank[(c*R + r[e])][ci*k2 + dst[e]]
-static __global__ void rotate_bank_bwd_kernel(const float* __restrict__ dbank, const int* __restrict__ csr_ptr,
-                                       const int* __restrict__ csr_r, const int* __restrict__ csr_dst,
-                                       const float* __restrict__ csr_w, float* __restrict__ dweight, int C, int Cin,
-                                       int k2, int R, int accumulate) {
-    // 32-bit index arithmetic (C*R*Cin*k2 < 2^31, checked by the caller); the entry loop is unrolled so that the gathers
-    // of four entries are in flight together (the sum keeps its order)
-    const unsigned total = (unsigned)C * Cin * k2;
-    const unsigned ldb = (unsigned)Cin * k2;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned s = i % (unsigned)k2;
-        const unsigned t = i / (unsigned)k2;
-        const unsigned ci = t % (unsigned)Cin;
-        const unsigned c = t / (unsigned)Cin;
-        const float* src = dbank + (size_t)c * R * ldb + ci * (unsigned)k2;
-        float acc = 0.f;
-        const int e1 = csr_ptr[s + 1];
-#pragma unroll 4
-        for (int e = csr_ptr[s]; e < e1; ++e)
-            acc += csr_w[e] * src[(size_t)csr_r[e] * ldb + csr_dst[e]];
-        if (accumulate) dweight[i] += acc; else dweight[i] = acc;
-    }
-}
+// (rotated filter bank: rotate_bank_kernels.hpp)
 
 // ------------------------------------------------------------------------------------------
 // Segmented row reductions:  out[seg][m][o] = sum_{n in segment} X[m][n] * V[n][o]   (V == nullptr -> 1, no = 1)

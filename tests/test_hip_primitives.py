@@ -114,7 +114,7 @@ def test_linear_wgrad_no_workspace():
     assert rel_err(dW, d.double() @ X.double().t()) < TOL
 
 
-@pytest.mark.parametrize('k,R,Cin,C', [(5, 4, 1, 3), (28, 8, 1, 4), (9, 16, 3, 2)])
+@pytest.mark.parametrize('k,R,Cin,C', [(5, 4, 1, 3), (28, 8, 1, 4), (9, 16, 3, 2), (7, 8, 3, 11), (32, 8, 1, 128)])
 def test_rotate_bank(k, R, Cin, C):
     from tvae import ops
     w = rnd(C, Cin, 1, k, k, seed=k)
@@ -837,7 +837,7 @@ def test_enc_tail_wgrad_wide_galaxy_size():
     call('tvae_enc_tail_wgrad_wide', D, N, rows_d, A, N, out, ws, ws.numel(), C, N, amax_d, amax_a)
     ref = D.double() @ A.double().t()
     assert row_rel_err(out[:rows_d], ref) < ROW_TOL
-    assert rel_err(out[:rows_d], ref) < 2e-6
+    assert rel_err(out[:rows_d], ref) < 1e-5        # (fp32 accumulation over 8 320 columns per workgroup: ~2e-6 measured)
 
 
 @pytest.mark.parametrize('S,L', [(256, 512), (100, 130), (67, 65), (64, 7), (5, 300), (256, 3)])
