@@ -1074,6 +1074,12 @@ class DecoderFn(torch.autograd.Function):
         F_, n_out = Wc.shape[0], Wo.shape[0]
         dev = xr.device
         gy = gy.contiguous().view(Nt, n_out)
+        gy_max = []                                      # max |gy|, formed once (one reduction over the output gradient) on first use
+
+        def gy_amax():
+            if not gy_max:
+                gy_max.append(_inf_norm(gy))
+            return gy_max[0]
         # last layer: one pass over h gives d (pre-activation gradient), its row sums and dWo
         gyT = gy.t().contiguous()
         dbo = _rowsum(gyT, n_out, Nt)
@@ -1109,7 +1115,7 @@ class DecoderFn(torch.autograd.Function):
         dmeas = torch.zeros(n_hidden + 1, dtype=torch.float32, device=dev) if (h3_deep and (n_hidden >= 2 or has_f)) else None
         d_bnd = None                                     # bound word of the stored gradient `d` (None: none / not stored)
         if h3_deep and not virt:
-            d_bnd = (_inf_norm(gy) * Wo.detach().abs().sum(0).amax()).reshape(1)
+            d_bnd = (gy_amax() * Wo.detach().abs().sum(0).amax()).reshape(1)
         for li in range(n_hidden - 1, -1, -1):
             W, b = hidden[li]
             hprev = hs[li]
@@ -1123,11 +1129,11 @@ class DecoderFn(torch.autograd.Function):
             xg_amax = None
             if parts() == 2 and use_vg and sbits is not None and va is None and li == 0 and ctx.h_bound is not None:
                 # one bound per unit (row of the X operand) where the forward formed them, else the tensor's
-                xg_amax = (ctx.h_rows if ctx.h_rows is not None else ctx.h_bound) * _inf_norm(vg[1])
+                xg_amax = (ctx.h_rows if ctx.h_rows is not None else ctx.h_bound) * gy_amax()      # (vg[1] is gy: n_out == 1)
             elif parts() == 2 and use_vg and sbits is not None and va is None and li > 0 and ctx.h_meas[li] is not None:
                 # (round 6) a deeper layer's stored input under its measured maximum, capped per unit by the row-sum chain
                 xb_ = ctx.h_meas[li] if ctx.rows_all[li] is None else torch.minimum(ctx.rows_all[li], ctx.h_meas[li])
-                xg_amax = xb_ * _inf_norm(vg[1])
+                xg_amax = xb_ * gy_amax()
             # plain form (both operands stored tensors) in h3: bound of d (one word) and of the layer's input -- the first
             # layer's analytic per-unit bound, or a deeper layer's measured maximum (capped unit by unit by the row-sum chain
             # where the forward formed it: a unit far below the others keeps its own scale)
@@ -1183,7 +1189,7 @@ class DecoderFn(torch.autograd.Function):
                 if two_val and li == 0 and n_hidden == 1 and has_f and parts() == 2:
                     # bound of the gradient this launch leaves in `dprev` (read again by the Fourier first layer's backward):
                     # |dX[k][n]| <= max |gy| * sum_m |wo[m] W[m][k]|
-                    ctx.d_bound = _inf_norm(vg[1]) * (W.detach().abs() * vg[0].detach().abs()[:, None]).sum(0).amax().reshape(1)
+                    ctx.d_bound = gy_amax() * (W.detach().abs() * vg[0].detach().abs()[:, None]).sum(0).amax().reshape(1)
                 fused_in = fuse_in
                 if fuse_in:
                     _note('dec.fuse_in')
