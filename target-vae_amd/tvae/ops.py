@@ -218,12 +218,14 @@ def _seglen(N: int) -> int:
     return max(2048, ((N + 255) // 256 + 3) // 4 * 4)
 
 
-def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[m] = sum_n X[m][n] (deterministic two-level reduction).  amax (a zeroed device word): also receives max |X|."""
+def _rowsum(X: torch.Tensor, M: int, N: int, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None,
+            ld: int = 0) -> torch.Tensor:
+    """out[m] = sum_n X[m][n] (deterministic two-level reduction).  amax (a zeroed device word): also receives max |X|.
+    ld: floats between rows of X (0 = N)."""
     sl = _seglen(N)
     nseg = (N + sl - 1) // sl
     tmp = torch.empty(nseg, M, dtype=torch.float32, device=X.device)
-    call('tvae_rowdot_seg', X, N, None, 1, M, N, sl, tmp, amax)
+    call('tvae_rowdot_seg', X, ld or N, None, 1, M, N, sl, tmp, amax)
     if out is None:
         out = torch.empty(M, dtype=torch.float32, device=X.device)
     call('tvae_seg_sum', tmp, nseg, M, out, 1.0, 0)
@@ -260,7 +262,7 @@ def _split_weight(W: torch.Tensor, rows: int, K: int, transpose: bool, key: str,
     return w3 if scale is None else (w3, csum)
 
 
-def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None):
+def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None, a_amax=None, x_amax=None, ld=0):
     """dW = dpre . X^T.  virt = (wo, gy, act): dpre is the saved activation H and the gradient wo[m]*gy[n]*act'(H) is formed
     on the fly; va = (xr, Wc, bc, LB, Np): X is the coordinate layer's output act(..), recomputed (split-pipe path only).
     bits: [H > 0] as stored sign bits (dpre may then be None).  rowdot_w = the layer's own weight [M][K]: also returns
@@ -278,7 +280,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
                                     (virt is None and va is None and a_amax is not None and x_amax is not None))) else _p3()
         rowdot = torch.empty(M, dtype=torch.float32, device=dev_) if rowdot_w is not None else None
         with _timed('tvae_linear_wgrad_x6', p, bool(virt) and virt[2] == ACT_LRELU):
-            call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0,
+            call('tvae_linear_wgrad_x6', dpre, X, dW, ws, ws.numel(), M, N, K, ld or N, ld or N, 0,
                  virt[0] if virt else None, virt[1] if virt else None, virt[2] if virt else act, LRELU_SLOPE,
                  *(va if va else (None, None, None, None, 0)), bits, p,
                  rowdot_w.contiguous() if rowdot_w is not None else None, K, rowdot,
@@ -287,7 +289,7 @@ def _wgrad(dpre, X, M, N, K, virt=None, va=None, act=0, bits=None, rowdot_w=None
         return dW if rowdot_w is None else (dW, rowdot)
     _expect(virt is None and va is None and rowdot_w is None, 'implicit operands need the split-pipe weight gradient')
     ws = workspace(dev_, max(need, 1 << 24))
-    call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, N, N, 0)
+    call('tvae_linear_wgrad', dpre, X, dW, ws, ws.numel(), M, N, K, ld or N, ld or N, 0)
     return dW
 
 
@@ -897,6 +899,20 @@ def decoder_padded_pixels(Np: int, B: int, F_: int, n_hidden: int, n_out: int, r
     return Np_p
 
 
+DEC_LD_PAD = int(os.environ.get('TVAE_DEC_LD_PAD', '64'))
+
+
+def _dec_ld(Nt: int, F_: int, n_hidden: int, fourier: bool) -> int:
+    """Row stride (floats) of the decoder's stored [features][B*Np] tensors.  The decoders that STORE activations and gradients
+    (Fourier first layer, two or more hidden layers) stream them again as the panels of their weight gradients; with a
+    power-of-two column count (galaxy: 8 x 128^2 = 2^17) the 512 rows of a panel sit 2^19 bytes apart, every one in the same
+    sets of the L2, and the four workgroups that share a panel each fetch it again (1.88 GB fetched for 0.54 GB,
+    profiles/r06_wgrad_probe.txt).  64 floats of padding per row take the rows off that spacing."""
+    if DEC_LD_PAD and (fourier or n_hidden >= 2) and Nt % 16384 == 0 and _dense_x6_ok(F_, Nt):      # (rows >= 64 KB x k apart)
+        return Nt + DEC_LD_PAD
+    return Nt
+
+
 class DecoderFn(torch.autograd.Function):
     """SpatialGenerator.forward (src/models.py:95-123): [Fourier] -> coord_linear + latent_linear -> act ->
     (Linear | ResidLinear, act) x (L-1) -> Linear(hid, n_out).  x [B][Np][2], z [B][zd] -> (B, Np, n_out).
@@ -921,6 +937,9 @@ class DecoderFn(torch.autograd.Function):
         dev = xr.device
         infer = _INFER
         LB = None
+        ldn = _dec_ld(Nt, F_, n_hidden, Wf is not None)
+        if ldn != Nt:
+            _note('dec.ld_pad')
         # Fourier-feature first layer on the split pipe: the per-image latent term joins the reduction (rows z[img(n)] under
         # the features, weights [Wc | Wl]) instead of being a per-image bias
         four_x6 = Wf is not None and _dense_x6_ok(F_, Nt)
@@ -938,19 +957,19 @@ class DecoderFn(torch.autograd.Function):
         virt_act = (FUSE_VIRT_ACT and FUSE_IN_TAIL and Wf is None and n_hidden >= 1 and not resid and 256 <= F_ <= 512
                     and Np % 128 == 0 and Nt >= 32 and _dense_x6_ok(F_, Nt))
         va = (xr.view(Nt, 2), Wc.contiguous(), bc, LB, Np) if virt_act else None
-        h = None if virt_act else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        h = None if virt_act else torch.empty(F_, ldn, dtype=torch.float32, device=dev)
         if virt_act:
             _note('dec.virt_act')
         elif Wf is not None:
             Ff = Wf.shape[0]
             zx = Wl.shape[1] if (four_x6 and Wl is not None) else 0
-            feat_all = torch.empty(Ff + zx, Nt, dtype=torch.float32, device=dev)
+            feat_all = torch.empty(Ff + zx, ldn, dtype=torch.float32, device=dev)
             feat = feat_all[:Ff]
-            call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, Nt, Ff, Nt)
+            call('tvae_fourier_fwd', xr, Wf.contiguous(), bf.contiguous(), sigma, feat, ldn, Ff, Nt)
             if four_x6:
                 _note('dec.four_x6')
                 if zx:
-                    feat_all[Ff:].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
+                    feat_all[Ff:, :Nt].view(zx, B, Np).copy_(z.contiguous().t().unsqueeze(2).expand(zx, B, Np))
                 Wfull = torch.cat([Wc, Wl], 1) if zx else Wc
                 # h3 (round 4): the streamed operand is cos(.) <= 1 over the latent rows: its bound max(1, max |z|) is known
                 # without looking at it; the layer's OUTPUT is then bounded by the largest absolute row sum of the weights
@@ -964,12 +983,12 @@ class DecoderFn(torch.autograd.Function):
                     _note('dec.four_h3')
                 w3c = _split_weight(Wfull, F_, Ff + zx, False, 'x6_dense_wc', nparts=p_c)
                 with _timed('tvae_linear_fwd_x6', p_c):
-                    call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, Nt, Nt, act, LRELU_SLOPE,
+                    call('tvae_linear_fwd_x6', w3c, feat_all, bc, None, h, F_, Nt, Ff + zx, ldn, ldn, act, LRELU_SLOPE,
                          None, None, None, None, None, None, None, 0, None, p_c, feat_amax if p_c == 2 else None)
             else:
-                call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, Nt, Nt, act, LRELU_SLOPE)
+                call('tvae_linear_fwd', Wc.contiguous(), feat, bc, LB, Np, None, h, F_, Nt, Ff, ldn, ldn, act, LRELU_SLOPE)
         else:
-            call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, Nt, F_, Nt, Np, act, LRELU_SLOPE)
+            call('tvae_dec_l0_fwd', xr, Wc.contiguous(), bc, LB, h, ldn, F_, Nt, Np, act, LRELU_SLOPE)
             if parts() == 2 and _dense_x6_ok(F_, Nt):      # the stored coordinate layer: |act(pre)| <= |pre| <= this bound
                 h_rows = _inf_norm(xr) * Wc.detach().abs().sum(1) + \
                     ((bc.detach()[None, :] + LB).abs().amax(0) if LB is not None else bc.detach().abs())      # per unit
@@ -1019,12 +1038,12 @@ class DecoderFn(torch.autograd.Function):
                 if no_h:
                     _note('dec.no_h_inference' if infer else 'dec.no_h')
                 else:
-                    hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+                    hn = torch.empty(F_, ldn, dtype=torch.float32, device=dev)
                 # this layer's output feeds another hidden layer: leave its maximum for that launch
                 emit = (meas_words[li:li + 1] if (meas_words is not None and li + 1 < n_hidden and hn is not None and not fuse)
                         else None)
                 with _timed('tvae_linear_fwd_x6', p_l):
-                    call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, Nt, Nt, act,
+                    call('tvae_linear_fwd_x6', w3, hs[-1], b, hs[-1] if resid else None, hn, F_, Nt, F_, ldn, ldn, act,
                          LRELU_SLOPE, Wo.contiguous() if fuse else None, bo if fuse else None, yh if fuse else None,
                          *(va if va and li == 0 else (None, None, None, None, 0)), sbits if li == n_hidden - 1 else None,
                          p_l, x_bound, emit)
@@ -1037,14 +1056,14 @@ class DecoderFn(torch.autograd.Function):
                 fused_out = fuse
                 _note('dec.fused_out' if fuse else 'dec.hidden_x6')
             else:
-                hn = torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+                hn = torch.empty(F_, ldn, dtype=torch.float32, device=dev)
                 call('tvae_linear_fwd', W.contiguous(), hs[-1], b, None, 1, hs[-1] if resid else None, hn, F_, Nt, F_,
-                     Nt, Nt, act, LRELU_SLOPE)
+                     ldn, ldn, act, LRELU_SLOPE)
                 rows_l = None
                 rows_all.append(None)
             hs.append(hn)
         if not fused_out:
-            call('tvae_coldot', hs[-1], Nt, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
+            call('tvae_coldot', hs[-1], ldn, F_, Nt, Wo.contiguous(), 1, F_, bo, n_out, yh)
         if infer:
             return yh
         ctx.save_for_backward(xr, z if Wl is not None else None, feat, LB if virt_act else None, *hs,
@@ -1073,6 +1092,7 @@ class DecoderFn(torch.autograd.Function):
         Nt = B * Np
         F_, n_out = Wc.shape[0], Wo.shape[0]
         dev = xr.device
+        ldn = _dec_ld(Nt, F_, n_hidden, has_f)           # (row stride of every stored [features][Nt] tensor, as in forward)
         gy = gy.contiguous().view(Nt, n_out)
         gy_max = []                                      # max |gy|, formed once (one reduction over the output gradient) on first use
 
@@ -1087,7 +1107,7 @@ class DecoderFn(torch.autograd.Function):
         # re-form inside the two GEMMs that consume it: it is then never written (dec_out_bwd only produces row sums)
         virt = (FUSE_VIRT_GRAD and n_out == 1 and n_hidden >= 1 and not resid and _dense_x6_ok(F_, Nt) and F_ >= 256
                 and Nt % 16 == 0)
-        d = None if virt else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+        d = None if virt else torch.empty(F_, ldn, dtype=torch.float32, device=dev)
         tot = torch.empty(1 + n_out, F_, dtype=torch.float32, device=dev)
         # two-valued implicit gradient: the data-gradient launch of the last hidden layer streams H anyway and returns the
         # two row sums this layer's backward needs of it (tot[0] = bias gradient below, tot[1] = dWo): no pass of its own
@@ -1096,7 +1116,7 @@ class DecoderFn(torch.autograd.Function):
         _expect(not no_h or (fuse_rs and ctx.sbits is not None), 'decoder backward without the saved activation needs the bits path')
         if not fuse_rs:
             part = workspace(dev, ((Nt + 1023) // 1024) * F_ * (1 + n_out))
-            call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], Nt, d, Nt, F_, Nt, act, LRELU_SLOPE, part,
+            call('tvae_dec_out_bwd', gy, n_out, Wo.contiguous(), hs[-1], ldn, d, ldn, F_, Nt, act, LRELU_SLOPE, part,
                  part.numel(), tot)
         else:
             _note('dec.row_sums_in_dgrad')
@@ -1145,19 +1165,19 @@ class DecoderFn(torch.autograd.Function):
                 elif ctx.h_meas[li] is not None:
                     xw_amax = ctx.h_meas[li] if ctx.rows_all[li] is None else torch.minimum(ctx.rows_all[li], ctx.h_meas[li])
             if from_bits:                              # + rowdot[m] = sum_k W[m][k] G[m][k] for dWo (the dgrad launch below)
-                dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax)
+                dW, rowdot = _wgrad(None, hprev, F_, Nt, F_, vg, va, act, sbits, rowdot_w=W, x_amax=xg_amax, ld=ldn)
             elif plain_h3 and xw_amax is not None:
                 _note('dec.wgrad_h3_meas')
-                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, None, None, act, None, a_amax=d_bnd, x_amax=xw_amax), None
+                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, None, None, act, None, a_amax=d_bnd, x_amax=xw_amax, ld=ldn), None
             else:
-                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits, x_amax=xg_amax), None
-            db = drow if drow is not None else _rowsum(d, F_, Nt)
+                dW, rowdot = _wgrad(dsrc, hprev, F_, Nt, F_, vg if use_vg else None, va, act, sbits, x_amax=xg_amax, ld=ldn), None
+            db = drow if drow is not None else _rowsum(d, F_, Nt, ld=ldn)
             drow = None
             # the data gradient of the FIRST hidden layer can feed the coordinate layer's backward from its epilogue
             # (coordinate gradient + per-panel row sums); its result is then never written
             fuse_in = (FUSE_IN_TAIL and li == 0 and not has_f and not resid and F_ <= 512 and Np % 128 == 0 and
                        _dense_x6_ok(F_, Nt))
-            dprev = None if fuse_in else torch.empty(F_, Nt, dtype=torch.float32, device=dev)
+            dprev = None if fuse_in else torch.empty(F_, ldn, dtype=torch.float32, device=dev)
             if _dense_x6_ok(F_, Nt):
                 # LeakyReLU: the implicit gradient in its two-valued form (3 MFMAs per block instead of 6)
                 two_val = use_vg and act == ACT_LRELU
@@ -1177,7 +1197,7 @@ class DecoderFn(torch.autograd.Function):
                 rs = two_val and fuse_rs
                 rs_part = _scratch(dev, 'dec_rs_part', (Nt // 128) * F_ * 2) if rs else None
                 with _timed('tvae_linear_dgrad_x6', p_d, two_val):
-                    call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt, act,
+                    call('tvae_linear_dgrad_x6', w3t, dsrc, d if resid else None, hprev, dprev, F_, Nt, F_, ldn, ldn, act,
                          LRELU_SLOPE, xr.view(Nt, 2) if fuse_in else None, Wc.contiguous() if fuse_in else None,
                          gxr_f if fuse_in else None, part_f if fuse_in else None, part_f.numel() if fuse_in else 0,
                          vg[0] if (use_vg and not two_val) else None, vg[1] if use_vg else None, csum,
@@ -1195,7 +1215,7 @@ class DecoderFn(torch.autograd.Function):
                     _note('dec.fuse_in')
                 d_bnd = emit
             else:
-                call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, Nt, Nt,
+                call('tvae_linear_dgrad', W.contiguous(), d, d if resid else None, hprev, dprev, F_, Nt, F_, ldn, ldn,
                      act, LRELU_SLOPE)
                 d_bnd = None
             d = dprev
@@ -1209,13 +1229,13 @@ class DecoderFn(torch.autograd.Function):
             dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
             call('tvae_dec_in_total', part_f, B, Np // 128, F_, Simg, dbc, dWc)
         elif has_f:
-            call('tvae_rowdot_seg', d, Nt, None, 1, F_, Nt, Np, Simg)
+            call('tvae_rowdot_seg', d, ldn, None, 1, F_, Nt, Np, Simg)
             call('tvae_seg_sum', Simg, B, F_, dbc, 1.0, 0)
         else:
             # one pass over d: coordinate gradient, per-image sums, bias and coordinate-weight gradients
             dWc = torch.empty(F_, 2, dtype=torch.float32, device=dev)
             part = workspace(dev, B * ((Np + 1023) // 1024) * F_ * 3)
-            call('tvae_dec_in_bwd', d, Nt, xr.view(Nt, 2), Wc.contiguous(), F_, B, Np, gxr, Simg, dbc, dWc, part,
+            call('tvae_dec_in_bwd', d, ldn, xr.view(Nt, 2), Wc.contiguous(), F_, B, Np, gxr, Simg, dbc, dWc, part,
                  part.numel())
         dWl = dz = None
         if has_l:
@@ -1231,18 +1251,18 @@ class DecoderFn(torch.autograd.Function):
             if d_bound is None and parts() == 2:
                 d_bound = d_bnd                          # (round 6) measured by the launch that stored d
             one = torch.ones(1, dtype=torch.float32, device=dev) if d_bound is not None else None
-            dWc = _wgrad(d, feat, F_, Nt, Ff, a_amax=d_bound, x_amax=one)
-            dfeat = torch.empty(Ff, Nt, dtype=torch.float32, device=dev)
+            dWc = _wgrad(d, feat, F_, Nt, Ff, a_amax=d_bound, x_amax=one, ld=ldn)
+            dfeat = torch.empty(Ff, ldn, dtype=torch.float32, device=dev)
             if _dense_x6_ok(Ff, Nt):
                 p_f = 2 if d_bound is not None else _p3()
                 w3t = _split_weight(Wc, Ff, F_, True, 'x6_dense_wct', nparts=p_f)
                 with _timed('tvae_linear_dgrad_x6', p_f):
-                    call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE,
+                    call('tvae_linear_dgrad_x6', w3t, d, None, None, dfeat, F_, Nt, Ff, ldn, ldn, ACT_NONE, LRELU_SLOPE,
                          None, None, None, None, 0, None, None, None, None, None, 0, None, 0, None, None, None, None, p_f,
                          None, None, None, d_bound)
             else:
-                call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, Nt, Nt, ACT_NONE, LRELU_SLOPE)
-            call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, Nt, Ff, Nt, gxr)
+                call('tvae_linear_dgrad', Wc.contiguous(), d, None, None, dfeat, F_, Nt, Ff, ldn, ldn, ACT_NONE, LRELU_SLOPE)
+            call('tvae_fourier_bwd', xr, Wf.contiguous(), bf.contiguous(), sigma, dfeat, ldn, Ff, Nt, gxr)
         out = [gxr, dz, None, None, None, None, dWc, dbc, dWl]
         for (dW, db) in grads_hidden:
             out += [dW, db]

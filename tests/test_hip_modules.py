@@ -1000,6 +1000,51 @@ def test_deep_decoder_runs_h3_on_measured_bounds(fourier, n_out, resid, gemm_mod
     assert float((g_dead - r_dead).abs().max() / r_dead.abs().max()) < 1e-3, 'dead unit row'
 
 
+@pytest.mark.parametrize('fourier,L,n_out,resid', [(True, 2, 1, False), (False, 3, 1, False), (True, 4, 3, False), (False, 3, 3, True)])
+def test_decoder_padded_row_stride_is_layout_only(fourier, L, n_out, resid, gemm_mode):
+    """Round 6: decoders that store activations / gradients (Fourier first layer, two or more hidden layers; galaxy: reference
+    train_galaxy.py:412-420, src/models.py:84-123) give their [features][B*Np] tensors a padded row stride when the column count
+    is a multiple of 2^14 (ops._dec_ld: the rows of a weight-gradient panel otherwise share their L2 sets).  Layout only: output
+    and every gradient bit for bit what the dense layout gives (TVAE_DEC_LD_PAD=0), and the padded path must be the one taken."""
+    import src.models as M
+    from tvae import ops
+    torch.manual_seed(3)
+    zd, hid, B, Np = 3, 512, 4, 4096                     # 2^14 columns
+    gen = M.SpatialGenerator(zd, hid, n_out=n_out, num_layers=L, resid=resid, fourier_expansion=fourier, sigma=0.1).to(dev())
+    x = (torch.rand(B, Np, 2, device=dev()) * 2 - 1)
+    z = torch.randn(B, zd, device=dev())
+    gy = torch.randn(B, Np, n_out, device=dev())
+
+    def run(pad):
+        old = ops.DEC_LD_PAD
+        ops.DEC_LD_PAD = pad
+        ops.PATH_LOG = set()
+        try:
+            for p_ in gen.parameters():
+                p_.grad = None
+            xg, zg = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            yh = gen(xg, zg)
+            (yh * gy).sum().backward()
+            torch.cuda.synchronize()
+            return [yh.detach(), xg.grad, zg.grad] + [p_.grad.clone() for p_ in gen.parameters()], set(ops.PATH_LOG)
+        finally:
+            ops.DEC_LD_PAD, ops.PATH_LOG = old, None
+
+    r1, took1 = run(64)
+    r0, took0 = run(0)
+    split = gemm_mode in ('x6', 'h3', 'bf16')
+    assert ('dec.ld_pad' in took1) == split and 'dec.ld_pad' not in took0, (took1, took0)
+    for a_, b_ in zip(r1, r0):
+        assert torch.equal(a_, b_)
+    with torch.no_grad():                                # inference path (no stored tensors besides the first layer's)
+        ops.DEC_LD_PAD = 64
+        try:
+            yi = gen(x, z)
+        finally:
+            ops.DEC_LD_PAD = 64 if int(os.environ.get('TVAE_DEC_LD_PAD', '64')) else 0
+    assert rel_err(yi, r0[0]) < 1e-6
+
+
 @pytest.mark.parametrize('geom', [(20, 20, 4, 3), (21, 20, 3, 2)])
 @pytest.mark.parametrize('zd', [10, 50])
 def test_encoder_with_many_head_rows_takes_the_wide_tail(zd, geom, gemm_mode):
