@@ -116,7 +116,12 @@ static __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __
 #pragma unroll
             for (int o = 0; o < NO; ++o) g[q][e][o] = n < cend ? gy[n * NO + o] : 0.f;
         }
-    for (int f = wave; f < F; f += 4) {
+    // gridDim.y slices of the F rows (round 6: with one workgroup per 1 024-column panel the galaxy shape -- 128 panels at 8 images
+    // -- left half the chip without a workgroup and the rest with four waves each: 2 TB/s); every (panel, row) is still summed
+    // by one wave in the same order
+    const int fper = (F + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int f_beg = (int)blockIdx.y * fper, f_end = min(F, f_beg + fper);
+    for (int f = f_beg + wave; f < f_end; f += 4) {
         float w[NO];
 #pragma unroll
         for (int o = 0; o < NO; ++o) w[o] = Wo[(long)o * F + f];
